@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Benchmark of the RandLA-Net hot path on MI355X (BASELINE.json metric: points/sec fwd+bwd on 12 800-pt tiles).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one batch of synthetic tiles already resident in HBM:
+train-mode forward (BatchNorm batch statistics, dropout, device-side random decimation) + cross-entropy +
+backward + (N>1: ONE flat 4.45 MB gradient all-reduce over RCCL) + Adam update.  Workload = BASELINE config 2:
+16 tiles x 12 800 points per GPU, K=16, F=9, C=6 (weak scaling: every rank owns its own 16 tiles; tiles are
+independent units, the gradient all-reduce is the only collective).  Arithmetic is fp32 (the reference's dtype).
+
+Rank 0 prints ONE JSON line with the contract keys plus
+  "fwd_only": eval-mode forward throughput of the same batch,
+  "roofline": achieved vs peak for the dominant kernel, timed live with HIP events on the launch stream,
+  "cpu_baseline": the CPU oracle (restated reference path, torch + cKDTree) timed on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tiles", type=int, default=16, help="tiles per GPU")
+    ap.add_argument("--points", type=int, default=12800, help="points per tile")
+    ap.add_argument("--neighbors", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-roofline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=2, help="tiles in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def timed(fn, steps, world):
+    """Time exactly ``steps`` calls bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def lfa_stage_roofline(net, x, pos, ptr, plan, reps=20):
+    """Roofline entry for the dominant kernel of the forward hot path: the fused LSE + attentive-pooling kernel
+    (lfa_fwd_kernel) of block 1 / lfa2 (ch=16) over all 204 800 points x 16 neighbours.  Algorithmic bytes per
+    launch (compulsory traffic only): read pos 12 B + x s*ch/2 + neighbour ids 4K per point, write
+    s*ch per point."""
+    from myria3d_amd import ops
+
+    n = x.shape[0]
+    K = net.num_neighbors
+    ch = net.block1.lfa2.mlp_attention.lins[0].weight.shape[0]
+    with torch.no_grad():
+        pos4 = ops.pad_pos(pos)
+        index = ops.KnnIndex(pos4, plan.ptrs[0])
+        idx, _ = index.query(K, qry=index)
+        xin = torch.randn(n, ch // 2, device=x.device)
+        enc_lin, enc_bn = net.block1.lfa2.mlp_encoder.lins[0], net.block1.lfa2.mlp_encoder.norms[0].module
+        w_att = net.block1.lfa2.mlp_attention.lins[0].weight
+        wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
+        wp = ops.pack_attention_weight(w_att)
+        out = torch.empty((n, ch), device=x.device)
+        st = torch.cuda.current_stream().cuda_stream
+        launch = lambda: ops.call("m3d_lfa_fwd", xin.data_ptr(), pos4.data_ptr(), idx.data_ptr(), n, K, ch,
+                                  wf.data_ptr(), bf.data_ptr(), wp.data_ptr(), ops.LRELU_SLOPE, out.data_ptr(), st)
+        for _ in range(3):
+            launch()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            launch()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+    bytes_alg = n * (12 + 4 * ch // 2 + 4 * K + 4 * ch)
+    achieved = bytes_alg / (ms * 1e-3) / 1e9
+    return {"kernel": f"lfa_fwd_kernel<16,16> (block1.lfa2, ch={ch}, n={n}, K={K})", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 4)}
+
+
+def cpu_baseline(tiles, points, K):
+    """The CPU oracle (op-for-op restatement of the reference path; kNN through cKDTree like torch_cluster's CPU
+    path) on a bounded sample: `tiles` tiles, fwd+bwd, all host cores."""
+    from oracle.randla_oracle import RandLANetOracle
+    from myria3d_amd.synthetic import synthetic_batch
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = RandLANetOracle(9, 6, num_neighbors=K, return_logits=True, knn="kdtree").train()
+    x, pos, batch, ptr, y = synthetic_batch([points] * tiles)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        out = net(x, pos, batch, ptr)
+        torch.nn.functional.cross_entropy(out, y).backward()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 10):
+        step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(tiles * points / dt, 1), "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"{tiles} tiles x {points} pts, fwd+bwd (train mode, CE loss), {reps} iterations after 1 warm-up, "
+                      "oracle/randla_oracle.py with cKDTree kNN"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from myria3d_amd import HipRandLANet, _lib, make_plan
+    from myria3d_amd.ddp import FlatGradAllReduce, broadcast_module_state, shard_tiles
+    from myria3d_amd.synthetic import synthetic_batch
+
+    _lib.lib()  # no fallback: fail here if the HIP library is missing
+    B, N, K = args.tiles, args.points, args.neighbors
+    tile_ids = shard_tiles(B * world, rank, world)  # weak scaling: B tiles per rank
+    x, pos, batch, ptr, y = synthetic_batch([N] * B, first_tile_id=tile_ids.start)
+    x, pos, ptr, y = x.to(dev), pos.to(dev), ptr.to(dev), y.to(dev)
+    torch.manual_seed(0)
+    net = HipRandLANet(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev)
+    broadcast_module_state(net)
+    plan = make_plan(ptr.tolist(), 4, K, dev)
+    opt = torch.optim.Adam(net.parameters(), lr=0.003933709606504788, capturable=True)  # configs/model/pyg_randla_net_model.yaml:4
+    reducer = FlatGradAllReduce(net.parameters())
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+
+    def train_step():
+        net.train()
+        for p in net.parameters():
+            p.grad.zero_()
+        out = net(x, pos, None, ptr, plan=plan)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        reducer()
+        opt.step()
+
+    def fwd_step():
+        net.eval()
+        with torch.no_grad():
+            net(x, pos, None, ptr, plan=plan)
+
+    launch = "eager"
+    step_fn, fwd_fn = train_step, fwd_step
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    train_step()
+                    fwd_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g_train, g_fwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_train):
+                train_step()
+            with torch.cuda.graph(g_fwd):
+                fwd_step()
+            step_fn, fwd_fn, launch = g_train.replay, g_fwd.replay, "hipgraph"
+        except Exception as e:  # capture is an optimisation, never a requirement
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            step_fn, fwd_fn, launch = train_step, fwd_step, "eager"
+
+    for _ in range(args.warmup):
+        step_fn()
+    dt = timed(step_fn, args.steps, world)
+    for _ in range(max(1, args.warmup // 2)):
+        fwd_fn()
+    dt_f = timed(fwd_fn, args.steps, world)
+
+    total_points = B * N * world
+    res = {
+        "metric": "points/sec fwd+bwd, RandLA-Net, 12 800-pt tiles",
+        "value": round(total_points * args.steps / dt, 1),
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"RandLA-Net train step (fwd + CE + bwd + grad all-reduce + Adam), {B} tiles x {N} pts per GPU, "
+                               f"K={K}, F=9, C=6, decimation 4 (BASELINE config 2, fp32)",
+                   "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
+                   "launch": launch},
+        "fwd_only": {"value": round(total_points * args.steps / dt_f, 1), "unit": "points/s",
+                     "ms_per_step": round(dt_f / args.steps * 1e3, 4), "mode": "eval, no_grad"},
+    }
+    if rank == 0:
+        if not args.skip_roofline:
+            try:
+                res["roofline"] = lfa_stage_roofline(net, x, pos, ptr, plan)
+            except Exception as e:
+                res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.skip_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_tiles, N, K)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/* m3d_hip.h — C ABI of libm3d_hip.so: the MI355X (gfx950) kernels behind the Myria3D RandLA-Net hot path.
+ *
+ * The reference (IGNF/myria3d) is pure Python and has no FFI of its own: everything native on this path is
+ * reached through the third-party wheels torch_cluster / torch_scatter / torch_geometric.
+ * Each entry point below therefore cites the reference call site whose arithmetic it replaces
+ * (paths relative to /root/reference).  The Python side (myria3d_amd/_lib.py) binds these with ctypes and
+ * passes `tensor.data_ptr()` + `torch.cuda.current_stream().cuda_stream`; see INTEGRATION.md for the stub a
+ * Myria3D maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller (torch) owns every buffer; no entry
+ *     point allocates user-visible memory (scratch comes in through `ws` arguments sized by *_workspace_bytes)
+ *   - everything is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises the device
+ *   - return value: 0 = ok, -1 = invalid argument, -2 = unsupported shape, -3 = launch failure; never throws
+ *   - re-entrant, no global mutable state
+ *   - feature matrices are row-major fp32; neighbour tables are dense int32 [n, k] with -1 padding where a
+ *     cloud has fewer than k points (the reference's edge lists simply have fewer edges there)
+ *   - `ptr` arrays are the PyG Batch.ptr vectors: int64 [num_clouds + 1], on the device
+ */
+#ifndef M3D_HIP_H
+#define M3D_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3D_ABI_VERSION 1
+int m3d_abi_version(void);
+
+/* ---- k nearest neighbours -----------------------------------------------------------------------------
+ * torch_cluster.knn as called by knn_graph(pos, K, batch, loop=True)
+ * (myria3d/models/modules/pyg_randla_net.py:180), knn_interpolate(k=1) (pyg_randla_net.py:250) and
+ * knn_interpolate(k=10) (myria3d/models/model.py:90-98).  Exact; squared-L2 within each cloud; self included;
+ * ascending by (d2, source index).  k <= 64. */
+size_t m3d_knn_workspace_bytes(int64_t n_src, int32_t num_clouds);
+/* builds the per-cloud search grid over the SOURCE points into ws */
+int m3d_knn_build(const float* pos_src, int32_t pos_stride /* floats per row, >= 3 */, const int64_t* ptr_src,
+                  int32_t num_clouds, int64_t n_src, void* ws, void* stream);
+/* queries: either pos_qry rows (row q -> idx_out[q]) or, if qry_ws != NULL, the points of another built
+ * workspace in its cell-sorted order (wave-coherent; each record carries its original row).  Self-kNN =
+ * qry_ws == ws.  d2_out may be NULL. */
+int m3d_knn_query(const void* ws, const int64_t* ptr_src, int32_t num_clouds, const float* pos_qry,
+                  int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
+                  int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */, void* stream);
+
+/* ---- SharedMLP GEMM -------------------------------------------------------------------------------------
+ * Linear of PyG MLP / torch.nn.Linear (pyg_randla_net.py:42,53,97-109), forward, dgrad and wgrad:
+ *   C[M,N] (+)= [A0[rows] | A1][M, k0+k1] * B[N, k0+k1]^T  (+ bias) -> *scale + shift -> LeakyReLU
+ * a_colmajor / b_colmajor: element (r,k) of that operand lives at p[k*ld + r].  a0_rows: optional int32 row
+ * gather on A0 (FPModule's x[nn], pyg_randla_net.py:250-251).  stat_sum/stat_sumsq: optional fp64 [N]
+ * accumulators (atomically added to) of the raw (pre scale/shift) output, for train-mode BatchNorm.
+ * accumulate != 0: atomically add into C (required when splitk > 1, which splits the K dimension). */
+int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_t* a0_rows, int32_t k0,
+                 const float* a1, int64_t lda1, int32_t k1, const float* b, int64_t ldb, int32_t b_colmajor,
+                 int64_t M, int32_t N, const float* bias, const float* scale, const float* shift, int32_t act,
+                 float slope, double* stat_sum, double* stat_sumsq, float* c, int64_t ldc, int32_t accumulate,
+                 int32_t splitk, void* stream);
+/* out[N] += column sums of x[M,N] (bias gradient of a Linear without BatchNorm: fc0, fc_classif) */
+int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream);
+
+/* ---- BatchNorm1d(momentum=0.01, eps=1e-6) of SharedMLP (pyg_randla_net.py:92-109) ------------------------ */
+int m3d_bn_finalize(const double* sum, const double* sumsq, int64_t count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* running_mean /* updated in place, may be NULL */,
+                    float* running_var, float* scale, float* shift, float* mean_out, float* invstd_out, int32_t N,
+                    void* stream);
+int m3d_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                     float eps, float* scale, float* shift, int32_t N, void* stream);
+/* y = act(z*scale+shift [+ z2*scale2+shift2]); the second term is the residual of DilatedResidualBlock
+ * (pyg_randla_net.py:186-187).  N % 4 == 0, contiguous rows. */
+int m3d_bn_apply(const float* z, const float* scale, const float* shift, const float* z2, const float* scale2,
+                 const float* shift2, int32_t act, float slope, float* y, int64_t M, int32_t N, void* stream);
+/* backward of m3d_bn_apply in train mode: dz (and dz2), dgamma/dbeta (and dgamma2/dbeta2).
+ * sums_ws: fp64 [3*N] scratch (zeroed inside). */
+int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+               const float* invstd, const float* z2, const float* scale2, const float* shift2, const float* mean2,
+               const float* invstd2, int32_t act, float slope, int64_t M, int32_t N, double* sums_ws, float* dz,
+               float* dz2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, void* stream);
+
+/* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
+int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,
+                    int32_t C, void* stream);
+int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64_t ldo, int64_t m, int32_t C,
+                         void* stream);
+int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64_t n, void* stream);
+/* decimation_indices(): slot r of cloud b <- ptr[b] + P_b(r), P_b a keyed pseudo-random permutation of
+ * [0, n_b); ptr_out is the decimated ptr (computed by the caller: max(1, n_b // factor) per cloud);
+ * seed: device uint64[1]. */
+int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds, const uint64_t* seed,
+                           uint32_t level, int32_t* idx_out, int64_t m, void* stream);
+
+/* ---- Local spatial encoding + attentive pooling (pyg_randla_net.py:112-152) ----------------------------- */
+/* first/second moments of the 10-vector r over all valid edges: mom65 = [sum r (10) | upper triangle of
+ * sum r r^T (55)], fp64, zeroed inside */
+int m3d_lfa_moments(const float* pos4, const int32_t* idx, int64_t n, int32_t K, double* mom65, void* stream);
+/* folds mlp_encoder's BatchNorm into its Linear.  mom65 != NULL: train mode (batch statistics over
+ * num_edges edges, running stats updated); mom65 == NULL: eval mode (running stats). */
+int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, const float* w /* [D,10] */, const float* b,
+                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* w_folded, float* b_folded, float* mean_out, float* invstd_out,
+                         int32_t D, void* stream);
+/* fused forward: out[n, CH] = sum_k softmax_k(W_att f_k) * f_k,  f_k = [x[j_k] | LeakyReLU(wf r_k + bf)].
+ * CH in {8,16,32,64,128,256}, K <= 32.  att_w_packed: W_att ([CH,CH] row-major, zero-padded to
+ * CHP = max(CH,16)) re-laid as [CHP/16][CHP/16][64 lanes][4]:
+ *   packed[nt][s4][lane][i] = W[16*nt + (lane & 15)][4*(4*s4 + i) + (lane >> 4)]. */
+int m3d_lfa_fwd(const float* x /* [n, CH/2] */, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
+                int32_t CH, const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                float slope, float* out, void* stream);
+/* unfused pieces (backward pass, fallback, cross-check): F[n*K, CH] edge features */
+int m3d_lfa_edge_features(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                          const float* enc_w_folded, const float* enc_b_folded, float slope, float* F, void* stream);
+int m3d_lfa_edge_softmax_fwd(const float* A, const float* F, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                             float* out, void* stream);
+/* A (attention logits) is overwritten with dA; dF <- dout * softmax */
+int m3d_lfa_edge_softmax_bwd(float* A_inout_dA, const float* F, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                             const float* dout, float* dF, void* stream);
+/* dx[n, CH/2] += scatter of dF[:, :CH/2];  G[CH/2][11] (fp64, zeroed inside) = sum_e dy_e [r_e | 1] */
+int m3d_lfa_edge_features_bwd(const float* dF, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
+                              int32_t CH, const float* enc_w_folded, const float* enc_b_folded, float slope,
+                              float* dx, double* G, void* stream);
+int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_edges, const float* w, const float* b,
+                             const float* gamma, const float* mean, const float* invstd, float* dw, float* db,
+                             float* dgamma, float* dbeta, int32_t D, void* stream);
+
+/* ---- knn_interpolate arithmetic (model.py:90-98; pyg_randla_net.py:250) ---------------------------------- */
+int m3d_idw_interpolate_fwd(const float* x, int64_t ldx, const int32_t* idx, const float* d2, int64_t n_qry,
+                            int32_t k, int32_t C, float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3D_HIP_H */

@@ -1,0 +1,11 @@
+"""myria3d_amd — MI355X (gfx950) native RandLA-Net hot path for IGNF/myria3d.
+
+Only what the path needs: ``csrc/`` (HIP kernels + the C ABI of ``include/m3d_hip.h``), the ctypes binding, and
+the host-side mirror of the reference's operator interface (``HipRandLANet``, ``knn_interpolate``,
+``scatter_sum``, ``register_in_model_zoo``).
+"""
+from .randla import HipRandLANet, make_plan  # noqa: F401
+from .interpolation import knn_interpolate, scatter_sum  # noqa: F401
+from .registration import register_in_model_zoo  # noqa: F401
+
+__all__ = ["HipRandLANet", "make_plan", "knn_interpolate", "scatter_sum", "register_in_model_zoo"]

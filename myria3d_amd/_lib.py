@@ -1,0 +1,89 @@
+"""ctypes binding of ``libm3d_hip.so`` (the C ABI declared in ``include/m3d_hip.h``).
+
+The library is built in-tree by ``myria3d_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is no CPU
+fallback: if the shared object is missing or a call returns a non-zero status the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm3d_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_p, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes): must mirror include/m3d_hip.h exactly (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "m3d_abi_version": (_i32, []),
+    "m3d_knn_workspace_bytes": (C.c_size_t, [_i64, _i32]),
+    "m3d_knn_build": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p]),
+    "m3d_knn_query": (_i32, [_p, _p, _i32, _p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
+    "m3d_gemm_f32": (_i32, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _i32,
+                            _f32, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "m3d_colsum_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
+    "m3d_bn_finalize": (_i32, [_p, _p, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
+    "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
+    "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,
+                          _p, _p, _p]),
+    "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
+    "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
+    "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
+    "m3d_decimation_indices": (_i32, [_p, _p, _i32, _p, _u32, _p, _i64, _p]),
+    "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
+    "m3d_lfa_edge_features": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p]),
+    "m3d_lfa_edge_softmax_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "m3d_lfa_edge_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "m3d_lfa_edge_features_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p, _p]),
+    "m3d_lfa_enc_bwd_finalize": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_idw_interpolate_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
+}
+
+_ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
+
+
+class M3DError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``libm3d_hip.so`` (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise M3DError("building libm3d_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise M3DError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C myria3d_amd/csrc`). myria3d_amd has no CPU/eager fallback by design."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.m3d_abi_version() != 1:
+            raise M3DError("libm3d_hip.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise :class:`M3DError` on a non-zero status."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise M3DError(f"{name} failed: {_ERRORS.get(rc, rc)}")

@@ -1,0 +1,272 @@
+// Train-mode BatchNorm1d pieces around the SharedMLP GEMMs (gfx950).
+//
+// Restates torch.nn.BatchNorm1d(momentum=0.01, eps=1e-6) as wrapped by PyG's BatchNorm inside SharedMLP
+// (/root/reference/myria3d/models/modules/pyg_randla_net.py:92-109): batch statistics over ALL rows of the
+// batch, biased variance for normalisation, unbiased for running_var.  The GEMM epilogue (gemm.hip) has
+// already accumulated per-column sum / sum-of-squares of the raw Linear output in fp64; here:
+//   m3d_bn_finalize   -> mean, invstd, folded (scale, shift), running-stat update
+//   m3d_bn_apply      -> y = act(z*scale + shift [+ z2*scale2 + shift2])     (the [+...] is the block's
+//                        residual: LeakyReLU(mlp2(x) + shortcut(x)), pyg_randla_net.py:186-187)
+//   m3d_bn_bwd_reduce / m3d_bn_bwd_apply -> gradient w.r.t. the raw Linear output(s), gamma, beta.
+// All HBM-bound elementwise / column-reduction kernels: float4 accesses, fp64 column accumulators.
+#include "m3d_common.h"
+#include "../../include/m3d_hip.h"
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* scale,
+                                   float* shift, float* mean_out, float* invstd_out, int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double mean = sum[n] / count;
+  double var = sumsq[n] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  double invstd = 1.0 / sqrt(var + (double)eps);
+  float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+  double sc = (double)g * invstd;
+  scale[n] = (float)sc;
+  shift[n] = (float)((double)b - mean * sc);
+  if (mean_out) mean_out[n] = (float)mean;
+  if (invstd_out) invstd_out[n] = (float)invstd;
+  if (running_mean) running_mean[n] = (float)((1.0 - momentum) * (double)running_mean[n] + momentum * mean);
+  if (running_var) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[n] = (float)((1.0 - momentum) * (double)running_var[n] + momentum * unbiased);
+  }
+}
+
+extern "C" int m3d_bn_finalize(const double* sum, const double* sumsq, int64_t count, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* scale, float* shift, float* mean_out, float* invstd_out,
+                               int32_t N, void* stream) {
+  if (!sum || !sumsq || !scale || !shift || N < 0 || count < 1) return M3D_ERR_INVALID;
+  if (N == 0) return M3D_OK;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
+                     invstd_out, N);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// eval-mode fold: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
+__global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                    float* scale, float* shift, int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double invstd = 1.0 / sqrt((double)rv[n] + (double)eps);
+  double sc = (double)gamma[n] * invstd;
+  scale[n] = (float)sc;
+  shift[n] = (float)((double)beta[n] - (double)rm[n] * sc);
+}
+
+extern "C" int m3d_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, float* scale, float* shift, int32_t N,
+                                void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || N < 0) return M3D_ERR_INVALID;
+  if (N == 0) return M3D_OK;
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, scale, shift, N);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// y = act(z*scale + shift [+ z2*scale2 + shift2]);  N % 4 == 0, rows contiguous (ld == N)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ z, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float4* __restrict__ z2,
+                                                       const float* __restrict__ scale2,
+                                                       const float* __restrict__ shift2, int act, float slope,
+                                                       float4* __restrict__ y, int64_t total4, int N4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    int c = (int)(i % N4) * 4;
+    float4 v = z[i];
+    float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+    float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (z2) {
+      float4 w = z2[i];
+      float4 s2 = *(const float4*)(scale2 + c), h2 = *(const float4*)(shift2 + c);
+      u.x += w.x * s2.x + h2.x; u.y += w.y * s2.y + h2.y; u.z += w.z * s2.z + h2.z; u.w += w.w * s2.w + h2.w;
+    }
+    if (act) { u.x = lrelu(u.x, slope); u.y = lrelu(u.y, slope); u.z = lrelu(u.z, slope); u.w = lrelu(u.w, slope); }
+    y[i] = u;
+  }
+}
+
+extern "C" int m3d_bn_apply(const float* z, const float* scale, const float* shift, const float* z2,
+                            const float* scale2, const float* shift2, int32_t act, float slope, float* y, int64_t M,
+                            int32_t N, void* stream) {
+  if (M < 0 || N < 0) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  if (!z || !scale || !shift || !y) return M3D_ERR_INVALID;
+  if (z2 && (!scale2 || !shift2)) return M3D_ERR_INVALID;
+  if (N % 4) return M3D_ERR_UNSUPPORTED;
+  int64_t total4 = M * (N / 4);
+  int64_t gx = m3d_cdiv(total4, 256 * 4);
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const float4*)z, scale,
+                     shift, (const float4*)z2, scale2, shift2, act, slope, (float4*)y, total4, N / 4);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, pass 1: sums[0][n] = sum_m dact, sums[1][n] = sum_m dact*zhat, sums[2][n] = sum_m dact*zhat2
+//   u = z*scale+shift (+ z2*scale2+shift2); dact = dy * (act ? (u>0 ? 1 : slope) : 1)
+//   zhat = (z - mean)*invstd
+// ------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+  const float* dy; const float* z; const float* scale; const float* shift; const float* mean; const float* invstd;
+  const float* z2; const float* scale2; const float* shift2; const float* mean2; const float* invstd2;
+  int act; float slope; int64_t M; int N;
+  double* sums;  // [3][N]
+  float* dz; float* dz2; float* dgamma; float* dbeta; float* dgamma2; float* dbeta2;
+};
+
+__device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, float4 zv, float4& z2v) {
+  float4 g = ((const float4*)a.dy)[i];
+  if (a.act) {
+    float4 sc = *(const float4*)(a.scale + c), sh = *(const float4*)(a.shift + c);
+    float4 u = make_float4(zv.x * sc.x + sh.x, zv.y * sc.y + sh.y, zv.z * sc.z + sh.z, zv.w * sc.w + sh.w);
+    if (a.z2) {
+      float4 s2 = *(const float4*)(a.scale2 + c), h2 = *(const float4*)(a.shift2 + c);
+      u.x += z2v.x * s2.x + h2.x; u.y += z2v.y * s2.y + h2.y; u.z += z2v.z * s2.z + h2.z; u.w += z2v.w * s2.w + h2.w;
+    }
+    g.x *= u.x > 0.f ? 1.f : a.slope; g.y *= u.y > 0.f ? 1.f : a.slope;
+    g.z *= u.z > 0.f ? 1.f : a.slope; g.w *= u.w > 0.f ? 1.f : a.slope;
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+  __shared__ double red[256 * 12];
+  const int tid = threadIdx.x;
+  const int N4 = a.N / 4;
+  const int CG = N4 < 256 ? N4 : 256;  // column groups handled per pass
+  const int rpp = 256 / CG;            // rows per pass
+  const int cg = tid % CG, rl = tid / CG;
+  for (int cb = 0; cb < N4; cb += CG) {
+    const int c4 = cb + cg;
+    double s[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s[j] = 0.0;
+    if (rl < rpp && c4 < N4) {
+      const int c = c4 * 4;
+      float4 mu = *(const float4*)(a.mean + c), is = *(const float4*)(a.invstd + c);
+      float4 mu2 = make_float4(0, 0, 0, 0), is2 = make_float4(0, 0, 0, 0);
+      if (a.z2) { mu2 = *(const float4*)(a.mean2 + c); is2 = *(const float4*)(a.invstd2 + c); }
+      for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < a.M; r += (int64_t)gridDim.x * rpp) {
+        int64_t i = r * N4 + c4;
+        float4 zv = ((const float4*)a.z)[i];
+        float4 z2v = make_float4(0, 0, 0, 0);
+        if (a.z2) z2v = ((const float4*)a.z2)[i];
+        float4 g = bn_dact(a, i, c, zv, z2v);
+        s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+        s[4] += (double)(g.x * ((zv.x - mu.x) * is.x)); s[5] += (double)(g.y * ((zv.y - mu.y) * is.y));
+        s[6] += (double)(g.z * ((zv.z - mu.z) * is.z)); s[7] += (double)(g.w * ((zv.w - mu.w) * is.w));
+        if (a.z2) {
+          s[8] += (double)(g.x * ((z2v.x - mu2.x) * is2.x)); s[9] += (double)(g.y * ((z2v.y - mu2.y) * is2.y));
+          s[10] += (double)(g.z * ((z2v.z - mu2.z) * is2.z)); s[11] += (double)(g.w * ((z2v.w - mu2.w) * is2.w));
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 12; ++j) red[j * 256 + tid] = s[j];
+    __syncthreads();
+    if (rl == 0 && c4 < N4) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        if (j >= 8 && !a.z2) break;
+        double v = 0.0;
+        for (int q = 0; q < rpp; ++q) v += red[j * 256 + q * CG + cg];
+        atomicAdd(&a.sums[(size_t)(j / 4) * a.N + c4 * 4 + (j & 3)], v);
+      }
+    }
+  }
+}
+
+// pass 2: dz = scale*(dact - s1/M - zhat*s2/M);  dz2 likewise with its own zhat2/s2';  dgamma = s2, dbeta = s1
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  const int N4 = a.N / 4;
+  const int64_t total4 = a.M * N4;
+  const double invM = 1.0 / (double)a.M;
+  if (blockIdx.x == 0) {
+    for (int n = threadIdx.x; n < a.N; n += 256) {
+      if (a.dbeta) a.dbeta[n] = (float)a.sums[n];
+      if (a.dgamma) a.dgamma[n] = (float)a.sums[a.N + n];
+      if (a.z2) {
+        if (a.dbeta2) a.dbeta2[n] = (float)a.sums[n];
+        if (a.dgamma2) a.dgamma2[n] = (float)a.sums[2 * (size_t)a.N + n];
+      }
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % N4) * 4;
+    float4 zv = ((const float4*)a.z)[i];
+    float4 z2v = make_float4(0, 0, 0, 0);
+    if (a.z2) z2v = ((const float4*)a.z2)[i];
+    float4 g = bn_dact(a, i, c, zv, z2v);
+    float m1[4], m2[4], m3[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m1[j] = (float)(a.sums[c + j] * invM);
+      m2[j] = (float)(a.sums[a.N + c + j] * invM);
+      m3[j] = a.z2 ? (float)(a.sums[2 * (size_t)a.N + c + j] * invM) : 0.f;
+    }
+    {
+      float4 mu = *(const float4*)(a.mean + c), is = *(const float4*)(a.invstd + c), sc = *(const float4*)(a.scale + c);
+      float4 o;
+      o.x = sc.x * (g.x - m1[0] - (zv.x - mu.x) * is.x * m2[0]);
+      o.y = sc.y * (g.y - m1[1] - (zv.y - mu.y) * is.y * m2[1]);
+      o.z = sc.z * (g.z - m1[2] - (zv.z - mu.z) * is.z * m2[2]);
+      o.w = sc.w * (g.w - m1[3] - (zv.w - mu.w) * is.w * m2[3]);
+      ((float4*)a.dz)[i] = o;
+    }
+    if (a.z2) {
+      float4 mu = *(const float4*)(a.mean2 + c), is = *(const float4*)(a.invstd2 + c), sc = *(const float4*)(a.scale2 + c);
+      float4 o;
+      o.x = sc.x * (g.x - m1[0] - (z2v.x - mu.x) * is.x * m3[0]);
+      o.y = sc.y * (g.y - m1[1] - (z2v.y - mu.y) * is.y * m3[1]);
+      o.z = sc.z * (g.z - m1[2] - (z2v.z - mu.z) * is.z * m3[2]);
+      o.w = sc.w * (g.w - m1[3] - (z2v.w - mu.w) * is.w * m3[3]);
+      ((float4*)a.dz2)[i] = o;
+    }
+  }
+}
+
+extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* z2, const float* scale2, const float* shift2,
+                          const float* mean2, const float* invstd2, int32_t act, float slope, int64_t M, int32_t N,
+                          double* sums_ws, float* dz, float* dz2, float* dgamma, float* dbeta, float* dgamma2,
+                          float* dbeta2, void* stream) {
+  if (M < 0 || N < 0) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  if (!dy || !z || !scale || !shift || !mean || !invstd || !sums_ws || !dz) return M3D_ERR_INVALID;
+  if (z2 && (!scale2 || !shift2 || !mean2 || !invstd2 || !dz2)) return M3D_ERR_INVALID;
+  if (N % 4) return M3D_ERR_UNSUPPORTED;
+  BnBwdArgs a;
+  a.dy = dy; a.z = z; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  a.z2 = z2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.invstd2 = invstd2;
+  a.act = act; a.slope = slope; a.M = M; a.N = N; a.sums = sums_ws;
+  a.dz = dz; a.dz2 = dz2; a.dgamma = dgamma; a.dbeta = dbeta; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 3 * (size_t)N, st) != hipSuccess) return M3D_ERR_LAUNCH;
+  const int N4 = N / 4;
+  const int CG = N4 < 256 ? N4 : 256;
+  const int rpp = 256 / CG;
+  int64_t gx = m3d_cdiv(M, (int64_t)rpp * 16);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
+  int64_t total4 = M * N4;
+  int64_t gy = m3d_cdiv(total4, 256 * 4);
+  if (gy > 4096) gy = 4096;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)gy), dim3(256), 0, st, a);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

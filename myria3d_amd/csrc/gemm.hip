@@ -1,0 +1,277 @@
+// fp32 MFMA GEMM for the SharedMLP 1x1 "convolutions" (gfx950).
+//
+// Replaces the Linear (+BatchNorm +LeakyReLU) stack that PyG's MLP runs for SharedMLP
+// (/root/reference/myria3d/models/modules/pyg_randla_net.py:97-109) and torch.nn.Linear
+// (pyg_randla_net.py:42,53), forward and both backward GEMMs.
+//
+//   C[M,N] (+)= A[M,K] * B[N,K]^T          (K = k0 + k1: A may be the concatenation of two column blocks,
+//                                            the first optionally row-gathered: FPModule's cat([x[nn], skip]))
+// v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain): 256-thread workgroup = 4 waves, 64 x (16*NT)
+// output tile, wave w owns rows 16w..16w+15 and NT accumulators; K is walked in chunks of 32 through LDS
+// tiles padded to a 34-float row stride (bank = 2*row + k: conflict-free fragment reads).
+// Either operand may be given "column-major" (element (r,k) at p[k*ld + r]) so that the same kernel serves
+// forward (A row-major, W row-major), dgrad (dZ row-major, W column-major) and wgrad (dZ^T, X^T: both
+// column-major, split over the reduction dimension with atomic accumulation).
+// Epilogue: + bias, per-column affine (folded eval BatchNorm), LeakyReLU, and — for train-mode BatchNorm —
+// per-column sum / sum-of-squares of the raw output accumulated in fp64.
+#include "m3d_common.h"
+#include "../../include/m3d_hip.h"
+
+#define BM 64
+#define BK 32
+#define LDS_STRIDE (BK + 2)
+
+struct GemmArgs {
+  const float* a0; int64_t lda0; const int32_t* a0_rows; int k0;
+  const float* a1; int64_t lda1; int k1;
+  int a_cm;
+  const float* b; int64_t ldb; int b_cm;
+  int64_t M; int N;
+  const float* bias; const float* scale; const float* shift; int act; float slope;
+  double* stat_sum; double* stat_sumsq;
+  float* c; int64_t ldc; int accumulate;
+  int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float As[BM * LDS_STRIDE];
+  __shared__ float Bs[16 * NT * LDS_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int BN = 16 * NT;
+  const int n0 = blockIdx.y * BN;
+  const int K = g.k0 + g.k1;
+  int64_t kbeg = 0, kend = K;
+  if (g.splitk > 1) {
+    kbeg = (int64_t)blockIdx.z * g.kchunk;
+    kend = kbeg + g.kchunk < (int64_t)K ? kbeg + g.kchunk : (int64_t)K;
+  }
+  const bool a_vec = !g.a_cm && ((g.lda0 & 3) == 0) && ((g.k0 & 3) == 0) && ((((uintptr_t)g.a0) & 15) == 0) &&
+                     (g.k1 == 0 || (((g.lda1 & 3) == 0) && ((((uintptr_t)g.a1) & 15) == 0)));
+  const bool b_vec = !g.b_cm && ((g.ldb & 3) == 0) && ((((uintptr_t)g.b) & 15) == 0);
+
+  double ssum[NT], ssq[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { ssum[t] = 0.0; ssq[t] = 0.0; }
+
+  const int64_t mtiles = (g.M + BM - 1) / BM;
+  for (int64_t mt = blockIdx.x; mt < mtiles; mt += gridDim.x) {
+    const int64_t m0 = mt * BM;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t kk = kbeg; kk < kend; kk += BK) {
+      // ---------------- stage A tile: As[r][k], r < 64, k < 32
+      if (!g.a_cm) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int f = tid + i * 256;
+          int r = f >> 3, c4 = (f & 7) * 4;
+          int64_t row = m0 + r;
+          int64_t kg = kk + c4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row < g.M) {
+            if (a_vec && kg + 3 < kend) {
+              if (kg < g.k0) {
+                int64_t rr = g.a0_rows ? (int64_t)g.a0_rows[row] : row;
+                v = *(const float4*)(g.a0 + rr * g.lda0 + kg);
+              } else {
+                v = *(const float4*)(g.a1 + row * g.lda1 + (kg - g.k0));
+              }
+            } else {
+              float tmp[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                int64_t kj = kg + j;
+                float e = 0.f;
+                if (kj < kend) {
+                  if (kj < g.k0) {
+                    int64_t rr = g.a0_rows ? (int64_t)g.a0_rows[row] : row;
+                    e = g.a0[rr * g.lda0 + kj];
+                  } else {
+                    e = g.a1[row * g.lda1 + (kj - g.k0)];
+                  }
+                }
+                tmp[j] = e;
+              }
+              v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+          }
+          float* d = &As[r * LDS_STRIDE + c4];
+          *(float2*)d = make_float2(v.x, v.y);
+          *(float2*)(d + 2) = make_float2(v.z, v.w);
+        }
+      } else {
+        // column-major A: element (row, k) at a0[k*lda0 + row]; coalesce along rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int f = tid + i * 256;
+          int k = f >> 4, r4 = (f & 15) * 4;
+          int64_t kg = kk + k;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int64_t row = m0 + r4 + j;
+            float e = 0.f;
+            if (kg < kend && row < g.M) e = g.a0[kg * g.lda0 + row];
+            As[(r4 + j) * LDS_STRIDE + k] = e;
+          }
+        }
+      }
+      // ---------------- stage B tile: Bs[n][k], n < BN, k < 32
+      if (!g.b_cm) {
+        for (int f = tid; f < BN * 8; f += 256) {
+          int r = f >> 3, c4 = (f & 7) * 4;
+          int n = n0 + r;
+          int64_t kg = kk + c4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (n < g.N) {
+            if (b_vec && kg + 3 < kend) {
+              v = *(const float4*)(g.b + (int64_t)n * g.ldb + kg);
+            } else {
+              float tmp[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) tmp[j] = (kg + j < kend) ? g.b[(int64_t)n * g.ldb + kg + j] : 0.f;
+              v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+          }
+          float* d = &Bs[r * LDS_STRIDE + c4];
+          *(float2*)d = make_float2(v.x, v.y);
+          *(float2*)(d + 2) = make_float2(v.z, v.w);
+        }
+      } else {
+        // column-major B: element (n, k) at b[k*ldb + n]; coalesce along n
+        for (int f = tid; f < BN * BK; f += 256) {
+          int k = f / BN, r = f % BN;
+          int n = n0 + r;
+          int64_t kg = kk + k;
+          float e = 0.f;
+          if (kg < kend && n < g.N) e = g.b[kg * g.ldb + n];
+          Bs[r * LDS_STRIDE + k] = e;
+        }
+      }
+      __syncthreads();
+      const float* ap = &As[(wid * 16 + lr) * LDS_STRIDE + lg];
+      const float* bp = &Bs[lr * LDS_STRIDE + lg];
+#pragma unroll
+      for (int s = 0; s < BK / 4; ++s) {
+        float a = ap[4 * s];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(a, bp[t * 16 * LDS_STRIDE + 4 * s], acc[t]);
+      }
+      __syncthreads();
+    }
+    // ---------------- epilogue. C layout: col = lr, row = lg*4 + reg
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + t * 16 + lr;
+      const bool ncol = n < g.N;
+      const float bia = (ncol && g.bias && blockIdx.z == 0) ? g.bias[n] : 0.f;
+      const float sc = (ncol && g.scale) ? g.scale[n] : 1.f;
+      const float sh = (ncol && g.shift) ? g.shift[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wid * 16 + lg * 4 + r;
+        if (ncol && row < g.M) {
+          float z = acc[t][r] + bia;
+          if (g.stat_sum) { ssum[t] += (double)z; ssq[t] += (double)z * (double)z; }
+          float y = z * sc + sh;
+          if (g.act) y = lrelu(y, g.slope);
+          float* cp = g.c + row * g.ldc + n;
+          if (g.accumulate) atomicAdd(cp, y); else *cp = y;
+        }
+      }
+    }
+  }
+  if (g.stat_sum) {
+    __shared__ double sred[4][2][16 * NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      double a = xgroup_sum_d(ssum[t]), q = xgroup_sum_d(ssq[t]);
+      if (lg == 0) { sred[wid][0][t * 16 + lr] = a; sred[wid][1][t * 16 + lr] = q; }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      int which = tid / BN, col = tid % BN;
+      int n = n0 + col;
+      if (n < g.N) {
+        double v = sred[0][which][col] + sred[1][which][col] + sred[2][which][col] + sred[3][which][col];
+        atomicAdd(which ? &g.stat_sumsq[n] : &g.stat_sum[n], v);
+      }
+    }
+  }
+}
+
+extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_t* a0_rows, int32_t k0,
+                            const float* a1, int64_t lda1, int32_t k1, const float* b, int64_t ldb,
+                            int32_t b_colmajor, int64_t M, int32_t N, const float* bias, const float* scale,
+                            const float* shift, int32_t act, float slope, double* stat_sum, double* stat_sumsq,
+                            float* c, int64_t ldc, int32_t accumulate, int32_t splitk, void* stream) {
+  if (M < 0 || N < 0 || k0 < 0 || k1 < 0) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  if (!c || !b || (k0 > 0 && !a0) || (k1 > 0 && !a1)) return M3D_ERR_INVALID;
+  if (a_colmajor && (k1 > 0 || a0_rows)) return M3D_ERR_UNSUPPORTED;
+  if ((stat_sum == nullptr) != (stat_sumsq == nullptr)) return M3D_ERR_INVALID;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && (!accumulate || stat_sum || scale || shift || act)) return M3D_ERR_INVALID;
+  if (k0 + k1 == 0) return M3D_ERR_INVALID;
+  GemmArgs g;
+  g.a0 = a0; g.lda0 = lda0; g.a0_rows = a0_rows; g.k0 = k0; g.a1 = a1; g.lda1 = lda1; g.k1 = k1;
+  g.a_cm = a_colmajor; g.b = b; g.ldb = ldb; g.b_cm = b_colmajor; g.M = M; g.N = N;
+  g.bias = bias; g.scale = scale; g.shift = shift; g.act = act; g.slope = slope;
+  g.stat_sum = stat_sum; g.stat_sumsq = stat_sumsq; g.c = c; g.ldc = ldc; g.accumulate = accumulate;
+  const int64_t K = (int64_t)k0 + k1;
+  int64_t kchunk = m3d_align(m3d_cdiv(K, splitk), BK);
+  splitk = (int)m3d_cdiv(K, kchunk);
+  g.splitk = splitk; g.kchunk = kchunk;
+  const int NT = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
+  const int64_t mtiles = m3d_cdiv(M, BM);
+  const int64_t ntiles = m3d_cdiv(N, 16 * NT);
+  // persistent over M tiles when column statistics are accumulated (fewer fp64 atomics per column)
+  int64_t gx = mtiles;
+  const int64_t cap = stat_sum ? 1024 : 65535;
+  if (gx > cap) gx = cap;
+  if (ntiles > 65535 || splitk > 65535) return M3D_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)gx, (unsigned)ntiles, (unsigned)splitk), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (NT == 1) hipLaunchKernelGGL(gemm_kernel<1>, grid, block, 0, st, g);
+  else if (NT == 2) hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, st, g);
+  else hipLaunchKernelGGL(gemm_kernel<4>, grid, block, 0, st, g);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// per-column sum of a row-major [M, N] matrix, accumulated (atomically) into out[N]:
+// the bias gradient of a Linear that is not followed by BatchNorm (fc0, fc_classif).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N,
+                                                     float* __restrict__ out) {
+  // thread = (column c = tid % Npad, row lane); grid-stride over rows
+  const int tid = threadIdx.x;
+  const int cols = N < 256 ? N : 256;
+  const int rows_per_pass = 256 / cols;
+  const int c = tid % cols, rl = tid / cols;
+  if (rl >= rows_per_pass) return;
+  for (int cb = 0; cb < N; cb += cols) {
+    int n = cb + c;
+    float acc = 0.f;
+    if (n < N)
+      for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + rl; r < M; r += (int64_t)gridDim.x * rows_per_pass)
+        acc += x[r * ld + n];
+    if (n < N) atomicAdd(&out[n], acc);
+  }
+}
+
+extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream) {
+  if (M < 0 || N < 0) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  if (!x || !out) return M3D_ERR_INVALID;
+  int cols = N < 256 ? N : 256;
+  int rpp = 256 / cols;
+  int64_t gx = m3d_cdiv(M, (int64_t)rpp * 8);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

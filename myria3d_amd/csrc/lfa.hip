@@ -1,0 +1,600 @@
+// Local Spatial Encoding + attentive pooling (RandLA-Net "LocalFeatureAggregation") for gfx950.
+//
+// Replaces LocalFeatureAggregation.propagate/message
+// (/root/reference/myria3d/models/modules/pyg_randla_net.py:112-152): PyG gathers x_j / pos_i / pos_j into
+// [E,.] tensors, runs mlp_encoder (Linear 10->d + BatchNorm + LeakyReLU) and mlp_attention (Linear ch->ch,
+// no bias) over every edge, a scatter-softmax over each centre's K neighbours, and a scatter-add.
+//
+// Here (forward, m3d_lfa_fwd): ONE kernel, nothing of size [E,.] ever reaches HBM.  A 256-thread workgroup
+// owns TC centres = TC*KP edge rows:
+//   phase 1  neighbour ids -> LDS; x_j rows gathered with 16-byte loads into an LDS tile F[rows][ch];
+//            relative position encoding r = [p_i, p_j, p_j-p_i, |p_j-p_i|] and the (BatchNorm-folded) encoder
+//            evaluated per edge on the VALU with wave-uniform weights -> F[:, d:ch]
+//   phase 2  attention logits A = F * W_att^T on v_mfma_f32_16x16x4_f32 (exact fp32): each 16-row MFMA tile is
+//            one centre's 16 neighbours; W_att comes pre-packed in fragment order (one coalesced 16-byte load
+//            per lane per 4 k-steps) and every B fragment is reused for the 4 M-tiles a wave owns
+//   phase 3  softmax over the neighbours directly in the MFMA C layout (4 registers + 2 cross-lane steps per
+//            channel) and the weighted sum with F re-read from LDS; 64-byte row segments written to HBM.
+// Train-mode BatchNorm of the encoder is folded as well: the encoder is affine in r, so the batch mean and
+// variance of W r + b over all edges follow from the first and second moments of r (m3d_lfa_moments, 65
+// numbers per level, fp64), see m3d_lfa_enc_finalize.
+//
+// Backward (round 1): recompute-based but unfused — m3d_lfa_edge_features materialises F, the generic GEMM
+// recomputes A, m3d_lfa_edge_softmax_bwd / m3d_lfa_edge_features_bwd do the per-edge calculus, and the
+// encoder's parameter gradients (through its train-mode BatchNorm) are reconstructed analytically from 11*d
+// accumulated numbers in m3d_lfa_enc_bwd_finalize.
+#include "m3d_common.h"
+#include "../../include/m3d_hip.h"
+
+struct LfaArgs {
+  const float* x;      // [n, D]
+  const float4* pos4;  // [n]
+  const int32_t* idx;  // [n, K], -1 padded
+  const float* wf;     // [D, 10] folded encoder weight
+  const float* bf;     // [D]     folded encoder bias
+  const float4* wp;    // packed attention weight, see m3d_hip.h
+  float* out;          // [n, CH]
+  int64_t n;
+  int K, CH, D;
+  float slope;
+};
+
+__device__ __forceinline__ void rel_pos(float4 pi, float4 pj, float (&r)[10]) {
+  float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+  r[0] = pi.x; r[1] = pi.y; r[2] = pi.z;
+  r[3] = pj.x; r[4] = pj.y; r[5] = pj.z;
+  r[6] = dx; r[7] = dy; r[8] = dz;
+  r[9] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+template <int CHP> struct LfaCfg {};
+template <> struct LfaCfg<16> { static constexpr int ROWS = 256; };
+template <> struct LfaCfg<32> { static constexpr int ROWS = 128; };
+template <> struct LfaCfg<64> { static constexpr int ROWS = 64; };
+template <> struct LfaCfg<128> { static constexpr int ROWS = 64; };
+template <> struct LfaCfg<256> { static constexpr int ROWS = 64; };
+
+template <int CHP, int KP>
+__global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
+  constexpr int ROWS = LfaCfg<CHP>::ROWS;
+  constexpr int TC = ROWS / KP;          // centres per workgroup
+  constexpr int KT = KP / 16;            // MFMA M-tiles per centre
+  constexpr int STR = CHP + 2;           // LDS row stride (floats): bank = 2*row + k for fragment reads
+  constexpr int MT = ROWS / 16, NT = CHP / 16;
+  constexpr int WN = NT < 4 ? NT : 4, WM = 4 / WN;
+  constexpr int NTW = NT / WN, MTW = MT / WM;
+  constexpr int S4 = CHP / 16;           // groups of 4 k-steps
+  static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
+  __shared__ float F[ROWS * STR];
+  __shared__ int nbr[ROWS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int D = a.D, CH = a.CH, K = a.K;
+  const int64_t c0 = (int64_t)blockIdx.x * TC;
+
+  // ---- phase 1a: neighbour ids
+  for (int e = tid; e < ROWS; e += 256) {
+    int ci = e / KP, k = e % KP;
+    int64_t i = c0 + ci;
+    int j = -1;
+    if (i < a.n && k < K) j = a.idx[i * K + k];
+    nbr[e] = j;
+  }
+  __syncthreads();
+  // ---- phase 1b: gather x_j into F[:, 0:D]; zero the padding columns (only when CH < CHP)
+  {
+    const int D4 = D >> 2;
+    for (int f = tid; f < ROWS * D4; f += 256) {
+      int e = f / D4, c4 = f % D4;
+      int j = nbr[e];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
+      float* d = &F[e * STR + c4 * 4];
+      *(float2*)d = make_float2(v.x, v.y);
+      *(float2*)(d + 2) = make_float2(v.z, v.w);
+    }
+    if (CH < CHP) {
+      const int P = CHP - CH;
+      for (int f = tid; f < ROWS * P; f += 256) F[(f / P) * STR + CH + (f % P)] = 0.f;
+    }
+  }
+  // ---- phase 1c: relative position encoding + folded encoder -> F[:, D:2D]
+  {
+    constexpr int NG = 256 / ROWS;
+    const int e = tid % ROWS;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / ROWS);
+    const int DG = D / NG;
+    const int j = nbr[e];
+    const int64_t i = c0 + e / KP;
+    float r[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) r[q] = 0.f;
+    if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
+    for (int c = grp * DG; c < (grp + 1) * DG; ++c) {
+      const float* w = a.wf + c * 10;
+      float v = a.bf[c];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+      F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: A = F * W_att^T on MFMA
+  const int wn = wid % WN, wm = wid / WN;
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+#pragma unroll 1
+  for (int s4 = 0; s4 < S4; ++s4) {
+    float4 b[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float av[MTW];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+      }
+    }
+  }
+
+  // ---- phase 3: softmax over each centre's neighbours + weighted sum, in the MFMA C layout
+#pragma unroll
+  for (int cc = 0; cc < MTW / KT; ++cc) {
+    const int mt0 = wm * MTW + cc * KT;
+    const int64_t i = c0 + mt0 / KT;
+    bool vr[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vr[kt][r] = nbr[(mt0 + kt) * 16 + lg * 4 + r] >= 0;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (wn * NTW + t) * 16 + lr;
+      float mx = -__builtin_inff();
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (vr[kt][r]) mx = fmaxf(mx, acc[cc * KT + kt][t][r]);
+      mx = xgroup_max(mx);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (vr[kt][r]) {
+            float p = __expf(acc[cc * KT + kt][t][r] - mx);
+            float f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
+            num += p * f;
+            den += p;
+          }
+      num = xgroup_sum(num);
+      den = xgroup_sum(den);
+      if (lg == 0 && i < a.n && col < CH) a.out[i * CH + col] = num / (den + 1e-16f);
+    }
+  }
+}
+
+template <int CHP>
+static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st) {
+  constexpr int ROWS = LfaCfg<CHP>::ROWS;
+  if (a.K <= 16) {
+    hipLaunchKernelGGL((lfa_fwd_kernel<CHP, 16>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((lfa_fwd_kernel<CHP, 32>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
+  }
+  if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
+  return M3D_OK;
+}
+
+extern "C" int m3d_lfa_fwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                           const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                           float slope, float* out, void* stream) {
+  if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed || !out) return M3D_ERR_INVALID;
+  if (K > 32) return M3D_ERR_UNSUPPORTED;
+  if (CH != 8 && CH != 16 && CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)pos4) & 15) || (((uintptr_t)att_w_packed) & 15)) return M3D_ERR_INVALID;
+  LfaArgs a;
+  a.x = x; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded;
+  a.wp = (const float4*)att_w_packed; a.out = out; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
+  hipStream_t st = (hipStream_t)stream;
+  switch (CH) {
+    case 8: case 16: return launch_lfa_fwd<16>(a, st);
+    case 32: return launch_lfa_fwd<32>(a, st);
+    case 64: return launch_lfa_fwd<64>(a, st);
+    case 128: return launch_lfa_fwd<128>(a, st);
+    default: return launch_lfa_fwd<256>(a, st);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// moments of r over all valid edges: mom[0:10] = sum r, mom[10:65] = sum r_p r_q (p<=q, row-major upper)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lfa_moments_kernel(const float4* __restrict__ pos4,
+                                                          const int32_t* __restrict__ idx, int64_t n, int K,
+                                                          double* __restrict__ mom) {
+  __shared__ double red[4][65];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double acc[65];
+#pragma unroll
+  for (int q = 0; q < 65; ++q) acc[q] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+    const float4 pi = pos4[i];
+    for (int k = 0; k < K; ++k) {
+      int j = idx[i * K + k];
+      if (j < 0) continue;
+      float r[10];
+      rel_pos(pi, pos4[j], r);
+      int o = 10;
+#pragma unroll
+      for (int p = 0; p < 10; ++p) {
+        acc[p] += (double)r[p];
+#pragma unroll
+        for (int q = p; q < 10; ++q) acc[o++] += (double)r[p] * (double)r[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 65; ++q) {
+    double v = wave_sum_d(acc[q]);
+    if (lane == 0) red[wid][q] = v;
+  }
+  __syncthreads();
+  if (tid < 65) atomicAdd(&mom[tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+extern "C" int m3d_lfa_moments(const float* pos4, const int32_t* idx, int64_t n, int32_t K, double* mom65,
+                               void* stream) {
+  if (n < 0 || K < 1) return M3D_ERR_INVALID;
+  if (!mom65) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(mom65, 0, 65 * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  if (n == 0) return M3D_OK;
+  if (!pos4 || !idx) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(n, 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(lfa_moments_kernel, dim3((unsigned)gx), dim3(256), 0, st, (const float4*)pos4, idx, n, K, mom65);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+__device__ __forceinline__ double mom2(const double* mom, int p, int q) {
+  if (p > q) { int t = p; p = q; q = t; }
+  // offset of (p,q), p<=q, in the row-major upper triangle of a 10x10 matrix
+  return mom[10 + p * 10 - (p * (p - 1)) / 2 + (q - p)];
+}
+
+// Train-mode fold of mlp_encoder's BatchNorm: z = W r + b is affine in r, so over the E edges
+//   mean_c = w_c . m + b_c,  var_c = w_c^T (M2/E - m m^T) w_c      (m = S1/E)
+// -> folded weights  wf = scale_c * w_c,  bf = scale_c*(b_c - mean_c) + beta_c,  scale_c = gamma_c/sqrt(var_c+eps)
+// In eval mode (mom == nullptr) the running statistics are used instead.
+__global__ void lfa_enc_finalize_kernel(const double* __restrict__ mom, double E, const float* __restrict__ w,
+                                        const float* __restrict__ b, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float eps, float momentum,
+                                        float* running_mean, float* running_var, float* wf, float* bf,
+                                        float* mean_out, float* invstd_out, int D) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  double mean, var;
+  if (mom) {
+    double m[10];
+    for (int p = 0; p < 10; ++p) m[p] = mom[p] / E;
+    mean = (double)b[c];
+    for (int p = 0; p < 10; ++p) mean += (double)w[c * 10 + p] * m[p];
+    var = 0.0;
+    for (int p = 0; p < 10; ++p)
+      for (int q = 0; q < 10; ++q)
+        var += (double)w[c * 10 + p] * (double)w[c * 10 + q] * (mom2(mom, p, q) / E - m[p] * m[q]);
+    if (var < 0.0) var = 0.0;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    if (running_var) {
+      double unb = E > 1.0 ? var * E / (E - 1.0) : var;
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  double invstd = 1.0 / sqrt(var + (double)eps);
+  double sc = (double)gamma[c] * invstd;
+  for (int p = 0; p < 10; ++p) wf[c * 10 + p] = (float)(sc * (double)w[c * 10 + p]);
+  bf[c] = (float)(sc * ((double)b[c] - mean) + (double)beta[c]);
+  if (mean_out) mean_out[c] = (float)mean;
+  if (invstd_out) invstd_out[c] = (float)invstd;
+}
+
+extern "C" int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, const float* w, const float* b,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* w_folded, float* b_folded,
+                                    float* mean_out, float* invstd_out, int32_t D, void* stream) {
+  if (D < 0) return M3D_ERR_INVALID;
+  if (D == 0) return M3D_OK;
+  if (!w || !b || !gamma || !beta || !w_folded || !b_folded) return M3D_ERR_INVALID;
+  if (mom65 && num_edges < 1) return M3D_ERR_INVALID;
+  if (!mom65 && (!running_mean || !running_var)) return M3D_ERR_INVALID;
+  hipLaunchKernelGGL(lfa_enc_finalize_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, mom65,
+                     (double)num_edges, w, b, gamma, beta, eps, momentum, running_mean, running_var, w_folded,
+                     b_folded, mean_out, invstd_out, D);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// unfused pieces (used by the backward pass; also a fallback / cross-check of the fused forward)
+// ------------------------------------------------------------------------------------------
+// F[e, 0:D] = x[j_e], F[e, D:CH] = LeakyReLU(wf r_e + bf);  rows of missing neighbours are zero.  e = i*K + k
+__global__ __launch_bounds__(256) void edge_features_kernel(LfaArgs a, float* __restrict__ Fout) {
+  const int C4 = a.CH >> 2, D4 = a.D >> 2;
+  const int64_t total = a.n * a.K * C4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t e = t / C4;
+    const int c4 = (int)(t % C4);
+    const int j = a.idx[e];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j >= 0) {
+      if (c4 < D4) {
+        v = *(const float4*)(a.x + (int64_t)j * a.D + c4 * 4);
+      } else {
+        float r[10];
+        rel_pos(a.pos4[e / a.K], a.pos4[j], r);
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = (c4 - D4) * 4 + u;
+          const float* w = a.wf + c * 10;
+          float s = a.bf[c];
+#pragma unroll
+          for (int q = 0; q < 10; ++q) s += w[q] * r[q];
+          o[u] = lrelu(s, a.slope);
+        }
+        v = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    ((float4*)Fout)[t] = v;
+  }
+}
+
+extern "C" int m3d_lfa_edge_features(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
+                                     int32_t CH, const float* enc_w_folded, const float* enc_b_folded, float slope,
+                                     float* F, void* stream) {
+  if (n < 0 || K < 1 || CH < 8 || (CH % 8)) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !F) return M3D_ERR_INVALID;
+  LfaArgs a;
+  a.x = x; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded; a.wp = nullptr;
+  a.out = nullptr; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
+  int64_t gx = m3d_cdiv(n * K * (CH / 4), 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(edge_features_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a, F);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// thread = (centre i, channel c).  mode 0: out[i,c] = sum_k softmax_k(A)[k,c] * F[k,c]
+// mode 1 (backward): additionally, given dout[i,c]:
+//    dA[e,c] = s * dout * (F - out)   (written over A),   dF[e,c] = dout * s
+__global__ __launch_bounds__(256) void edge_softmax_kernel(float* __restrict__ A, const float* __restrict__ Fm,
+                                                           const int32_t* __restrict__ idx, int64_t n, int K, int CH,
+                                                           const float* __restrict__ dout, float* __restrict__ out,
+                                                           float* __restrict__ dF, int mode) {
+  const int64_t total = n * CH;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / CH;
+    const int c = (int)(t % CH);
+    const int32_t* nb = idx + i * K;
+    const int64_t base = i * K * (int64_t)CH + c;
+    float mx = -__builtin_inff();
+    for (int k = 0; k < K; ++k)
+      if (nb[k] >= 0) mx = fmaxf(mx, A[base + (int64_t)k * CH]);
+    float num = 0.f, den = 0.f;
+    for (int k = 0; k < K; ++k)
+      if (nb[k] >= 0) {
+        float p = __expf(A[base + (int64_t)k * CH] - mx);
+        num += p * Fm[base + (int64_t)k * CH];
+        den += p;
+      }
+    const float inv = 1.f / (den + 1e-16f);
+    const float o = num * inv;
+    if (mode == 0) {
+      out[t] = o;
+    } else {
+      const float g = dout[t];
+      for (int k = 0; k < K; ++k) {
+        const int64_t p_ = base + (int64_t)k * CH;
+        float da = 0.f, df = 0.f;
+        if (nb[k] >= 0) {
+          float s = __expf(A[p_] - mx) * inv;
+          da = s * g * (Fm[p_] - o);
+          df = g * s;
+        }
+        A[p_] = da;
+        dF[p_] = df;
+      }
+    }
+  }
+}
+
+extern "C" int m3d_lfa_edge_softmax_fwd(const float* A, const float* F, const int32_t* idx, int64_t n, int32_t K,
+                                        int32_t CH, float* out, void* stream) {
+  if (n < 0 || K < 1 || CH < 1) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!A || !F || !idx || !out) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(n * CH, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(edge_softmax_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (float*)A, F, idx, n,
+                     K, CH, nullptr, out, nullptr, 0);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+extern "C" int m3d_lfa_edge_softmax_bwd(float* A_inout_dA, const float* F, const int32_t* idx, int64_t n, int32_t K,
+                                        int32_t CH, const float* dout, float* dF, void* stream) {
+  if (n < 0 || K < 1 || CH < 1) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!A_inout_dA || !F || !idx || !dout || !dF) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(n * CH, 256);
+  if (gx > 16384) gx = 16384;
+  hipLaunchKernelGGL(edge_softmax_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, A_inout_dA, F, idx, n,
+                     K, CH, dout, nullptr, dF, 1);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// Backward of edge_features: given dF[E, CH]
+//   dx[j_e, 0:D] += dF[e, 0:D]                                          (atomic scatter)
+//   dy[e, c] = dF[e, D+c] * lrelu'(wf_c r_e + bf_c);  G[c, 0:10] += dy * r_e,  G[c, 10] += dy   (fp64)
+#define EFB 256
+__global__ __launch_bounds__(256) void edge_features_bwd_kernel(LfaArgs a, const float* __restrict__ dF,
+                                                                float* __restrict__ dx, double* __restrict__ G) {
+  __shared__ __attribute__((aligned(16))) float rt[EFB][12];
+  __shared__ int nb[EFB];
+  __shared__ double gred[256 * 11];
+  const int tid = threadIdx.x;
+  const int D = a.D, CH = a.CH, D4 = D >> 2;
+  const int64_t E = a.n * a.K;
+  // G part: thread owns channel c = tid % Dg of group grp; channels beyond 256 are looped (D <= 128 in this net)
+  const int Dg = D < 256 ? D : 256;
+  const int ng = 256 / Dg;
+  const int c = tid % Dg, grp = tid / Dg;
+  const bool gthread = grp < ng;
+  float w[10], bias = 0.f;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) w[q] = gthread ? a.wf[c * 10 + q] : 0.f;
+  if (gthread) bias = a.bf[c];
+  double g[11];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) g[q] = 0.0;
+
+  for (int64_t e0 = (int64_t)blockIdx.x * EFB; e0 < E; e0 += (int64_t)gridDim.x * EFB) {
+    {
+      const int64_t e = e0 + tid;
+      int j = -1;
+      if (e < E) j = a.idx[e];
+      float r[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) r[q] = 0.f;
+      if (j >= 0) rel_pos(a.pos4[e / a.K], a.pos4[j], r);
+#pragma unroll
+      for (int q = 0; q < 10; ++q) rt[tid][q] = r[q];
+      rt[tid][10] = j >= 0 ? 1.f : 0.f;
+      rt[tid][11] = 0.f;
+      nb[tid] = j;
+    }
+    __syncthreads();
+    const int cnt = (int)((E - e0) < EFB ? (E - e0) : EFB);
+    // scatter dx
+    for (int f = tid; f < cnt * D4; f += 256) {
+      const int el = f / D4, c4 = f % D4;
+      const int j = nb[el];
+      if (j >= 0) {
+        float4 v = *(const float4*)(dF + (e0 + el) * (int64_t)CH + c4 * 4);
+        float* d = dx + (int64_t)j * D + c4 * 4;
+        atomicAdd(d + 0, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+      }
+    }
+    // accumulate G
+    if (gthread) {
+      float gp[11];
+#pragma unroll
+      for (int q = 0; q < 11; ++q) gp[q] = 0.f;
+      for (int el = grp; el < cnt; el += ng) {
+        const float4 r0 = *(const float4*)&rt[el][0], r1 = *(const float4*)&rt[el][4], r2 = *(const float4*)&rt[el][8];
+        const float rr[11] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z};
+        float pre = bias;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) pre += w[q] * rr[q];
+        float dy = dF[(e0 + el) * (int64_t)CH + D + c] * (pre > 0.f ? 1.f : a.slope);
+#pragma unroll
+        for (int q = 0; q < 11; ++q) gp[q] += dy * rr[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 11; ++q) g[q] += (double)gp[q];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 11; ++q) gred[q * 256 + tid] = g[q];
+  __syncthreads();
+  if (tid < Dg) {
+    for (int q = 0; q < 11; ++q) {
+      double v = 0.0;
+      for (int u = 0; u < ng; ++u) v += gred[q * 256 + u * Dg + tid];
+      atomicAdd(&G[tid * 11 + q], v);
+    }
+  }
+}
+
+extern "C" int m3d_lfa_edge_features_bwd(const float* dF, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
+                                         int32_t CH, const float* enc_w_folded, const float* enc_b_folded,
+                                         float slope, float* dx, double* G, void* stream) {
+  if (n < 0 || K < 1 || CH < 8 || (CH % 8)) return M3D_ERR_INVALID;
+  if (CH / 2 > 256) return M3D_ERR_UNSUPPORTED;
+  if (!G) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(G, 0, sizeof(double) * 11 * (size_t)(CH / 2), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  if (n == 0) return M3D_OK;
+  if (!dF || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !dx) return M3D_ERR_INVALID;
+  LfaArgs a;
+  a.x = nullptr; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded; a.wp = nullptr;
+  a.out = nullptr; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
+  int64_t gx = m3d_cdiv(n * K, EFB);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(edge_features_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, st, a, dF, dx, G);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// Parameter gradients of mlp_encoder (Linear 10->D + train-mode BatchNorm) from G (see lfa.hip header):
+//   dbeta = g0, dgamma = invstd*(w.G + (b-mean) g0)
+//   dW[c,q] = scale*( G[c,q] - (g0/E) S1[q] - (dgamma/E) * invstd*( sum_p w_p M2[p,q] + (b-mean) S1[q] ) )
+//   db = 0 (BatchNorm removes the mean)
+__global__ void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G, const double* __restrict__ mom, double E,
+                                            const float* __restrict__ w, const float* __restrict__ b,
+                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                            const float* __restrict__ invstd, float* dw, float* db, float* dgamma,
+                                            float* dbeta, int D) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  const double* g = G + c * 11;
+  const double g0 = g[10];
+  const double is = (double)invstd[c], mu = (double)mean[c], bb = (double)b[c];
+  double wg = 0.0;
+  for (int p = 0; p < 10; ++p) wg += (double)w[c * 10 + p] * g[p];
+  const double dgam = is * (wg + (bb - mu) * g0);
+  const double sc = (double)gamma[c] * is;
+  for (int q = 0; q < 10; ++q) {
+    double wm = 0.0;
+    for (int p = 0; p < 10; ++p) wm += (double)w[c * 10 + p] * mom2(mom, p, q);
+    double zr = is * (wm + (bb - mu) * mom[q]);
+    dw[c * 10 + q] = (float)(sc * (g[q] - (g0 / E) * mom[q] - (dgam / E) * zr));
+  }
+  db[c] = 0.f;
+  dgamma[c] = (float)dgam;
+  dbeta[c] = (float)g0;
+}
+
+extern "C" int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_edges, const float* w,
+                                        const float* b, const float* gamma, const float* mean, const float* invstd,
+                                        float* dw, float* db, float* dgamma, float* dbeta, int32_t D, void* stream) {
+  if (D < 0) return M3D_ERR_INVALID;
+  if (D == 0) return M3D_OK;
+  if (!G || !mom65 || !w || !b || !gamma || !mean || !invstd || !dw || !db || !dgamma || !dbeta || num_edges < 1)
+    return M3D_ERR_INVALID;
+  hipLaunchKernelGGL(lfa_enc_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, mom65,
+                     (double)num_edges, w, b, gamma, mean, invstd, dw, db, dgamma, dbeta, D);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

@@ -1,0 +1,157 @@
+// Row gather / scatter-add, xyz padding and device-side random decimation (gfx950).
+//
+// Replaces, for /root/reference/myria3d/models/modules/pyg_randla_net.py:
+//   * `tensor[idx_decim]` in decimate() (:234-238) and the x[nn] gather inside knn_interpolate(k=1) (:250)
+//       -> m3d_gather_rows; its autograd transpose -> m3d_scatter_add_rows
+//   * decimation_indices() (:192-231): a Python loop of per-cloud torch.randperm calls with host syncs
+//       -> m3d_decimation_indices: one launch; slot r of cloud b gets ptr[b] + P_b(r) where P_b is a keyed
+//          pseudo-random permutation of [0, n_b) (cycle-walking balanced Feistel network), i.e. the head of a
+//          random permutation, exactly the reference's sampling scheme without materialising the permutation.
+#include "m3d_common.h"
+#include "../../include/m3d_hip.h"
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t ld,
+                                                          const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                          int64_t m, int C) {
+  if ((C & 3) == 0 && (ld & 3) == 0) {
+    const int C4 = C >> 2;
+    const int64_t total = m * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      int64_t r = i / C4;
+      int c = (int)(i % C4);
+      int64_t s = idx ? (int64_t)idx[r] : r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s >= 0) v = *(const float4*)(src + s * ld + c * 4);
+      ((float4*)out)[i] = v;
+    }
+  } else {
+    const int64_t total = m * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      int64_t r = i / C;
+      int c = (int)(i % C);
+      int64_t s = idx ? (int64_t)idx[r] : r;
+      out[i] = s >= 0 ? src[s * ld + c] : 0.f;
+    }
+  }
+}
+
+extern "C" int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx, float* out, int64_t m, int32_t C,
+                               void* stream) {
+  if (m < 0 || C < 0) return M3D_ERR_INVALID;
+  if (m == 0 || C == 0) return M3D_OK;
+  if (!src || !out) return M3D_ERR_INVALID;
+  if ((((uintptr_t)src) & 15) || (((uintptr_t)out) & 15)) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(m * (int64_t)((C + 3) / 4), 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, ld, idx, out, m,
+                     C);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src,
+                                                               const int32_t* __restrict__ idx,
+                                                               float* __restrict__ out, int64_t ldo, int64_t m,
+                                                               int C) {
+  const int64_t total = m * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t r = i / C;
+    int c = (int)(i % C);
+    int64_t d = (int64_t)idx[r];
+    if (d >= 0) atomicAdd(out + d * ldo + c, src[i]);
+  }
+}
+
+extern "C" int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64_t ldo, int64_t m,
+                                    int32_t C, void* stream) {
+  if (m < 0 || C < 0) return M3D_ERR_INVALID;
+  if (m == 0 || C == 0) return M3D_OK;
+  if (!src || !out || !idx) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(m * (int64_t)C, 256 * 2);
+  if (gx > 8192) gx = 8192;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, idx, out,
+                     ldo, m, C);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// [n,3] (row stride `stride` floats) -> [n,4] with w = 0: 16-byte rows for single-load neighbour gathers
+__global__ __launch_bounds__(256) void pad_pos_kernel(const float* __restrict__ pos, int stride, float4* __restrict__ out,
+                                                      int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float* p = pos + i * stride;
+    out[i] = make_float4(p[0], p[1], p[2], 0.f);
+  }
+}
+
+extern "C" int m3d_pad_pos(const float* pos, int32_t stride, float* out4, int64_t n, void* stream) {
+  if (n < 0 || stride < 3) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!pos || !out4 || (((uintptr_t)out4) & 15)) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(n, 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(pad_pos_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, pos, stride, (float4*)out4,
+                     n);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// decimation indices
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t r, uint32_t n, uint32_t key) {
+  if (n <= 1) return 0;
+  int bits = 32 - __clz(n - 1);  // ceil(log2 n), n >= 2
+  int half = (bits + 1) >> 1;
+  uint32_t mask = (1u << half) - 1u;
+  uint32_t x = r;
+  do {
+    uint32_t L = x >> half, R = x & mask;
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+      uint32_t f = mix32(R ^ (key + 0x9e3779b9u * (uint32_t)(round + 1))) & mask;
+      uint32_t t = L ^ f;
+      L = R;
+      R = t;
+    }
+    x = (L << half) | R;
+  } while (x >= n);
+  return x;
+}
+
+__global__ __launch_bounds__(256) void decimation_kernel(const int64_t* __restrict__ ptr,
+                                                         const int64_t* __restrict__ ptr_out, int B,
+                                                         const uint64_t* __restrict__ seed, uint32_t level,
+                                                         int32_t* __restrict__ idx_out, int64_t m) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m) return;
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (ptr_out[mid] <= t) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  const uint32_t r = (uint32_t)(t - ptr_out[b]);
+  const uint32_t n = (uint32_t)(ptr[b + 1] - ptr[b]);
+  const uint64_t s = seed[0];
+  uint32_t key = mix32((uint32_t)s ^ mix32((uint32_t)(s >> 32) + 0x85ebca6bu * (level + 1u)) ^ mix32((uint32_t)b * 0xc2b2ae35u + 1u));
+  idx_out[t] = (int32_t)(ptr[b] + (int64_t)feistel_perm(r, n, key));
+}
+
+extern "C" int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds,
+                                      const uint64_t* seed, uint32_t level, int32_t* idx_out, int64_t m,
+                                      void* stream) {
+  if (num_clouds < 0 || m < 0) return M3D_ERR_INVALID;
+  if (m == 0 || num_clouds == 0) return M3D_OK;
+  if (!ptr || !ptr_out || !seed || !idx_out) return M3D_ERR_INVALID;
+  hipLaunchKernelGGL(decimation_kernel, dim3((unsigned)m3d_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, ptr,
+                     ptr_out, num_clouds, seed, level, idx_out, m);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

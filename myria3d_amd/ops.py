@@ -1,0 +1,410 @@
+"""Thin Python wrappers (and autograd glue) over the C ABI of ``libm3d_hip.so``.
+
+Every function here launches hand-written HIP kernels on the current torch stream; torch is used only to own
+device memory, to provide the stream and for autograd bookkeeping.  Reference call sites are cited per op
+(paths relative to ``/root/reference``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ._lib import call, lib
+
+LRELU_SLOPE = 0.2  # myria3d/models/modules/pyg_randla_net.py:92
+BN_MOMENTUM = 0.01  # pyg_randla_net.py:94
+BN_EPS = 1e-6  # pyg_randla_net.py:94
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: Tensor, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+# --------------------------------------------------------------------------------------------------
+# kNN  (torch_cluster.knn via knn_graph / knn_interpolate: pyg_randla_net.py:180,250; model.py:90)
+# --------------------------------------------------------------------------------------------------
+class KnnIndex:
+    """Per-cloud search grid over a set of source points (device workspace owned by a torch tensor)."""
+
+    def __init__(self, pos: Tensor, ptr: Tensor):
+        assert pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 2 and pos.stride(1) == 1
+        assert ptr.is_cuda and ptr.dtype == torch.int64 and ptr.is_contiguous()
+        self.n = pos.shape[0]
+        self.num_clouds = ptr.numel() - 1
+        self.ptr = ptr
+        nbytes = lib().m3d_knn_workspace_bytes(self.n, self.num_clouds)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
+        call("m3d_knn_build", _p(pos), pos.stride(0), _p(ptr), self.num_clouds, self.n, _p(self.ws), _st())
+
+    def query(self, k: int, qry: Optional["KnnIndex"] = None, pos_qry: Optional[Tensor] = None,
+              ptr_qry: Optional[Tensor] = None, want_d2: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+        """``qry`` (another built index, possibly ``self``) gives wave-coherent cell-sorted queries;
+        otherwise ``pos_qry``/``ptr_qry`` rows are queried in order.  Returns int32 ``[nq, k]`` (+ fp32 d2)."""
+        if qry is not None:
+            nq, ptr_q, qws, pq, qs = qry.n, qry.ptr, qry.ws, None, 0
+            assert qry.num_clouds == self.num_clouds
+        else:
+            assert pos_qry is not None and ptr_qry is not None and pos_qry.stride(1) == 1
+            nq, ptr_q, qws, pq, qs = pos_qry.shape[0], ptr_qry, None, pos_qry, pos_qry.stride(0)
+        idx = torch.empty((nq, k), dtype=torch.int32, device=self.ws.device)
+        d2 = torch.empty((nq, k), dtype=torch.float32, device=self.ws.device) if want_d2 else None
+        call("m3d_knn_query", _p(self.ws), _p(self.ptr), self.num_clouds, _p(pq), qs, _p(qws), _p(ptr_q), nq, k,
+             _p(idx), _p(d2), _st())
+        return idx, d2
+
+
+# --------------------------------------------------------------------------------------------------
+# GEMM / BatchNorm primitives
+# --------------------------------------------------------------------------------------------------
+def gemm(a0: Tensor, b: Tensor, M: int, N: int, k0: int, *, lda0: Optional[int] = None, a_cm: bool = False,
+         rows: Optional[Tensor] = None, a1: Optional[Tensor] = None, k1: int = 0, lda1: Optional[int] = None,
+         b_cm: bool = False, ldb: Optional[int] = None, bias: Optional[Tensor] = None,
+         scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, act: bool = False,
+         stats: Optional[Tensor] = None, out: Optional[Tensor] = None, ldc: Optional[int] = None,
+         accumulate: bool = False, splitk: int = 1) -> Tensor:
+    """C[M,N] (+)= [A0[rows] | A1] B^T, see ``m3d_gemm_f32`` in include/m3d_hip.h."""
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a0.device)
+    lda0 = lda0 if lda0 is not None else (a0.stride(0) if not a_cm else a0.stride(0))
+    lda1 = lda1 if lda1 is not None else (a1.stride(0) if a1 is not None else 0)
+    ldb = ldb if ldb is not None else b.stride(0)
+    ldc = ldc if ldc is not None else out.stride(0)
+    s_sum = s_sq = None
+    if stats is not None:
+        s_sum, s_sq = stats[0].data_ptr(), stats[1].data_ptr()
+    call("m3d_gemm_f32", _p(a0), lda0, int(a_cm), _p(rows), k0, _p(a1), lda1, k1, _p(b), ldb, int(b_cm), M, N,
+         _p(bias), _p(scale), _p(shift), int(act), LRELU_SLOPE, s_sum, s_sq, _p(out), ldc, int(accumulate), splitk,
+         _st())
+    return out
+
+
+def _splitk_for(red: int, m: int, n: int) -> int:
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    return max(1, min(1024 // max(tiles, 1), red // 256))
+
+
+def linear_dgrad(dz: Tensor, w: Tensor) -> Tensor:
+    """dX[M,K] = dZ[M,N] W[N,K]   (W stored [out,in] like torch.nn.Linear)."""
+    M, N = dz.shape
+    K = w.shape[1]
+    return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0))
+
+
+def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None, x1: Optional[Tensor] = None,
+                 k1: int = 0) -> Tensor:
+    """dW[N, k0+k1] = dZ^T [X0[rows] | X1]; the reduction over the M rows is split across workgroups."""
+    M, N = dz.shape
+    dw = torch.zeros((N, k0 + k1), dtype=torch.float32, device=dz.device)
+    if M == 0:
+        return dw
+    if rows is not None:
+        x0 = gather_rows(x0, rows)
+    for xs, off, kk in ((x0, 0, k0), (x1, k0, k1)):
+        if kk == 0:
+            continue
+        # C[N, kk] += A[N, M] B[kk, M]^T with A = dZ^T, B = Xs^T, both "column-major" views of row-major data
+        gemm(dz, xs, N, kk, M, lda0=dz.stride(0), a_cm=True, b_cm=True, ldb=xs.stride(0), out=dw[:, off:],
+             ldc=dw.stride(0), accumulate=True, splitk=_splitk_for(M, N, kk))
+    return dw
+
+
+def colsum(x: Tensor) -> Tensor:
+    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    call("m3d_colsum_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _st())
+    return out
+
+
+def gather_rows(src: Tensor, idx: Optional[Tensor]) -> Tensor:
+    """``src[idx]`` for a row-major fp32 matrix (decimate(): pyg_randla_net.py:234-238)."""
+    m = idx.numel() if idx is not None else src.shape[0]
+    out = torch.empty((m, src.shape[1]), dtype=torch.float32, device=src.device)
+    call("m3d_gather_rows", _p(src), src.stride(0), _p(idx), _p(out), m, src.shape[1], _st())
+    return out
+
+
+def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int) -> Tensor:
+    out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
+    call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], _st())
+    return out
+
+
+def pad_pos(pos: Tensor) -> Tensor:
+    out = torch.empty((pos.shape[0], 4), dtype=torch.float32, device=pos.device)
+    call("m3d_pad_pos", _p(pos), pos.stride(0), _p(out), pos.shape[0], _st())
+    return out
+
+
+def decimation_indices(ptr: Tensor, ptr_out: Tensor, m: int, seed: Tensor, level: int) -> Tensor:
+    """decimation_indices() (pyg_randla_net.py:192-231) in one launch; ``seed``: device int64[1]."""
+    idx = torch.empty(m, dtype=torch.int32, device=ptr.device)
+    call("m3d_decimation_indices", _p(ptr), _p(ptr_out), ptr.numel() - 1, _p(seed), level, _p(idx), m, _st())
+    return idx
+
+
+def bn_fold_eval(bn: torch.nn.BatchNorm1d) -> Tuple[Tensor, Tensor]:
+    n = bn.num_features
+    scale = torch.empty(n, dtype=torch.float32, device=bn.weight.device)
+    shift = torch.empty_like(scale)
+    call("m3d_bn_fold_eval", _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var), float(bn.eps),
+         _p(scale), _p(shift), n, _st())
+    return scale, shift
+
+
+def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
+    """mean/invstd/(scale, shift) from the fp64 column sums; updates the running statistics in place."""
+    if count < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [{count}, {bn.num_features}]")
+    n = bn.num_features
+    dev = stats.device
+    scale, shift, mean, invstd = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+    call("m3d_bn_finalize", stats[0].data_ptr(), stats[1].data_ptr(), count, _p(bn.weight), _p(bn.bias),
+         float(bn.eps), float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean),
+         _p(invstd), n, _st())
+    bn.num_batches_tracked += 1
+    return scale, shift, mean, invstd
+
+
+def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Tensor] = None,
+             scale2: Optional[Tensor] = None, shift2: Optional[Tensor] = None) -> Tensor:
+    y = torch.empty_like(z)
+    call("m3d_bn_apply", _p(_chk(z)), _p(scale), _p(shift), _p(z2), _p(scale2), _p(shift2), int(act), LRELU_SLOPE,
+         _p(y), z.shape[0], z.shape[1], _st())
+    return y
+
+
+def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=None, mean2=None, invstd2=None):
+    M, N = z.shape
+    dev = z.device
+    sums = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    dz = torch.empty_like(z)
+    dgamma, dbeta = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    dz2 = dgamma2 = dbeta2 = None
+    if z2 is not None:
+        dz2 = torch.empty_like(z2)
+        dgamma2, dbeta2 = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    call("m3d_bn_bwd", _p(_chk(dy)), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), _p(z2), _p(scale2),
+         _p(shift2), _p(mean2), _p(invstd2), int(act), LRELU_SLOPE, M, N, _p(sums), _p(dz), _p(dz2), _p(dgamma),
+         _p(dbeta), _p(dgamma2), _p(dbeta2), _st())
+    return dz, dgamma, dbeta, dz2, dgamma2, dbeta2
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd: Linear (fc0, fc_classif: pyg_randla_net.py:42,53)
+# --------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dy, x, x.shape[1])
+        return dx, dw, colsum(dy)
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd: one SharedMLP layer in train mode = Linear -> BatchNorm(batch stats) -> [LeakyReLU]
+# (pyg_randla_net.py:97-109).  The input may be cat([x0[rows], x1]) (FPModule, pyg_randla_net.py:249-252).
+# --------------------------------------------------------------------------------------------------
+class SharedLayerTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows):
+        M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
+        N = w.shape[0]
+        k0 = x0.shape[1]
+        k1 = x1.shape[1] if x1 is not None else 0
+        stats = torch.zeros((2, N), dtype=torch.float64, device=w.device)
+        z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats)
+        scale, shift, mean, invstd = bn_finalize(stats, M, bn)
+        y = bn_apply(z, scale, shift, act)
+        ctx.save_for_backward(x0, x1, w, z, scale, shift, mean, invstd, rows)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, w, z, scale, shift, mean, invstd, rows = ctx.saved_tensors
+        dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act)
+        k0 = x0.shape[1]
+        k1 = x1.shape[1] if x1 is not None else 0
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            dxc = linear_dgrad(dz, w)
+            if ctx.needs_input_grad[0]:
+                dx0 = dxc[:, :k0]
+                if rows is not None:
+                    dx0 = scatter_add_rows(dx0.contiguous(), rows, x0.shape[0])
+                elif k1:
+                    dx0 = dx0.contiguous()
+            if x1 is not None and ctx.needs_input_grad[1]:
+                dx1 = dxc[:, k0:].contiguous()
+        dw = linear_wgrad(dz, x0, k0, rows, x1, k1)
+        db = torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None
+
+
+# LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
+class ResidualTailTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns):
+        M, N = x2.shape[0], w2.shape[0]
+        st2 = torch.zeros((2, N), dtype=torch.float64, device=w2.device)
+        sts = torch.zeros((2, N), dtype=torch.float64, device=w2.device)
+        z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2)
+        zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts)
+        sc2, sh2, mu2, is2 = bn_finalize(st2, M, bn2)
+        scs, shs, mus, iss = bn_finalize(sts, M, bns)
+        y = bn_apply(z2, sc2, sh2, True, zs, scs, shs)
+        ctx.save_for_backward(x2, w2, z2, sc2, sh2, mu2, is2, xs, ws, zs, scs, shs, mus, iss)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2, z2, sc2, sh2, mu2, is2, xs, ws, zs, scs, shs, mus, iss = ctx.saved_tensors
+        dz2, dg2, db2, dzs, dgs, dbs = bn_bwd(dy.contiguous(), z2, sc2, sh2, mu2, is2, True, zs, scs, shs, mus, iss)
+        dx2 = linear_dgrad(dz2, w2)
+        dxs = linear_dgrad(dzs, ws)
+        dw2 = linear_wgrad(dz2, x2, x2.shape[1])
+        dws = linear_wgrad(dzs, xs, xs.shape[1])
+        return (dx2, dw2, torch.zeros_like(db2), dg2, db2, None, dxs, dws, torch.zeros_like(dbs), dgs, dbs, None)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return gather_rows(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return scatter_add_rows(dy.contiguous(), idx, ctx.n), None
+
+
+# --------------------------------------------------------------------------------------------------
+# Local spatial encoding + attentive pooling (pyg_randla_net.py:112-152)
+# --------------------------------------------------------------------------------------------------
+def pack_attention_weight(w: Tensor) -> Tensor:
+    """[CH,CH] row-major -> MFMA B-fragment order expected by ``m3d_lfa_fwd`` (layout: include/m3d_hip.h)."""
+    ch = w.shape[0]
+    chp = max(ch, 16)
+    if chp != ch:
+        wpad = torch.zeros((chp, chp), dtype=w.dtype, device=w.device)
+        wpad[:ch, :ch] = w
+        w = wpad
+    nt = chp // 16
+    # W[16*nt + r][4*(4*s4 + i) + g]  ->  [nt][s4][g][r][i]   (lane = 16*g + r)
+    return w.reshape(nt, 16, nt, 4, 4).permute(0, 2, 4, 1, 3).contiguous()
+
+
+def lfa_moments(pos4: Tensor, idx: Tensor) -> Tensor:
+    mom = torch.empty(65, dtype=torch.float64, device=pos4.device)
+    call("m3d_lfa_moments", _p(pos4), _p(idx), idx.shape[0], idx.shape[1], _p(mom), _st())
+    return mom
+
+
+def lfa_enc_fold(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int):
+    """Fold mlp_encoder's BatchNorm into its Linear (train: batch moments + running-stat update; eval: running)."""
+    D = enc_lin.weight.shape[0]
+    dev = enc_lin.weight.device
+    wf = torch.empty((D, 10), dtype=torch.float32, device=dev)
+    bf, mean, invstd = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
+    if mom is not None and num_edges < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [{num_edges}, {D}]")
+    call("m3d_lfa_enc_finalize", _p(mom), num_edges, _p(enc_lin.weight), _p(enc_lin.bias), _p(enc_bn.weight),
+         _p(enc_bn.bias), float(enc_bn.eps), float(enc_bn.momentum), _p(enc_bn.running_mean),
+         _p(enc_bn.running_var), _p(wf), _p(bf), _p(mean), _p(invstd), D, _st())
+    if mom is not None:
+        enc_bn.num_batches_tracked += 1
+    return wf, bf, mean, invstd
+
+
+def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor) -> Tensor:
+    n, K = idx.shape
+    ch = w_att.shape[0]
+    out = torch.empty((n, ch), dtype=torch.float32, device=x.device)
+    call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(pack_attention_weight(w_att)),
+         LRELU_SLOPE, _p(out), _st())
+    return out
+
+
+def lfa_forward_unfused(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor) -> Tensor:
+    """Same result through the materialising kernels (cross-check of the fused kernel; any K)."""
+    n, K = idx.shape
+    ch = w_att.shape[0]
+    F = torch.empty((n * K, ch), dtype=torch.float32, device=x.device)
+    call("m3d_lfa_edge_features", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(F), _st())
+    A = gemm(F, w_att, n * K, ch, ch)
+    out = torch.empty((n, ch), dtype=torch.float32, device=x.device)
+    call("m3d_lfa_edge_softmax_fwd", _p(A), _p(F), _p(idx), n, K, ch, _p(out), _st())
+    return out
+
+
+class LFATrainFn(torch.autograd.Function):
+    """aggregate() of LocalFeatureAggregation in train mode (encoder BatchNorm on batch statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att):
+        x = x.contiguous()
+        wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
+        out = lfa_forward(x, pos4, idx, wf, bf, w_att)
+        ctx.save_for_backward(x, pos4, idx, mom, wf, bf, mean, invstd, enc_w, enc_b, enc_gamma, w_att)
+        ctx.num_edges = num_edges
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, pos4, idx, mom, wf, bf, mean, invstd, enc_w, enc_b, enc_gamma, w_att = ctx.saved_tensors
+        n, K = idx.shape
+        ch = w_att.shape[0]
+        D = ch // 2
+        dev = x.device
+        E = n * K
+        F = torch.empty((E, ch), dtype=torch.float32, device=dev)
+        call("m3d_lfa_edge_features", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(F), _st())
+        A = gemm(F, w_att, E, ch, ch)
+        dF = torch.empty((E, ch), dtype=torch.float32, device=dev)
+        call("m3d_lfa_edge_softmax_bwd", _p(A), _p(F), _p(idx), n, K, ch, _p(dout.contiguous()), _p(dF), _st())
+        dA = A
+        # dW_att[c,k] = sum_e dA[e,c] F[e,k]
+        dw_att = torch.zeros((ch, ch), dtype=torch.float32, device=dev)
+        gemm(dA, F, ch, ch, E, lda0=ch, a_cm=True, b_cm=True, ldb=ch, out=dw_att, accumulate=True,
+             splitk=_splitk_for(E, ch, ch))
+        # dF += dA W_att
+        gemm(dA, w_att, E, ch, ch, b_cm=True, ldb=w_att.stride(0), out=dF, accumulate=True)
+        dx = torch.zeros((n, D), dtype=torch.float32, device=dev)
+        G = torch.empty(11 * D, dtype=torch.float64, device=dev)
+        call("m3d_lfa_edge_features_bwd", _p(dF), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(dx),
+             _p(G), _st())
+        dw = torch.empty((D, 10), dtype=torch.float32, device=dev)
+        db, dgamma, dbeta = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
+        call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
+             _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, _st())
+        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att
+
+
+# --------------------------------------------------------------------------------------------------
+# knn_interpolate (model.py:90-98, pyg_randla_net.py:250)
+# --------------------------------------------------------------------------------------------------
+def idw_interpolate(x: Tensor, idx: Tensor, d2: Tensor) -> Tensor:
+    nq, k = idx.shape
+    y = torch.empty((nq, x.shape[1]), dtype=torch.float32, device=x.device)
+    call("m3d_idw_interpolate_fwd", _p(_chk(x)), x.stride(0), _p(idx), _p(d2), nq, k, x.shape[1], _p(y), _st())
+    return y

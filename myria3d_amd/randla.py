@@ -1,0 +1,275 @@
+"""``HipRandLANet`` — MI355X-native drop-in for ``myria3d.models.modules.pyg_randla_net.PyGRandLANet``.
+
+Same constructor keywords, same ``forward(x, pos, batch, ptr)``, same ``state_dict`` keys/shapes as the reference
+(``/root/reference/myria3d/models/modules/pyg_randla_net.py:22-88``; key names per PyG's ``MLP``/``BatchNorm``
+wrappers), so ``Model.load_from_checkpoint`` and the Hydra config surface keep working.  All
+per-point arithmetic runs in the hand-written HIP kernels of ``libm3d_hip.so``; the ``torch.nn`` modules below
+only *hold* parameters and buffers.
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers mirroring PyG's module tree (keys: lins.i.{weight,bias}, norms.i.module.*)
+# ----------------------------------------------------------------------------------------------
+class _BatchNormHolder(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.module = nn.BatchNorm1d(channels, eps=ops.BN_EPS, momentum=ops.BN_MOMENTUM)
+
+
+class SharedMLPParams(nn.Module):
+    """Parameters of ``SharedMLP(channels, ...)`` (pyg_randla_net.py:97-109)."""
+
+    def __init__(self, channels: Sequence[int], act: bool = True, norm: bool = True, bias: bool = True,
+                 dropout: Optional[Sequence[float]] = None):
+        super().__init__()
+        nl = len(channels) - 1
+        self.act, self.has_norm = act, norm
+        self.dropout = list(dropout) if dropout is not None else [0.0] * nl
+        self.lins = nn.ModuleList([nn.Linear(channels[i], channels[i + 1], bias=bias) for i in range(nl)])
+        self.norms = nn.ModuleList([_BatchNormHolder(channels[i + 1]) if norm else nn.Identity() for i in range(nl)])
+
+
+class LFAParams(nn.Module):
+    def __init__(self, channels: int):
+        super().__init__()
+        self.mlp_encoder = SharedMLPParams([10, channels // 2])
+        self.mlp_attention = SharedMLPParams([channels, channels], act=False, norm=False, bias=False)
+        self.mlp_post_attention = SharedMLPParams([channels, channels])
+
+
+class BlockParams(nn.Module):
+    def __init__(self, d_in: int, d_out: int):
+        super().__init__()
+        self.mlp1 = SharedMLPParams([d_in, d_out // 8])
+        self.shortcut = SharedMLPParams([d_in, d_out], act=False)
+        self.mlp2 = SharedMLPParams([d_out // 2, d_out], act=False)
+        self.lfa1 = LFAParams(d_out // 4)
+        self.lfa2 = LFAParams(d_out // 2)
+
+
+class FPParams(nn.Module):
+    def __init__(self, mlp: SharedMLPParams):
+        super().__init__()
+        self.nn = mlp
+
+
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class LevelPlan:
+    """Host-side description of a batch at every resolution level (sizes are known from ``ptr``)."""
+
+    sizes: List[List[int]]  # per level, per cloud
+    ptrs: List[Tensor]  # device int64 [B+1] per level
+    totals: List[int]
+    num_edges: List[int] = field(default_factory=list)  # valid kNN edges per encoder level
+
+
+def make_plan(ptr_host: Sequence[int], decimation: int, num_neighbors: int, device, levels: int = 4) -> LevelPlan:
+    sizes = [[int(ptr_host[i + 1]) - int(ptr_host[i]) for i in range(len(ptr_host) - 1)]]
+    for _ in range(levels):
+        sizes.append([max(1, n // decimation) for n in sizes[-1]])  # pyg_randla_net.py:215-217
+    ptrs, totals = [], []
+    for s in sizes:
+        p = [0]
+        for n in s:
+            p.append(p[-1] + n)
+        ptrs.append(torch.tensor(p, dtype=torch.int64, device=device))
+        totals.append(p[-1])
+    num_edges = [sum(n * min(num_neighbors, n) for n in s) for s in sizes[:levels]]
+    return LevelPlan(sizes, ptrs, totals, num_edges)
+
+
+class HipRandLANet(nn.Module):
+    """RandLA-Net for batched variable-size point clouds on one MI355X.
+
+    Args (identical to the reference, pyg_randla_net.py:23-30):
+        num_features, num_classes, decimation=4, num_neighbors=16, return_logits=False
+    """
+
+    def __init__(self, num_features: int, num_classes: int, decimation: int = 4, num_neighbors: int = 16,
+                 return_logits: bool = False):
+        super().__init__()
+        self.decimation = decimation
+        self.num_neighbors = num_neighbors
+        self.return_logits = return_logits
+        d_bottleneck = max(32, num_classes, num_features)
+        self.fc0 = nn.Linear(num_features, d_bottleneck)
+        self.block1 = BlockParams(d_bottleneck, 32)
+        self.block2 = BlockParams(32, 128)
+        self.block3 = BlockParams(128, 256)
+        self.block4 = BlockParams(256, 512)
+        self.mlp_summit = SharedMLPParams([512, 512])
+        self.fp4 = FPParams(SharedMLPParams([512 + 256, 256]))
+        self.fp3 = FPParams(SharedMLPParams([256 + 128, 128]))
+        self.fp2 = FPParams(SharedMLPParams([128 + 32, 32]))
+        self.fp1 = FPParams(SharedMLPParams([32 + 32, d_bottleneck]))
+        self.mlp_classif = SharedMLPParams([d_bottleneck, 64, 32], dropout=[0.0, 0.5])
+        self.fc_classif = nn.Linear(32, num_classes)
+        # device-side RNG state for decimation (bumped every forward; hipGraph-replay safe)
+        self.register_buffer("_decim_seed", torch.tensor([0x5DEECE66D], dtype=torch.int64), persistent=False)
+        self._plans: Dict[tuple, LevelPlan] = {}
+        self._warned_eval_grad = False
+
+    # ------------------------------------------------------------------------------------------
+    def plan_for(self, ptr: Tensor) -> LevelPlan:
+        """One device->host read of ``ptr`` per forward (the reference syncs 2*B times per level,
+        pyg_randla_net.py:219-229); cached by tile sizes."""
+        key = tuple(ptr.tolist())
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 64:
+                self._plans.clear()
+            plan = make_plan(key, self.decimation, self.num_neighbors, ptr.device)
+            self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------------------------------
+    def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
+                      rows: Optional[Tensor] = None, train: bool = False) -> Tensor:
+        lin, bn = mlp.lins[li], mlp.norms[li].module
+        if train:
+            return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
+        scale, shift = ops.bn_fold_eval(bn)
+        M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
+        return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
+                        k1=0 if x1 is None else x1.shape[1], bias=lin.bias, scale=scale, shift=shift, act=mlp.act)
+
+    def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
+             train: bool) -> Tensor:
+        enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
+        w_att = p.mlp_attention.lins[0].weight
+        if train:
+            agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
+                                       enc_bn.bias, enc_lin, enc_bn, w_att)
+        else:
+            wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
+            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att)
+        return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
+
+    def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, num_edges: int, train: bool,
+               rec: Optional[dict], name: str) -> Tensor:
+        idx, _ = index.query(self.num_neighbors, qry=index)  # knn_graph(loop=True), pyg_randla_net.py:180
+        mom = ops.lfa_moments(pos4, idx) if train else None
+        h = self._shared_layer(blk.mlp1, 0, x, train=train)
+        if rec is not None:
+            rec[name + ".knn_idx"], rec[name + ".mlp1"] = idx, h
+        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train)
+        if rec is not None:
+            rec[name + ".lfa1"] = h
+        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train)
+        l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
+        ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
+        if train:
+            out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
+                                                ns.weight, ns.bias, ns)
+        else:
+            sc2, sh2 = ops.bn_fold_eval(n2)
+            scs, shs = ops.bn_fold_eval(ns)
+            z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias)
+            zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias)
+            out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
+        if rec is not None:
+            rec[name + ".out"] = out
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x: Optional[Tensor], pos: Tensor, batch: Optional[Tensor], ptr: Tensor,
+                decimation_idx: Optional[List[Tensor]] = None, dropout_mask: Optional[Tensor] = None,
+                plan: Optional[LevelPlan] = None, record: Optional[dict] = None) -> Tensor:
+        """``forward(x, pos, batch, ptr) -> [sum N, num_classes]`` (pyg_randla_net.py:55-88).
+
+        ``batch`` is accepted for signature parity and unused (``ptr`` carries the same information).
+        Testing/benchmark extras: injected ``decimation_idx`` (one index tensor per level), injected dropout
+        keep-``dropout_mask``, a pre-computed ``plan`` (skips the ptr read-back; needed under hipGraph capture),
+        ``record`` of intermediates."""
+        if self.decimation < 1:
+            raise ValueError(
+                "Argument `decimation_factor` should be higher than (or equal to) 1 for downsampling. "
+                f"(Current value: {self.decimation})"
+            )
+        if not pos.is_cuda:
+            raise RuntimeError("HipRandLANet runs on an MI355X (cuda/HIP device) only; there is no CPU fallback")
+        x = x if x is not None else pos
+        x = x.to(torch.float32).contiguous()
+        pos = pos.to(torch.float32).contiguous()
+        train = self.training
+        if not train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if not self._warned_eval_grad:
+                warnings.warn("HipRandLANet: eval-mode forward is inference-only (no autograd graph is recorded)")
+                self._warned_eval_grad = True
+        ctx = torch.enable_grad() if (train and torch.is_grad_enabled()) else torch.no_grad()
+        with ctx:
+            return self._forward(x, pos, ptr.to(torch.int64).contiguous(), decimation_idx, dropout_mask, plan,
+                                 record, train)
+
+    def _forward(self, x, pos, ptr, decimation_idx, dropout_mask, plan, record, train):
+        if plan is None:
+            plan = self.plan_for(ptr)
+        blocks = (self.block1, self.block2, self.block3, self.block4)
+        pos4 = [ops.pad_pos(pos)]
+        index: List[ops.KnnIndex] = []
+        feats: List[Tensor] = []
+        dec_idx: List[Tensor] = []
+        if decimation_idx is None:
+            self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
+        h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias) if train else \
+            ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
+        for lvl, blk in enumerate(blocks):
+            index.append(ops.KnnIndex(pos4[lvl], plan.ptrs[lvl]))
+            h = self._block(blk, h, pos4[lvl], index[lvl], plan.num_edges[lvl], train, record, f"block{lvl + 1}")
+            feats.append(h)
+            if decimation_idx is not None:
+                idx = decimation_idx[lvl].to(device=h.device, dtype=torch.int32).contiguous()
+                assert idx.numel() == plan.totals[lvl + 1]
+            else:
+                idx = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
+                                             self._decim_seed, lvl)
+            dec_idx.append(idx)
+            h = ops.GatherRowsFn.apply(h, idx) if train else ops.gather_rows(h, idx)  # decimate(): :234-238
+            pos4.append(ops.gather_rows(pos4[lvl], idx))
+        self.last_decimation_idx = dec_idx
+        h = self._shared_layer(self.mlp_summit, 0, h, train=train)
+        if record is not None:
+            record["summit"] = h
+        # decoder: FPModule(k=1) x4 (pyg_randla_net.py:76-79, 241-253)
+        coarse_index = ops.KnnIndex(pos4[4], plan.ptrs[4])
+        for fp, lvl in ((self.fp4, 3), (self.fp3, 2), (self.fp2, 1), (self.fp1, 0)):
+            src_index = coarse_index if lvl == 3 else index[lvl + 1]
+            nn_idx, _ = src_index.query(1, qry=index[lvl])  # 1-NN of every level-`lvl` point among level lvl+1
+            if lvl == 0:
+                skip = feats[0]
+            else:  # skip = decimated output of the previous block
+                skip = ops.GatherRowsFn.apply(feats[lvl - 1], dec_idx[lvl - 1]) if train else \
+                    ops.gather_rows(feats[lvl - 1], dec_idx[lvl - 1])
+            # knn_interpolate(k=1) == x[nn] (weights cancel); fused as a row gather into the GEMM's A operand
+            h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train)
+            if record is not None:
+                record[f"fp{lvl + 1}"] = h
+        h = self._shared_layer(self.mlp_classif, 0, h, train=train)
+        h = self._shared_layer(self.mlp_classif, 1, h, train=train)
+        p = self.mlp_classif.dropout[1]
+        if train and p > 0.0:
+            if dropout_mask is not None:
+                h = h * (dropout_mask.to(h.dtype) / (1.0 - p))
+            else:
+                h = F.dropout(h, p=p, training=True)
+        if train:
+            logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias)
+        else:
+            logits = ops.gemm(h, self.fc_classif.weight, h.shape[0], self.fc_classif.weight.shape[0], h.shape[1],
+                              bias=self.fc_classif.bias)
+        if self.return_logits:
+            return logits
+        return logits.log_softmax(dim=-1)

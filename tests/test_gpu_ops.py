@@ -1,0 +1,339 @@
+"""GPU parity tests, op by op: every HIP kernel reached through the C ABI vs the CPU oracle / plain torch fp32-fp64.
+
+Tolerances are written next to each check.  Integer/index work (kNN, gathers, decimation) is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import fill_params_deterministic, rand_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(name, got, ref, rtol, atol):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    worst = (err - tol).max().item() if err.numel() else 0.0
+    print(f"[parity] {name}: max_abs_err={err.max().item() if err.numel() else 0:.3e} ref_max={ref.abs().max().item() if ref.numel() else 0:.3e}")
+    assert worst <= 0, f"{name}: max abs err {err.max().item():.3e} exceeds tol (rtol={rtol}, atol={atol})"
+
+
+# ----------------------------------------------------------------------------------------------- kNN
+def _knn_case(device, pos, ptr, k):
+    from myria3d_amd import ops
+    from oracle.randla_oracle import knn_exact
+
+    ref_idx, ref_d2 = knn_exact(pos, ptr.tolist(), pos, ptr.tolist(), k)
+    index = ops.KnnIndex(pos.to(device), ptr.to(device))
+    idx, d2 = index.query(k, qry=index, want_d2=True)
+    assert torch.equal(idx.cpu().long(), ref_idx), "self-kNN indices differ from the oracle"
+    assert torch.equal(d2.cpu(), ref_d2), "self-kNN squared distances are not bit-identical"
+    # row-order queries (qmode 0) must give the same table
+    idx2, _ = index.query(k, pos_qry=pos.to(device), ptr_qry=ptr.to(device))
+    assert torch.equal(idx2.cpu().long(), ref_idx)
+
+
+@pytest.mark.parametrize("sizes", [[300, 211], [50, 50], [3000], [1, 2, 17, 5], [1]])
+@pytest.mark.parametrize("k", [16, 1, 10])
+def test_knn_self_bit_exact(device, sizes, k):
+    _, pos, _, ptr = rand_batch(sizes, seed=len(sizes) + k)
+    _knn_case(device, pos, ptr, k)
+
+
+def test_knn_lidar_tile_and_duplicates(device):
+    from oracle.randla_oracle import synthetic_batch
+
+    _, pos, _, ptr, _ = synthetic_batch([2500, 1800])
+    _knn_case(device, pos, ptr, 16)
+    # duplicated points (MinimumNumNodes duplicates points: myria3d/pctl/transforms/transforms.py:74-77)
+    pos_dup = torch.cat([pos[:40].repeat(8, 1), pos[:200]])
+    _knn_case(device, pos_dup, torch.tensor([0, pos_dup.shape[0]]), 16)
+    # degenerate: all points identical / collinear in z
+    same = torch.zeros(100, 3) + 0.25
+    _knn_case(device, same, torch.tensor([0, 100]), 16)
+    line = torch.zeros(300, 3)
+    line[:, 2] = torch.linspace(0, 1, 300)
+    _knn_case(device, line, torch.tensor([0, 300]), 16)
+
+
+def test_knn_k32_and_cross_set(device):
+    from myria3d_amd import ops
+    from oracle.randla_oracle import knn_exact
+
+    _, pos, _, ptr = rand_batch([700, 450], seed=3)
+    _knn_case(device, pos, ptr, 32)
+    # 1-NN / 3-NN of every point among a random subset (decoder upsampling pattern)
+    sub = torch.cat([torch.randperm(700)[:175], 700 + torch.randperm(450)[:112]])
+    ptr_s = torch.tensor([0, 175, 287])
+    src = pos[sub].contiguous()
+    for k in (1, 3):
+        ref_idx, ref_d2 = knn_exact(src, ptr_s.tolist(), pos, ptr.tolist(), k)
+        si = ops.KnnIndex(src.to(device), ptr_s.to(device))
+        qi = ops.KnnIndex(pos.to(device), ptr.to(device))
+        idx, d2 = si.query(k, qry=qi, want_d2=True)
+        assert torch.equal(idx.cpu().long(), ref_idx)
+        assert torch.equal(d2.cpu(), ref_d2)
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,K,N", [(1000, 9, 32), (777, 32, 4), (513, 64, 128), (300, 768, 256), (100, 32, 6),
+                                   (65, 10, 8), (2, 512, 512)])
+def test_gemm_forward(device, M, K, N):
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M + K + N)
+    a = torch.from_numpy(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+    b = torch.from_numpy(rs.uniform(-1, 1, (N,)).astype(np.float32))
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, (N,)).astype(np.float32))
+    sh = torch.from_numpy(rs.uniform(-1, 1, (N,)).astype(np.float32))
+    ref = a.double() @ w.double().t() + b.double()
+    stats = torch.zeros((2, N), dtype=torch.float64, device=device)
+    got = ops.gemm(a.to(device), w.to(device), M, N, K, bias=b.to(device), stats=stats)
+    # fp32 MFMA == fmaf chain; error bound ~ K * eps * sum|a||w|
+    _close("gemm", got, ref, 1e-5, 2e-6 * K)
+    _close("gemm.stat_sum", stats[0], ref.sum(0), 1e-6, 1e-4)
+    _close("gemm.stat_sumsq", stats[1], (ref * ref).sum(0), 1e-6, 1e-3)
+    got2 = ops.gemm(a.to(device), w.to(device), M, N, K, bias=b.to(device), scale=sc.to(device), shift=sh.to(device),
+                    act=True)
+    ref2 = torch.nn.functional.leaky_relu(ref * sc.double() + sh.double(), 0.2)
+    _close("gemm.affine_lrelu", got2, ref2, 1e-5, 4e-6 * K)
+
+
+def test_gemm_gather_concat_and_transposes(device):
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(7)
+    n_c, M, k0, k1, N = 90, 333, 128, 32, 32
+    xc = torch.from_numpy(rs.uniform(-1, 1, (n_c, k0)).astype(np.float32))
+    xs = torch.from_numpy(rs.uniform(-1, 1, (M, k1)).astype(np.float32))
+    rows = torch.from_numpy(rs.randint(0, n_c, (M,)).astype(np.int32))
+    w = torch.from_numpy(rs.uniform(-1, 1, (N, k0 + k1)).astype(np.float32))
+    ref = torch.cat([xc[rows.long()], xs], 1).double() @ w.double().t()
+    got = ops.gemm(xc.to(device), w.to(device), M, N, k0, rows=rows.to(device), a1=xs.to(device), k1=k1)
+    _close("gemm.gather_concat", got, ref, 1e-5, 4e-4)
+    # dgrad: dX = dZ W
+    dz = torch.from_numpy(rs.uniform(-1, 1, (M, N)).astype(np.float32))
+    _close("gemm.dgrad", ops.linear_dgrad(dz.to(device), w.to(device)), dz.double() @ w.double(), 1e-5, 1e-4)
+    # wgrad: dW = dZ^T [X0[rows] | X1]   (split-K + atomics)
+    dw = ops.linear_wgrad(dz.to(device), xc.to(device), k0, rows.to(device), xs.to(device), k1)
+    _close("gemm.wgrad", dw, dz.double().t() @ torch.cat([xc[rows.long()], xs], 1).double(), 1e-5, 2e-3)
+    big = torch.from_numpy(rs.uniform(-1, 1, (20000, 16)).astype(np.float32))
+    dzb = torch.from_numpy(rs.uniform(-1, 1, (20000, 8)).astype(np.float32))
+    _close("gemm.wgrad_long", ops.linear_wgrad(dzb.to(device), big.to(device), 16), dzb.double().t() @ big.double(),
+           1e-5, 5e-3)
+    _close("colsum", ops.colsum(dzb.to(device)), dzb.double().sum(0), 1e-5, 5e-3)
+
+
+# ----------------------------------------------------------------------------------------------- SharedMLP layer (train)
+def _cpu_layer(x, w, b, gamma, beta, act):
+    lin = torch.nn.Linear(w.shape[1], w.shape[0])
+    bn = torch.nn.BatchNorm1d(w.shape[0], eps=1e-6, momentum=0.01)
+    with torch.no_grad():
+        lin.weight.copy_(w), lin.bias.copy_(b), bn.weight.copy_(gamma), bn.bias.copy_(beta)
+    lin, bn = lin.double(), bn.double()
+    y = bn(lin(x))
+    return (torch.nn.functional.leaky_relu(y, 0.2) if act else y), lin, bn
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1000, 32, 32, True), (517, 64, 128, False), (3, 512, 512, True)])
+def test_shared_layer_train_fwd_bwd(device, M, K, N, act):
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M)
+    x = torch.from_numpy(rs.uniform(-1, 1, (M, K))).double().requires_grad_(True)
+    w = torch.from_numpy(rs.uniform(-1, 1, (N, K)) / np.sqrt(K)).float()
+    b = torch.from_numpy(rs.uniform(-1, 1, (N,))).float()
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, (N,))).float()
+    beta = torch.from_numpy(rs.uniform(-0.5, 0.5, (N,))).float()
+    gy = torch.from_numpy(rs.uniform(-1, 1, (M, N))).double()
+    y_ref, lin, bn_ref = _cpu_layer(x, w, b, gamma, beta, act)
+    y_ref.backward(gy)
+
+    bn = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+    xg = x.detach().float().to(device).requires_grad_(True)
+    wg, bg = w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    with torch.no_grad():
+        bn.weight.copy_(gamma), bn.bias.copy_(beta)
+    y = ops.SharedLayerTrainFn.apply(xg, None, wg, bg, bn.weight, bn.bias, bn, act, None)
+    y.backward(gy.float().to(device))
+    s = 1.0 if M > 10 else 30.0  # tiny batches: 1/std amplification
+    _close("layer.y", y, y_ref, 1e-4 * s, 1e-5 * s)
+    _close("layer.running_mean", bn.running_mean, bn_ref.running_mean, 1e-5, 1e-6)
+    _close("layer.running_var", bn.running_var, bn_ref.running_var, 1e-5, 1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    _close("layer.dx", xg.grad, x.grad, 1e-3 * s, 1e-5 * s)
+    _close("layer.dW", wg.grad, lin.weight.grad, 1e-3 * s, 1e-4 * s)
+    _close("layer.dgamma", bn.weight.grad, bn_ref.weight.grad, 1e-3 * s, 1e-4 * s)
+    _close("layer.dbeta", bn.bias.grad, bn_ref.bias.grad, 1e-3 * s, 1e-4 * s)
+    _close("layer.dbias", bg.grad, lin.bias.grad, 0, 1e-3)  # analytically zero
+
+
+def test_residual_tail_train(device):
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(11)
+    M, K2, Ks, N = 700, 16, 32, 32
+    x2 = torch.from_numpy(rs.uniform(-1, 1, (M, K2))).double().requires_grad_(True)
+    xs = torch.from_numpy(rs.uniform(-1, 1, (M, Ks))).double().requires_grad_(True)
+    prm = [torch.from_numpy(rs.uniform(-1, 1, s)).float() for s in ((N, K2), (N,), (N,), (N,), (N, Ks), (N,), (N,), (N,))]
+    prm[2] = prm[2] * 0.5 + 1.0
+    prm[6] = prm[6] * 0.5 + 1.0
+    y2, lin2, bn2r = _cpu_layer(x2, prm[0], prm[1], prm[2], prm[3], False)
+    ys, lins, bnsr = _cpu_layer(xs, prm[4], prm[5], prm[6], prm[7], False)
+    ref = torch.nn.functional.leaky_relu(y2 + ys, 0.2)
+    gy = torch.from_numpy(rs.uniform(-1, 1, (M, N))).double()
+    ref.backward(gy)
+    bn2 = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+    bns = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+    with torch.no_grad():
+        bn2.weight.copy_(prm[2]), bn2.bias.copy_(prm[3]), bns.weight.copy_(prm[6]), bns.bias.copy_(prm[7])
+    g = lambda t: t.detach().float().to(device).requires_grad_(True)
+    x2g, xsg, w2, b2, ws_, bs_ = g(x2), g(xs), g(prm[0]), g(prm[1]), g(prm[4]), g(prm[5])
+    y = ops.ResidualTailTrainFn.apply(x2g, w2, b2, bn2.weight, bn2.bias, bn2, xsg, ws_, bs_, bns.weight, bns.bias, bns)
+    y.backward(gy.float().to(device))
+    _close("tail.y", y, ref, 1e-4, 1e-5)
+    _close("tail.dx2", x2g.grad, x2.grad, 1e-3, 1e-5)
+    _close("tail.dxs", xsg.grad, xs.grad, 1e-3, 1e-5)
+    _close("tail.dW2", w2.grad, lin2.weight.grad, 1e-3, 1e-4)
+    _close("tail.dWs", ws_.grad, lins.weight.grad, 1e-3, 1e-4)
+    _close("tail.dgamma2", bn2.weight.grad, bn2r.weight.grad, 1e-3, 1e-4)
+    _close("tail.dbetas", bns.bias.grad, bnsr.bias.grad, 1e-3, 1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- rows / decimation
+def test_gather_scatter_decimation(device):
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(5)
+    src = torch.from_numpy(rs.uniform(-1, 1, (1000, 32)).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, 1000, (4000,)).astype(np.int32))
+    got = ops.gather_rows(src.to(device), idx.to(device))
+    assert torch.equal(got.cpu(), src[idx.long()])
+    src3 = src[:, :3].contiguous()
+    assert torch.equal(ops.gather_rows(src3.to(device), idx.to(device)).cpu(), src3[idx.long()])
+    sc = ops.scatter_add_rows(got, idx.to(device), 1000)
+    ref = torch.zeros(1000, 32, dtype=torch.float64).index_add_(0, idx.long(), src[idx.long()].double())
+    _close("scatter_add", sc, ref, 1e-6, 1e-5)
+    p4 = ops.pad_pos(src3.to(device)).cpu()
+    assert torch.equal(p4[:, :3], src3) and bool((p4[:, 3] == 0).all())
+    # decimation: per cloud, m distinct in-range indices; different seeds/levels give different subsets
+    sizes = [1000, 37, 4, 1, 12800]
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    new = [max(1, n // 4) for n in sizes]
+    ptr_out = torch.tensor([0] + list(np.cumsum(new)), dtype=torch.int64)
+    seed = torch.tensor([12345], dtype=torch.int64, device=device)
+    a = ops.decimation_indices(ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), seed, 0).cpu().long()
+    b = ops.decimation_indices(ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), seed, 1).cpu().long()
+    for c in range(len(sizes)):
+        seg = a[ptr_out[c]:ptr_out[c + 1]]
+        assert seg.numel() == new[c] and seg.unique().numel() == new[c]
+        assert bool((seg >= ptr[c]).all()) and bool((seg < ptr[c + 1]).all())
+    assert not torch.equal(a, b)
+    # the keyed permutation is a bijection: asking for ALL slots returns every point exactly once
+    full = ops.decimation_indices(ptr.to(device), ptr.to(device), int(ptr[-1]), seed, 0).cpu().long()
+    assert torch.equal(full.sort().values, torch.arange(int(ptr[-1])))
+    # roughly uniform: mean of selected local ranks ~ n/2
+    seg = (a[ptr_out[4]:ptr_out[5]] - ptr[4]).double()
+    assert abs(seg.mean().item() / 12800 - 0.5) < 0.03
+
+
+# ----------------------------------------------------------------------------------------------- LFA
+def _lfa_setup(ch, sizes, k, seed):
+    from oracle.randla_oracle import LocalFeatureAggregation, dense_to_edge_index, knn_exact
+
+    x, pos, _, ptr = rand_batch(sizes, num_features=ch // 2, seed=seed)
+    x = x * 2 - 1
+    lfa = LocalFeatureAggregation(ch)
+    fill_params_deterministic(lfa, seed)
+    idx, _ = knn_exact(pos, ptr.tolist(), pos, ptr.tolist(), k)
+    return x, pos, ptr, lfa, idx, dense_to_edge_index(idx)
+
+
+@pytest.mark.parametrize("ch", [8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("k", [16, 32])
+def test_lfa_eval_forward(device, ch, k):
+    from myria3d_amd import ops
+
+    x, pos, ptr, lfa, idx, ei = _lfa_setup(ch, [150, 9, 77], k, seed=ch + k)
+    lfa.eval()
+    with torch.no_grad():
+        ref = lfa.aggregate(ei, x, pos)
+    enc_lin, enc_bn = lfa.mlp_encoder.lins[0].to(device), lfa.mlp_encoder.norms[0].module.to(device)
+    w_att = lfa.mlp_attention.lins[0].weight.to(device)
+    wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
+    pos4 = ops.pad_pos(pos.to(device))
+    idx32 = idx.to(torch.int32).to(device)
+    got = ops.lfa_forward(x.to(device), pos4, idx32, wf, bf, w_att)
+    _close(f"lfa_fwd(ch={ch},k={k})", got, ref, 2e-5, 2e-5)
+    got_u = ops.lfa_forward_unfused(x.to(device), pos4, idx32, wf, bf, w_att)
+    _close(f"lfa_unfused(ch={ch},k={k})", got_u, ref, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("ch", [8, 16, 64, 256])
+def test_lfa_train_forward_backward(device, ch):
+    from myria3d_amd import ops
+
+    k = 16
+    x, pos, ptr, lfa, idx, ei = _lfa_setup(ch, [200, 11, 90], k, seed=ch)
+    lfa = lfa.double().train()
+    xr = x.double().requires_grad_(True)
+    ref = lfa.aggregate(ei, xr, pos.double())
+    gy = torch.from_numpy(np.random.RandomState(ch).uniform(-1, 1, tuple(ref.shape)))
+    ref.backward(gy)
+    enc_lin_r, enc_bn_r = lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module
+
+    import copy
+    from oracle.randla_oracle import LocalFeatureAggregation
+    g = LocalFeatureAggregation(ch)
+    fill_params_deterministic(g, ch)
+    g = g.to(device).train()
+    enc_lin, enc_bn = g.mlp_encoder.lins[0], g.mlp_encoder.norms[0].module
+    w_att = g.mlp_attention.lins[0].weight
+    pos4 = ops.pad_pos(pos.to(device))
+    idx32 = idx.to(torch.int32).to(device)
+    sizes = (ptr[1:] - ptr[:-1]).tolist()
+    num_edges = sum(n * min(k, n) for n in sizes)
+    mom = ops.lfa_moments(pos4, idx32)
+    xg = x.to(device).requires_grad_(True)
+    out = ops.LFATrainFn.apply(xg, pos4, idx32, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
+                               enc_bn.bias, enc_lin, enc_bn, w_att)
+    out.backward(gy.float().to(device))
+    _close(f"lfa_train.out(ch={ch})", out, ref, 1e-4, 1e-4)
+    _close("lfa_train.running_mean", enc_bn.running_mean, enc_bn_r.running_mean, 1e-4, 1e-5)
+    _close("lfa_train.running_var", enc_bn.running_var, enc_bn_r.running_var, 1e-4, 1e-5)
+    sc = max(1.0, gy.abs().max().item())
+    _close("lfa_train.dx", xg.grad, xr.grad, 1e-3, 1e-4 * sc)
+    _close("lfa_train.dW_att", w_att.grad, lfa.mlp_attention.lins[0].weight.grad, 1e-3, 1e-3)
+    _close("lfa_train.dW_enc", enc_lin.weight.grad, enc_lin_r.weight.grad, 2e-3, 2e-3)
+    _close("lfa_train.dgamma_enc", enc_bn.weight.grad, enc_bn_r.weight.grad, 2e-3, 2e-3)
+    _close("lfa_train.dbeta_enc", enc_bn.bias.grad, enc_bn_r.bias.grad, 2e-3, 2e-3)
+    _close("lfa_train.db_enc", enc_lin.bias.grad, enc_lin_r.bias.grad, 0, 2e-3)
+
+
+# ----------------------------------------------------------------------------------------------- interpolation
+@pytest.mark.parametrize("k", [10, 3, 1])
+def test_knn_interpolate_dropin(device, k):
+    import myria3d_amd
+    from oracle.randla_oracle import knn_interpolate as ref_interp
+
+    rs = np.random.RandomState(k)
+    nx, ny = [400, 250], [1500, 900]
+    pos_x = torch.from_numpy(rs.uniform(0, 1, (sum(nx), 3)).astype(np.float32))
+    pos_y = torch.from_numpy(rs.uniform(0, 1, (sum(ny), 3)).astype(np.float32))
+    pos_y[:50] = pos_x[:50]  # coincident points: w = 1/1e-16 path
+    x = torch.from_numpy(rs.uniform(-3, 3, (sum(nx), 7)).astype(np.float32))
+    bx = torch.repeat_interleave(torch.arange(2), torch.tensor(nx))
+    by = torch.repeat_interleave(torch.arange(2), torch.tensor(ny))
+    ref = ref_interp(x.double(), pos_x, pos_y, [0, 400, 650], [0, 1500, 2400], k)
+    got = myria3d_amd.knn_interpolate(x.to(device), pos_x.to(device), pos_y.to(device), bx.to(device), by.to(device), k=k)
+    _close(f"knn_interpolate(k={k})", got, ref, 1e-4, 1e-5)
+    # scatter_sum drop-in (myria3d/models/interpolation.py:116)
+    index = torch.from_numpy(rs.randint(0, 300, (sum(ny),)))
+    out = myria3d_amd.scatter_sum(got, index.to(device), dim=0, out=torch.zeros(300, 7, device=device))
+    ref_s = torch.zeros(300, 7, dtype=torch.float64).index_add_(0, index, got.cpu().double())
+    _close("scatter_sum", out, ref_s, 1e-5, 1e-4)
