@@ -96,8 +96,10 @@ def test_gemm_forward(device, M, K, N):
     got = ops.gemm(a.to(device), w.to(device), M, N, K, bias=b.to(device), stats=stats)
     # fp32 MFMA == fmaf chain; error bound ~ K * eps * sum|a||w|
     _close("gemm", got, ref, 1e-5, 2e-6 * K)
-    _close("gemm.stat_sum", stats[0], ref.sum(0), 1e-6, 1e-4)
-    _close("gemm.stat_sumsq", stats[1], (ref * ref).sum(0), 1e-6, 1e-3)
+    # the statistics are those of the fp32 outputs: allow M * eps_f32 * |z|max (and its square) of rounding
+    zmax = ref.abs().max().item()
+    _close("gemm.stat_sum", stats[0], ref.sum(0), 1e-6, 2e-7 * M * zmax + 1e-5)
+    _close("gemm.stat_sumsq", stats[1], (ref * ref).sum(0), 1e-6, 4e-7 * M * zmax * zmax + 1e-5)
     got2 = ops.gemm(a.to(device), w.to(device), M, N, K, bias=b.to(device), scale=sc.to(device), shift=sh.to(device),
                     act=True)
     ref2 = torch.nn.functional.leaky_relu(ref * sc.double() + sh.double(), 0.2)
