@@ -246,19 +246,26 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
 // the bias gradient of a Linear that is not followed by BatchNorm (fc0, fc_classif).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N,
                                                      float* __restrict__ out) {
-  // thread = (column c = tid % Npad, row lane); grid-stride over rows
+  // thread = (column c = tid % cols, row lane rl); grid-stride over rows; one atomic per column per workgroup
+  // (same-address atomics serialise at ~15 ns each on MI355X: never one per thread)
+  __shared__ float red[256];
   const int tid = threadIdx.x;
   const int cols = N < 256 ? N : 256;
-  const int rows_per_pass = 256 / cols;
+  const int rpp = 256 / cols;
   const int c = tid % cols, rl = tid / cols;
-  if (rl >= rows_per_pass) return;
   for (int cb = 0; cb < N; cb += cols) {
-    int n = cb + c;
+    const int n = cb + c;
     float acc = 0.f;
-    if (n < N)
-      for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + rl; r < M; r += (int64_t)gridDim.x * rows_per_pass)
-        acc += x[r * ld + n];
-    if (n < N) atomicAdd(&out[n], acc);
+    if (rl < rpp && n < N)
+      for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < M; r += (int64_t)gridDim.x * rpp) acc += x[r * ld + n];
+    __syncthreads();
+    red[tid] = acc;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+      float v = 0.f;
+      for (int q = 0; q < rpp; ++q) v += red[q * cols + c];
+      atomicAdd(&out[n], v);
+    }
   }
 }
 
@@ -268,8 +275,8 @@ extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, 
   if (!x || !out) return M3D_ERR_INVALID;
   int cols = N < 256 ? N : 256;
   int rpp = 256 / cols;
-  int64_t gx = m3d_cdiv(M, (int64_t)rpp * 8);
-  if (gx > 1024) gx = 1024;
+  int64_t gx = m3d_cdiv(M, (int64_t)rpp * 16);
+  if (gx > 512) gx = 512;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out);
   M3D_CHECK_LAUNCH();

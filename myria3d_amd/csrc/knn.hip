@@ -181,11 +181,19 @@ __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float
 template <int KMAX>
 __device__ __forceinline__ void scan_range(u64 (&best)[KMAX], const float4* __restrict__ sorted, int p0, int p1,
                                            float qx, float qy, float qz) {
-  for (int p = p0; p < p1; ++p) {
-    float4 s = sorted[p];
-    float d2 = dist2_exact(qx, qy, qz, s);
-    u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(s.w);
-    topk_insert<KMAX>(best, key);
+  // 4 candidates per trip: four independent 16-byte loads in flight per lane (the loop is latency-bound otherwise)
+  for (int p = p0; p < p1; p += 4) {
+    const int last = p1 - 1;
+    float4 s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] = sorted[min(p + u, last)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float d2 = dist2_exact(qx, qy, qz, s[u]);
+      u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(s[u].w);
+      if (p + u > last) key = ~0ull;
+      topk_insert<KMAX>(best, key);
+    }
   }
 }
 

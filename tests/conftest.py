@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    import torch
+
+    torch.set_num_threads(min(4, torch.get_num_threads()))  # oversubscribed CI hosts are slower with every core
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
