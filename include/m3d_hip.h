@@ -106,7 +106,16 @@ int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, const float* w 
 int m3d_lfa_fwd(const float* x /* [n, CH/2] */, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
                 int32_t CH, const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
                 float slope, float* out, void* stream);
-/* unfused pieces (backward pass, fallback, cross-check): F[n*K, CH] edge features */
+/* fused backward of m3d_lfa_fwd (recomputes the forward tile-by-tile; nothing of size [E,.] in HBM):
+ *   dx[n, CH/2]  += d/dx           (atomically accumulated: zero it first)
+ *   dw_att[CH,CH] = d/dW_att,  G[CH/2][11] (fp64) = sum_e dy_e [r_e | 1]  (input of m3d_lfa_enc_bwd_finalize)
+ * att_wt_packed: W_att^T packed like att_w_packed.  ws: m3d_lfa_bwd_workspace_bytes(n, K, CH) bytes of scratch. */
+size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH);
+int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att, double* G,
+                void* ws, void* stream);
+/* unfused pieces (fallback for K > 32, cross-check of the fused kernels): F[n*K, CH] edge features */
 int m3d_lfa_edge_features(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                           const float* enc_w_folded, const float* enc_b_folded, float slope, float* F, void* stream);
 int m3d_lfa_edge_softmax_fwd(const float* A, const float* F, const int32_t* idx, int64_t n, int32_t K, int32_t CH,

@@ -36,6 +36,8 @@ SIGNATURES = {
     "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
+    "m3d_lfa_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
+    "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _p, _p]),
     "m3d_lfa_edge_features": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p]),
     "m3d_lfa_edge_softmax_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "m3d_lfa_edge_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),

@@ -1,0 +1,411 @@
+// Fused backward of Local Spatial Encoding + attentive pooling (gfx950).
+//
+// Autograd transpose of LocalFeatureAggregation.propagate/message
+// (/root/reference/myria3d/models/modules/pyg_randla_net.py:112-152), which upstream runs as ~30 separate
+// gather / scatter / GEMM / softmax backward kernels over [E,.] tensors kept alive from the forward pass.
+//
+// Here nothing of size [E,.] exists in HBM in either direction: the workgroup recomputes its F tile and attention
+// logits exactly like lfa_fwd_kernel, then (all GEMMs on v_mfma_f32_16x16x4_f32, tiles in LDS)
+//   3'  softmax over each centre's neighbours in the MFMA C layout,  s = softmax(A),  out = sum s*F,
+//         dA = s * dout * (F - out)  -> LDS tile DA;   accumulator <- dout * s   (direct path of d(s*F)/dF)
+//   4   dF  = dout*s + DA * W_att            (A operand: DA tile, B: W_att^T pre-packed in fragment order)
+//   5   dW_att += DA^T * F                   (per-workgroup partial kept in registers across its whole loop)
+//   6   dx[j_e, :] += dF[e, :D]              (fp32 atomics straight from the accumulator: 64-byte row segments)
+//       dy = dF[e, D:] * LeakyReLU'(lse)     -> LDS
+//   7   G += dy^T * [r | 1]                  (11 numbers per encoder channel: everything the encoder's Linear +
+//                                             train-mode BatchNorm backward needs, see m3d_lfa_enc_bwd_finalize)
+// Workgroup partials of dW_att and G are written with plain stores and summed by a second tiny kernel
+// (deterministic; same-address atomics cost ~15 ns each on MI355X and would dominate).
+#include "m3d_common.h"
+#include "lfa_common.h"
+#include "../../include/m3d_hip.h"
+
+struct LfaBwdArgs {
+  const float* x; const float4* pos4; const int32_t* idx;
+  const float* wf; const float* bf;
+  const float4* wp;   // packed W_att    (GEMM-1 B fragments)
+  const float4* wpt;  // packed W_att^T  (GEMM-2 B fragments)
+  const float* dout;  // [n, CH]
+  float* dx;          // [n, D], atomically accumulated
+  float* dw_part;     // [parts][CHP*CHP]
+  float* g_part;      // [parts][GP*16],  GP = max(16, D)
+  int64_t n;
+  int K, CH, D;
+  float slope;
+};
+
+template <int CHP> struct BwdCfg { static constexpr int NW = CHP >= 256 ? 8 : 4; };
+
+template <int CHP, int KP>
+__global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArgs a) {
+  constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
+  constexpr int ROWS = LfaCfg<CHP>::ROWS;
+  constexpr int TC = ROWS / KP, KT = KP / 16;
+  constexpr int STR = CHP + 2, RSTR = 18;
+  constexpr int MT = ROWS / 16, NT = CHP / 16;
+  constexpr int WN = NT < NW ? NT : NW, WM = NW / WN;
+  constexpr int NTW = NT / WN, MTW = MT / WM;
+  constexpr int S4 = CHP / 16;
+  static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
+  // GEMM-3 (dW_att) tile ownership
+  constexpr int T3 = NT * NT;
+  constexpr int KSPL3 = T3 >= NW ? 1 : NW / T3;
+  constexpr int TPW3 = T3 >= NW ? T3 / NW : 1;
+  constexpr int KTW3 = TPW3 < NT ? TPW3 : NT;
+  constexpr int CTW3 = TPW3 / KTW3;
+  // GEMM-4 (G) tile ownership: GT tiles of 16 encoder channels
+  constexpr int DP = CHP / 2 < 16 ? 16 : CHP / 2;  // padded encoder width
+  constexpr int GT = DP / 16;
+  constexpr int KSPL4 = GT >= NW ? 1 : NW / GT;
+  static_assert(GT <= NW, "one G tile per wave at most");
+
+  __shared__ float F[ROWS * STR];
+  __shared__ float DA[ROWS * STR];
+  __shared__ float RT[ROWS * RSTR];
+  __shared__ int nbr[ROWS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int D = a.D, CH = a.CH, K = a.K;
+  const int wn = wid % WN, wm = wid / WN;
+
+  // persistent accumulators
+  f32x4 acc3[CTW3][KTW3];
+#pragma unroll
+  for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+    for (int k = 0; k < KTW3; ++k) acc3[c][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 accg = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int t0 = (wid / KSPL3) * TPW3;
+  const int ct0 = t0 / NT, kt0 = t0 % NT, ks3 = wid % KSPL3;
+  const int gt = wid / KSPL4, ks4 = wid % KSPL4;
+
+  const int64_t ngroups = (a.n + TC - 1) / TC;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t c0 = grp * TC;
+    // ---- phase 1a: neighbour ids
+    for (int e = tid; e < ROWS; e += NTHR) {
+      int ci = e / KP, k = e % KP;
+      int64_t i = c0 + ci;
+      int j = -1;
+      if (i < a.n && k < K) j = a.idx[i * K + k];
+      nbr[e] = j;
+    }
+    __syncthreads();
+    // ---- phase 1b: gather x_j
+    {
+      const int D4 = D >> 2;
+      for (int f = tid; f < ROWS * D4; f += NTHR) {
+        int e = f / D4, c4 = f % D4;
+        int j = nbr[e];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
+        float* d = &F[e * STR + c4 * 4];
+        *(float2*)d = make_float2(v.x, v.y);
+        *(float2*)(d + 2) = make_float2(v.z, v.w);
+      }
+      if (CH < CHP) {
+        const int P = CHP - CH;
+        for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
+      }
+    }
+    // ---- phase 1c: r, folded encoder -> F[:, D:2D];  [r | 1 | 0...] -> RT
+    {
+      constexpr int NG = NTHR / ROWS;
+      const int e = tid % ROWS;
+      const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
+      const int DG = D / NG;
+      const int j = nbr[e];
+      const int64_t i = c0 + e / KP;
+      float r[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) r[q] = 0.f;
+      if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
+      if (grp_c == 0) {
+        float* rt = &RT[e * RSTR];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) rt[q] = r[q];
+        rt[10] = j >= 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 11; q < 16; ++q) rt[q] = 0.f;
+      }
+      for (int c = grp_c * DG; c < (grp_c + 1) * DG; ++c) {
+        const float* w = a.wf + c * 10;
+        float v = a.bf[c];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+        F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: A = F * W_att^T
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+#pragma unroll 1
+      for (int s4 = 0; s4 < S4; ++s4) {
+        float4 b[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float av[MTW];
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+          }
+        }
+      }
+    }
+
+    // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
+#pragma unroll
+    for (int cc = 0; cc < MTW / KT; ++cc) {
+      const int mt0 = wm * MTW + cc * KT;
+      const int64_t i = c0 + mt0 / KT;
+      bool vr[KT][4];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vr[kt][r] = nbr[(mt0 + kt) * 16 + lg * 4 + r] >= 0;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wn * NTW + t) * 16 + lr;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (vr[kt][r]) mx = fmaxf(mx, acc[cc * KT + kt][t][r]);
+        mx = xgroup_max(mx);
+        float num = 0.f, den = 0.f;
+        float fv[KT][4];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = 0.f, f = 0.f;
+            if (vr[kt][r]) {
+              p = __expf(acc[cc * KT + kt][t][r] - mx);
+              f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
+            }
+            num += p * f;
+            den += p;
+            acc[cc * KT + kt][t][r] = p;
+            fv[kt][r] = f;
+          }
+        num = xgroup_sum(num);
+        den = xgroup_sum(den);
+        const float inv = 1.f / (den + 1e-16f);
+        const float o = num * inv;
+        const float g = (i < a.n && col < CH) ? a.dout[i * CH + col] : 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float s = acc[cc * KT + kt][t][r] * inv;
+            DA[((mt0 + kt) * 16 + lg * 4 + r) * STR + col] = s * g * (fv[kt][r] - o);
+            acc[cc * KT + kt][t][r] = g * s;
+          }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 4: dF = dout*s + DA * W_att
+    {
+      const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
+#pragma unroll 1
+      for (int s4 = 0; s4 < S4; ++s4) {
+        float4 b[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float av[MTW];
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+          }
+        }
+      }
+    }
+    // ---- phase 5: dW_att[c, k] += sum_e DA[e, c] * F[e, k]
+    {
+#pragma unroll 2
+      for (int s = ks3; s < ROWS / 4; s += KSPL3) {
+        const int eo = (4 * s + lg) * STR + lr;
+        float av[CTW3], bv[KTW3];
+#pragma unroll
+        for (int c = 0; c < CTW3; ++c) av[c] = DA[eo + (ct0 + c) * 16];
+#pragma unroll
+        for (int k = 0; k < KTW3; ++k) bv[k] = F[eo + (kt0 + k) * 16];
+#pragma unroll
+        for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+          for (int k = 0; k < KTW3; ++k) acc3[c][k] = mfma16(av[c], bv[k], acc3[c][k]);
+      }
+    }
+    __syncthreads();
+    // ---- phase 6: scatter dx; dy -> DA[:, D:2D]
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wn * NTW + t) * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (wm * MTW + m) * 16 + lg * 4 + r;
+          const float v = acc[m][t][r];
+          if (col < D) {
+            const int j = nbr[row];
+            if (j >= 0) atomicAdd(a.dx + (int64_t)j * D + col, v);
+          } else if (col < CH) {
+            const float lse = F[row * STR + col];
+            DA[row * STR + col] = v * (lse > 0.f ? 1.f : a.slope);
+          }
+        }
+      }
+    __syncthreads();
+    // ---- phase 7: G[c', q] += sum_e dy[e, c'] * [r|1][e, q]
+    if (wid < GT * KSPL4) {
+      const bool crow = gt * 16 + lr < D;
+#pragma unroll 4
+      for (int s = ks4; s < ROWS / 4; s += KSPL4) {
+        const int e = 4 * s + lg;
+        const float av = crow ? DA[e * STR + D + gt * 16 + lr] : 0.f;
+        const float bv = RT[e * RSTR + lr];
+        accg = mfma16(av, bv, accg);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write this workgroup's partials
+  {
+    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPL3 + ks3) * (CHP * CHP);
+#pragma unroll
+    for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+      for (int k = 0; k < KTW3; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dst[((ct0 + c) * 16 + lg * 4 + r) * CHP + (kt0 + k) * 16 + lr] = acc3[c][k][r];
+    if (wid < GT * KSPL4) {
+      float* gd = a.g_part + ((size_t)blockIdx.x * KSPL4 + ks4) * (DP * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gd[(gt * 16 + lg * 4 + r) * 16 + lr] = accg[r];
+    }
+  }
+}
+
+// sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64)
+__global__ __launch_bounds__(256) void lfa_bwd_reduce_kernel(const float* __restrict__ dw_part, int parts3, int CHP,
+                                                             int CH, float* __restrict__ dw_att,
+                                                             const float* __restrict__ g_part, int parts4, int DP,
+                                                             int D, double* __restrict__ G) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nw = CHP * CHP;
+  if (t < nw) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < parts3; p += 4) {
+      s0 += dw_part[(size_t)p * nw + t];
+      s1 += dw_part[(size_t)(p + 1) * nw + t];
+      s2 += dw_part[(size_t)(p + 2) * nw + t];
+      s3 += dw_part[(size_t)(p + 3) * nw + t];
+    }
+    for (; p < parts3; ++p) s0 += dw_part[(size_t)p * nw + t];
+    const int c = t / CHP, k = t % CHP;
+    if (c < CH && k < CH) dw_att[c * CH + k] = (s0 + s1) + (s2 + s3);
+  } else {
+    const int u = t - nw;
+    if (u < DP * 16) {
+      double s = 0.0;
+      for (int p = 0; p < parts4; ++p) s += (double)g_part[(size_t)p * DP * 16 + u];
+      const int c = u / 16, q = u % 16;
+      if (c < D && q < 11) G[c * 11 + q] = s;
+    }
+  }
+}
+
+struct BwdPlan { int chp, rows, grid, kspl3, kspl4, dp; };
+
+static inline BwdPlan bwd_plan(int64_t n, int K, int CH) {
+  BwdPlan p;
+  p.chp = CH < 16 ? 16 : CH;
+  p.rows = p.chp == 16 ? 256 : (p.chp == 32 ? 128 : 64);
+  const int kp = K <= 16 ? 16 : 32;
+  const int tc = p.rows / kp;
+  const int nw = p.chp >= 256 ? 8 : 4;
+  const int nt = p.chp / 16;
+  p.kspl3 = nt * nt >= nw ? 1 : nw / (nt * nt);
+  p.dp = p.chp / 2 < 16 ? 16 : p.chp / 2;
+  const int gt = p.dp / 16;
+  p.kspl4 = gt >= nw ? 1 : nw / gt;
+  const int64_t ngroups = m3d_cdiv(n, tc);
+  // resident workgroups: bounded by LDS (2 tiles of rows*(chp+2) floats)
+  const int cap = p.chp >= 256 ? 256 : (p.chp >= 128 ? 512 : (p.chp >= 64 ? 768 : 1024));
+  p.grid = (int)(ngroups < cap ? (ngroups < 1 ? 1 : ngroups) : cap);
+  return p;
+}
+
+extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) {
+  if (n < 0 || K < 1 || CH < 8) return 0;
+  BwdPlan p = bwd_plan(n, K, CH);
+  return ((size_t)p.grid * p.kspl3 * p.chp * p.chp + (size_t)p.grid * p.kspl4 * p.dp * 16) * sizeof(float) + 256;
+}
+
+template <int CHP>
+static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st) {
+  constexpr int NTHR = BwdCfg<CHP>::NW * 64;
+  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CHP, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((lfa_bwd_kernel<CHP, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+}
+
+extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                           const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                           const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
+                           double* G, void* ws, void* stream) {
+  if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
+  if (K > 32) return M3D_ERR_UNSUPPORTED;
+  if (CH != 8 && CH != 16 && CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
+  if (!dw_att || !G || !ws) return M3D_ERR_INVALID;
+  if (n > 0 && (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed || !att_wt_packed || !dout || !dx))
+    return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  BwdPlan p = bwd_plan(n, K, CH);
+  LfaBwdArgs a;
+  a.x = x; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded;
+  a.wp = (const float4*)att_w_packed; a.wpt = (const float4*)att_wt_packed; a.dout = dout; a.dx = dx;
+  a.dw_part = (float*)ws;
+  a.g_part = a.dw_part + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
+  a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
+  int rc;
+  switch (p.chp) {
+    case 16: rc = launch_lfa_bwd<16>(a, p, st); break;
+    case 32: rc = launch_lfa_bwd<32>(a, p, st); break;
+    case 64: rc = launch_lfa_bwd<64>(a, p, st); break;
+    case 128: rc = launch_lfa_bwd<128>(a, p, st); break;
+    default: rc = launch_lfa_bwd<256>(a, p, st); break;
+  }
+  if (rc != M3D_OK) return rc;
+  const int total = p.chp * p.chp + p.dp * 16;
+  hipLaunchKernelGGL(lfa_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.dw_part, p.grid * p.kspl3,
+                     p.chp, CH, dw_att, a.g_part, p.grid * p.kspl4, p.dp, CH / 2, G);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

@@ -339,9 +339,11 @@ def lfa_enc_fold(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int):
 def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor) -> Tensor:
     n, K = idx.shape
     ch = w_att.shape[0]
+    if K > 32:  # the fused kernels tile one centre's neighbours onto <= 2 MFMA row tiles
+        return lfa_forward_unfused(x, pos4, idx, wf, bf, w_att)
     out = torch.empty((n, ch), dtype=torch.float32, device=x.device)
-    call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(pack_attention_weight(w_att)),
-         LRELU_SLOPE, _p(out), _st())
+    wp = pack_attention_weight(w_att)  # named local: stays alive until the launch is enqueued
+    call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), _st())
     return out
 
 
@@ -360,6 +362,8 @@ def lfa_forward_unfused(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Te
 class LFATrainFn(torch.autograd.Function):
     """aggregate() of LocalFeatureAggregation in train mode (encoder BatchNorm on batch statistics)."""
 
+    force_unfused_backward = False  # tests flip this to cross-check the fused backward kernel
+
     @staticmethod
     def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att):
         x = x.contiguous()
@@ -376,28 +380,45 @@ class LFATrainFn(torch.autograd.Function):
         ch = w_att.shape[0]
         D = ch // 2
         dev = x.device
-        E = n * K
-        F = torch.empty((E, ch), dtype=torch.float32, device=dev)
-        call("m3d_lfa_edge_features", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(F), _st())
-        A = gemm(F, w_att, E, ch, ch)
-        dF = torch.empty((E, ch), dtype=torch.float32, device=dev)
-        call("m3d_lfa_edge_softmax_bwd", _p(A), _p(F), _p(idx), n, K, ch, _p(dout.contiguous()), _p(dF), _st())
-        dA = A
-        # dW_att[c,k] = sum_e dA[e,c] F[e,k]
-        dw_att = torch.zeros((ch, ch), dtype=torch.float32, device=dev)
-        gemm(dA, F, ch, ch, E, lda0=ch, a_cm=True, b_cm=True, ldb=ch, out=dw_att, accumulate=True,
-             splitk=_splitk_for(E, ch, ch))
-        # dF += dA W_att
-        gemm(dA, w_att, E, ch, ch, b_cm=True, ldb=w_att.stride(0), out=dF, accumulate=True)
+        dout = dout.contiguous()
         dx = torch.zeros((n, D), dtype=torch.float32, device=dev)
         G = torch.empty(11 * D, dtype=torch.float64, device=dev)
-        call("m3d_lfa_edge_features_bwd", _p(dF), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(dx),
-             _p(G), _st())
+        if K <= 32 and not LFATrainFn.force_unfused_backward:
+            dw_att = torch.empty((ch, ch), dtype=torch.float32, device=dev)
+            ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
+            # keep both packed copies alive in named locals: two temporaries inside one call expression would be
+            # handed the SAME block by the caching allocator (the first is freed before the second is allocated)
+            wp, wpt = pack_attention_weight(w_att), pack_attention_weight(w_att.t())
+            call("m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
+                 _p(dout), _p(dx), _p(dw_att), _p(G), _p(ws), _st())
+        else:
+            dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
         dw = torch.empty((D, 10), dtype=torch.float32, device=dev)
         db, dgamma, dbeta = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
         call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
              _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, _st())
         return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att
+
+
+def _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G):
+    """Backward through materialised [E, ch] tensors (any K; cross-check of ``m3d_lfa_bwd``)."""
+    n, K = idx.shape
+    ch = w_att.shape[0]
+    dev = x.device
+    E = n * K
+    F = torch.empty((E, ch), dtype=torch.float32, device=dev)
+    call("m3d_lfa_edge_features", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(F), _st())
+    A = gemm(F, w_att, E, ch, ch)
+    dF = torch.empty((E, ch), dtype=torch.float32, device=dev)
+    call("m3d_lfa_edge_softmax_bwd", _p(A), _p(F), _p(idx), n, K, ch, _p(dout), _p(dF), _st())
+    dA = A
+    dw_att = torch.zeros((ch, ch), dtype=torch.float32, device=dev)  # dW_att[c,k] = sum_e dA[e,c] F[e,k]
+    gemm(dA, F, ch, ch, E, lda0=ch, a_cm=True, b_cm=True, ldb=ch, out=dw_att, accumulate=True,
+         splitk=_splitk_for(E, ch, ch))
+    gemm(dA, w_att, E, ch, ch, b_cm=True, ldb=w_att.stride(0), out=dF, accumulate=True)  # dF += dA W_att
+    call("m3d_lfa_edge_features_bwd", _p(dF), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), LRELU_SLOPE, _p(dx), _p(G),
+         _st())
+    return dw_att
 
 
 # --------------------------------------------------------------------------------------------------

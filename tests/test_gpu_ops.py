@@ -276,11 +276,14 @@ def test_lfa_eval_forward(device, ch, k):
     _close(f"lfa_unfused(ch={ch},k={k})", got_u, ref, 2e-5, 2e-5)
 
 
-@pytest.mark.parametrize("ch", [8, 16, 64, 256])
-def test_lfa_train_forward_backward(device, ch):
+@pytest.mark.parametrize("ch,k,fused", [(8, 16, True), (16, 16, True), (32, 16, True), (64, 16, True), (128, 16, True),
+                                        (256, 16, True), (16, 32, True), (128, 32, True), (8, 16, False),
+                                        (64, 16, False), (32, 40, True)])
+def test_lfa_train_forward_backward(device, ch, k, fused):
+    """fused=True: m3d_lfa_bwd; fused=False: the materialising fallback (also what K > 32 uses)."""
     from myria3d_amd import ops
 
-    k = 16
+    ops.LFATrainFn.force_unfused_backward = not fused
     x, pos, ptr, lfa, idx, ei = _lfa_setup(ch, [200, 11, 90], k, seed=ch)
     lfa = lfa.double().train()
     xr = x.double().requires_grad_(True)
@@ -305,16 +308,26 @@ def test_lfa_train_forward_backward(device, ch):
     out = ops.LFATrainFn.apply(xg, pos4, idx32, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
                                enc_bn.bias, enc_lin, enc_bn, w_att)
     out.backward(gy.float().to(device))
-    _close(f"lfa_train.out(ch={ch})", out, ref, 1e-4, 1e-4)
-    _close("lfa_train.running_mean", enc_bn.running_mean, enc_bn_r.running_mean, 1e-4, 1e-5)
-    _close("lfa_train.running_var", enc_bn.running_var, enc_bn_r.running_var, 1e-4, 1e-5)
     sc = max(1.0, gy.abs().max().item())
-    _close("lfa_train.dx", xg.grad, xr.grad, 1e-3, 1e-4 * sc)
-    _close("lfa_train.dW_att", w_att.grad, lfa.mlp_attention.lins[0].weight.grad, 1e-3, 1e-3)
-    _close("lfa_train.dW_enc", enc_lin.weight.grad, enc_lin_r.weight.grad, 2e-3, 2e-3)
-    _close("lfa_train.dgamma_enc", enc_bn.weight.grad, enc_bn_r.weight.grad, 2e-3, 2e-3)
-    _close("lfa_train.dbeta_enc", enc_bn.bias.grad, enc_bn_r.bias.grad, 2e-3, 2e-3)
-    _close("lfa_train.db_enc", enc_lin.bias.grad, enc_lin_r.bias.grad, 0, 2e-3)
+    checks = [
+        (f"lfa_train.out(ch={ch})", out, ref, 1e-4, 1e-4),
+        ("lfa_train.running_mean", enc_bn.running_mean, enc_bn_r.running_mean, 1e-4, 1e-5),
+        ("lfa_train.running_var", enc_bn.running_var, enc_bn_r.running_var, 1e-4, 1e-5),
+        ("lfa_train.dx", xg.grad, xr.grad, 1e-3, 1e-4 * sc),
+        ("lfa_train.dW_att", w_att.grad, lfa.mlp_attention.lins[0].weight.grad, 1e-3, 1e-3),
+        ("lfa_train.dW_enc", enc_lin.weight.grad, enc_lin_r.weight.grad, 2e-3, 2e-3),
+        ("lfa_train.dgamma_enc", enc_bn.weight.grad, enc_bn_r.weight.grad, 2e-3, 2e-3),
+        ("lfa_train.dbeta_enc", enc_bn.bias.grad, enc_bn_r.bias.grad, 2e-3, 2e-3),
+        ("lfa_train.db_enc", enc_lin.bias.grad, enc_lin_r.bias.grad, 0, 2e-3),
+    ]
+    failures = []
+    for c in checks:
+        try:
+            _close(*c)
+        except AssertionError as e:
+            failures.append(str(e))
+    ops.LFATrainFn.force_unfused_backward = False
+    assert not failures, failures
 
 
 # ----------------------------------------------------------------------------------------------- interpolation
