@@ -174,8 +174,8 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    from myria3d_amd import HipRandLANet, _lib, make_plan
-    from myria3d_amd.ddp import FlatGradAllReduce, broadcast_module_state, shard_tiles
+    from myria3d_amd import FusedAdam, HipRandLANet, _lib, cross_entropy, make_plan
+    from myria3d_amd.ddp import broadcast_module_state, shard_tiles
     from myria3d_amd.synthetic import synthetic_batch
 
     _lib.lib()  # no fallback: fail here if the HIP library is missing
@@ -185,20 +185,19 @@ def main():
     x, pos, ptr, y = x.to(dev), pos.to(dev), ptr.to(dev), y.to(dev)
     torch.manual_seed(0)
     net = HipRandLANet(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev)
+    # every parameter / gradient becomes a view of one flat buffer: the backward kernels accumulate into it, RCCL
+    # all-reduces it as ONE 4.45 MB bucket, m3d_adam_step updates (and clears) it in one launch
+    net.flatten_parameters()
     broadcast_module_state(net)
     plan = make_plan(ptr.tolist(), 4, K, dev)
-    opt = torch.optim.Adam(net.parameters(), lr=0.003933709606504788, capturable=True)  # configs/model/pyg_randla_net_model.yaml:4
-    reducer = FlatGradAllReduce(net.parameters())
+    opt = FusedAdam(net, lr=0.003933709606504788, all_reduce=True)  # lr: configs/model/pyg_randla_net_model.yaml:4
 
     def train_step():
         net.train()
-        for p in net.parameters():
-            p.grad = None  # AccumulateGrad then adopts the produced gradient: no zero-fill / add kernels
         out = net(x, pos, None, ptr, plan=plan)
-        loss = torch.nn.functional.cross_entropy(out, y)
+        loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
         loss.backward()
-        reducer()
-        opt.step()
+        opt.step()  # (N>1: flat-gradient all-reduce) + Adam + gradient clear
 
     def fwd_step():
         net.eval()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 1
+#define M3D_ABI_VERSION 2
 int m3d_abi_version(void);
 
 /* ---- k nearest neighbours -----------------------------------------------------------------------------
@@ -71,11 +71,13 @@ int m3d_bn_fold_eval(const float* gamma, const float* beta, const float* running
 int m3d_bn_apply(const float* z, const float* scale, const float* shift, const float* z2, const float* scale2,
                  const float* shift2, int32_t act, float slope, float* y, int64_t M, int32_t N, void* stream);
 /* backward of m3d_bn_apply in train mode: dz (and dz2), dgamma/dbeta (and dgamma2/dbeta2).
- * sums_ws: fp64 [3*N] scratch (zeroed inside). */
+ * sums_ws: fp64 [3*N] scratch (zeroed inside).  accumulate_param_grads != 0: dgamma/dbeta are gradient sinks
+ * (e.g. slices of the flat gradient buffer) and are added to instead of overwritten. */
 int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* z2, const float* scale2, const float* shift2, const float* mean2,
                const float* invstd2, int32_t act, float slope, int64_t M, int32_t N, double* sums_ws, float* dz,
-               float* dz2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2, void* stream);
+               float* dz2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
+               int32_t accumulate_param_grads, void* stream);
 
 /* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
 int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,
@@ -113,8 +115,9 @@ int m3d_lfa_fwd(const float* x /* [n, CH/2] */, const float* pos4, const int32_t
 size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH);
 int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                 const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
-                const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att, double* G,
-                void* ws, void* stream);
+                const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
+                int32_t accumulate_dw /* != 0: add into dw_att instead of overwriting */, double* G, void* ws,
+                void* stream);
 /* unfused pieces (fallback for K > 32, cross-check of the fused kernels): F[n*K, CH] edge features */
 int m3d_lfa_edge_features(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                           const float* enc_w_folded, const float* enc_b_folded, float slope, float* F, void* stream);
@@ -129,11 +132,30 @@ int m3d_lfa_edge_features_bwd(const float* dF, const float* pos4, const int32_t*
                               float* dx, double* G, void* stream);
 int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_edges, const float* w, const float* b,
                              const float* gamma, const float* mean, const float* invstd, float* dw, float* db,
-                             float* dgamma, float* dbeta, int32_t D, void* stream);
+                             float* dgamma, float* dbeta, int32_t D, int32_t accumulate, void* stream);
 
 /* ---- knn_interpolate arithmetic (model.py:90-98; pyg_randla_net.py:250) ---------------------------------- */
 int m3d_idw_interpolate_fwd(const float* x, int64_t ldx, const int32_t* idx, const float* d2, int64_t n_qry,
                             int32_t k, int32_t C, float* y, void* stream);
+
+/* ---- training step: loss and optimizer -------------------------------------------------------------------
+ * torch.nn.CrossEntropyLoss(ignore_index=65, reduction="mean") on the logits (myria3d/models/model.py:118,
+ * configs/model/criterion/CrossEntropyLoss.yaml:1-3).  lse: [n] scratch kept for the backward; acc2: fp64 [2]
+ * (sum of row losses, number of non-ignored rows; zeroed inside); loss: fp32 [1]. */
+int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
+                    int64_t ignore_index, float* lse, double* acc2, float* loss, void* stream);
+/* dlogits[n, C] (contiguous) = gout[0] * d loss / d logits */
+int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
+                    int64_t ignore_index, const float* lse, const double* acc2, const float* gout, float* dlogits,
+                    void* stream);
+/* torch.optim.Adam (configs/model/optimizer/Adam.yaml:1-4; lr from configs/model/pyg_randla_net_model.yaml:4) in ONE
+ * launch over flat, 16-byte aligned fp32 buffers of n (multiple of 4) elements.  state: fp32 [1] step counter on
+ * the device (incremented inside, so a replayed hipGraph keeps counting).  lr_dev: optional device fp32 [1]
+ * overriding `lr` (schedulers under graph replay).  grad_scale multiplies the gradient on the way in (1/world
+ * after a SUM all-reduce); zero_grad != 0 clears the gradient buffer after it has been consumed. */
+int m3d_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* state, const float* lr_dev,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  int32_t zero_grad, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,5 +7,7 @@ the host-side mirror of the reference's operator interface (``HipRandLANet``, ``
 from .randla import HipRandLANet, make_plan  # noqa: F401
 from .interpolation import knn_interpolate, scatter_sum  # noqa: F401
 from .registration import register_in_model_zoo  # noqa: F401
+from .train import FusedAdam, cross_entropy  # noqa: F401
 
-__all__ = ["HipRandLANet", "make_plan", "knn_interpolate", "scatter_sum", "register_in_model_zoo"]
+__all__ = ["HipRandLANet", "make_plan", "knn_interpolate", "scatter_sum", "register_in_model_zoo", "FusedAdam",
+           "cross_entropy"]

@@ -28,7 +28,7 @@ SIGNATURES = {
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
     "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
     "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,
-                          _p, _p, _p]),
+                          _p, _p, _i32, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
     "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
@@ -37,14 +37,19 @@ SIGNATURES = {
     "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
     "m3d_lfa_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
-    "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _p, _p]),
+    "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
     "m3d_lfa_edge_features": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p]),
     "m3d_lfa_edge_softmax_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "m3d_lfa_edge_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "m3d_lfa_edge_features_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p, _p]),
-    "m3d_lfa_enc_bwd_finalize": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_lfa_enc_bwd_finalize": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
     "m3d_idw_interpolate_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "m3d_ce_loss_fwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p]),
+    "m3d_ce_loss_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p]),
+    "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
+
+ABI_VERSION = 2  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 
@@ -78,7 +83,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.m3d_abi_version() != 1:
+        if handle.m3d_abi_version() != ABI_VERSION:
             raise M3DError("libm3d_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -124,6 +124,7 @@ struct BnBwdArgs {
   int act; float slope; int64_t M; int N;
   double* sums;  // [3][N]
   float* dz; float* dz2; float* dgamma; float* dbeta; float* dgamma2; float* dbeta2;
+  int acc_pg;  // != 0: add into dgamma/dbeta (gradient sinks) instead of overwriting
 };
 
 __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, float4 zv, float4& z2v) {
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const double invM = 1.0 / (double)a.M;
   if (blockIdx.x == 0) {
     for (int n = threadIdx.x; n < a.N; n += 256) {
-      if (a.dbeta) a.dbeta[n] = (float)a.sums[n];
-      if (a.dgamma) a.dgamma[n] = (float)a.sums[a.N + n];
+      if (a.dbeta) a.dbeta[n] = (a.acc_pg ? a.dbeta[n] : 0.f) + (float)a.sums[n];
+      if (a.dgamma) a.dgamma[n] = (a.acc_pg ? a.dgamma[n] : 0.f) + (float)a.sums[a.N + n];
       if (a.z2) {
-        if (a.dbeta2) a.dbeta2[n] = (float)a.sums[n];
-        if (a.dgamma2) a.dgamma2[n] = (float)a.sums[2 * (size_t)a.N + n];
+        if (a.dbeta2) a.dbeta2[n] = (a.acc_pg ? a.dbeta2[n] : 0.f) + (float)a.sums[n];
+        if (a.dgamma2) a.dgamma2[n] = (a.acc_pg ? a.dgamma2[n] : 0.f) + (float)a.sums[2 * (size_t)a.N + n];
       }
     }
   }
@@ -242,7 +243,7 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
                           const float* invstd, const float* z2, const float* scale2, const float* shift2,
                           const float* mean2, const float* invstd2, int32_t act, float slope, int64_t M, int32_t N,
                           double* sums_ws, float* dz, float* dz2, float* dgamma, float* dbeta, float* dgamma2,
-                          float* dbeta2, void* stream) {
+                          float* dbeta2, int32_t accumulate_param_grads, void* stream) {
   if (M < 0 || N < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
   if (!dy || !z || !scale || !shift || !mean || !invstd || !sums_ws || !dz) return M3D_ERR_INVALID;
@@ -253,6 +254,7 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   a.z2 = z2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.invstd2 = invstd2;
   a.act = act; a.slope = slope; a.M = M; a.N = N; a.sums = sums_ws;
   a.dz = dz; a.dz2 = dz2; a.dgamma = dgamma; a.dbeta = dbeta; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2;
+  a.acc_pg = accumulate_param_grads;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 3 * (size_t)N, st) != hipSuccess) return M3D_ERR_LAUNCH;
   const int N4 = N / 4;

@@ -538,7 +538,7 @@ __global__ void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G, const 
                                             const float* __restrict__ w, const float* __restrict__ b,
                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                             const float* __restrict__ invstd, float* dw, float* db, float* dgamma,
-                                            float* dbeta, int D) {
+                                            float* dbeta, int D, int acc) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= D) return;
   const double* g = G + c * 11;
@@ -552,22 +552,24 @@ __global__ void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G, const 
     double wm = 0.0;
     for (int p = 0; p < 10; ++p) wm += (double)w[c * 10 + p] * mom2(mom, p, q);
     double zr = is * (wm + (bb - mu) * mom[q]);
-    dw[c * 10 + q] = (float)(sc * (g[q] - (g0 / E) * mom[q] - (dgam / E) * zr));
+    const float dwv = (float)(sc * (g[q] - (g0 / E) * mom[q] - (dgam / E) * zr));
+    dw[c * 10 + q] = acc ? dw[c * 10 + q] + dwv : dwv;
   }
-  db[c] = 0.f;
-  dgamma[c] = (float)dgam;
-  dbeta[c] = (float)g0;
+  if (!acc) db[c] = 0.f;  // BatchNorm removes the mean: d/d(bias) is exactly 0
+  dgamma[c] = acc ? dgamma[c] + (float)dgam : (float)dgam;
+  dbeta[c] = acc ? dbeta[c] + (float)g0 : (float)g0;
 }
 
 extern "C" int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_edges, const float* w,
                                         const float* b, const float* gamma, const float* mean, const float* invstd,
-                                        float* dw, float* db, float* dgamma, float* dbeta, int32_t D, void* stream) {
+                                        float* dw, float* db, float* dgamma, float* dbeta, int32_t D,
+                                        int32_t accumulate, void* stream) {
   if (D < 0) return M3D_ERR_INVALID;
   if (D == 0) return M3D_OK;
   if (!G || !mom65 || !w || !b || !gamma || !mean || !invstd || !dw || !db || !dgamma || !dbeta || num_edges < 1)
     return M3D_ERR_INVALID;
   hipLaunchKernelGGL(lfa_enc_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, mom65,
-                     (double)num_edges, w, b, gamma, mean, invstd, dw, db, dgamma, dbeta, D);
+                     (double)num_edges, w, b, gamma, mean, invstd, dw, db, dgamma, dbeta, D, accumulate);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

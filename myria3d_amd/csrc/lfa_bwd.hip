@@ -311,32 +311,39 @@ __global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArg
   }
 }
 
-// sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64)
+// sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64).  blockIdx.x owns 256 consecutive
+// elements, blockIdx.y a contiguous chunk of the partials; chunks are combined with one atomic per element per
+// chunk into the (pre-zeroed) outputs, so the pass runs at HBM speed instead of one block walking every partial.
 __global__ __launch_bounds__(256) void lfa_bwd_reduce_kernel(const float* __restrict__ dw_part, int parts3, int CHP,
                                                              int CH, float* __restrict__ dw_att,
                                                              const float* __restrict__ g_part, int parts4, int DP,
                                                              int D, double* __restrict__ G) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int nw = CHP * CHP;
+  const int ny = gridDim.y, y = blockIdx.y;
   if (t < nw) {
+    const int per = (parts3 + ny - 1) / ny;
+    const int p0 = y * per, p1 = min(parts3, p0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 3 < parts3; p += 4) {
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
       s0 += dw_part[(size_t)p * nw + t];
       s1 += dw_part[(size_t)(p + 1) * nw + t];
       s2 += dw_part[(size_t)(p + 2) * nw + t];
       s3 += dw_part[(size_t)(p + 3) * nw + t];
     }
-    for (; p < parts3; ++p) s0 += dw_part[(size_t)p * nw + t];
+    for (; p < p1; ++p) s0 += dw_part[(size_t)p * nw + t];
     const int c = t / CHP, k = t % CHP;
-    if (c < CH && k < CH) dw_att[c * CH + k] = (s0 + s1) + (s2 + s3);
+    if (c < CH && k < CH && p1 > p0) atomicAdd(&dw_att[c * CH + k], (s0 + s1) + (s2 + s3));
   } else {
     const int u = t - nw;
     if (u < DP * 16) {
+      const int per = (parts4 + ny - 1) / ny;
+      const int p0 = y * per, p1 = min(parts4, p0 + per);
       double s = 0.0;
-      for (int p = 0; p < parts4; ++p) s += (double)g_part[(size_t)p * DP * 16 + u];
+      for (int p = p0; p < p1; ++p) s += (double)g_part[(size_t)p * DP * 16 + u];
       const int c = u / 16, q = u % 16;
-      if (c < D && q < 11) G[c * 11 + q] = s;
+      if (c < D && q < 11 && p1 > p0) atomicAdd(&G[c * 11 + q], s);
     }
   }
 }
@@ -379,7 +386,7 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st)
 extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                            const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
                            const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
-                           double* G, void* ws, void* stream) {
+                           int32_t accumulate_dw, double* G, void* ws, void* stream) {
   if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
   if (K > 32) return M3D_ERR_UNSUPPORTED;
   if (CH != 8 && CH != 16 && CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
@@ -404,8 +411,16 @@ extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx
   }
   if (rc != M3D_OK) return rc;
   const int total = p.chp * p.chp + p.dp * 16;
-  hipLaunchKernelGGL(lfa_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a.dw_part, p.grid * p.kspl3,
-                     p.chp, CH, dw_att, a.g_part, p.grid * p.kspl4, p.dp, CH / 2, G);
+  const int gx = (total + 255) / 256;
+  const int parts = p.grid * p.kspl3;
+  int gy = 2048 / gx;            // ~2k blocks in flight; >= 8 partials per chunk
+  if (gy > parts / 8) gy = parts / 8;
+  if (gy < 1) gy = 1;
+  if (!accumulate_dw && hipMemsetAsync(dw_att, 0, sizeof(float) * (size_t)CH * CH, st) != hipSuccess)
+    return M3D_ERR_LAUNCH;
+  if (hipMemsetAsync(G, 0, sizeof(double) * 11 * (size_t)(CH / 2), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(lfa_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, a.dw_part, parts, p.chp, CH, dw_att,
+                     a.g_part, p.grid * p.kspl4, p.dp, CH / 2, G);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

@@ -1,0 +1,155 @@
+// Loss and optimizer kernels of the training step (gfx950).
+//
+// The reference gets these from torch through Lightning:
+//   * torch.nn.CrossEntropyLoss(ignore_index=65) applied to the net's logits
+//     (/root/reference/myria3d/models/model.py:118, configs/model/criterion/CrossEntropyLoss.yaml:1-3)
+//   * torch.optim.Adam(lr=3.93e-3) (/root/reference/configs/model/optimizer/Adam.yaml:1-4,
+//     configs/model/pyg_randla_net_model.yaml:4)
+// torch's generic kernels cost ~0.3 ms (nll_loss fwd+bwd on [204 800, 6]) and ~250 tiny launches (capturable
+// Adam over 141 parameter tensors) per step; here the loss is two streaming kernels and the optimizer is ONE
+// launch over the flat parameter / gradient buffers (the same flat buffer RCCL all-reduces).
+#include "m3d_common.h"
+#include "../../include/m3d_hip.h"
+
+#define CE_MAXC 64
+
+// acc[0] += sum of per-row losses, acc[1] += number of rows with target != ignore_index; lse[i] = logsumexp(row i)
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                     const int64_t* __restrict__ target, int64_t n, int C,
+                                                     int64_t ignore_index, float* __restrict__ lse,
+                                                     double* __restrict__ acc) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double ls = 0.0, cnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+    const float* row = logits + i * ld;
+    float mx = -__builtin_inff();
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(row[c] - mx);
+    const float l = mx + logf(s);
+    lse[i] = l;
+    const int64_t t = target[i];
+    if (t != ignore_index && t >= 0 && t < C) {
+      ls += (double)(l - row[t]);
+      cnt += 1.0;
+    }
+  }
+  ls = wave_sum_d(ls);
+  cnt = wave_sum_d(cnt);
+  if (lane == 0) { red[0][wid] = ls; red[1][wid] = cnt; }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(&acc[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&acc[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+__global__ void ce_finalize_kernel(const double* __restrict__ acc, float* __restrict__ loss) {
+  // mean over the non-ignored rows (0/0 = NaN when every row is ignored, like torch)
+  loss[0] = (float)(acc[0] / acc[1]);
+}
+
+// dlogits[i, c] = gout * (softmax(i)[c] - [c == target_i]) / count   (0 for ignored rows)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                     const int64_t* __restrict__ target, int64_t n, int C,
+                                                     int64_t ignore_index, const float* __restrict__ lse,
+                                                     const double* __restrict__ acc, const float* __restrict__ gout,
+                                                     float* __restrict__ dlogits) {
+  const float g = gout[0] / (float)acc[1];
+  const int64_t total = n * C;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / C;
+    const int c = (int)(t % C);
+    const int64_t y = target[i];
+    float d = 0.f;
+    if (y != ignore_index && y >= 0 && y < C) d = g * (expf(logits[i * ld + c] - lse[i]) - (c == (int)y ? 1.f : 0.f));
+    dlogits[t] = d;
+  }
+}
+
+extern "C" int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
+                               int64_t ignore_index, float* lse, double* acc2, float* loss, void* stream) {
+  if (n < 0 || C < 1) return M3D_ERR_INVALID;
+  if (!acc2 || !loss) return M3D_ERR_INVALID;
+  if (n > 0 && (!logits || !target || !lse)) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  if (n > 0) {
+    int64_t gx = m3d_cdiv(n, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)gx), dim3(256), 0, st, logits, ld, target, n, C, ignore_index, lse,
+                       acc2);
+  }
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, st, acc2, loss);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+extern "C" int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
+                               int64_t ignore_index, const float* lse, const double* acc2, const float* gout,
+                               float* dlogits, void* stream) {
+  if (n < 0 || C < 1) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!logits || !target || !lse || !acc2 || !gout || !dlogits) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(n * C, 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, logits, ld, target, n, C,
+                     ignore_index, lse, acc2, gout, dlogits);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam over flat buffers.  state[0] = step count (float, incremented here by a 1-thread launch so that a
+// replayed hipGraph keeps counting), matching torch.optim.Adam(amsgrad=False, maximize=False):
+//   g' = g + wd*p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
+//   p -= lr / (1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// grad_scale multiplies g on the way in (1/world_size after a SUM all-reduce); zero_grad != 0 clears g.
+// ------------------------------------------------------------------------------------------
+__global__ void adam_tick_kernel(float* __restrict__ state) { state[0] += 1.f; }
+
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float4* __restrict__ g,
+                                                   float4* __restrict__ m, float4* __restrict__ v,
+                                                   const float* __restrict__ state, const float* __restrict__ lr_dev,
+                                                   float lr, float b1, float b2, float eps, float wd, float gscale,
+                                                   int zero_grad, int64_t n4) {
+  const float t = state[0];
+  const float lrv = lr_dev ? lr_dev[0] : lr;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step = lrv / bc1, rs = 1.f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 pv = p[i], gv = g[i], mv = m[i], vv = v[i];
+    float* pp = (float*)&pv; float* gp = (float*)&gv; float* mp = (float*)&mv; float* vp = (float*)&vv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gg = gp[j] * gscale + wd * pp[j];
+      mp[j] = mp[j] + (1.f - b1) * (gg - mp[j]);
+      vp[j] = b2 * vp[j] + (1.f - b2) * gg * gg;
+      pp[j] -= step * mp[j] / (sqrtf(vp[j]) * rs + eps);
+    }
+    p[i] = pv; m[i] = mv; v[i] = vv;
+    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+extern "C" int m3d_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* state,
+                             const float* lr_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             float grad_scale, int32_t zero_grad, int64_t n, void* stream) {
+  if (n < 0 || (n & 3)) return M3D_ERR_INVALID;  // flat buffers are padded to a multiple of 4 floats
+  if (!state) return M3D_ERR_INVALID;
+  if (n > 0 && (!params || !grads || !exp_avg || !exp_avg_sq)) return M3D_ERR_INVALID;
+  if ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15)
+    return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, state);
+  if (n > 0) {
+    int64_t gx = m3d_cdiv(n / 4, 256);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx), dim3(256), 0, st, (float4*)params, (float4*)grads,
+                       (float4*)exp_avg, (float4*)exp_avg_sq, state, lr_dev, lr, beta1, beta2, eps, weight_decay,
+                       grad_scale, zero_grad, n / 4);
+  }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

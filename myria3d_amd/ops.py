@@ -102,12 +102,15 @@ def linear_dgrad(dz: Tensor, w: Tensor) -> Tensor:
 
 
 def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None, x1: Optional[Tensor] = None,
-                 k1: int = 0) -> Tensor:
-    """dW[N, k0+k1] = dZ^T [X0[rows] | X1]; the reduction over the M rows is split across workgroups."""
+                 k1: int = 0, out: Optional[Tensor] = None) -> Optional[Tensor]:
+    """dW[N, k0+k1] = dZ^T [X0[rows] | X1]; the reduction over the M rows is split across workgroups.
+    ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a slice of the flat gradient buffer) that is added to;
+    nothing is returned then."""
     M, N = dz.shape
-    dw = torch.zeros((N, k0 + k1), dtype=torch.float32, device=dz.device)
+    sink = out is not None
+    dw = out if sink else torch.zeros((N, k0 + k1), dtype=torch.float32, device=dz.device)
     if M == 0:
-        return dw
+        return None if sink else dw
     if rows is not None:
         x0 = gather_rows(x0, rows)
     for xs, off, kk in ((x0, 0, k0), (x1, k0, k1)):
@@ -116,13 +119,16 @@ def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None,
         # C[N, kk] += A[N, M] B[kk, M]^T with A = dZ^T, B = Xs^T, both "column-major" views of row-major data
         gemm(dz, xs, N, kk, M, lda0=dz.stride(0), a_cm=True, b_cm=True, ldb=xs.stride(0), out=dw[:, off:],
              ldc=dw.stride(0), accumulate=True, splitk=_splitk_for(M, N, kk))
-    return dw
+    return None if sink else dw
 
 
-def colsum(x: Tensor) -> Tensor:
-    out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+def colsum(x: Tensor, out: Optional[Tensor] = None) -> Optional[Tensor]:
+    """Column sums; with ``out`` (a gradient sink) they are added to it and nothing is returned."""
+    sink = out is not None
+    if not sink:
+        out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
     call("m3d_colsum_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _st())
-    return out
+    return None if sink else out
 
 
 def gather_rows(src: Tensor, idx: Optional[Tensor]) -> Tensor:
@@ -183,19 +189,29 @@ def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Te
     return y
 
 
-def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=None, mean2=None, invstd2=None):
+def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=None, mean2=None, invstd2=None,
+           sinks=None):
+    """``sinks = (dgamma, dbeta[, dgamma2, dbeta2])``: gradient sinks that are added to (None is returned for them)."""
     M, N = z.shape
     dev = z.device
     sums = torch.empty(3 * N, dtype=torch.float64, device=dev)
     dz = torch.empty_like(z)
-    dgamma, dbeta = torch.empty(N, device=dev), torch.empty(N, device=dev)
     dz2 = dgamma2 = dbeta2 = None
+    if sinks is not None:
+        dgamma, dbeta = sinks[0], sinks[1]
+        if z2 is not None:
+            dgamma2, dbeta2 = sinks[2], sinks[3]
+    else:
+        dgamma, dbeta = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        if z2 is not None:
+            dgamma2, dbeta2 = torch.empty(N, device=dev), torch.empty(N, device=dev)
     if z2 is not None:
         dz2 = torch.empty_like(z2)
-        dgamma2, dbeta2 = torch.empty(N, device=dev), torch.empty(N, device=dev)
     call("m3d_bn_bwd", _p(_chk(dy)), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), _p(z2), _p(scale2),
          _p(shift2), _p(mean2), _p(invstd2), int(act), LRELU_SLOPE, M, N, _p(sums), _p(dz), _p(dz2), _p(dgamma),
-         _p(dbeta), _p(dgamma2), _p(dbeta2), _st())
+         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None), _st())
+    if sinks is not None:
+        return dz, None, None, dz2, None, None
     return dz, dgamma, dbeta, dz2, dgamma2, dbeta2
 
 
@@ -203,19 +219,24 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
 # autograd: Linear (fc0, fc_classif: pyg_randla_net.py:42,53)
 # --------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
+    """``sinks = (grad_w, grad_b)`` or None: see ``HipRandLANet.flatten_parameters`` (parameter gradients are
+    accumulated straight into the flat gradient buffer and autograd gets None for them)."""
+
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, sinks=None):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
+        ctx.sinks = sinks
         return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=b)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        sk = ctx.sinks
         dy = dy.contiguous()
         dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dy, x, x.shape[1])
-        return dx, dw, colsum(dy)
+        dw = linear_wgrad(dy, x, x.shape[1], out=sk[0] if sk else None)
+        return dx, dw, colsum(dy, out=sk[1] if sk else None), None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -224,7 +245,9 @@ class LinearFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows):
+    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None):
+        # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None
+        ctx.sinks = sinks
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         N = w.shape[0]
         k0 = x0.shape[1]
@@ -240,7 +263,9 @@ class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x0, x1, w, z, scale, shift, mean, invstd, rows = ctx.saved_tensors
-        dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act)
+        sk = ctx.sinks
+        dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act,
+                                            sinks=(sk[2], sk[3]) if sk else None)
         k0 = x0.shape[1]
         k1 = x1.shape[1] if x1 is not None else 0
         dx0 = dx1 = None
@@ -254,15 +279,16 @@ class SharedLayerTrainFn(torch.autograd.Function):
                     dx0 = dx0.contiguous()
             if x1 is not None and ctx.needs_input_grad[1]:
                 dx1 = dxc[:, k0:].contiguous()
-        dw = linear_wgrad(dz, x0, k0, rows, x1, k1)
-        db = torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None
+        dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None)
+        db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
 class ResidualTailTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns):
+    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None):
+        ctx.sinks = (sinks2, sinkss) if sinks2 is not None else None
         M, N = x2.shape[0], w2.shape[0]
         st2 = torch.zeros((2, N), dtype=torch.float64, device=w2.device)
         sts = torch.zeros((2, N), dtype=torch.float64, device=w2.device)
@@ -277,12 +303,16 @@ class ResidualTailTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, w2, z2, sc2, sh2, mu2, is2, xs, ws, zs, scs, shs, mus, iss = ctx.saved_tensors
-        dz2, dg2, db2, dzs, dgs, dbs = bn_bwd(dy.contiguous(), z2, sc2, sh2, mu2, is2, True, zs, scs, shs, mus, iss)
+        sk = ctx.sinks
+        dz2, dg2, db2, dzs, dgs, dbs = bn_bwd(dy.contiguous(), z2, sc2, sh2, mu2, is2, True, zs, scs, shs, mus, iss,
+                                              sinks=(sk[0][2], sk[0][3], sk[1][2], sk[1][3]) if sk else None)
         dx2 = linear_dgrad(dz2, w2)
         dxs = linear_dgrad(dzs, ws)
-        dw2 = linear_wgrad(dz2, x2, x2.shape[1])
-        dws = linear_wgrad(dzs, xs, xs.shape[1])
-        return (dx2, dw2, torch.zeros_like(db2), dg2, db2, None, dxs, dws, torch.zeros_like(dbs), dgs, dbs, None)
+        dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None)
+        dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None)
+        z0_2 = None if sk else torch.zeros_like(db2)
+        z0_s = None if sk else torch.zeros_like(dbs)
+        return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None)
 
 
 class GatherRowsFn(torch.autograd.Function):
@@ -365,7 +395,10 @@ class LFATrainFn(torch.autograd.Function):
     force_unfused_backward = False  # tests flip this to cross-check the fused backward kernel
 
     @staticmethod
-    def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att):
+    def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att,
+                sinks=None):
+        # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
+        ctx.sinks = sinks
         x = x.contiguous()
         wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
         out = lfa_forward(x, pos4, idx, wf, bf, w_att)
@@ -380,24 +413,32 @@ class LFATrainFn(torch.autograd.Function):
         ch = w_att.shape[0]
         D = ch // 2
         dev = x.device
+        sk = ctx.sinks
         dout = dout.contiguous()
         dx = torch.zeros((n, D), dtype=torch.float32, device=dev)
         G = torch.empty(11 * D, dtype=torch.float64, device=dev)
         if K <= 32 and not LFATrainFn.force_unfused_backward:
-            dw_att = torch.empty((ch, ch), dtype=torch.float32, device=dev)
+            dw_att = sk[4] if sk else torch.empty((ch, ch), dtype=torch.float32, device=dev)
             ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
             # keep both packed copies alive in named locals: two temporaries inside one call expression would be
             # handed the SAME block by the caching allocator (the first is freed before the second is allocated)
             wp, wpt = pack_attention_weight(w_att), pack_attention_weight(w_att.t())
             call("m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
-                 _p(dout), _p(dx), _p(dw_att), _p(G), _p(ws), _st())
+                 _p(dout), _p(dx), _p(dw_att), int(sk is not None), _p(G), _p(ws), _st())
         else:
             dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
-        dw = torch.empty((D, 10), dtype=torch.float32, device=dev)
-        db, dgamma, dbeta = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
+            if sk:
+                sk[4].add_(dw_att)
+        if sk:
+            dw, db, dgamma, dbeta = sk[0], sk[1], sk[2], sk[3]
+        else:
+            dw = torch.empty((D, 10), dtype=torch.float32, device=dev)
+            db, dgamma, dbeta = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
         call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
-             _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, _st())
-        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att
+             _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, int(sk is not None), _st())
+        if sk:
+            return (dx,) + (None,) * 12
+        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None
 
 
 def _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G):
@@ -429,3 +470,39 @@ def idw_interpolate(x: Tensor, idx: Tensor, d2: Tensor) -> Tensor:
     y = torch.empty((nq, x.shape[1]), dtype=torch.float32, device=x.device)
     call("m3d_idw_interpolate_fwd", _p(_chk(x)), x.stride(0), _p(idx), _p(d2), nq, k, x.shape[1], _p(y), _st())
     return y
+
+
+# --------------------------------------------------------------------------------------------------
+# training step: loss (model.py:118) and optimizer (configs/model/optimizer/Adam.yaml)
+# --------------------------------------------------------------------------------------------------
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = _chk(logits.contiguous())
+        n, C = logits.shape
+        dev = logits.device
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        acc = torch.empty(2, dtype=torch.float64, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        call("m3d_ce_loss_fwd", _p(logits), logits.stride(0), _p(target), n, C, ignore_index, _p(lse), _p(acc), _p(loss),
+             _st())
+        ctx.save_for_backward(logits, target, lse, acc)
+        ctx.ignore_index = ignore_index
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, lse, acc = ctx.saved_tensors
+        n, C = logits.shape
+        d = torch.empty_like(logits)
+        gout = gout.reshape(1).to(torch.float32).contiguous()
+        call("m3d_ce_loss_bwd", _p(logits), logits.stride(0), _p(target), n, C, ctx.ignore_index, _p(lse), _p(acc),
+             _p(gout), _p(d), _st())
+        return d, None, None
+
+
+def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:
+    """``torch.nn.functional.cross_entropy(logits, target, ignore_index=..., reduction="mean")`` for ``[n, C]``
+    fp32 logits and int64 class targets (the reference's criterion, model.py:118)."""
+    assert target.dtype == torch.int64 and target.is_cuda and target.is_contiguous()
+    return CrossEntropyFn.apply(logits, target, int(ignore_index))

@@ -121,6 +121,71 @@ class HipRandLANet(nn.Module):
         self.register_buffer("_decim_seed", torch.tensor([0x5DEECE66D], dtype=torch.int64), persistent=False)
         self._plans: Dict[tuple, LevelPlan] = {}
         self._warned_eval_grad = False
+        self._use_sinks = False
+        self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
+
+    # ------------------------------------------------------------------------------------------
+    # flat parameter / gradient buffers (opt-in): every parameter becomes a view of ONE fp32 buffer and every
+    # .grad a view of a second one.  The backward kernels then accumulate parameter gradients straight into that
+    # buffer ("gradient sinks"; autograd sees None for them), RCCL all-reduces it as a single 4.45 MB bucket and
+    # m3d_adam_step updates the whole model in one launch.  state_dict() / load_state_dict() are unaffected.
+    def flatten_parameters(self) -> "HipRandLANet":
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != "cuda" or any(p.dtype != torch.float32 for p in params):
+            raise RuntimeError("flatten_parameters(): move the module to the HIP device (fp32) first")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # every slice stays 16-byte aligned
+        flat_p = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        flat_g = torch.zeros_like(flat_p)
+        off = 0
+        with torch.no_grad():
+            for p, sz in zip(params, sizes):
+                n = p.numel()
+                flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + n].view(p.shape)
+                p.grad = flat_g[off:off + n].view(p.shape)
+                off += sz
+        self._flat = (flat_p, flat_g)
+        return self
+
+    @property
+    def flat_parameters(self) -> Optional[Tensor]:
+        return self._flat[0] if self._flat is not None else None
+
+    @property
+    def flat_grads(self) -> Optional[Tensor]:
+        return self._flat[1] if self._flat is not None else None
+
+    def _check_flat(self) -> bool:
+        """True when the gradient sinks can be used for this step; repairs detached .grad views
+        (``zero_grad(set_to_none=True)``) and re-flattens after ``.to()`` / ``load_state_dict(assign=True)``."""
+        if self._flat is None:
+            return False
+        flat_p, flat_g = self._flat
+        off, ok, lost_grad = 0, True, False
+        for p in self.parameters():
+            n = p.numel()
+            if p.data_ptr() != flat_p.data_ptr() + 4 * off:
+                ok = False
+                break
+            if p.grad is None or p.grad.data_ptr() != flat_g.data_ptr() + 4 * off:
+                lost_grad = True
+            off += (n + 3) // 4 * 4
+        if not ok:
+            self.flatten_parameters()
+            return True
+        if lost_grad:
+            flat_g.zero_()
+            off = 0
+            for p in self.parameters():
+                n = p.numel()
+                p.grad = flat_g[off:off + n].view(p.shape)
+                off += (n + 3) // 4 * 4
+        return True
+
+    @staticmethod
+    def _sinks(*params):
+        return tuple(p.grad for p in params)
 
     # ------------------------------------------------------------------------------------------
     def plan_for(self, ptr: Tensor) -> LevelPlan:
@@ -140,7 +205,9 @@ class HipRandLANet(nn.Module):
                       rows: Optional[Tensor] = None, train: bool = False) -> Tensor:
         lin, bn = mlp.lins[li], mlp.norms[li].module
         if train:
-            return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
+            sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
+            return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
+                                                sk)
         scale, shift = ops.bn_fold_eval(bn)
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
@@ -151,8 +218,10 @@ class HipRandLANet(nn.Module):
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
         if train:
+            sk = self._sinks(enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, w_att) if self._use_sinks \
+                else None
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                                       enc_bn.bias, enc_lin, enc_bn, w_att)
+                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk)
         else:
             wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
             agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att)
@@ -172,8 +241,10 @@ class HipRandLANet(nn.Module):
         l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
         ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
         if train:
+            sk2 = self._sinks(l2.weight, l2.bias, n2.weight, n2.bias) if self._use_sinks else None
+            sks = self._sinks(ls.weight, ls.bias, ns.weight, ns.bias) if self._use_sinks else None
             out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
-                                                ns.weight, ns.bias, ns)
+                                                ns.weight, ns.bias, ns, sk2, sks)
         else:
             sc2, sh2 = ops.bn_fold_eval(n2)
             scs, shs = ops.bn_fold_eval(ns)
@@ -217,6 +288,7 @@ class HipRandLANet(nn.Module):
     def _forward(self, x, pos, ptr, decimation_idx, dropout_mask, plan, record, train):
         if plan is None:
             plan = self.plan_for(ptr)
+        self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
         blocks = (self.block1, self.block2, self.block3, self.block4)
         pos4 = [ops.pad_pos(pos)]
         index: List[ops.KnnIndex] = []
@@ -224,7 +296,8 @@ class HipRandLANet(nn.Module):
         dec_idx: List[Tensor] = []
         if decimation_idx is None:
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
-        h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias) if train else \
+        h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
+                               self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
         for lvl, blk in enumerate(blocks):
             index.append(ops.KnnIndex(pos4[lvl], plan.ptrs[lvl]))
@@ -266,7 +339,9 @@ class HipRandLANet(nn.Module):
             else:
                 h = F.dropout(h, p=p, training=True)
         if train:
-            logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias)
+            logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias,
+                                        self._sinks(self.fc_classif.weight, self.fc_classif.bias)
+                                        if self._use_sinks else None)
         else:
             logits = ops.gemm(h, self.fc_classif.weight, h.shape[0], self.fc_classif.weight.shape[0], h.shape[1],
                               bias=self.fc_classif.bias)

@@ -46,7 +46,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(handle, name), f"{name} declared in m3d_hip.h but not exported by libm3d_hip.so"
     handle.m3d_abi_version.restype = ctypes.c_int32
-    assert handle.m3d_abi_version() == 1
+    assert handle.m3d_abi_version() == _lib.ABI_VERSION
 
 
 def test_ctypes_signatures_mirror_the_header():
