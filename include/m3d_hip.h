@@ -48,19 +48,31 @@ int m3d_knn_query(const void* ws, const int64_t* ptr_src, int32_t num_clouds, co
  * Linear of PyG MLP / torch.nn.Linear (pyg_randla_net.py:42,53,97-109), forward, dgrad and wgrad:
  *   C[M,N] (+)= [A0[rows] | A1][M, k0+k1] * B[N, k0+k1]^T  (+ bias) -> *scale + shift -> LeakyReLU
  * a_colmajor / b_colmajor: element (r,k) of that operand lives at p[k*ld + r].  a0_rows: optional int32 row
- * gather on A0 (FPModule's x[nn], pyg_randla_net.py:250-251).  stat_sum/stat_sumsq: optional fp64 [N]
- * accumulators (atomically added to) of the raw (pre scale/shift) output, for train-mode BatchNorm.
+ * gather on A0 (FPModule's x[nn], pyg_randla_net.py:250-251).  stat_part: optional fp64
+ * [stat_parts][2][N] buffer receiving per-workgroup partial column sums / sums of squares of the raw (pre
+ * scale/shift) output for train-mode BatchNorm (fully overwritten, no zero-fill needed; summed by
+ * m3d_bn_finalize); stat_parts must equal m3d_gemm_stat_parts(M, N, k0 + k1).
  * accumulate != 0: atomically add into C (required when splitk > 1, which splits the K dimension). */
+int m3d_gemm_stat_parts(int64_t M, int32_t N, int32_t K);
 int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_t* a0_rows, int32_t k0,
                  const float* a1, int64_t lda1, int32_t k1, const float* b, int64_t ldb, int32_t b_colmajor,
                  int64_t M, int32_t N, const float* bias, const float* scale, const float* shift, int32_t act,
-                 float slope, double* stat_sum, double* stat_sumsq, float* c, int64_t ldc, int32_t accumulate,
+                 float slope, double* stat_part, int32_t stat_parts, float* c, int64_t ldc, int32_t accumulate,
                  int32_t splitk, void* stream);
+/* Linear weight gradient  dW[N, k0+k1] (+)= dZ[M,N]^T [X0[x0_rows] | X1]   (autograd transpose of the Linear in
+ * SharedMLP / FPModule, pyg_randla_net.py:97-109,249-252).  The rows are split over workgroups; the splits meet in
+ * the workspace (m3d_linear_wgrad_workspace_bytes(M, N, k0+k1) bytes, may be 0), not in same-address atomics.
+ * accumulate != 0: add into dW (a gradient sink) instead of overwriting it. */
+size_t m3d_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* x0, int64_t ldx0, const int32_t* x0_rows,
+                         int32_t k0, const float* x1, int64_t ldx1, int32_t k1, int64_t M, int32_t N, float* dw,
+                         int64_t lddw, int32_t accumulate, void* ws, void* stream);
 /* out[N] += column sums of x[M,N] (bias gradient of a Linear without BatchNorm: fc0, fc_classif) */
 int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream);
 
 /* ---- BatchNorm1d(momentum=0.01, eps=1e-6) of SharedMLP (pyg_randla_net.py:92-109) ------------------------ */
-int m3d_bn_finalize(const double* sum, const double* sumsq, int64_t count, const float* gamma, const float* beta,
+int m3d_bn_finalize(const double* stat_part /* [parts][2][N] from m3d_gemm_f32 */, int32_t parts, int64_t count,
+                    const float* gamma, const float* beta,
                     float eps, float momentum, float* running_mean /* updated in place, may be NULL */,
                     float* running_var, float* scale, float* shift, float* mean_out, float* invstd_out, int32_t N,
                     void* stream);

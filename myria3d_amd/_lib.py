@@ -21,10 +21,13 @@ SIGNATURES = {
     "m3d_knn_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_knn_build": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p]),
     "m3d_knn_query": (_i32, [_p, _p, _i32, _p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
+    "m3d_gemm_stat_parts": (_i32, [_i64, _i32, _i32]),
     "m3d_gemm_f32": (_i32, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _i32,
-                            _f32, _p, _p, _p, _i64, _i32, _i32, _p]),
+                            _f32, _p, _i32, _p, _i64, _i32, _i32, _p]),
+    "m3d_linear_wgrad_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
+    "m3d_linear_wgrad_f32": (_i32, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _i64, _i32, _p, _i64, _i32, _p, _p]),
     "m3d_colsum_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
-    "m3d_bn_finalize": (_i32, [_p, _p, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_bn_finalize": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
     "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
     "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,

@@ -12,14 +12,23 @@
 #include "m3d_common.h"
 #include "../../include/m3d_hip.h"
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, float* scale,
-                                   float* shift, float* mean_out, float* invstd_out, int N) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  double mean = sum[n] / count;
-  double var = sumsq[n] / count - mean * mean;
+// one wave per column: lanes sum the per-workgroup partial rows written by the GEMM ([parts][2][N], fp64)
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restrict__ part, int parts, double count,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum,
+                                                         float* running_mean, float* running_var, float* scale,
+                                                         float* shift, float* mean_out, float* invstd_out, int N) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int p = lane; p < parts; p += 64) {
+    s += part[((size_t)p * 2 + 0) * N + n];
+    q += part[((size_t)p * 2 + 1) * N + n];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane != 0) return;
+  double mean = s / count;
+  double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
   double invstd = 1.0 / sqrt(var + (double)eps);
   float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
@@ -35,15 +44,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double*
   }
 }
 
-extern "C" int m3d_bn_finalize(const double* sum, const double* sumsq, int64_t count, const float* gamma,
+extern "C" int m3d_bn_finalize(const double* stat_part, int32_t parts, int64_t count, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean,
                                float* running_var, float* scale, float* shift, float* mean_out, float* invstd_out,
                                int32_t N, void* stream) {
-  if (!sum || !sumsq || !scale || !shift || N < 0 || count < 1) return M3D_ERR_INVALID;
+  if (!stat_part || parts < 1 || !scale || !shift || N < 0 || count < 1) return M3D_ERR_INVALID;
   if (N == 0) return M3D_OK;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, sumsq,
-                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out,
-                     invstd_out, N);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, stat_part, parts, (double)count,
+                     gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean_out, invstd_out, N);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

@@ -21,17 +21,8 @@
 #define BK 32
 #define LDS_STRIDE (BK + 2)
 
-struct GemmArgs {
-  const float* a0; int64_t lda0; const int32_t* a0_rows; int k0;
-  const float* a1; int64_t lda1; int k1;
-  int a_cm;
-  const float* b; int64_t ldb; int b_cm;
-  int64_t M; int N;
-  const float* bias; const float* scale; const float* shift; int act; float slope;
-  double* stat_sum; double* stat_sumsq;
-  float* c; int64_t ldc; int accumulate;
-  int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
-};
+#include <stdlib.h>
+#include "gemm_common.h"
 
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -203,34 +194,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+extern "C" int m3d_gemm_stat_parts(int64_t M, int32_t N, int32_t K) { return m3d_gemm_direct_stat_parts(M, N, K); }
+
 extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_t* a0_rows, int32_t k0,
                             const float* a1, int64_t lda1, int32_t k1, const float* b, int64_t ldb,
                             int32_t b_colmajor, int64_t M, int32_t N, const float* bias, const float* scale,
-                            const float* shift, int32_t act, float slope, double* stat_sum, double* stat_sumsq,
+                            const float* shift, int32_t act, float slope, double* stat_part, int32_t stat_parts,
                             float* c, int64_t ldc, int32_t accumulate, int32_t splitk, void* stream) {
   if (M < 0 || N < 0 || k0 < 0 || k1 < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
   if (!c || !b || (k0 > 0 && !a0) || (k1 > 0 && !a1)) return M3D_ERR_INVALID;
   if (a_colmajor && (k1 > 0 || a0_rows)) return M3D_ERR_UNSUPPORTED;
-  if ((stat_sum == nullptr) != (stat_sumsq == nullptr)) return M3D_ERR_INVALID;
+  if (stat_part && stat_parts != m3d_gemm_stat_parts(M, N, k0 + k1)) return M3D_ERR_INVALID;
   if (splitk < 1) splitk = 1;
-  if (splitk > 1 && (!accumulate || stat_sum || scale || shift || act)) return M3D_ERR_INVALID;
+  if (splitk > 1 && (!accumulate || stat_part || scale || shift || act)) return M3D_ERR_INVALID;
   if (k0 + k1 == 0) return M3D_ERR_INVALID;
   GemmArgs g;
   g.a0 = a0; g.lda0 = lda0; g.a0_rows = a0_rows; g.k0 = k0; g.a1 = a1; g.lda1 = lda1; g.k1 = k1;
   g.a_cm = a_colmajor; g.b = b; g.ldb = ldb; g.b_cm = b_colmajor; g.M = M; g.N = N;
   g.bias = bias; g.scale = scale; g.shift = shift; g.act = act; g.slope = slope;
-  g.stat_sum = stat_sum; g.stat_sumsq = stat_sumsq; g.c = c; g.ldc = ldc; g.accumulate = accumulate;
+  g.stat_part = stat_part; g.stat_sum = stat_part; g.stat_sumsq = stat_part ? stat_part + N : nullptr; g.c = c; g.ldc = ldc; g.accumulate = accumulate;
   const int64_t K = (int64_t)k0 + k1;
   int64_t kchunk = m3d_align(m3d_cdiv(K, splitk), BK);
   splitk = (int)m3d_cdiv(K, kchunk);
   g.splitk = splitk; g.kchunk = kchunk;
+  {
+    // fragment-direct kernels (gemm_direct.hip) cover the network's shapes; this LDS-tiled kernel is the fallback
+    // (and, with M3D_GEMM_LEGACY=1 in the environment, the cross-check used by the tests)
+    static const bool legacy = getenv("M3D_GEMM_LEGACY") != nullptr && getenv("M3D_GEMM_LEGACY")[0] == '1';
+    if (!legacy) {
+      const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
+      if (rc != 1) return rc;
+    }
+  }
+  // fallback: atomically accumulated statistics in partial row 0, the other rows stay zero
+  if (stat_part && hipMemsetAsync(stat_part, 0, sizeof(double) * 2 * (size_t)N * stat_parts, (hipStream_t)stream) != hipSuccess)
+    return M3D_ERR_LAUNCH;
   const int NT = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
   const int64_t mtiles = m3d_cdiv(M, BM);
   const int64_t ntiles = m3d_cdiv(N, 16 * NT);
   // persistent over M tiles when column statistics are accumulated (fewer fp64 atomics per column)
   int64_t gx = mtiles;
-  const int64_t cap = stat_sum ? 1024 : 65535;
+  const int64_t cap = stat_part ? 1024 : 65535;
   if (gx > cap) gx = cap;
   if (ntiles > 65535 || splitk > 65535) return M3D_ERR_UNSUPPORTED;
   dim3 grid((unsigned)gx, (unsigned)ntiles, (unsigned)splitk), block(256);

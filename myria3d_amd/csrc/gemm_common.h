@@ -1,0 +1,22 @@
+// Argument block shared by the SharedMLP GEMM kernels (gemm.hip: LDS-tiled fallback; gemm_direct.hip: the
+// LDS-free fragment-direct kernels).  See m3d_gemm_f32 in include/m3d_hip.h for the meaning of each field.
+#pragma once
+#include "m3d_common.h"
+
+struct GemmArgs {
+  const float* a0; int64_t lda0; const int32_t* a0_rows; int k0;
+  const float* a1; int64_t lda1; int k1;
+  int a_cm;
+  const float* b; int64_t ldb; int b_cm;
+  int64_t M; int N;
+  const float* bias; const float* scale; const float* shift; int act; float slope;
+  double* stat_sum; double* stat_sumsq;  // LDS-tiled fallback: atomically accumulated [N] vectors (row 0 of stat_part)
+  double* stat_part;                     // direct kernels: [gridDim.x][2][N] per-workgroup partials, plainly stored
+  float* c; int64_t ldc; int accumulate;
+  int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
+};
+
+// gemm_direct.hip: returns M3D_OK when it handled the problem, 1 when the shape is not covered (caller falls back)
+int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st);
+// number of statistics partial rows the direct kernels write for a forward GEMM of this shape (>= 1)
+int m3d_gemm_direct_stat_parts(int64_t M, int N, int K);

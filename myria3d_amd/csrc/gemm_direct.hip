@@ -1,0 +1,631 @@
+// LDS-free fp32 MFMA GEMMs for the SharedMLP layers (gfx950): fragments are loaded straight from global memory
+// in the v_mfma_f32_16x16x4_f32 operand layout, so there is no staging, no barrier and no exposed load latency
+// between K chunks.
+//
+// Replaces the Linear of PyG's MLP / torch.nn.Linear (/root/reference/myria3d/models/modules/pyg_randla_net.py:
+// 42,53,97-109) forward, dgrad and wgrad; same semantics as the LDS-tiled kernel in gemm.hip, which stays as the
+// fallback for shapes these kernels do not cover.
+//
+// The network's GEMMs are tall and skinny (M = 204 800 ... 800 rows, K, N <= 768), i.e. HBM- or latency-bound, so
+// the layouts are chosen for 16-byte global accesses rather than for MFMA reuse:
+//   * the product is computed TRANSPOSED, D[n][m] = sum_k W[n][k] X[m][k]: MFMA A operand = weight tile,
+//     B operand = 16 rows of X.  A lane then owns 4 CONSECUTIVE output columns of one row (C/D layout: row
+//     (lane>>4)*4+r, col lane&15) -> one float4 store per 16x16 tile instead of four scattered dwords;
+//   * within a 16-wide K chunk, MFMA step i of the chunk uses k = 16q + 4*(lane>>4) + i for BOTH operands (a
+//     permutation of the reduction order), so each lane's four k values are one float4 of its row: one 16-byte
+//     load per lane per chunk for X and for W.
+//   * every load in a hot loop is an UNCONDITIONAL buffer load: out-of-range rows / columns / k use an out-of-bounds
+//     offset, for which the hardware returns 0.  (Guarding loads with branches or selects makes the compiler sink
+//     them into per-load basic blocks, each behind its own s_waitcnt vmcnt(0) — measured 3-5x slower on these
+//     latency-bound shapes.)
+// Kernels:
+//   gemm_rowstream_kernel<NT,KQ,MODE,..>   K <= 64, per-wave column slice <= 64: the weight slice lives in registers
+//                                 and the wave streams 16-row tiles (204 800-row layers: pure HBM streaming)
+//   gemm_kloop_kernel<NTW,MODE,..>   any K: weights re-read from L1/L2 every chunk (deep layers: few rows, long K)
+//   wgrad2_kernel<TN,TK>          dW[n][k] = sum_m dZ[m][n] X[m][k]: the reduction runs over the rows; every wave
+//                                 owns one row split and stores its partial to a workspace that wgrad_reduce_kernel
+//                                 sums (no LDS atomics, no same-address global atomics)
+// Train-mode BatchNorm column statistics (sum, sum of squares of the raw output) are accumulated in fp64 per lane,
+// then across lanes / waves (LDS); every workgroup stores its partial row and m3d_bn_finalize sums the rows.
+#include <stdlib.h>
+#include "gemm_common.h"
+#include "../../include/m3d_hip.h"
+
+__device__ __forceinline__ float f4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// ------------------------------------------------------------------------------------------
+// branch-free operand fragments: buffer loads with hardware range checking.  Every operand gets a raw buffer
+// descriptor of 2 GiB; a lane whose row / column / k is out of range uses the byte offset OOB (= the descriptor
+// size), for which the hardware returns 0 without touching memory.  No select, no branch, nothing the compiler can
+// sink behind a condition: the loads of a tile issue back to back.
+// ------------------------------------------------------------------------------------------
+#define M3D_BUF_BYTES 0x80000000u
+#define OOB 0x80000000u
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, M3D_BUF_BYTES, 0x00020000);
+}
+__device__ __forceinline__ float4 ld4(rsrc_t r, unsigned off) {
+  f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+// (the b32 builtin returns the raw 32 bits as an integer: reinterpret, do not convert)
+__device__ __forceinline__ float ld1(rsrc_t r, unsigned off) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+struct ARow {
+  unsigned o0;  // byte offset of the (gathered) row in A0, OOB when the row does not exist
+  unsigned o1;  // byte offset of the row in A1, OOB without a second operand
+};
+
+__device__ __forceinline__ ARow a_row(const GemmArgs& g, int64_t m) {
+  const bool ok = m < g.M;
+  const int64_t mc = ok ? m : 0;
+  int64_t rr = mc;
+  if (g.a0_rows) rr = (int64_t)g.a0_rows[mc];
+  ARow r;
+  r.o0 = (ok && rr >= 0) ? (unsigned)(rr * g.lda0 * 4) : OOB;
+  r.o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.lda1 * 4) : OOB;
+  return r;
+}
+
+// elements k .. k+3 of the (concatenated) row, zeros past K / for missing rows.
+// VEC: k0, k1 multiples of 4, 16-byte aligned rows -> the four elements are one float4 of A0 or of A1 (CAT: a second
+// operand exists; the lane's offset is OOB in the operand that does not hold k).  !VEC: single operand, dword loads.
+template <bool VEC, bool CAT>
+__device__ __forceinline__ float4 a_frag(const GemmArgs& g, rsrc_t ra0, rsrc_t ra1, const ARow& r, int k, int K) {
+  if (VEC) {
+    const bool in0 = k < g.k0;
+    const unsigned f0 = (in0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
+    float4 v = ld4(ra0, f0);
+    if (CAT) {
+      const unsigned f1 = (!in0 && k < K && r.o1 != OOB) ? r.o1 + 4u * (unsigned)(k - g.k0) : OOB;
+      const float4 u = ld4(ra1, f1);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    return v;
+  } else {
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = ld1(ra0, (k + j < K && r.o0 != OOB) ? r.o0 + 4u * (unsigned)(k + j) : OOB);
+    return make_float4(t[0], t[1], t[2], t[3]);
+  }
+}
+
+// W[n][k .. k+3]   (BCM: element (n, k) at b[k*ldb + n]); zeros for n >= N or k >= K
+template <bool VEC, bool BCM>
+__device__ __forceinline__ float4 w_frag(const GemmArgs& g, rsrc_t rb, int n, int k, int K) {
+  const bool nok = n < g.N;
+  if (BCM) {
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      t[j] = ld1(rb, (nok && k + j < K) ? 4u * (unsigned)((k + j) * (int)g.ldb + n) : OOB);
+    return make_float4(t[0], t[1], t[2], t[3]);
+  }
+  const unsigned base = 4u * (unsigned)(n * (int)g.ldb + k);
+  if (VEC) return ld4(rb, (nok && k < K) ? base : OOB);
+  float t[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = ld1(rb, (nok && k + j < K) ? base + 4u * j : OOB);
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+
+// Epilogue modes (template parameter MODE): the network never needs statistics and an affine map in one launch
+//   0 PLAIN   + bias                      (dgrad, plain Linear)
+//   1 STATS   + bias, column sum/sumsq    (train-mode SharedMLP: BatchNorm statistics of the raw output)
+//   2 AFFINE  + bias, *scale + shift, act (eval-mode SharedMLP: folded BatchNorm + LeakyReLU)
+template <int MODE>
+struct Epi {
+  float4 bia, sc, sh;
+};
+
+template <int MODE>
+__device__ __forceinline__ Epi<MODE> epi_load(const GemmArgs& g, int n0) {
+  // buffer loads: a null bias / scale / shift pointer simply reads as OOB (= 0) — no branches, no serialised waits
+  const rsrc_t rbias = mk_rsrc(g.bias), rsc = mk_rsrc(g.scale), rsh = mk_rsrc(g.shift);
+  Epi<MODE> e;
+  float b[4], s[4], h[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + r;
+    const bool ok = n < g.N;
+    b[r] = ld1(rbias, (ok && g.bias) ? 4u * (unsigned)n : OOB);
+    s[r] = 1.f; h[r] = 0.f;
+    if (MODE == 2) {
+      const float sv = ld1(rsc, (ok && g.scale) ? 4u * (unsigned)n : OOB);
+      s[r] = (ok && g.scale) ? sv : 1.f;
+      h[r] = ld1(rsh, (ok && g.shift) ? 4u * (unsigned)n : OOB);
+    }
+  }
+  e.bia = make_float4(b[0], b[1], b[2], b[3]);
+  e.sc = make_float4(s[0], s[1], s[2], s[3]);
+  e.sh = make_float4(h[0], h[1], h[2], h[3]);
+  return e;
+}
+
+// finish one 16x16 tile owned by this lane: columns n0..n0+3 of row m
+template <int MODE>
+__device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e, f32x4 acc, int64_t m, int n0, bool cvec,
+                                          double (&ssum)[4], double (&ssq)[4]) {
+  const bool rowok = m < g.M;
+  float y[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float z = acc[r] + f4(e.bia, r);
+    if (MODE == 1) {
+      // fp64: columns with |mean| >> std (tiny batches at the deepest level) lose the variance otherwise
+      const double zd = (rowok && n0 + r < g.N) ? (double)z : 0.0;
+      ssum[r] += zd;
+      ssq[r] += zd * zd;
+    }
+    float v = z;
+    if (MODE == 2) {
+      v = z * f4(e.sc, r) + f4(e.sh, r);
+      if (g.act) v = lrelu(v, g.slope);
+    }
+    y[r] = v;
+  }
+  if (!rowok) return;
+  float* cp = g.c + m * g.ldc + n0;
+  if (cvec) {  // N % 4 == 0, ldc % 4 == 0, 16-byte aligned C
+    if (n0 < g.N) *(float4*)cp = make_float4(y[0], y[1], y[2], y[3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n0 + r < g.N) cp[r] = y[r];
+  }
+}
+
+// per-lane fp64 column partials -> over the 16 row lanes -> LDS over the workgroup's waves -> this workgroup's
+// partial row of stat_part.  Lane (lr, lg) holds columns nb + 16t + 4lg + r.
+template <int NT, int NWAVES>
+__device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&ssum)[NT][4], double (&ssq)[NT][4]) {
+  __shared__ double sred[NWAVES][2][16 * NT];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a = ssum[t][r], q = ssq[t][r];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+      if (lr == 0) { sred[wid][0][t * 16 + lg * 4 + r] = a; sred[wid][1][t * 16 + lg * 4 + r] = q; }
+    }
+  __syncthreads();
+  if (threadIdx.x < 2 * 16 * NT) {
+    const int which = threadIdx.x / (16 * NT), col = threadIdx.x % (16 * NT);
+    const int n = nb + col;
+    if (n < g.N) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) v += sred[w][which][col];
+      // plain store of this workgroup's partial (summed by m3d_bn_finalize): no same-address atomics, no zero-fill,
+      // bitwise reproducible
+      g.stat_part[((size_t)blockIdx.x * 2 + which) * g.N + n] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K <= 16*KQ <= 64, column slice 16*NT <= 64: weights in registers, rows streamed.
+// grid: (row workgroups, column slices); 4 waves per workgroup take interleaved 16-row tiles.
+// ------------------------------------------------------------------------------------------
+template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM>
+__global__ __launch_bounds__(256) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int K = g.k0 + g.k1;
+  const int nb = blockIdx.y * 16 * NT;
+  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b);
+  float4 w[NT][KQ];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) w[t][q] = w_frag<VEC, BCM>(g, rb, nb + 16 * t + lr, 16 * q + 4 * lg, K);
+  Epi<MODE> e[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) e[t] = epi_load<MODE>(g, nb + 16 * t + 4 * lg);
+  double ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.0; ssq[t][r] = 0.0; }
+
+  const int64_t ntiles = (g.M + 15) >> 4;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += stride) {
+    const int64_t m = tile * 16 + lr;
+    const ARow row = a_row(g, m);
+    float4 a[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(f4(w[t][q], i), f4(a[q], i), acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) epi_store<MODE>(g, e[t], acc[t], m, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+  }
+  if (MODE == 1) stats_flush<NT, 4>(g, nb, ssum, ssq);
+}
+
+// ------------------------------------------------------------------------------------------
+// any K: weights streamed from L1/L2 chunk by chunk.  grid: (row workgroups, column slices of 16*NTW)
+// ------------------------------------------------------------------------------------------
+template <int NTW, int MODE, bool VEC, bool CAT, bool BCM>
+__global__ __launch_bounds__(256) void gemm_kloop_kernel(GemmArgs g, int cvec) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int K = g.k0 + g.k1;
+  const int KQ = (K + 15) >> 4;
+  const int nb = blockIdx.y * 16 * NTW;
+  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b);
+  Epi<MODE> e[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) e[t] = epi_load<MODE>(g, nb + 16 * t + 4 * lg);
+  double ssum[NTW][4], ssq[NTW][4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.0; ssq[t][r] = 0.0; }
+
+  const int64_t ntiles = (g.M + 15) >> 4;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += stride) {
+    const int64_t m = tile * 16 + lr;
+    const ARow row = a_row(g, m);
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int q = 0; q < KQ; ++q) {
+      const int k = 16 * q + 4 * lg;
+      const float4 a = a_frag<VEC, CAT>(g, ra0, ra1, row, k, K);
+      float4 w[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) w[t] = w_frag<VEC, BCM>(g, rb, nb + 16 * t + lr, k, K);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = mfma16(f4(w[t], i), f4(a, i), acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) epi_store<MODE>(g, e[t], acc[t], m, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+  }
+  if (MODE == 1) stats_flush<NTW, 4>(g, nb, ssum, ssq);
+}
+
+// ------------------------------------------------------------------------------------------
+// dispatch of the forward / dgrad kernels
+// ------------------------------------------------------------------------------------------
+// variants: 0 vec, 1 vec + concatenated A (forward of the FP modules), 2 vec + column-major W (dgrad), 3 scalar loads,
+// 4 scalar loads + column-major W
+template <int NT, int KQ, int MODE>
+static void launch_rs(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 1: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 2: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    case 3: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    default: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+  }
+}
+
+template <int NT, int KQ>
+static void launch_rs_mode(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (mode == 1) launch_rs<NT, KQ, 1>(g, variant, grid, st, cvec);
+  else if (mode == 2) launch_rs<NT, KQ, 2>(g, variant, grid, st, cvec);
+  else launch_rs<NT, KQ, 0>(g, variant, grid, st, cvec);
+}
+
+template <int NT>
+static void launch_rowstream(const GemmArgs& g, int mode, int KQ, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (KQ == 1) launch_rs_mode<NT, 1>(g, mode, variant, grid, st, cvec);
+  else if (KQ == 2) launch_rs_mode<NT, 2>(g, mode, variant, grid, st, cvec);
+  else launch_rs_mode<NT, 4>(g, mode, variant, grid, st, cvec);
+}
+
+template <int NTW, int MODE>
+static void launch_kl(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 1: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 2: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    case 3: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    default: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+  }
+}
+
+template <int NTW>
+static void launch_kloop(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (mode == 1) launch_kl<NTW, 1>(g, variant, grid, st, cvec);
+  else if (mode == 2) launch_kl<NTW, 2>(g, variant, grid, st, cvec);
+  else launch_kl<NTW, 0>(g, variant, grid, st, cvec);
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// launch geometry of the forward / dgrad kernels (shared with m3d_gemm_direct_stat_parts)
+struct RowPlan { int rowstream, NT, KQ; int64_t wgs, slices; };
+static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
+  RowPlan p;
+  const int64_t ntiles = m3d_cdiv(M, 16);
+  const int ncol16 = (int)m3d_cdiv(N, 16);
+  p.rowstream = K <= 64;
+  p.KQ = K <= 16 ? 1 : (K <= 32 ? 2 : 4);
+  if (p.rowstream) {
+    int NT = ncol16 >= 4 ? 4 : (ncol16 >= 2 ? 2 : 1);
+    while (NT > 1 && NT * p.KQ > 8) NT >>= 1;          // <= 8 weight float4 (32 VGPRs) per lane
+    if (mode != 0 && NT == 4 && p.KQ >= 2) NT = 2;      // statistics / affine registers on top: stay <= 128 VGPRs
+    p.NT = NT;
+  } else {
+    // K > 64: pick the per-wave column slice so that ~4096 waves exist
+    const int64_t units = ntiles * ncol16;
+    p.NT = units >= 16384 ? 4 : (units >= 4096 ? 2 : 1);
+  }
+  p.slices = m3d_cdiv(ncol16, p.NT);
+  // ~4096 waves to fill 1024 SIMDs, at most 16 tiles per wave
+  int64_t wgs = m3d_cdiv(ntiles, 4);
+  int64_t cap = 1024 / p.slices;
+  if (cap < m3d_cdiv(ntiles, 64)) cap = m3d_cdiv(ntiles, 64);
+  if (cap < 1) cap = 1;
+  if (wgs > cap) wgs = cap;
+  if (wgs < 1) wgs = 1;
+  p.wgs = wgs;
+  return p;
+}
+
+int m3d_gemm_direct_stat_parts(int64_t M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  return (int)plan_rows(M, N, K, 1).wgs;
+}
+
+int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
+  const int K = g.k0 + g.k1;
+  // debugging aid: M3D_GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
+  static const int disable = getenv("M3D_GEMM_DISABLE") ? atoi(getenv("M3D_GEMM_DISABLE")) : 0;
+  if (g.a_cm || g.accumulate || g.splitk > 1) return 1;  // column-major A / split-K: the LDS-tiled kernel
+  if ((disable & 2) && K <= 64) return 1;
+  if ((disable & 4) && K > 64) return 1;
+  if ((disable & 8) && g.stat_part) return 1;
+  const bool affine = g.scale || g.shift || g.act;
+  if (g.stat_part && affine) return 1;
+  const int mode = g.stat_part ? 1 : (affine ? 2 : 0);
+  // vector loads: every fragment is one aligned float4
+  const bool vec = ((g.lda0 & 3) == 0) && ((g.k0 & 3) == 0) && al16(g.a0) &&
+                   (g.k1 == 0 || (((g.lda1 & 3) == 0) && ((g.k1 & 3) == 0) && al16(g.a1))) &&
+                   (g.b_cm || (((g.ldb & 3) == 0) && al16(g.b)));
+  const int cvec = ((g.ldc & 3) == 0) && al16(g.c) && ((g.N & 3) == 0);
+  if (!vec && g.k1 != 0) return 1;       // the scalar variant reads a single A operand
+  if (g.b_cm && (g.k1 != 0 || mode != 0)) return 1;  // column-major W is the dgrad pattern only
+  // 32-bit byte offsets inside 2 GiB buffer descriptors (a gathered A0 is assumed no larger than A1 / C rows)
+  const int64_t lim = (int64_t)M3D_BUF_BYTES - 64;
+  if (g.M * g.lda0 * 4 > lim || (g.k1 > 0 && g.M * g.lda1 * 4 > lim) || (int64_t)(g.b_cm ? K : g.N) * g.ldb * 4 > lim)
+    return 1;
+  const int variant = vec ? (g.b_cm ? 2 : (g.k1 > 0 ? 1 : 0)) : (g.b_cm ? 4 : 3);
+  const RowPlan rp = plan_rows(g.M, g.N, K, mode);
+  if (rp.slices > 65535) return 1;
+  dim3 grid((unsigned)rp.wgs, (unsigned)rp.slices);
+  if (rp.rowstream) {
+    if (rp.NT == 4) launch_rowstream<4>(g, mode, rp.KQ, variant, grid, st, cvec);
+    else if (rp.NT == 2) launch_rowstream<2>(g, mode, rp.KQ, variant, grid, st, cvec);
+    else launch_rowstream<1>(g, mode, rp.KQ, variant, grid, st, cvec);
+  } else {
+    if (rp.NT == 4) launch_kloop<4>(g, mode, variant, grid, st, cvec);
+    else if (rp.NT == 2) launch_kloop<2>(g, mode, variant, grid, st, cvec);
+    else launch_kloop<1>(g, mode, variant, grid, st, cvec);
+  }
+  return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// m3d_linear_wgrad_f32: dW[N, k0+k1] (+)= dZ[M,N]^T [X0[rows] | X1]
+// MFMA A operand = dZ^T (i = n, kk = row), B operand = X (kk = row, j = k): per 4-row step a lane loads one dword
+// of dZ and one of X per tile (16 consecutive lanes = 64 contiguous bytes of a row).  The concatenation / row
+// gather of the FP modules is read in place.  Row splits do not meet in same-address atomics: split s stores its
+// [N, K] partial into the workspace and wgrad_reduce_kernel adds the partials.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dz; int64_t lddz;
+  const float* x0; int64_t ldx0; const int32_t* rows; int k0;
+  const float* x1; int64_t ldx1; int k1;
+  int64_t M; int N;
+  float* dw; int64_t lddw; int accumulate;
+  float* ws;  // [S][N][K] partials (S > 1)
+  int S; int64_t steps_per_split;
+};
+
+template <int TN, int TK>
+struct WgradFrag {
+  float a[TN], b[TK];
+};
+
+// operands of the 4-row step `s` (rows 4s .. 4s+3, this lane: row 4s + lg); buffer loads, no branches
+template <int TN, int TK>
+__device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc_t rz, rsrc_t rx0, rsrc_t rx1, int64_t s,
+                                                        bool live, int nb, int kb, int lr, int lg, int K) {
+  WgradFrag<TN, TK> f;
+  const int64_t m = 4 * s + lg;
+  const bool ok = live && m < g.M;
+  const int64_t mc = ok ? m : 0;
+  int64_t rr = mc;
+  if (g.rows) rr = (int64_t)g.rows[mc];
+  const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
+  const unsigned o0 = (ok && rr >= 0) ? (unsigned)(rr * g.ldx0 * 4) : OOB;
+  const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    const int n = nb + 16 * a + lr;
+    f.a[a] = ld1(rz, (oz != OOB && n < g.N) ? oz + 4u * (unsigned)n : OOB);
+  }
+#pragma unroll
+  for (int b = 0; b < TK; ++b) {
+    const int k = kb + 16 * b + lr;
+    const bool in0 = k < g.k0;
+    // both operands are always read: the one that does not hold column k is OOB (returns 0, no memory access)
+    f.b[b] = ld1(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)k : OOB) +
+             ld1(rx1, (!in0 && k < K && o1 != OOB) ? o1 + 4u * (unsigned)(k - g.k0) : OOB);
+  }
+  return f;
+}
+
+// every WAVE is one row split (no LDS, no barrier: LDS float atomics run at ~1 lane per 3 clocks on gfx950 and
+// made a cross-wave reduction the dominant cost); its [16*TN, 16*TK] partial goes from the accumulators to ws
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void wgrad2_kernel(WgradArgs g) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int K = g.k0 + g.k1;
+  const int nb = blockIdx.y * 16 * TN, kb = blockIdx.z * 16 * TK;
+  const int64_t steps_total = (g.M + 3) >> 2;
+  const int64_t split = (int64_t)blockIdx.x * 4 + wid;
+  if (split >= g.S) return;
+  const int64_t s0 = split * g.steps_per_split;
+  const int64_t s1 = s0 + g.steps_per_split < steps_total ? s0 + g.steps_per_split : steps_total;
+  f32x4 acc[TN][TK];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const rsrc_t rz = mk_rsrc(g.dz), rx0 = mk_rsrc(g.x0), rx1 = mk_rsrc(g.x1);
+
+  // two 4-row steps per trip: 2*(TN+TK) independent loads in flight per lane
+  for (int64_t s = s0; s < s1; s += 2) {
+    const WgradFrag<TN, TK> f0 = wgrad_load<TN, TK>(g, rz, rx0, rx1, s, true, nb, kb, lr, lg, K);
+    const WgradFrag<TN, TK> f1 = wgrad_load<TN, TK>(g, rz, rx0, rx1, s + 1, s + 1 < s1, nb, kb, lr, lg, K);
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f0.a[a], f0.b[b], acc[a][b]);
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f1.a[a], f1.b[b], acc[a][b]);
+  }
+  // D layout: row n = 16a + 4lg + r, col k = 16b + lr  (16 lanes = 64 contiguous bytes per store)
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + 16 * a + 4 * lg + r, k = kb + 16 * b + lr;
+        if (n < g.N && k < K) {
+          if (g.S > 1) {
+            g.ws[((size_t)split * g.N + n) * K + k] = acc[a][b][r];
+          } else {
+            float* cp = g.dw + (int64_t)n * g.lddw + k;
+            *cp = g.accumulate ? *cp + acc[a][b][r] : acc[a][b][r];
+          }
+        }
+      }
+}
+
+// dw[n][k] (+)= sum_s ws[s][n][k]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int N, int K,
+                                                           float* __restrict__ dw, int64_t lddw, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int E = N * K;
+  if (e >= E) return;
+  const int per = (S + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * per, p1 = min(S, p0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = p0;
+  for (; p + 3 < p1; p += 4) {
+    s0 += ws[(size_t)p * E + e];
+    s1 += ws[(size_t)(p + 1) * E + e];
+    s2 += ws[(size_t)(p + 2) * E + e];
+    s3 += ws[(size_t)(p + 3) * E + e];
+  }
+  for (; p < p1; ++p) s0 += ws[(size_t)p * E + e];
+  const float v = (s0 + s1) + (s2 + s3);
+  float* cp = dw + (int64_t)(e / K) * lddw + (e % K);
+  if (gridDim.y == 1) *cp = accumulate ? *cp + v : v;
+  else if (p1 > p0) atomicAdd(cp, v);
+}
+
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, int64_t ld, int N, int K) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < N * K) p[(int64_t)(e / K) * ld + (e % K)] = 0.f;
+}
+
+struct WgradPlan { int TN, TK; int64_t by, bz, S, spw; };
+static WgradPlan wgrad_plan(int64_t M, int N, int K) {
+  WgradPlan p;
+  const int tn = (int)m3d_cdiv(N, 16), tk = (int)m3d_cdiv(K, 16);
+  p.TN = tn >= 4 ? 4 : (tn >= 2 ? 2 : 1);
+  p.TK = tk >= 4 ? 4 : (tk >= 2 ? 2 : 1);
+  p.by = m3d_cdiv(N, 16 * p.TN);
+  p.bz = m3d_cdiv(K, 16 * p.TK);
+  const int64_t steps_total = m3d_cdiv(M, 4);
+  static const int target = getenv("M3D_WGRAD_WAVES") ? atoi(getenv("M3D_WGRAD_WAVES")) : 2048;
+  int64_t S = m3d_cdiv(target, p.by * p.bz);  // ~2048 waves, each one row split
+  if (S > steps_total / 8) S = steps_total / 8;  // >= 8 steps (32 rows) per wave
+  if (S < 1) S = 1;
+  p.spw = m3d_cdiv(steps_total > 0 ? steps_total : 1, S);
+  p.S = m3d_cdiv(steps_total > 0 ? steps_total : 1, p.spw);
+  return p;
+}
+
+extern "C" size_t m3d_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const WgradPlan p = wgrad_plan(M, N, K);
+  return p.S > 1 ? (size_t)p.S * N * K * sizeof(float) : 0;
+}
+
+template <int TN>
+static void launch_wgrad2(const WgradArgs& g, int TK, dim3 grid, hipStream_t st) {
+  switch (TK) {
+    case 1: hipLaunchKernelGGL((wgrad2_kernel<TN, 1>), grid, dim3(256), 0, st, g); break;
+    case 2: hipLaunchKernelGGL((wgrad2_kernel<TN, 2>), grid, dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((wgrad2_kernel<TN, 4>), grid, dim3(256), 0, st, g); break;
+  }
+}
+
+extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* x0, int64_t ldx0,
+                                    const int32_t* x0_rows, int32_t k0, const float* x1, int64_t ldx1, int32_t k1,
+                                    int64_t M, int32_t N, float* dw, int64_t lddw, int32_t accumulate, void* ws,
+                                    void* stream) {
+  if (M < 0 || N < 0 || k0 < 0 || k1 < 0) return M3D_ERR_INVALID;
+  const int K = k0 + k1;
+  if (N == 0 || K == 0) return M3D_OK;
+  if (!dw) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (!accumulate) hipLaunchKernelGGL(zero_rows_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, dw, lddw, N, K);
+    M3D_CHECK_LAUNCH();
+    return M3D_OK;
+  }
+  if (!dz || k0 < 1 || !x0 || (k1 > 0 && !x1)) return M3D_ERR_INVALID;
+  const WgradPlan p = wgrad_plan(M, N, K);
+  if (p.S > 1 && !ws) return M3D_ERR_INVALID;
+  if (p.by > 65535 || p.bz > 65535) return M3D_ERR_UNSUPPORTED;
+  {  // 32-bit byte offsets inside 2 GiB buffer descriptors
+    const int64_t lim = (int64_t)M3D_BUF_BYTES - 64;
+    if (M * lddz * 4 > lim || M * ldx0 * 4 > lim || (k1 > 0 && M * ldx1 * 4 > lim)) return M3D_ERR_UNSUPPORTED;
+  }
+  WgradArgs g;
+  g.dz = dz; g.lddz = lddz; g.x0 = x0; g.ldx0 = ldx0; g.rows = x0_rows; g.k0 = k0; g.x1 = x1; g.ldx1 = ldx1; g.k1 = k1;
+  g.M = M; g.N = N; g.dw = dw; g.lddw = lddw; g.accumulate = accumulate; g.ws = (float*)ws; g.S = (int)p.S;
+  g.steps_per_split = p.spw;
+  dim3 grid((unsigned)m3d_cdiv(p.S, 4), (unsigned)p.by, (unsigned)p.bz);
+  if (p.TN == 4) launch_wgrad2<4>(g, p.TK, grid, st);
+  else if (p.TN == 2) launch_wgrad2<2>(g, p.TK, grid, st);
+  else launch_wgrad2<1>(g, p.TK, grid, st);
+  if (p.S > 1) {
+    const int E = N * K;
+    const int gx = (E + 255) / 256;
+    int gy = (int)(p.S / 16);  // >= 16 partials per chunk
+    if (gy > 2048 / gx) gy = 2048 / gx;
+    if (gy < 1) gy = 1;
+    if (gy > 1 && !accumulate) hipLaunchKernelGGL(zero_rows_kernel, dim3(gx), dim3(256), 0, st, dw, lddw, N, K);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, (const float*)ws, (int)p.S, N, K, dw, lddw,
+                       accumulate);
+  }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

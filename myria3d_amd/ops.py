@@ -80,13 +80,17 @@ def gemm(a0: Tensor, b: Tensor, M: int, N: int, k0: int, *, lda0: Optional[int] 
     lda1 = lda1 if lda1 is not None else (a1.stride(0) if a1 is not None else 0)
     ldb = ldb if ldb is not None else b.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
-    s_sum = s_sq = None
-    if stats is not None:
-        s_sum, s_sq = stats[0].data_ptr(), stats[1].data_ptr()
     call("m3d_gemm_f32", _p(a0), lda0, int(a_cm), _p(rows), k0, _p(a1), lda1, k1, _p(b), ldb, int(b_cm), M, N,
-         _p(bias), _p(scale), _p(shift), int(act), LRELU_SLOPE, s_sum, s_sq, _p(out), ldc, int(accumulate), splitk,
-         _st())
+         _p(bias), _p(scale), _p(shift), int(act), LRELU_SLOPE, _p(stats), 0 if stats is None else stats.shape[0],
+         _p(out), ldc, int(accumulate), splitk, _st())
     return out
+
+
+def stat_buffer(M: int, N: int, K: int, device) -> Tensor:
+    """fp64 ``[parts, 2, N]`` buffer for the train-mode BatchNorm statistics of a ``[M,K] x [N,K]^T`` GEMM: every
+    row-workgroup of the GEMM stores its partial column sums / sums of squares (no zero-fill, no atomics) and
+    ``bn_finalize`` adds the rows."""
+    return torch.empty((lib().m3d_gemm_stat_parts(M, N, K), 2, N), dtype=torch.float64, device=device)
 
 
 def _splitk_for(red: int, m: int, n: int) -> int:
@@ -103,22 +107,17 @@ def linear_dgrad(dz: Tensor, w: Tensor) -> Tensor:
 
 def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None, x1: Optional[Tensor] = None,
                  k1: int = 0, out: Optional[Tensor] = None) -> Optional[Tensor]:
-    """dW[N, k0+k1] = dZ^T [X0[rows] | X1]; the reduction over the M rows is split across workgroups.
-    ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a slice of the flat gradient buffer) that is added to;
-    nothing is returned then."""
+    """dW[N, k0+k1] = dZ^T [X0[rows] | X1] (``m3d_linear_wgrad_f32``): the reduction over the M rows is split across
+    workgroups whose partials meet in a workspace.  ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a
+    slice of the flat gradient buffer) that is added to; nothing is returned then."""
     M, N = dz.shape
+    K = k0 + k1
     sink = out is not None
-    dw = out if sink else torch.zeros((N, k0 + k1), dtype=torch.float32, device=dz.device)
-    if M == 0:
-        return None if sink else dw
-    if rows is not None:
-        x0 = gather_rows(x0, rows)
-    for xs, off, kk in ((x0, 0, k0), (x1, k0, k1)):
-        if kk == 0:
-            continue
-        # C[N, kk] += A[N, M] B[kk, M]^T with A = dZ^T, B = Xs^T, both "column-major" views of row-major data
-        gemm(dz, xs, N, kk, M, lda0=dz.stride(0), a_cm=True, b_cm=True, ldb=xs.stride(0), out=dw[:, off:],
-             ldc=dw.stride(0), accumulate=True, splitk=_splitk_for(M, N, kk))
+    dw = out if sink else torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    nbytes = lib().m3d_linear_wgrad_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dz.device) if nbytes else None
+    call("m3d_linear_wgrad_f32", _p(dz), dz.stride(0), _p(x0), x0.stride(0), _p(rows), k0, _p(x1),
+         x1.stride(0) if x1 is not None else 0, k1, M, N, _p(dw), dw.stride(0), int(sink), _p(ws), _st())
     return None if sink else dw
 
 
@@ -168,13 +167,14 @@ def bn_fold_eval(bn: torch.nn.BatchNorm1d) -> Tuple[Tensor, Tensor]:
 
 
 def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
-    """mean/invstd/(scale, shift) from the fp64 column sums; updates the running statistics in place."""
+    """mean/invstd/(scale, shift) from the fp64 partial column sums (``stat_buffer``); updates the running statistics
+    in place."""
     if count < 2:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [{count}, {bn.num_features}]")
     n = bn.num_features
     dev = stats.device
     scale, shift, mean, invstd = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
-    call("m3d_bn_finalize", stats[0].data_ptr(), stats[1].data_ptr(), count, _p(bn.weight), _p(bn.bias),
+    call("m3d_bn_finalize", _p(stats), stats.shape[0], count, _p(bn.weight), _p(bn.bias),
          float(bn.eps), float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean),
          _p(invstd), n, _st())
     bn.num_batches_tracked += 1
@@ -252,7 +252,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
         N = w.shape[0]
         k0 = x0.shape[1]
         k1 = x1.shape[1] if x1 is not None else 0
-        stats = torch.zeros((2, N), dtype=torch.float64, device=w.device)
+        stats = stat_buffer(M, N, k0 + k1, w.device)
         z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats)
         scale, shift, mean, invstd = bn_finalize(stats, M, bn)
         y = bn_apply(z, scale, shift, act)
@@ -290,8 +290,8 @@ class ResidualTailTrainFn(torch.autograd.Function):
     def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None):
         ctx.sinks = (sinks2, sinkss) if sinks2 is not None else None
         M, N = x2.shape[0], w2.shape[0]
-        st2 = torch.zeros((2, N), dtype=torch.float64, device=w2.device)
-        sts = torch.zeros((2, N), dtype=torch.float64, device=w2.device)
+        st2 = stat_buffer(M, N, x2.shape[1], w2.device)
+        sts = stat_buffer(M, N, xs.shape[1], w2.device)
         z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2)
         zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts)
         sc2, sh2, mu2, is2 = bn_finalize(st2, M, bn2)

@@ -81,7 +81,8 @@ def test_knn_k32_and_cross_set(device):
 
 # ----------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,K,N", [(1000, 9, 32), (777, 32, 4), (513, 64, 128), (300, 768, 256), (100, 32, 6),
-                                   (65, 10, 8), (2, 512, 512)])
+                                   (65, 10, 8), (2, 512, 512), (20000, 32, 32), (5000, 64, 64), (4099, 16, 16),
+                                   (3000, 160, 32), (1000, 256, 512), (70000, 8, 8), (33, 48, 20)])
 def test_gemm_forward(device, M, K, N):
     from myria3d_amd import ops
 
@@ -92,8 +93,10 @@ def test_gemm_forward(device, M, K, N):
     sc = torch.from_numpy(rs.uniform(0.5, 1.5, (N,)).astype(np.float32))
     sh = torch.from_numpy(rs.uniform(-1, 1, (N,)).astype(np.float32))
     ref = a.double() @ w.double().t() + b.double()
-    stats = torch.zeros((2, N), dtype=torch.float64, device=device)
+    stats = ops.stat_buffer(M, N, K, device)
+    stats.fill_(float("nan"))  # must be fully overwritten
     got = ops.gemm(a.to(device), w.to(device), M, N, K, bias=b.to(device), stats=stats)
+    stats = stats.sum(0)
     # fp32 MFMA == fmaf chain; error bound ~ K * eps * sum|a||w|
     _close("gemm", got, ref, 1e-5, 2e-6 * K)
     # the statistics are those of the fp32 outputs: allow M * eps_f32 * |z|max (and its square) of rounding
@@ -104,6 +107,25 @@ def test_gemm_forward(device, M, K, N):
                     act=True)
     ref2 = torch.nn.functional.leaky_relu(ref * sc.double() + sh.double(), 0.2)
     _close("gemm.affine_lrelu", got2, ref2, 1e-5, 4e-6 * K)
+
+
+@pytest.mark.parametrize("M,N,K", [(30000, 32, 32), (1001, 6, 32), (777, 32, 9), (1000, 128, 200), (4096, 64, 16),
+                                   (3, 512, 768), (12800, 4, 32), (5, 8, 8)])
+def test_wgrad_and_dgrad(device, M, N, K):
+    """dW = dZ^T X (rows split over workgroups, atomically combined) and dX = dZ W, vs fp64."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M + N + K)
+    dz = torch.from_numpy(rs.uniform(-1, 1, (M, N)).astype(np.float32))
+    x = torch.from_numpy(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+    dw = ops.linear_wgrad(dz.to(device), x.to(device), K)
+    _close("wgrad", dw, dz.double().t() @ x.double(), 1e-5, 3e-6 * np.sqrt(M) + 2e-7 * M)
+    sink = torch.ones((N, K), device=device)
+    assert ops.linear_wgrad(dz.to(device), x.to(device), K, out=sink) is None
+    _close("wgrad.sink", sink, 1.0 + dz.double().t() @ x.double(), 1e-5, 3e-6 * np.sqrt(M) + 2e-7 * M)
+    dx = ops.linear_dgrad(dz.to(device), w.to(device))
+    _close("dgrad", dx, dz.double() @ w.double(), 1e-5, 2e-6 * N)
 
 
 def test_gemm_gather_concat_and_transposes(device):
