@@ -34,15 +34,21 @@ int m3d_abi_version(void);
  * knn_interpolate(k=10) (myria3d/models/model.py:90-98).  Exact; squared-L2 within each cloud; self included;
  * ascending by (d2, source index).  k <= 64. */
 size_t m3d_knn_workspace_bytes(int64_t n_src, int32_t num_clouds);
+/* byte offset, inside a built workspace, of the cell-sorted arrays: which = 0: float4 [n_src] (x, y, z, bits of the
+ * original row); 1: perm int32 [n_src] (sorted slot -> original row); 2: inv int32 [n_src] (original row -> slot).
+ * Cell-sorted order is the spatially coherent order the net works in internally. */
+size_t m3d_knn_workspace_offset(int64_t n_src, int32_t num_clouds, int32_t which);
 /* builds the per-cloud search grid over the SOURCE points into ws */
 int m3d_knn_build(const float* pos_src, int32_t pos_stride /* floats per row, >= 3 */, const int64_t* ptr_src,
                   int32_t num_clouds, int64_t n_src, void* ws, void* stream);
 /* queries: either pos_qry rows (row q -> idx_out[q]) or, if qry_ws != NULL, the points of another built
  * workspace in its cell-sorted order (wave-coherent; each record carries its original row).  Self-kNN =
- * qry_ws == ws.  d2_out may be NULL. */
-int m3d_knn_query(const void* ws, const int64_t* ptr_src, int32_t num_clouds, const float* pos_qry,
+ * qry_ws == ws.  d2_out may be NULL.  sorted_io != 0 (needs qry_ws): output row = the query's cell-sorted slot and
+ * neighbour ids = cell-sorted slots of the source workspace (selection and tie-breaking stay on original rows). */
+int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds, const float* pos_qry,
                   int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
-                  int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */, void* stream);
+                  int32_t sorted_io, int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */,
+                  void* stream);
 
 /* ---- SharedMLP GEMM -------------------------------------------------------------------------------------
  * Linear of PyG MLP / torch.nn.Linear (pyg_randla_net.py:42,53,97-109), forward, dgrad and wgrad:
@@ -83,8 +89,10 @@ int m3d_bn_fold_eval(const float* gamma, const float* beta, const float* running
 int m3d_bn_apply(const float* z, const float* scale, const float* shift, const float* z2, const float* scale2,
                  const float* shift2, int32_t act, float slope, float* y, int64_t M, int32_t N, void* stream);
 /* backward of m3d_bn_apply in train mode: dz (and dz2), dgamma/dbeta (and dgamma2/dbeta2).
- * sums_ws: fp64 [3*N] scratch (zeroed inside).  accumulate_param_grads != 0: dgamma/dbeta are gradient sinks
+ * sums_ws: m3d_bn_bwd_workspace_bytes(M, N) bytes of scratch (per-block partial column sums, no atomics).
+ * accumulate_param_grads != 0: dgamma/dbeta are gradient sinks
  * (e.g. slices of the flat gradient buffer) and are added to instead of overwritten. */
+size_t m3d_bn_bwd_workspace_bytes(int64_t M, int32_t N);
 int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* z2, const float* scale2, const float* shift2, const float* mean2,
                const float* invstd2, int32_t act, float slope, int64_t M, int32_t N, double* sums_ws, float* dz,
@@ -117,6 +125,8 @@ int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, const float* w 
  * CH in {8,16,32,64,128,256}, K <= 32.  att_w_packed: W_att ([CH,CH] row-major, zero-padded to
  * CHP = max(CH,16)) re-laid as [CHP/16][CHP/16][64 lanes][4]:
  *   packed[nt][s4][lane][i] = W[16*nt + (lane & 15)][4*(4*s4 + i) + (lane >> 4)]. */
+/* packs W_att (and, if packed_t != NULL, W_att^T) into that order: max(CH,16)^2 floats each */
+int m3d_lfa_pack_att(const float* w /* [CH, CH] row-major */, int32_t CH, float* packed, float* packed_t, void* stream);
 int m3d_lfa_fwd(const float* x /* [n, CH/2] */, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
                 int32_t CH, const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
                 float slope, float* out, void* stream);

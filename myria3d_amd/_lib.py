@@ -20,7 +20,8 @@ SIGNATURES = {
     "m3d_abi_version": (_i32, []),
     "m3d_knn_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_knn_build": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p]),
-    "m3d_knn_query": (_i32, [_p, _p, _i32, _p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
+    "m3d_knn_workspace_offset": (C.c_size_t, [_i64, _i32, _i32]),
+    "m3d_knn_query": (_i32, [_p, _p, _i64, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "m3d_gemm_stat_parts": (_i32, [_i64, _i32, _i32]),
     "m3d_gemm_f32": (_i32, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _i32,
                             _f32, _p, _i32, _p, _i64, _i32, _i32, _p]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "m3d_bn_finalize": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
     "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
+    "m3d_bn_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,
                           _p, _p, _i32, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
@@ -38,6 +40,7 @@ SIGNATURES = {
     "m3d_decimation_indices": (_i32, [_p, _p, _i32, _p, _u32, _p, _i64, _p]),
     "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_lfa_pack_att": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
     "m3d_lfa_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),

@@ -150,51 +150,74 @@ __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, 
   return g;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+// grid (row blocks, column passes): block (x, y) owns rows [x*rows_per_block, ...) and 256/rpp float4 column groups.
+// Per-thread fp32 partials over <= ~8 rows (all loads of the unrolled trip in flight), fp64 across threads (LDS),
+// one plain-stored partial row per block: part[x][3][N]  (summed by bn_bwd_finalize_kernel — no atomics).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int rows_per_block, double* __restrict__ part) {
   __shared__ double red[256 * 12];
   const int tid = threadIdx.x;
   const int N4 = a.N / 4;
-  const int CG = N4 < 256 ? N4 : 256;  // column groups handled per pass
+  const int CG = N4 < 256 ? N4 : 256;  // column groups per block
   const int rpp = 256 / CG;            // rows per pass
   const int cg = tid % CG, rl = tid / CG;
-  for (int cb = 0; cb < N4; cb += CG) {
-    const int c4 = cb + cg;
-    double s[12];
+  const int c4 = blockIdx.y * CG + cg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < a.M ? r0 + rows_per_block : a.M;
+  float s[12];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) s[j] = 0.0;
-    if (rl < rpp && c4 < N4) {
-      const int c = c4 * 4;
-      float4 mu = *(const float4*)(a.mean + c), is = *(const float4*)(a.invstd + c);
-      float4 mu2 = make_float4(0, 0, 0, 0), is2 = make_float4(0, 0, 0, 0);
-      if (a.z2) { mu2 = *(const float4*)(a.mean2 + c); is2 = *(const float4*)(a.invstd2 + c); }
-      for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < a.M; r += (int64_t)gridDim.x * rpp) {
-        int64_t i = r * N4 + c4;
-        float4 zv = ((const float4*)a.z)[i];
-        float4 z2v = make_float4(0, 0, 0, 0);
-        if (a.z2) z2v = ((const float4*)a.z2)[i];
-        float4 g = bn_dact(a, i, c, zv, z2v);
-        s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-        s[4] += (double)(g.x * ((zv.x - mu.x) * is.x)); s[5] += (double)(g.y * ((zv.y - mu.y) * is.y));
-        s[6] += (double)(g.z * ((zv.z - mu.z) * is.z)); s[7] += (double)(g.w * ((zv.w - mu.w) * is.w));
-        if (a.z2) {
-          s[8] += (double)(g.x * ((z2v.x - mu2.x) * is2.x)); s[9] += (double)(g.y * ((z2v.y - mu2.y) * is2.y));
-          s[10] += (double)(g.z * ((z2v.z - mu2.z) * is2.z)); s[11] += (double)(g.w * ((z2v.w - mu2.w) * is2.w));
-        }
+  for (int j = 0; j < 12; ++j) s[j] = 0.f;
+  if (rl < rpp && c4 < N4) {
+    const int c = c4 * 4;
+    const float4 mu = *(const float4*)(a.mean + c), is = *(const float4*)(a.invstd + c);
+    float4 mu2 = make_float4(0, 0, 0, 0), is2 = make_float4(0, 0, 0, 0);
+    if (a.z2) { mu2 = *(const float4*)(a.mean2 + c); is2 = *(const float4*)(a.invstd2 + c); }
+#pragma unroll 4
+    for (int64_t r = r0 + rl; r < r1; r += rpp) {
+      const int64_t i = r * N4 + c4;
+      const float4 zv = ((const float4*)a.z)[i];
+      float4 z2v = make_float4(0, 0, 0, 0);
+      if (a.z2) z2v = ((const float4*)a.z2)[i];
+      const float4 g = bn_dact(a, i, c, zv, z2v);
+      s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+      s[4] += g.x * ((zv.x - mu.x) * is.x); s[5] += g.y * ((zv.y - mu.y) * is.y);
+      s[6] += g.z * ((zv.z - mu.z) * is.z); s[7] += g.w * ((zv.w - mu.w) * is.w);
+      if (a.z2) {
+        s[8] += g.x * ((z2v.x - mu2.x) * is2.x); s[9] += g.y * ((z2v.y - mu2.y) * is2.y);
+        s[10] += g.z * ((z2v.z - mu2.z) * is2.z); s[11] += g.w * ((z2v.w - mu2.w) * is2.w);
       }
     }
-    __syncthreads();
+  }
 #pragma unroll
-    for (int j = 0; j < 12; ++j) red[j * 256 + tid] = s[j];
-    __syncthreads();
-    if (rl == 0 && c4 < N4) {
+  for (int j = 0; j < 12; ++j) red[j * 256 + tid] = (double)s[j];
+  __syncthreads();
+  if (rl == 0 && c4 < N4) {
+    double* dst = part + (size_t)blockIdx.x * 3 * a.N;
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        if (j >= 8 && !a.z2) break;
-        double v = 0.0;
+    for (int j = 0; j < 12; ++j) {
+      double v = 0.0;
+      if (j < 8 || a.z2)
         for (int q = 0; q < rpp; ++q) v += red[j * 256 + q * CG + cg];
-        atomicAdd(&a.sums[(size_t)(j / 4) * a.N + c4 * 4 + (j & 3)], v);
-      }
+      dst[(size_t)(j / 4) * a.N + c4 * 4 + (j & 3)] = v;
     }
+  }
+}
+
+// one wave per (which, column): sums[which][n] = sum over the partial rows; also the parameter gradients
+// dbeta = s1, dgamma = s2 (dgamma2 = s3)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(BnBwdArgs a, const double* __restrict__ part, int parts) {
+  const int n = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
+  double v = 0.0;
+  for (int p = lane; p < parts; p += 64) v += part[((size_t)p * 3 + which) * a.N + n];
+  v = wave_sum_d(v);
+  if (lane != 0) return;
+  a.sums[(size_t)which * a.N + n] = v;
+  if (which == 0) {
+    if (a.dbeta) a.dbeta[n] = (a.acc_pg ? a.dbeta[n] : 0.f) + (float)v;
+    if (a.z2 && a.dbeta2) a.dbeta2[n] = (a.acc_pg ? a.dbeta2[n] : 0.f) + (float)v;
+  } else if (which == 1) {
+    if (a.dgamma) a.dgamma[n] = (a.acc_pg ? a.dgamma[n] : 0.f) + (float)v;
+  } else if (a.z2 && a.dgamma2) {
+    a.dgamma2[n] = (a.acc_pg ? a.dgamma2[n] : 0.f) + (float)v;
   }
 }
 
@@ -203,16 +226,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const int N4 = a.N / 4;
   const int64_t total4 = a.M * N4;
   const double invM = 1.0 / (double)a.M;
-  if (blockIdx.x == 0) {
-    for (int n = threadIdx.x; n < a.N; n += 256) {
-      if (a.dbeta) a.dbeta[n] = (a.acc_pg ? a.dbeta[n] : 0.f) + (float)a.sums[n];
-      if (a.dgamma) a.dgamma[n] = (a.acc_pg ? a.dgamma[n] : 0.f) + (float)a.sums[a.N + n];
-      if (a.z2) {
-        if (a.dbeta2) a.dbeta2[n] = (a.acc_pg ? a.dbeta2[n] : 0.f) + (float)a.sums[n];
-        if (a.dgamma2) a.dgamma2[n] = (a.acc_pg ? a.dgamma2[n] : 0.f) + (float)a.sums[2 * (size_t)a.N + n];
-      }
-    }
-  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % N4) * 4;
     float4 zv = ((const float4*)a.z)[i];
@@ -247,6 +260,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   }
 }
 
+struct BnBwdPlan { int64_t blocks, rows_per_block, passes; };
+static BnBwdPlan bn_bwd_plan(int64_t M, int N) {
+  BnBwdPlan p;
+  const int N4 = N / 4;
+  const int CG = N4 < 256 ? N4 : 256;
+  const int rpp = 256 / CG;
+  p.passes = m3d_cdiv(N4, CG);
+  int64_t blocks = m3d_cdiv(M, (int64_t)rpp * 8);  // ~8 rows per thread
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  p.rows_per_block = m3d_align(m3d_cdiv(M, blocks), rpp);
+  p.blocks = m3d_cdiv(M, p.rows_per_block);
+  return p;
+}
+
+extern "C" size_t m3d_bn_bwd_workspace_bytes(int64_t M, int32_t N) {
+  if (M <= 0 || N <= 0 || (N % 4)) return 0;
+  return sizeof(double) * 3 * (size_t)N * (size_t)(1 + bn_bwd_plan(M, N).blocks);
+}
+
 extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* z2, const float* scale2, const float* shift2,
                           const float* mean2, const float* invstd2, int32_t act, float slope, int64_t M, int32_t N,
@@ -264,14 +297,13 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   a.dz = dz; a.dz2 = dz2; a.dgamma = dgamma; a.dbeta = dbeta; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2;
   a.acc_pg = accumulate_param_grads;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sums_ws, 0, sizeof(double) * 3 * (size_t)N, st) != hipSuccess) return M3D_ERR_LAUNCH;
+  const BnBwdPlan pl = bn_bwd_plan(M, N);
+  double* part = sums_ws + 3 * (size_t)N;  // sums_ws = [3][N] totals, then [blocks][3][N] partial rows
   const int N4 = N / 4;
-  const int CG = N4 < 256 ? N4 : 256;
-  const int rpp = 256 / CG;
-  int64_t gx = m3d_cdiv(M, (int64_t)rpp * 16);
-  if (gx > 1024) gx = 1024;
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)gx), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)pl.blocks, (unsigned)pl.passes), dim3(256), 0, st, a,
+                     (int)pl.rows_per_block, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)N, z2 ? 3 : 2), dim3(64), 0, st, a, (const double*)part,
+                     (int)pl.blocks);
   int64_t total4 = M * N4;
   int64_t gy = m3d_cdiv(total4, 256 * 4);
   if (gy > 4096) gy = 4096;

@@ -23,13 +23,18 @@
 struct KnnWs {
   float* gridp;     // [B][8]: xmin, ymin, inv_h, h, eps, (int)Gx, (int)Gy, (int)n
   int* cell_start;  // [B][CELLS_MAX + 1]
-  float4* sorted;   // [n_src]
+  float4* sorted;   // [n_src]  (x, y, z, bits of the original row) in cell-sorted order
+  int* perm;        // [n_src]  perm[slot] = original row
+  int* inv;         // [n_src]  inv[original row] = slot
 };
 
 static inline size_t ws_gridp_bytes(int B) { return (size_t)m3d_align((int64_t)B * GP_STRIDE * 4, 256); }
 static inline size_t ws_cells_bytes(int B) { return (size_t)m3d_align((int64_t)B * (CELLS_MAX + 1) * 4, 256); }
 
-static inline KnnWs ws_carve(void* ws, int B) {
+static inline size_t ws_sorted_bytes(int64_t n) { return (size_t)m3d_align(n * (int64_t)sizeof(float4), 256); }
+static inline size_t ws_perm_bytes(int64_t n) { return (size_t)m3d_align(n * (int64_t)sizeof(int), 256); }
+
+static inline KnnWs ws_carve(void* ws, int B, int64_t n) {
   KnnWs w;
   char* p = (char*)ws;
   w.gridp = (float*)p;
@@ -37,12 +42,25 @@ static inline KnnWs ws_carve(void* ws, int B) {
   w.cell_start = (int*)p;
   p += ws_cells_bytes(B);
   w.sorted = (float4*)p;
+  p += ws_sorted_bytes(n);
+  w.perm = (int*)p;
+  p += ws_perm_bytes(n);
+  w.inv = (int*)p;
   return w;
 }
 
 extern "C" size_t m3d_knn_workspace_bytes(int64_t n_src, int32_t num_clouds) {
   if (n_src < 0 || num_clouds < 0) return 0;
-  return ws_gridp_bytes(num_clouds) + ws_cells_bytes(num_clouds) + (size_t)n_src * sizeof(float4) + 256;
+  return ws_gridp_bytes(num_clouds) + ws_cells_bytes(num_clouds) + ws_sorted_bytes(n_src) + 2 * ws_perm_bytes(n_src) + 256;
+}
+
+// byte offsets of the cell-sorted arrays inside a built workspace: which = 0 sorted float4 [n] (x, y, z, row bits),
+// 1 perm int32 [n] (slot -> original row), 2 inv int32 [n] (original row -> slot)
+extern "C" size_t m3d_knn_workspace_offset(int64_t n_src, int32_t num_clouds, int32_t which) {
+  size_t o = ws_gridp_bytes(num_clouds) + ws_cells_bytes(num_clouds);
+  if (which >= 1) o += ws_sorted_bytes(n_src);
+  if (which >= 2) o += ws_perm_bytes(n_src);
+  return o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -148,6 +166,8 @@ __global__ __launch_bounds__(1024) void knn_build_kernel(const float* __restrict
     int cy = min(Gy - 1, max(0, (int)((y - gy0) * inv_h)));
     int slot = atomicAdd(&cnt[cy * Gx + cx], 1);
     w.sorted[s0 + slot] = make_float4(x, y, z, __int_as_float((int)(s0 + i)));
+    w.perm[s0 + slot] = (int)(s0 + i);
+    w.inv[s0 + i] = (int)(s0 + slot);
   }
 }
 
@@ -204,7 +224,8 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
                                                         const float* __restrict__ pos_qry, int qstride,
                                                         const float4* __restrict__ qsorted,
                                                         const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
-                                                        int* __restrict__ idx_out, float* __restrict__ d2_out) {
+                                                        int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                        int sorted_io) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_qry) return;
   // cloud of this query: largest b with ptr_qry[b] <= t
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
   int64_t orow;
   if (qsorted) {
     float4 q = qsorted[t];
-    qx = q.x; qy = q.y; qz = q.z; orow = (int64_t)__float_as_int(q.w);
+    qx = q.x; qy = q.y; qz = q.z; orow = sorted_io ? t : (int64_t)__float_as_int(q.w);
   } else {
     const float* p = pos_qry + t * qstride;
     qx = p[0]; qy = p[1]; qz = p[2]; orow = t;
@@ -270,7 +291,9 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
   for (int j = 0; j < KMAX; ++j) {
     if (j < k) {
       bool ok = best[j] != ~0ull;
-      io[j] = ok ? (int)(unsigned)(best[j] & 0xffffffffull) : -1;
+      int id = ok ? (int)(unsigned)(best[j] & 0xffffffffull) : -1;
+      if (sorted_io && ok) id = w.inv[id];  // neighbours selected by (d2, original row); reported as cell-sorted slots
+      io[j] = id;
       if (d2_out) d2_out[orow * k + j] = ok ? __uint_as_float((unsigned)(best[j] >> 32)) : __builtin_inff();
     }
   }
@@ -281,28 +304,30 @@ extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int
   if (!ptr_src || !ws || num_clouds < 0 || n_src < 0 || pos_stride < 3) return M3D_ERR_INVALID;
   if (num_clouds == 0) return M3D_OK;
   if (!pos_src && n_src > 0) return M3D_ERR_INVALID;
-  KnnWs w = ws_carve(ws, num_clouds);
+  KnnWs w = ws_carve(ws, num_clouds, n_src);
   hipLaunchKernelGGL(knn_build_kernel, dim3(num_clouds), dim3(1024), 0, (hipStream_t)stream, pos_src, pos_stride,
                      ptr_src, w);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
 
-extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int32_t num_clouds, const float* pos_qry,
-                             int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
-                             int32_t* idx_out, float* d2_out, void* stream) {
+extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds,
+                             const float* pos_qry, int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry,
+                             int64_t n_qry, int32_t k, int32_t sorted_io, int32_t* idx_out, float* d2_out,
+                             void* stream) {
   if (!ws || !ptr_src || !ptr_qry || !idx_out || num_clouds < 0 || n_qry < 0) return M3D_ERR_INVALID;
   if (k < 1 || k > 64) return M3D_ERR_UNSUPPORTED;  // upstream CUDA kNN asserts k <= 100
   if (!pos_qry && !qry_ws && n_qry > 0) return M3D_ERR_INVALID;
   if (pos_qry && qry_stride < 3) return M3D_ERR_INVALID;
+  if (sorted_io && !qry_ws) return M3D_ERR_INVALID;  // sorted rows are defined by the query workspace
   if (n_qry == 0 || num_clouds == 0) return M3D_OK;
-  KnnWs w = ws_carve((void*)ws, num_clouds);
-  const float4* qs = qry_ws ? ws_carve((void*)qry_ws, num_clouds).sorted : nullptr;
+  KnnWs w = ws_carve((void*)ws, num_clouds, n_src);
+  const float4* qs = qry_ws ? ws_carve((void*)qry_ws, num_clouds, n_qry).sorted : nullptr;
   dim3 grid((unsigned)m3d_cdiv(n_qry, 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(KM)                                                                                              \
   hipLaunchKernelGGL(knn_query_kernel<KM>, grid, block, 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, qs, \
-                     ptr_qry, n_qry, k, idx_out, d2_out)
+                     ptr_qry, n_qry, k, idx_out, d2_out, sorted_io)
   if (k == 1) LAUNCH(1);
   else if (k <= 4) LAUNCH(4);
   else if (k <= 8) LAUNCH(8);

@@ -27,8 +27,13 @@
 #include "lfa_common.h"
 #include "../../include/m3d_hip.h"
 
-template <int CHP, int KP>
+// CH is a template parameter: with a runtime channel count the index arithmetic of the gather / encoder loops
+// (f / D4, f % D4, ...) compiled to integer divisions and made the ch <= 32 kernels VALU-issue-bound
+// (rocprofv3 SQ_INSTS_VALU: 650 VALU instructions per wave of 64 edges at ch = 16).
+template <int CH, int KP>
 __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
+  constexpr int CHP = CH < 16 ? 16 : CH;
+  constexpr int D = CH / 2;
   constexpr int ROWS = LfaCfg<CHP>::ROWS;
   constexpr int TC = ROWS / KP;          // centres per workgroup
   constexpr int KT = KP / 16;            // MFMA M-tiles per centre
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int D = a.D, CH = a.CH, K = a.K;
+  const int K = a.K;
   const int64_t c0 = (int64_t)blockIdx.x * TC;
 
   // ---- phase 1a: neighbour ids
@@ -57,10 +62,11 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   __syncthreads();
   // ---- phase 1b: gather x_j into F[:, 0:D]; zero the padding columns (only when CH < CHP)
   {
-    const int D4 = D >> 2;
+    constexpr int D4 = D >> 2;
+#pragma unroll
     for (int f = tid; f < ROWS * D4; f += 256) {
-      int e = f / D4, c4 = f % D4;
-      int j = nbr[e];
+      const int e = f / D4, c4 = f % D4;
+      const int j = nbr[e];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
       float* d = &F[e * STR + c4 * 4];
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
       *(float2*)(d + 2) = make_float2(v.z, v.w);
     }
     if (CH < CHP) {
-      const int P = CHP - CH;
+      constexpr int P = CHP - CH;
       for (int f = tid; f < ROWS * P; f += 256) F[(f / P) * STR + CH + (f % P)] = 0.f;
     }
   }
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
     constexpr int NG = 256 / ROWS;
     const int e = tid % ROWS;
     const int grp = __builtin_amdgcn_readfirstlane(tid / ROWS);
-    const int DG = D / NG;
+    constexpr int DG = D / NG;
     const int j = nbr[e];
     const int64_t i = c0 + e / KP;
     float r[10];
@@ -159,13 +165,13 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   }
 }
 
-template <int CHP>
+template <int CH>
 static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st) {
-  constexpr int ROWS = LfaCfg<CHP>::ROWS;
+  constexpr int ROWS = LfaCfg<(CH < 16 ? 16 : CH)>::ROWS;
   if (a.K <= 16) {
-    hipLaunchKernelGGL((lfa_fwd_kernel<CHP, 16>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((lfa_fwd_kernel<CHP, 32>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 32>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
   return M3D_OK;
@@ -185,12 +191,38 @@ extern "C" int m3d_lfa_fwd(const float* x, const float* pos4, const int32_t* idx
   a.wp = (const float4*)att_w_packed; a.out = out; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
   hipStream_t st = (hipStream_t)stream;
   switch (CH) {
-    case 8: case 16: return launch_lfa_fwd<16>(a, st);
+    case 8: return launch_lfa_fwd<8>(a, st);
+    case 16: return launch_lfa_fwd<16>(a, st);
     case 32: return launch_lfa_fwd<32>(a, st);
     case 64: return launch_lfa_fwd<64>(a, st);
     case 128: return launch_lfa_fwd<128>(a, st);
     default: return launch_lfa_fwd<256>(a, st);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// W_att [CH,CH] -> MFMA B-fragment order (layout: include/m3d_hip.h), for W and for W^T in one launch
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lfa_pack_att_kernel(const float* __restrict__ w, int CH, int CHP,
+                                                           float* __restrict__ packed, float* __restrict__ packed_t) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= CHP * CHP) return;
+  const int S4 = CHP / 16;
+  const int i = t & 3, lane = (t >> 2) & 63, s4 = (t >> 8) % S4, nt = (t >> 8) / S4;
+  const int row = 16 * nt + (lane & 15), col = 4 * (4 * s4 + i) + (lane >> 4);
+  const bool ok = row < CH && col < CH;
+  packed[t] = ok ? w[row * CH + col] : 0.f;
+  if (packed_t) packed_t[t] = ok ? w[col * CH + row] : 0.f;
+}
+
+extern "C" int m3d_lfa_pack_att(const float* w, int32_t CH, float* packed, float* packed_t, void* stream) {
+  if (CH < 1 || !w || !packed) return M3D_ERR_INVALID;
+  const int CHP = CH < 16 ? 16 : CH;
+  if (CHP % 16) return M3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lfa_pack_att_kernel, dim3((CHP * CHP + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, CH, CHP,
+                     packed, packed_t);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -254,36 +286,42 @@ __device__ __forceinline__ double mom2(const double* mom, int p, int q) {
 //   mean_c = w_c . m + b_c,  var_c = w_c^T (M2/E - m m^T) w_c      (m = S1/E)
 // -> folded weights  wf = scale_c * w_c,  bf = scale_c*(b_c - mean_c) + beta_c,  scale_c = gamma_c/sqrt(var_c+eps)
 // In eval mode (mom == nullptr) the running statistics are used instead.
-__global__ void lfa_enc_finalize_kernel(const double* __restrict__ mom, double E, const float* __restrict__ w,
-                                        const float* __restrict__ b, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, float eps, float momentum,
-                                        float* running_mean, float* running_var, float* wf, float* bf,
-                                        float* mean_out, float* invstd_out, int D) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per encoder channel (the serial 10x10 fp64 loop of a one-thread-per-channel kernel cost ~10 us)
+__global__ __launch_bounds__(64) void lfa_enc_finalize_kernel(const double* __restrict__ mom, double E,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float momentum,
+                                                              float* running_mean, float* running_var, float* wf,
+                                                              float* bf, float* mean_out, float* invstd_out, int D) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= D) return;
   double mean, var;
   if (mom) {
-    double m[10];
-    for (int p = 0; p < 10; ++p) m[p] = mom[p] / E;
-    mean = (double)b[c];
-    for (int p = 0; p < 10; ++p) mean += (double)w[c * 10 + p] * m[p];
-    var = 0.0;
-    for (int p = 0; p < 10; ++p)
-      for (int q = 0; q < 10; ++q)
-        var += (double)w[c * 10 + p] * (double)w[c * 10 + q] * (mom2(mom, p, q) / E - m[p] * m[q]);
+    // lane l: terms (p, q) = l, l + 64 of  w^T (M2/E - m m^T) w;  lanes < 10 also the mean term w_p m_p
+    double pv = 0.0, pm = 0.0;
+    for (int t = lane; t < 100; t += 64) {
+      const int p = t / 10, q = t % 10;
+      pv += (double)w[c * 10 + p] * (double)w[c * 10 + q] * (mom2(mom, p, q) / E - (mom[p] / E) * (mom[q] / E));
+    }
+    if (lane < 10) pm = (double)w[c * 10 + lane] * (mom[lane] / E);
+    var = wave_sum_d(pv);
+    mean = wave_sum_d(pm) + (double)b[c];
     if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * invstd;
+  if (lane < 10) wf[c * 10 + lane] = (float)(sc * (double)w[c * 10 + lane]);
+  if (lane != 0) return;
+  if (mom) {
     if (running_mean) running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
     if (running_var) {
       double unb = E > 1.0 ? var * E / (E - 1.0) : var;
       running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
     }
-  } else {
-    mean = (double)running_mean[c];
-    var = (double)running_var[c];
   }
-  double invstd = 1.0 / sqrt(var + (double)eps);
-  double sc = (double)gamma[c] * invstd;
-  for (int p = 0; p < 10; ++p) wf[c * 10 + p] = (float)(sc * (double)w[c * 10 + p]);
   bf[c] = (float)(sc * ((double)b[c] - mean) + (double)beta[c]);
   if (mean_out) mean_out[c] = (float)mean;
   if (invstd_out) invstd_out[c] = (float)invstd;
@@ -298,7 +336,7 @@ extern "C" int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, cons
   if (!w || !b || !gamma || !beta || !w_folded || !b_folded) return M3D_ERR_INVALID;
   if (mom65 && num_edges < 1) return M3D_ERR_INVALID;
   if (!mom65 && (!running_mean || !running_var)) return M3D_ERR_INVALID;
-  hipLaunchKernelGGL(lfa_enc_finalize_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, mom65,
+  hipLaunchKernelGGL(lfa_enc_finalize_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, mom65,
                      (double)num_edges, w, b, gamma, beta, eps, momentum, running_mean, running_var, w_folded,
                      b_folded, mean_out, invstd_out, D);
   M3D_CHECK_LAUNCH();
@@ -534,27 +572,32 @@ extern "C" int m3d_lfa_edge_features_bwd(const float* dF, const float* pos4, con
 //   dbeta = g0, dgamma = invstd*(w.G + (b-mean) g0)
 //   dW[c,q] = scale*( G[c,q] - (g0/E) S1[q] - (dgamma/E) * invstd*( sum_p w_p M2[p,q] + (b-mean) S1[q] ) )
 //   db = 0 (BatchNorm removes the mean)
-__global__ void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G, const double* __restrict__ mom, double E,
-                                            const float* __restrict__ w, const float* __restrict__ b,
-                                            const float* __restrict__ gamma, const float* __restrict__ mean,
-                                            const float* __restrict__ invstd, float* dw, float* db, float* dgamma,
-                                            float* dbeta, int D, int acc) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G,
+                                                                  const double* __restrict__ mom, double E,
+                                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, float* dw, float* db,
+                                                                  float* dgamma, float* dbeta, int D, int acc) {
+  // one wave per channel; lane q < 10 owns dW[c, q]
+  const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= D) return;
   const double* g = G + c * 11;
   const double g0 = g[10];
   const double is = (double)invstd[c], mu = (double)mean[c], bb = (double)b[c];
-  double wg = 0.0;
-  for (int p = 0; p < 10; ++p) wg += (double)w[c * 10 + p] * g[p];
+  const double wg = wave_sum_d(lane < 10 ? (double)w[c * 10 + lane] * g[lane] : 0.0);
   const double dgam = is * (wg + (bb - mu) * g0);
   const double sc = (double)gamma[c] * is;
-  for (int q = 0; q < 10; ++q) {
+  if (lane < 10) {
+    const int q = lane;
     double wm = 0.0;
+#pragma unroll
     for (int p = 0; p < 10; ++p) wm += (double)w[c * 10 + p] * mom2(mom, p, q);
-    double zr = is * (wm + (bb - mu) * mom[q]);
+    const double zr = is * (wm + (bb - mu) * mom[q]);
     const float dwv = (float)(sc * (g[q] - (g0 / E) * mom[q] - (dgam / E) * zr));
     dw[c * 10 + q] = acc ? dw[c * 10 + q] + dwv : dwv;
   }
+  if (lane != 0) return;
   if (!acc) db[c] = 0.f;  // BatchNorm removes the mean: d/d(bias) is exactly 0
   dgamma[c] = acc ? dgamma[c] + (float)dgam : (float)dgam;
   dbeta[c] = acc ? dbeta[c] + (float)g0 : (float)g0;
@@ -568,7 +611,7 @@ extern "C" int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, in
   if (D == 0) return M3D_OK;
   if (!G || !mom65 || !w || !b || !gamma || !mean || !invstd || !dw || !db || !dgamma || !dbeta || num_edges < 1)
     return M3D_ERR_INVALID;
-  hipLaunchKernelGGL(lfa_enc_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(64), 0, (hipStream_t)stream, G, mom65,
+  hipLaunchKernelGGL(lfa_enc_bwd_finalize_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, G, mom65,
                      (double)num_edges, w, b, gamma, mean, invstd, dw, db, dgamma, dbeta, D, accumulate);
   M3D_CHECK_LAUNCH();
   return M3D_OK;

@@ -16,6 +16,7 @@
 //                                             train-mode BatchNorm backward needs, see m3d_lfa_enc_bwd_finalize)
 // Workgroup partials of dW_att and G are written with plain stores and summed by a second tiny kernel
 // (deterministic; same-address atomics cost ~15 ns each on MI355X and would dominate).
+#include <stdlib.h>
 #include "m3d_common.h"
 #include "lfa_common.h"
 #include "../../include/m3d_hip.h"
@@ -31,13 +32,16 @@ struct LfaBwdArgs {
   float* g_part;      // [parts][GP*16],  GP = max(16, D)
   int64_t n;
   int K, CH, D;
+  int dbg;  // timing experiments only (M3D_LFA_BWD_DBG): 1 = skip the dx atomics, 2 = skip phases 4-7
   float slope;
 };
 
 template <int CHP> struct BwdCfg { static constexpr int NW = CHP >= 256 ? 8 : 4; };
 
-template <int CHP, int KP>
-__global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArgs a) {
+template <int CH, int KP>
+__global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_kernel(LfaBwdArgs a) {
+  constexpr int CHP = CH < 16 ? 16 : CH;
+  constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
   constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
   constexpr int ROWS = LfaCfg<CHP>::ROWS;
   constexpr int TC = ROWS / KP, KT = KP / 16;
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArg
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int D = a.D, CH = a.CH, K = a.K;
+  const int K = a.K;
   const int wn = wid % WN, wm = wid / WN;
 
   // persistent accumulators
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArg
     __syncthreads();
     // ---- phase 1b: gather x_j
     {
-      const int D4 = D >> 2;
+      constexpr int D4 = D >> 2;
       for (int f = tid; f < ROWS * D4; f += NTHR) {
         int e = f / D4, c4 = f % D4;
         int j = nbr[e];
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArg
         *(float2*)(d + 2) = make_float2(v.z, v.w);
       }
       if (CH < CHP) {
-        const int P = CHP - CH;
+        constexpr int P = CHP - CH;
         for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
       }
     }
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArg
       constexpr int NG = NTHR / ROWS;
       const int e = tid % ROWS;
       const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
-      const int DG = D / NG;
+      constexpr int DG = D / NG;
       const int j = nbr[e];
       const int64_t i = c0 + e / KP;
       float r[10];
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(BwdCfg<CHP>::NW * 64) void lfa_bwd_kernel(LfaBwdArg
           const float v = acc[m][t][r];
           if (col < D) {
             const int j = nbr[row];
-            if (j >= 0) atomicAdd(a.dx + (int64_t)j * D + col, v);
+            if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
           } else if (col < CH) {
             const float lse = F[row * STR + col];
             DA[row * STR + col] = v * (lse > 0.f ? 1.f : a.slope);
@@ -375,11 +379,11 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
   return ((size_t)p.grid * p.kspl3 * p.chp * p.chp + (size_t)p.grid * p.kspl4 * p.dp * 16) * sizeof(float) + 256;
 }
 
-template <int CHP>
+template <int CH>
 static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st) {
-  constexpr int NTHR = BwdCfg<CHP>::NW * 64;
-  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CHP, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((lfa_bwd_kernel<CHP, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
+  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
 
@@ -401,8 +405,11 @@ extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx
   a.dw_part = (float*)ws;
   a.g_part = a.dw_part + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
   a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
+  static const int dbg = getenv("M3D_LFA_BWD_DBG") ? atoi(getenv("M3D_LFA_BWD_DBG")) : 0;
+  a.dbg = dbg;
   int rc;
-  switch (p.chp) {
+  switch (CH) {
+    case 8: rc = launch_lfa_bwd<8>(a, p, st); break;
     case 16: rc = launch_lfa_bwd<16>(a, p, st); break;
     case 32: rc = launch_lfa_bwd<32>(a, p, st); break;
     case 64: rc = launch_lfa_bwd<64>(a, p, st); break;

@@ -47,20 +47,43 @@ class KnnIndex:
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
         call("m3d_knn_build", _p(pos), pos.stride(0), _p(ptr), self.num_clouds, self.n, _p(self.ws), _st())
 
+    def _view(self, which: int, dtype, cols: int) -> Tensor:
+        off = lib().m3d_knn_workspace_offset(self.n, self.num_clouds, which)
+        nbytes = self.n * cols * 4
+        return self.ws[off:off + nbytes].view(dtype).view(self.n, cols) if cols > 1 else \
+            self.ws[off:off + nbytes].view(dtype)
+
+    @property
+    def sorted_pos4(self) -> Tensor:
+        """float4 ``[n, 4]`` (x, y, z, bits of the original row) in cell-sorted order (a view of the workspace)."""
+        return self._view(0, torch.float32, 4)
+
+    @property
+    def perm(self) -> Tensor:
+        """int32 ``[n]``: cell-sorted slot -> original row."""
+        return self._view(1, torch.int32, 1)
+
+    @property
+    def inv(self) -> Tensor:
+        """int32 ``[n]``: original row -> cell-sorted slot."""
+        return self._view(2, torch.int32, 1)
+
     def query(self, k: int, qry: Optional["KnnIndex"] = None, pos_qry: Optional[Tensor] = None,
-              ptr_qry: Optional[Tensor] = None, want_d2: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+              ptr_qry: Optional[Tensor] = None, want_d2: bool = False,
+              sorted_io: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
         """``qry`` (another built index, possibly ``self``) gives wave-coherent cell-sorted queries;
-        otherwise ``pos_qry``/``ptr_qry`` rows are queried in order.  Returns int32 ``[nq, k]`` (+ fp32 d2)."""
+        otherwise ``pos_qry``/``ptr_qry`` rows are queried in order.  Returns int32 ``[nq, k]`` (+ fp32 d2).
+        ``sorted_io``: rows and neighbour ids are cell-sorted slots (of ``qry`` / of ``self``)."""
         if qry is not None:
             nq, ptr_q, qws, pq, qs = qry.n, qry.ptr, qry.ws, None, 0
             assert qry.num_clouds == self.num_clouds
         else:
-            assert pos_qry is not None and ptr_qry is not None and pos_qry.stride(1) == 1
+            assert pos_qry is not None and ptr_qry is not None and pos_qry.stride(1) == 1 and not sorted_io
             nq, ptr_q, qws, pq, qs = pos_qry.shape[0], ptr_qry, None, pos_qry, pos_qry.stride(0)
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.ws.device)
         d2 = torch.empty((nq, k), dtype=torch.float32, device=self.ws.device) if want_d2 else None
-        call("m3d_knn_query", _p(self.ws), _p(self.ptr), self.num_clouds, _p(pq), qs, _p(qws), _p(ptr_q), nq, k,
-             _p(idx), _p(d2), _st())
+        call("m3d_knn_query", _p(self.ws), _p(self.ptr), self.n, self.num_clouds, _p(pq), qs, _p(qws), _p(ptr_q), nq, k,
+             int(sorted_io), _p(idx), _p(d2), _st())
         return idx, d2
 
 
@@ -138,6 +161,14 @@ def gather_rows(src: Tensor, idx: Optional[Tensor]) -> Tensor:
     return out
 
 
+def gather_i32(src: Tensor, idx: Tensor) -> Tensor:
+    """``src[idx]`` for int32 vectors (bit copies through the row-gather kernel): composes index maps on the device."""
+    assert src.dtype == torch.int32 and idx.dtype == torch.int32 and src.is_contiguous()
+    out = torch.empty(idx.numel(), dtype=torch.int32, device=src.device)
+    call("m3d_gather_rows", _p(src), 1, _p(idx), _p(out), idx.numel(), 1, _st())
+    return out
+
+
 def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int) -> Tensor:
     out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
     call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], _st())
@@ -177,7 +208,8 @@ def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
     call("m3d_bn_finalize", _p(stats), stats.shape[0], count, _p(bn.weight), _p(bn.bias),
          float(bn.eps), float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(scale), _p(shift), _p(mean),
          _p(invstd), n, _st())
-    bn.num_batches_tracked += 1
+    if not getattr(bn, "_m3d_flat_counter", False):  # flattened nets bump all counters with one add per step
+        bn.num_batches_tracked += 1
     return scale, shift, mean, invstd
 
 
@@ -194,7 +226,7 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
     """``sinks = (dgamma, dbeta[, dgamma2, dbeta2])``: gradient sinks that are added to (None is returned for them)."""
     M, N = z.shape
     dev = z.device
-    sums = torch.empty(3 * N, dtype=torch.float64, device=dev)
+    sums = torch.empty(lib().m3d_bn_bwd_workspace_bytes(M, N) // 8, dtype=torch.float64, device=dev)
     dz = torch.empty_like(z)
     dz2 = dgamma2 = dbeta2 = None
     if sinks is not None:
@@ -344,6 +376,15 @@ def pack_attention_weight(w: Tensor) -> Tensor:
     return w.reshape(nt, 16, nt, 4, 4).permute(0, 2, 4, 1, 3).contiguous()
 
 
+def pack_attention_weights(w: Tensor, with_transpose: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """``pack_attention_weight(w)`` (and of ``w.t()``) in ONE kernel launch (``m3d_lfa_pack_att``)."""
+    chp = max(w.shape[0], 16)
+    wp = torch.empty(chp * chp, dtype=torch.float32, device=w.device)
+    wpt = torch.empty_like(wp) if with_transpose else None
+    call("m3d_lfa_pack_att", _p(_chk(w)), w.shape[0], _p(wp), _p(wpt), _st())
+    return wp, wpt
+
+
 def lfa_moments(pos4: Tensor, idx: Tensor) -> Tensor:
     mom = torch.empty(65, dtype=torch.float64, device=pos4.device)
     call("m3d_lfa_moments", _p(pos4), _p(idx), idx.shape[0], idx.shape[1], _p(mom), _st())
@@ -361,18 +402,20 @@ def lfa_enc_fold(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int):
     call("m3d_lfa_enc_finalize", _p(mom), num_edges, _p(enc_lin.weight), _p(enc_lin.bias), _p(enc_bn.weight),
          _p(enc_bn.bias), float(enc_bn.eps), float(enc_bn.momentum), _p(enc_bn.running_mean),
          _p(enc_bn.running_var), _p(wf), _p(bf), _p(mean), _p(invstd), D, _st())
-    if mom is not None:
+    if mom is not None and not getattr(enc_bn, "_m3d_flat_counter", False):
         enc_bn.num_batches_tracked += 1
     return wf, bf, mean, invstd
 
 
-def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor) -> Tensor:
+def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor,
+                wp: Optional[Tensor] = None) -> Tensor:
     n, K = idx.shape
     ch = w_att.shape[0]
     if K > 32:  # the fused kernels tile one centre's neighbours onto <= 2 MFMA row tiles
         return lfa_forward_unfused(x, pos4, idx, wf, bf, w_att)
     out = torch.empty((n, ch), dtype=torch.float32, device=x.device)
-    wp = pack_attention_weight(w_att)  # named local: stays alive until the launch is enqueued
+    if wp is None:
+        wp, _ = pack_attention_weights(w_att, False)  # named local: stays alive until the launch is enqueued
     call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), _st())
     return out
 
@@ -401,7 +444,9 @@ class LFATrainFn(torch.autograd.Function):
         ctx.sinks = sinks
         x = x.contiguous()
         wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
-        out = lfa_forward(x, pos4, idx, wf, bf, w_att)
+        wp, wpt = pack_attention_weights(w_att, True) if idx.shape[1] <= 32 else (None, None)
+        out = lfa_forward(x, pos4, idx, wf, bf, w_att, wp)
+        ctx.packed = (wp, wpt)
         ctx.save_for_backward(x, pos4, idx, mom, wf, bf, mean, invstd, enc_w, enc_b, enc_gamma, w_att)
         ctx.num_edges = num_edges
         return out
@@ -420,9 +465,7 @@ class LFATrainFn(torch.autograd.Function):
         if K <= 32 and not LFATrainFn.force_unfused_backward:
             dw_att = sk[4] if sk else torch.empty((ch, ch), dtype=torch.float32, device=dev)
             ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
-            # keep both packed copies alive in named locals: two temporaries inside one call expression would be
-            # handed the SAME block by the caching allocator (the first is freed before the second is allocated)
-            wp, wpt = pack_attention_weight(w_att), pack_attention_weight(w_att.t())
+            wp, wpt = ctx.packed  # packed in the forward pass (one launch for both orientations)
             call("m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
                  _p(dout), _p(dx), _p(dw_att), int(sk is not None), _p(G), _p(ws), _st())
         else:

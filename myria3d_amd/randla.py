@@ -145,6 +145,12 @@ class HipRandLANet(nn.Module):
                 p.data = flat_p[off:off + n].view(p.shape)
                 p.grad = flat_g[off:off + n].view(p.shape)
                 off += sz
+        # BatchNorm step counters: views of one int64 vector, bumped by a single add per training forward
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm1d)]
+        self._nbt_flat = torch.stack([m.num_batches_tracked.to(dev) for m in bns]).contiguous()
+        for i, m in enumerate(bns):
+            m.num_batches_tracked = self._nbt_flat[i]  # registered buffer: same state_dict key, now a view
+            m._m3d_flat_counter = True
         self._flat = (flat_p, flat_g)
         return self
 
@@ -229,14 +235,16 @@ class HipRandLANet(nn.Module):
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, num_edges: int, train: bool,
                rec: Optional[dict], name: str) -> Tensor:
-        idx, _ = index.query(self.num_neighbors, qry=index)  # knn_graph(loop=True), pyg_randla_net.py:180
+        # knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
+        idx, _ = index.query(self.num_neighbors, qry=index, sorted_io=True)
         mom = ops.lfa_moments(pos4, idx) if train else None
         h = self._shared_layer(blk.mlp1, 0, x, train=train)
         if rec is not None:
-            rec[name + ".knn_idx"], rec[name + ".mlp1"] = idx, h
+            rec[name + ".knn_idx"] = _knn_to_reference_order(idx, index)
+            rec[name + ".mlp1"] = h[index.inv.long()]
         h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train)
         if rec is not None:
-            rec[name + ".lfa1"] = h
+            rec[name + ".lfa1"] = h[index.inv.long()]
         h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train)
         l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
         ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
@@ -252,7 +260,7 @@ class HipRandLANet(nn.Module):
             zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias)
             out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
         if rec is not None:
-            rec[name + ".out"] = out
+            rec[name + ".out"] = out[index.inv.long()]
         return out
 
     # ------------------------------------------------------------------------------------------
@@ -286,65 +294,86 @@ class HipRandLANet(nn.Module):
                                  record, train)
 
     def _forward(self, x, pos, ptr, decimation_idx, dropout_mask, plan, record, train):
+        """Internally every level lives in the CELL-SORTED order of its kNN grid (spatially coherent: a centre's
+        neighbours sit a few cache lines away instead of anywhere in the tile).  ``perm[l]`` maps a level's sorted
+        slot to its reference row (level 0: the caller's row; level l+1: position in the decimation index list),
+        ``inv[l]`` is the inverse.  Inputs are permuted once, logits are un-permuted once; decimation composes with
+        the next level's permutation into a single row gather."""
         if plan is None:
             plan = self.plan_for(ptr)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
+        if train and self._flat is not None:
+            self._nbt_flat += 1
         blocks = (self.block1, self.block2, self.block3, self.block4)
-        pos4 = [ops.pad_pos(pos)]
-        index: List[ops.KnnIndex] = []
+        index: List[ops.KnnIndex] = [ops.KnnIndex(ops.pad_pos(pos), plan.ptrs[0])]
+        pos4: List[Tensor] = [index[0].sorted_pos4]
         feats: List[Tensor] = []
-        dec_idx: List[Tensor] = []
+        hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
+        dec_ref: List[Tensor] = []
         if decimation_idx is None:
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
+        x = ops.GatherRowsFn.apply(x, index[0].perm) if x.requires_grad else ops.gather_rows(x, index[0].perm)
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
                                self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
         for lvl, blk in enumerate(blocks):
-            index.append(ops.KnnIndex(pos4[lvl], plan.ptrs[lvl]))
             h = self._block(blk, h, pos4[lvl], index[lvl], plan.num_edges[lvl], train, record, f"block{lvl + 1}")
             feats.append(h)
+            # decimate(): pyg_randla_net.py:234-238.  d_int: sorted slots of this level that survive, listed in the
+            # reference order of the next level; d_ref: the same as reference rows of this level
             if decimation_idx is not None:
-                idx = decimation_idx[lvl].to(device=h.device, dtype=torch.int32).contiguous()
-                assert idx.numel() == plan.totals[lvl + 1]
+                d_ref = decimation_idx[lvl].to(device=h.device, dtype=torch.int32).contiguous()
+                assert d_ref.numel() == plan.totals[lvl + 1]
+                d_int = ops.gather_i32(index[lvl].inv, d_ref)
             else:
-                idx = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
-                                             self._decim_seed, lvl)
-            dec_idx.append(idx)
-            h = ops.GatherRowsFn.apply(h, idx) if train else ops.gather_rows(h, idx)  # decimate(): :234-238
-            pos4.append(ops.gather_rows(pos4[lvl], idx))
-        self.last_decimation_idx = dec_idx
+                d_int = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
+                                               self._decim_seed, lvl)
+                d_ref = ops.gather_i32(index[lvl].perm, d_int)
+            dec_ref.append(d_ref)
+            nxt = ops.KnnIndex(ops.gather_rows(pos4[lvl], d_int), plan.ptrs[lvl + 1])
+            src = ops.gather_i32(d_int, nxt.perm)  # sorted slot of level lvl+1 -> sorted slot of level lvl
+            index.append(nxt)
+            pos4.append(nxt.sorted_pos4)
+            h = ops.GatherRowsFn.apply(h, src) if train else ops.gather_rows(h, src)
+            hin.append(h)
+        self.last_decimation_idx = dec_ref
         h = self._shared_layer(self.mlp_summit, 0, h, train=train)
         if record is not None:
-            record["summit"] = h
+            record["summit"] = h[index[4].inv.long()]
         # decoder: FPModule(k=1) x4 (pyg_randla_net.py:76-79, 241-253)
-        coarse_index = ops.KnnIndex(pos4[4], plan.ptrs[4])
         for fp, lvl in ((self.fp4, 3), (self.fp3, 2), (self.fp2, 1), (self.fp1, 0)):
-            src_index = coarse_index if lvl == 3 else index[lvl + 1]
-            nn_idx, _ = src_index.query(1, qry=index[lvl])  # 1-NN of every level-`lvl` point among level lvl+1
-            if lvl == 0:
-                skip = feats[0]
-            else:  # skip = decimated output of the previous block
-                skip = ops.GatherRowsFn.apply(feats[lvl - 1], dec_idx[lvl - 1]) if train else \
-                    ops.gather_rows(feats[lvl - 1], dec_idx[lvl - 1])
+            # 1-NN of every level-`lvl` point among level lvl+1 (both in sorted slots)
+            nn_idx, _ = index[lvl + 1].query(1, qry=index[lvl], sorted_io=True)
+            skip = feats[0] if lvl == 0 else hin[lvl]  # b1_out, resp. the decimated output of block lvl
             # knn_interpolate(k=1) == x[nn] (weights cancel); fused as a row gather into the GEMM's A operand
             h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train)
             if record is not None:
-                record[f"fp{lvl + 1}"] = h
+                record[f"fp{lvl + 1}"] = h[index[lvl].inv.long()]
         h = self._shared_layer(self.mlp_classif, 0, h, train=train)
         h = self._shared_layer(self.mlp_classif, 1, h, train=train)
         p = self.mlp_classif.dropout[1]
         if train and p > 0.0:
-            if dropout_mask is not None:
-                h = h * (dropout_mask.to(h.dtype) / (1.0 - p))
+            if dropout_mask is not None:  # given in the caller's row order
+                mask = ops.gather_rows(dropout_mask.to(h.dtype).contiguous(), index[0].perm)
+                h = h * (mask / (1.0 - p))
             else:
                 h = F.dropout(h, p=p, training=True)
         if train:
             logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias,
                                         self._sinks(self.fc_classif.weight, self.fc_classif.bias)
                                         if self._use_sinks else None)
+            logits = ops.GatherRowsFn.apply(logits, index[0].inv)  # back to the caller's row order
         else:
             logits = ops.gemm(h, self.fc_classif.weight, h.shape[0], self.fc_classif.weight.shape[0], h.shape[1],
                               bias=self.fc_classif.bias)
+            logits = ops.gather_rows(logits, index[0].inv)
         if self.return_logits:
             return logits
         return logits.log_softmax(dim=-1)
+
+
+def _knn_to_reference_order(idx: Tensor, index: "ops.KnnIndex") -> Tensor:
+    """Test/record helper: a sorted-slot kNN table as reference rows x reference neighbour ids."""
+    perm = index.perm.long()
+    ref = torch.where(idx >= 0, perm[idx.clamp(min=0).long()], torch.full_like(idx, -1).long())
+    return ref[index.inv.long()].to(torch.int32)

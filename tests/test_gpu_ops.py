@@ -229,6 +229,16 @@ def test_residual_tail_train(device):
     _close("tail.dbetas", bns.bias.grad, bnsr.bias.grad, 1e-3, 1e-4)
 
 
+def test_attention_weight_pack_kernel_matches_host_packing(device):
+    from myria3d_amd import ops
+
+    for ch in (8, 16, 64, 256):
+        w = torch.randn(ch, ch, device=device)
+        wp, wpt = ops.pack_attention_weights(w, True)
+        assert torch.equal(wp, ops.pack_attention_weight(w).reshape(-1))
+        assert torch.equal(wpt, ops.pack_attention_weight(w.t()).reshape(-1))
+
+
 # ----------------------------------------------------------------------------------------------- rows / decimation
 def test_gather_scatter_decimation(device):
     from myria3d_amd import ops
