@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm3d_hip.so")
+LIB_PATH = os.environ.get("M3D_LIB") or os.path.join(_HERE, "libm3d_hip.so")  # M3D_LIB: tuning-sweep variants
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 _p, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32

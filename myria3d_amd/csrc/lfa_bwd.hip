@@ -36,14 +36,66 @@ struct LfaBwdArgs {
   float slope;
 };
 
-template <int CHP> struct BwdCfg { static constexpr int NW = CHP >= 256 ? 8 : 4; };
+// tile geometry of the backward kernel per padded channel count: edge rows per workgroup iteration, waves per
+// workgroup, cap on resident (persistent) workgroups.  Overridable at compile time for tuning sweeps.
+#ifndef BWD_ROWS_16
+#define BWD_ROWS_16 256
+#endif
+#ifndef BWD_ROWS_32
+#define BWD_ROWS_32 128
+#endif
+#ifndef BWD_ROWS_64
+#define BWD_ROWS_64 128
+#endif
+#ifndef BWD_ROWS_128
+#define BWD_ROWS_128 64
+#endif
+#ifndef BWD_ROWS_256
+#define BWD_ROWS_256 64
+#endif
+#ifndef BWD_NW_16
+#define BWD_NW_16 4
+#endif
+#ifndef BWD_NW_32
+#define BWD_NW_32 4
+#endif
+#ifndef BWD_NW_64
+#define BWD_NW_64 8
+#endif
+#ifndef BWD_NW_128
+#define BWD_NW_128 4
+#endif
+#ifndef BWD_NW_256
+#define BWD_NW_256 8
+#endif
+#ifndef BWD_CAP_16
+#define BWD_CAP_16 1024
+#endif
+#ifndef BWD_CAP_32
+#define BWD_CAP_32 1024
+#endif
+#ifndef BWD_CAP_64
+#define BWD_CAP_64 512
+#endif
+#ifndef BWD_CAP_128
+#define BWD_CAP_128 512
+#endif
+#ifndef BWD_CAP_256
+#define BWD_CAP_256 256
+#endif
+template <int CHP> struct BwdCfg {};
+template <> struct BwdCfg<16> { static constexpr int ROWS = BWD_ROWS_16, NW = BWD_NW_16, CAP = BWD_CAP_16; };
+template <> struct BwdCfg<32> { static constexpr int ROWS = BWD_ROWS_32, NW = BWD_NW_32, CAP = BWD_CAP_32; };
+template <> struct BwdCfg<64> { static constexpr int ROWS = BWD_ROWS_64, NW = BWD_NW_64, CAP = BWD_CAP_64; };
+template <> struct BwdCfg<128> { static constexpr int ROWS = BWD_ROWS_128, NW = BWD_NW_128, CAP = BWD_CAP_128; };
+template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = BWD_NW_256, CAP = BWD_CAP_256; };
 
 template <int CH, int KP>
 __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
   constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
-  constexpr int ROWS = LfaCfg<CHP>::ROWS;
+  constexpr int ROWS = BwdCfg<CHP>::ROWS;
   constexpr int TC = ROWS / KP, KT = KP / 16;
   constexpr int STR = CHP + 2, RSTR = 18;
   constexpr int MT = ROWS / 16, NT = CHP / 16;
@@ -143,6 +195,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
     }
     __syncthreads();
 
+    if (a.dbg & 2) continue;   // timing experiment: phase 1 only
     // ---- phase 2: A = F * W_att^T
     f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -171,6 +224,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
       }
     }
 
+    if (a.dbg & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
 #pragma unroll
     for (int cc = 0; cc < MTW / KT; ++cc) {
@@ -224,6 +278,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
     }
     __syncthreads();
 
+    if (a.dbg & 8) continue;   // timing experiment: phases 1-3
     // ---- phase 4: dF = dout*s + DA * W_att
     {
       const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
@@ -263,6 +318,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
       }
     }
     __syncthreads();
+    if (a.dbg & 16) continue;  // timing experiment: phases 1-5
     // ---- phase 6: scatter dx; dy -> DA[:, D:2D]
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
@@ -283,6 +339,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
         }
       }
     __syncthreads();
+    if (a.dbg & 32) continue;  // timing experiment: phases 1-6
     // ---- phase 7: G[c', q] += sum_e dy[e, c'] * [r|1][e, q]
     if (wid < GT * KSPL4) {
       const bool crow = gt * 16 + lr < D;
@@ -357,10 +414,10 @@ struct BwdPlan { int chp, rows, grid, kspl3, kspl4, dp; };
 static inline BwdPlan bwd_plan(int64_t n, int K, int CH) {
   BwdPlan p;
   p.chp = CH < 16 ? 16 : CH;
-  p.rows = p.chp == 16 ? 256 : (p.chp == 32 ? 128 : 64);
+  p.rows = p.chp == 16 ? BwdCfg<16>::ROWS : (p.chp == 32 ? BwdCfg<32>::ROWS : (p.chp == 64 ? BwdCfg<64>::ROWS : (p.chp == 128 ? BwdCfg<128>::ROWS : BwdCfg<256>::ROWS)));
   const int kp = K <= 16 ? 16 : 32;
   const int tc = p.rows / kp;
-  const int nw = p.chp >= 256 ? 8 : 4;
+  const int nw = p.chp == 16 ? BwdCfg<16>::NW : (p.chp == 32 ? BwdCfg<32>::NW : (p.chp == 64 ? BwdCfg<64>::NW : (p.chp == 128 ? BwdCfg<128>::NW : BwdCfg<256>::NW)));
   const int nt = p.chp / 16;
   p.kspl3 = nt * nt >= nw ? 1 : nw / (nt * nt);
   p.dp = p.chp / 2 < 16 ? 16 : p.chp / 2;
@@ -368,7 +425,7 @@ static inline BwdPlan bwd_plan(int64_t n, int K, int CH) {
   p.kspl4 = gt >= nw ? 1 : nw / gt;
   const int64_t ngroups = m3d_cdiv(n, tc);
   // resident workgroups: bounded by LDS (2 tiles of rows*(chp+2) floats)
-  const int cap = p.chp >= 256 ? 256 : (p.chp >= 128 ? 512 : (p.chp >= 64 ? 768 : 1024));
+  const int cap = p.chp == 16 ? BwdCfg<16>::CAP : (p.chp == 32 ? BwdCfg<32>::CAP : (p.chp == 64 ? BwdCfg<64>::CAP : (p.chp == 128 ? BwdCfg<128>::CAP : BwdCfg<256>::CAP)));
   p.grid = (int)(ngroups < cap ? (ngroups < 1 ? 1 : ngroups) : cap);
   return p;
 }

@@ -122,6 +122,8 @@ class HipRandLANet(nn.Module):
         self._plans: Dict[tuple, LevelPlan] = {}
         self._warned_eval_grad = False
         self._use_sinks = False
+        self._streams: Dict = {}
+        self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
 
     # ------------------------------------------------------------------------------------------
@@ -233,11 +235,9 @@ class HipRandLANet(nn.Module):
             agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att)
         return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
 
-    def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, num_edges: int, train: bool,
-               rec: Optional[dict], name: str) -> Tensor:
-        # knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
-        idx, _ = index.query(self.num_neighbors, qry=index, sorted_io=True)
-        mom = ops.lfa_moments(pos4, idx) if train else None
+    def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
+               mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str) -> Tensor:
+        # idx: knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
         h = self._shared_layer(blk.mlp1, 0, x, train=train)
         if rec is not None:
             rec[name + ".knn_idx"] = _knn_to_reference_order(idx, index)
@@ -293,6 +293,54 @@ class HipRandLANet(nn.Module):
             return self._forward(x, pos, ptr.to(torch.int64).contiguous(), decimation_idx, dropout_mask, plan,
                                  record, train)
 
+    def _geometry(self, pos: Tensor, plan: LevelPlan, decimation_idx, train: bool) -> "_Geometry":
+        """Everything that depends on positions only — kNN grids and tables of the 4 levels, encoder moments, random
+        decimation, the decoder's 1-NN tables — enqueued on a SIDE stream: these kernels are latency / VALU-bound
+        and overlap with the MFMA- and HBM-bound feature kernels of the main stream (under hipGraph capture the two
+        streams become parallel branches of the graph).  ``wait(stage)`` makes the main stream wait for a stage."""
+        main = torch.cuda.current_stream()
+        side = self._side_stream(pos.device) if self.overlap_geometry else main
+        g = _Geometry(main, side)
+        if side is not main:
+            side.wait_stream(main)
+        K = self.num_neighbors
+        with torch.cuda.stream(side):
+            g.index.append(ops.KnnIndex(ops.pad_pos(pos), plan.ptrs[0]))
+            g.pos4.append(g.index[0].sorted_pos4)
+            g.mark()                                                            # stage 0
+            for lvl in range(4):
+                ix = g.index[lvl]
+                idx, _ = ix.query(K, qry=ix, sorted_io=True)
+                g.knn.append(idx)
+                g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
+                g.mark()                                                        # stage 1 + 2*lvl
+                # decimate(): pyg_randla_net.py:234-238.  d_int: sorted slots of this level that survive, listed in
+                # the reference order of the next level; d_ref: the same as reference rows of this level
+                if decimation_idx is not None:
+                    d_ref = decimation_idx[lvl].to(device=pos.device, dtype=torch.int32).contiguous()
+                    assert d_ref.numel() == plan.totals[lvl + 1]
+                    d_int = ops.gather_i32(ix.inv, d_ref)
+                else:
+                    d_int = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
+                                                   self._decim_seed, lvl)
+                    d_ref = ops.gather_i32(ix.perm, d_int)
+                g.dec_ref.append(d_ref)
+                nxt = ops.KnnIndex(ops.gather_rows(g.pos4[lvl], d_int), plan.ptrs[lvl + 1])
+                g.src.append(ops.gather_i32(d_int, nxt.perm))  # sorted slot of level lvl+1 -> sorted slot of level lvl
+                g.index.append(nxt)
+                g.pos4.append(nxt.sorted_pos4)
+                g.mark()                                                        # stage 2 + 2*lvl
+            for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
+                g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True)[0])
+            g.mark()                                                            # stage 9
+        return g
+
+    def _side_stream(self, device) -> "torch.cuda.Stream":
+        st = self._streams.get(device)
+        if st is None:
+            st = self._streams[device] = torch.cuda.Stream(device=device)
+        return st
+
     def _forward(self, x, pos, ptr, decimation_idx, dropout_mask, plan, record, train):
         """Internally every level lives in the CELL-SORTED order of its kNN grid (spatially coherent: a centre's
         neighbours sit a few cache lines away instead of anywhere in the tile).  ``perm[l]`` maps a level's sorted
@@ -305,45 +353,33 @@ class HipRandLANet(nn.Module):
         if train and self._flat is not None:
             self._nbt_flat += 1
         blocks = (self.block1, self.block2, self.block3, self.block4)
-        index: List[ops.KnnIndex] = [ops.KnnIndex(ops.pad_pos(pos), plan.ptrs[0])]
-        pos4: List[Tensor] = [index[0].sorted_pos4]
-        feats: List[Tensor] = []
-        hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
-        dec_ref: List[Tensor] = []
         if decimation_idx is None:
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
+        geo = self._geometry(pos, plan, decimation_idx, train)
+        index, pos4, dec_ref = geo.index, geo.pos4, geo.dec_ref
+        feats: List[Tensor] = []
+        hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
+        geo.wait(0)
         x = ops.GatherRowsFn.apply(x, index[0].perm) if x.requires_grad else ops.gather_rows(x, index[0].perm)
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
                                self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
         for lvl, blk in enumerate(blocks):
-            h = self._block(blk, h, pos4[lvl], index[lvl], plan.num_edges[lvl], train, record, f"block{lvl + 1}")
+            geo.wait(1 + 2 * lvl)  # kNN table (+ encoder moments) of this level
+            h = self._block(blk, h, pos4[lvl], index[lvl], geo.knn[lvl], geo.mom[lvl], plan.num_edges[lvl], train,
+                            record, f"block{lvl + 1}")
             feats.append(h)
-            # decimate(): pyg_randla_net.py:234-238.  d_int: sorted slots of this level that survive, listed in the
-            # reference order of the next level; d_ref: the same as reference rows of this level
-            if decimation_idx is not None:
-                d_ref = decimation_idx[lvl].to(device=h.device, dtype=torch.int32).contiguous()
-                assert d_ref.numel() == plan.totals[lvl + 1]
-                d_int = ops.gather_i32(index[lvl].inv, d_ref)
-            else:
-                d_int = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
-                                               self._decim_seed, lvl)
-                d_ref = ops.gather_i32(index[lvl].perm, d_int)
-            dec_ref.append(d_ref)
-            nxt = ops.KnnIndex(ops.gather_rows(pos4[lvl], d_int), plan.ptrs[lvl + 1])
-            src = ops.gather_i32(d_int, nxt.perm)  # sorted slot of level lvl+1 -> sorted slot of level lvl
-            index.append(nxt)
-            pos4.append(nxt.sorted_pos4)
-            h = ops.GatherRowsFn.apply(h, src) if train else ops.gather_rows(h, src)
+            geo.wait(2 + 2 * lvl)  # decimation map into the next level
+            h = ops.GatherRowsFn.apply(h, geo.src[lvl]) if train else ops.gather_rows(h, geo.src[lvl])
             hin.append(h)
         self.last_decimation_idx = dec_ref
+        geo.wait(9)  # decoder 1-NN tables
         h = self._shared_layer(self.mlp_summit, 0, h, train=train)
         if record is not None:
             record["summit"] = h[index[4].inv.long()]
         # decoder: FPModule(k=1) x4 (pyg_randla_net.py:76-79, 241-253)
         for fp, lvl in ((self.fp4, 3), (self.fp3, 2), (self.fp2, 1), (self.fp1, 0)):
-            # 1-NN of every level-`lvl` point among level lvl+1 (both in sorted slots)
-            nn_idx, _ = index[lvl + 1].query(1, qry=index[lvl], sorted_io=True)
+            nn_idx = geo.nn[lvl]  # 1-NN of every level-`lvl` point among level lvl+1 (both in sorted slots)
             skip = feats[0] if lvl == 0 else hin[lvl]  # b1_out, resp. the decimated output of block lvl
             # knn_interpolate(k=1) == x[nn] (weights cancel); fused as a row gather into the GEMM's A operand
             h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train)
@@ -370,6 +406,31 @@ class HipRandLANet(nn.Module):
         if self.return_logits:
             return logits
         return logits.log_softmax(dim=-1)
+
+
+class _Geometry:
+    """Position-only intermediates of one forward pass (see ``HipRandLANet._geometry``)."""
+
+    def __init__(self, main, side):
+        self.main, self.side = main, side
+        self.index: List[ops.KnnIndex] = []
+        self.pos4: List[Tensor] = []
+        self.knn: List[Tensor] = []
+        self.mom: List[Optional[Tensor]] = []
+        self.src: List[Tensor] = []
+        self.dec_ref: List[Tensor] = []
+        self.nn: List[Tensor] = []
+        self.events: List = []
+
+    def mark(self) -> None:
+        if self.side is not self.main:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.events.append(ev)
+
+    def wait(self, stage: int) -> None:
+        if self.side is not self.main:
+            self.main.wait_event(self.events[stage])
 
 
 def _knn_to_reference_order(idx: Tensor, index: "ops.KnnIndex") -> Tensor:
