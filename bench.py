@@ -11,7 +11,8 @@ independent units, the gradient all-reduce is the only collective).  Arithmetic 
 
 Rank 0 prints ONE JSON line with the contract keys plus
   "fwd_only": eval-mode forward throughput of the same batch,
-  "roofline": achieved vs peak for the dominant kernel, timed live with HIP events on the launch stream,
+  "roofline": achieved vs peak for the dominant kernel (LFA backward, fp32 MFMA), timed live with HIP events on the
+              launch stream; "roofline_knn_lse_stage": the HBM-class kernels of the kNN + LSE gather at level 1,
   "cpu_baseline": the CPU oracle (restated reference path, torch + cKDTree) timed on a bounded sample.
 """
 from __future__ import annotations
@@ -66,43 +67,88 @@ def timed(fn, steps, world):
     return dt
 
 
-def lfa_stage_roofline(net, x, pos, ptr, plan, reps=20):
-    """Roofline entry for the dominant kernel of the forward hot path: the fused LSE + attentive-pooling kernel
-    (lfa_fwd_kernel) of block 1 / lfa2 (ch=16) over all 204 800 points x 16 neighbours.  Algorithmic bytes per
-    launch (compulsory traffic only): read pos 12 B + x s*ch/2 + neighbour ids 4K per point, write
-    s*ch per point."""
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak (= fp32 vector peak)
+
+
+def _time_launch(launch, reps=20):
+    """Average duration (ms) of one launch, HIP events on the launch stream (torch's current stream)."""
+    for _ in range(3):
+        launch()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        launch()
+        b.record()
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in evs) / reps
+
+
+def stage_rooflines(net, pos, plan):
+    """Roofline entries, timed live.  ``dominant``: the kernel with the largest share of the training step —
+    lfa_bwd_kernel<64,16> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an fp32-MFMA kernel:
+    3 x 2 x n x K x (ch^2 + 10 ch/2) flop per launch (recomputed attention GEMM + its two backward GEMMs).
+    ``knn_lse``: the HBM-class kernels of the kNN + LSE-gather stage at level 1 (204 800 points), algorithmic bytes
+    per launch from SURVEY 8d: kNN read 12 n + write 4 n K; LFA(ch) read n (12 + 4 ch/2 + 4 K), write 4 n ch."""
     from myria3d_amd import ops
 
-    n = x.shape[0]
     K = net.num_neighbors
-    ch = net.block1.lfa2.mlp_attention.lins[0].weight.shape[0]
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
     with torch.no_grad():
-        pos4 = ops.pad_pos(pos)
-        index = ops.KnnIndex(pos4, plan.ptrs[0])
-        idx, _ = index.query(K, qry=index)
-        xin = torch.randn(n, ch // 2, device=x.device)
-        enc_lin, enc_bn = net.block1.lfa2.mlp_encoder.lins[0], net.block1.lfa2.mlp_encoder.norms[0].module
-        w_att = net.block1.lfa2.mlp_attention.lins[0].weight
+        net.overlap_geometry, keep = False, net.overlap_geometry
+        geo = net._geometry(pos, plan, None, True)
+        net.overlap_geometry = keep
+        # ---- dominant kernel: LFA backward at level 2, ch = 64
+        lfa = net.block2.lfa2
+        ch = lfa.mlp_attention.lins[0].weight.shape[0]
+        n2, D = geo.pos4[1].shape[0], ch // 2
+        xin = torch.randn(n2, D, device=pos.device)
+        dout = torch.randn(n2, ch, device=pos.device)
+        enc_lin, enc_bn = lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module
         wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
-        wp = ops.pack_attention_weight(w_att)
-        out = torch.empty((n, ch), device=x.device)
-        st = torch.cuda.current_stream().cuda_stream
-        launch = lambda: ops.call("m3d_lfa_fwd", xin.data_ptr(), pos4.data_ptr(), idx.data_ptr(), n, K, ch,
-                                  wf.data_ptr(), bf.data_ptr(), wp.data_ptr(), ops.LRELU_SLOPE, out.data_ptr(), st)
-        for _ in range(3):
-            launch()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evs:
-            a.record()
-            launch()
-            b.record()
-        torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b in evs) / reps
-    bytes_alg = n * (12 + 4 * ch // 2 + 4 * K + 4 * ch)
-    achieved = bytes_alg / (ms * 1e-3) / 1e9
-    return {"kernel": f"lfa_fwd_kernel<16,16> (block1.lfa2, ch={ch}, n={n}, K={K})", "bound": "hbm",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "algorithmic_bytes_per_launch": bytes_alg, "avg_launch_ms": round(ms, 4)}
+        wp, wpt = ops.pack_attention_weights(lfa.mlp_attention.lins[0].weight, True)
+        dx = torch.zeros((n2, D), device=pos.device)
+        dw = torch.empty((ch, ch), device=pos.device)
+        G = torch.empty(11 * D, dtype=torch.float64, device=pos.device)
+        ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n2, K, ch), dtype=torch.uint8, device=pos.device)
+        ms = _time_launch(lambda: ops.call(
+            "m3d_lfa_bwd", xin.data_ptr(), geo.pos4[1].data_ptr(), geo.knn[1].data_ptr(), n2, K, ch, wf.data_ptr(),
+            bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+            0, G.data_ptr(), ws.data_ptr(), st))
+        flop = 3 * 2 * n2 * K * (ch * ch + 10 * D)
+        tf = flop / (ms * 1e-3) / 1e12
+        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
+                           "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                           "algorithmic_flop_per_launch": flop, "avg_launch_ms": round(ms, 4)}
+        # ---- kNN + LSE gather stage at level 1
+        n1 = geo.pos4[0].shape[0]
+        ix = geo.index[0]
+        idx = torch.empty((n1, K), dtype=torch.int32, device=pos.device)
+        ms_knn = _time_launch(lambda: ops.call(
+            "m3d_knn_query", ix.ws.data_ptr(), ix.ptr.data_ptr(), n1, ix.num_clouds, None, 0, ix.ws.data_ptr(),
+            ix.ptr.data_ptr(), n1, K, 1, idx.data_ptr(), None, st))
+        lfa1 = net.block1.lfa2
+        ch1 = lfa1.mlp_attention.lins[0].weight.shape[0]
+        x1 = torch.randn(n1, ch1 // 2, device=pos.device)
+        wf1, bf1, _, _ = ops.lfa_enc_fold(lfa1.mlp_encoder.lins[0], lfa1.mlp_encoder.norms[0].module, None, 0)
+        wp1, _ = ops.pack_attention_weights(lfa1.mlp_attention.lins[0].weight, False)
+        o1 = torch.empty((n1, ch1), device=pos.device)
+        ms_lfa = _time_launch(lambda: ops.call(
+            "m3d_lfa_fwd", x1.data_ptr(), geo.pos4[0].data_ptr(), geo.knn[0].data_ptr(), n1, K, ch1, wf1.data_ptr(),
+            bf1.data_ptr(), wp1.data_ptr(), ops.LRELU_SLOPE, o1.data_ptr(), st))
+        b_knn = n1 * (12 + 4 * K)
+        b_lfa = n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1)
+        out["knn_lse"] = [
+            {"kernel": f"knn_query_kernel<16> (level 1, n={n1}, K={K})", "bound": "hbm",
+             "achieved": round(b_knn / (ms_knn * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(b_knn / (ms_knn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_knn,
+             "avg_launch_ms": round(ms_knn, 4)},
+            {"kernel": f"lfa_fwd_kernel<16,16> (block1.lfa2, ch={ch1}, n={n1}, K={K})", "bound": "hbm",
+             "achieved": round(b_lfa / (ms_lfa * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(b_lfa / (ms_lfa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_lfa,
+             "avg_launch_ms": round(ms_lfa, 4)}]
+    return out
 
 
 def _pick_threads():
@@ -192,12 +238,17 @@ def main():
     plan = make_plan(ptr.tolist(), 4, K, dev)
     opt = FusedAdam(net, lr=0.003933709606504788, all_reduce=True)  # lr: configs/model/pyg_randla_net_model.yaml:4
 
-    def train_step():
+    def fwd_bwd():
         net.train()
         out = net(x, pos, None, ptr, plan=plan)
         loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
         loss.backward()
-        opt.step()  # (N>1: flat-gradient all-reduce) + Adam + gradient clear
+        if net.grad_side is not None:
+            net.grad_side.join()  # weight-gradient side stream rejoins (must happen inside a captured region)
+
+    def train_step():
+        fwd_bwd()
+        opt.step()  # (N>1: ONE flat-gradient all-reduce over RCCL) + Adam + gradient clear
 
     def fwd_step():
         net.eval()
@@ -206,6 +257,9 @@ def main():
 
     launch = "eager"
     step_fn, fwd_fn = train_step, fwd_step
+    # hipGraph: the forward+loss+backward launch sequence (~600 kernels, parallel branches for the position-only work
+    # and the weight gradients) is captured once and replayed (eager launching is host-bound at ~10 us per kernel).
+    # With N > 1 the optimizer (all-reduce + 2 launches) stays outside the graph so that no collective is captured
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -218,10 +272,19 @@ def main():
             torch.cuda.synchronize()
             g_train, g_fwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_train):
-                train_step()
+                if world == 1:
+                    train_step()  # no collective: the optimizer launches are part of the graph
+                else:
+                    fwd_bwd()
             with torch.cuda.graph(g_fwd):
                 fwd_step()
-            step_fn, fwd_fn, launch = g_train.replay, g_fwd.replay, "hipgraph"
+
+            def graph_step():
+                g_train.replay()
+                if world > 1:
+                    opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
+
+            step_fn, fwd_fn, launch = graph_step, g_fwd.replay, "hipgraph"
         except Exception as e:  # capture is an optimisation, never a requirement
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -259,7 +322,9 @@ def main():
     if rank == 0:
         if not args.skip_roofline:
             try:
-                res["roofline"] = lfa_stage_roofline(net, x, pos, ptr, plan)
+                rl = stage_rooflines(net, pos, plan)
+                res["roofline"] = rl["dominant"]
+                res["roofline_knn_lse_stage"] = rl["knn_lse"]
             except Exception as e:
                 res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.skip_cpu_baseline:

@@ -128,19 +128,51 @@ def linear_dgrad(dz: Tensor, w: Tensor) -> Tensor:
     return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0))
 
 
+class GradSideStream:
+    """Weight-gradient kernels are leaves of the backward pass (nothing downstream reads dW before the optimizer), so
+    with gradient sinks they can run on a side stream next to the dgrad / BatchNorm / LFA chain.  The owner
+    (``FusedAdam``) calls ``join()`` before it reads the gradients; operand tensors are kept alive until then."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.keep: list = []
+
+    def run(self, fn, *tensors):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)  # operands were produced on the main stream
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.append(tensors)      # their memory must not be recycled by the main stream before join()
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+
+_grad_side: Optional[GradSideStream] = None  # set by HipRandLANet while a flat-gradient backward may run
+
+
 def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None, x1: Optional[Tensor] = None,
                  k1: int = 0, out: Optional[Tensor] = None) -> Optional[Tensor]:
     """dW[N, k0+k1] = dZ^T [X0[rows] | X1] (``m3d_linear_wgrad_f32``): the reduction over the M rows is split across
-    workgroups whose partials meet in a workspace.  ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a
-    slice of the flat gradient buffer) that is added to; nothing is returned then."""
+    waves whose partials meet in a workspace.  ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a slice of the
+    flat gradient buffer) that is added to; nothing is returned then (and the kernels may run on the gradient side
+    stream)."""
     M, N = dz.shape
     K = k0 + k1
     sink = out is not None
     dw = out if sink else torch.empty((N, K), dtype=torch.float32, device=dz.device)
     nbytes = lib().m3d_linear_wgrad_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dz.device) if nbytes else None
-    call("m3d_linear_wgrad_f32", _p(dz), dz.stride(0), _p(x0), x0.stride(0), _p(rows), k0, _p(x1),
-         x1.stride(0) if x1 is not None else 0, k1, M, N, _p(dw), dw.stride(0), int(sink), _p(ws), _st())
+
+    def launch():
+        call("m3d_linear_wgrad_f32", _p(dz), dz.stride(0), _p(x0), x0.stride(0), _p(rows), k0, _p(x1),
+             x1.stride(0) if x1 is not None else 0, k1, M, N, _p(dw), dw.stride(0), int(sink), _p(ws), _st())
+
+    if sink and _grad_side is not None:
+        _grad_side.run(launch, dz, x0, x1, rows, ws)
+    else:
+        launch()
     return None if sink else dw
 
 

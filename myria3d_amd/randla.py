@@ -124,6 +124,7 @@ class HipRandLANet(nn.Module):
         self._use_sinks = False
         self._streams: Dict = {}
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
+        self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
 
     # ------------------------------------------------------------------------------------------
@@ -154,6 +155,7 @@ class HipRandLANet(nn.Module):
             m.num_batches_tracked = self._nbt_flat[i]  # registered buffer: same state_dict key, now a view
             m._m3d_flat_counter = True
         self._flat = (flat_p, flat_g)
+        self._flat_ends = (params[0], params[-1])
         return self
 
     @property
@@ -190,6 +192,18 @@ class HipRandLANet(nn.Module):
                 p.grad = flat_g[off:off + n].view(p.shape)
                 off += (n + 3) // 4 * 4
         return True
+
+    def _flat_intact(self) -> bool:
+        """O(1) variant of ``_check_flat`` for the optimizer's hot path: first and last parameter still sit in the
+        flat buffers (a ``.to()`` or ``zero_grad(set_to_none=True)`` moves / detaches all of them)."""
+        if self._flat is None:
+            return False
+        flat_p, flat_g = self._flat
+        first, last = self._flat_ends
+        return (first.data_ptr() == flat_p.data_ptr() and first.grad is not None
+                and first.grad.data_ptr() == flat_g.data_ptr() and last.grad is not None
+                and last.data_ptr() + 4 * last.numel() <= flat_p.data_ptr() + 4 * flat_p.numel()
+                and last.data_ptr() >= flat_p.data_ptr())
 
     @staticmethod
     def _sinks(*params):
@@ -352,6 +366,8 @@ class HipRandLANet(nn.Module):
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
         if train and self._flat is not None:
             self._nbt_flat += 1
+        # weight gradients on a side stream: only with gradient sinks and an optimizer that joins the stream
+        ops._grad_side = self.grad_side if self._use_sinks else None
         blocks = (self.block1, self.block2, self.block3, self.block4)
         if decimation_idx is None:
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe

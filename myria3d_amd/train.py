@@ -25,7 +25,7 @@ class FusedAdam(torch.optim.Optimizer):
     the 4.45 MB bucket, no packing copies."""
 
     def __init__(self, net, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 all_reduce: bool = False):
+                 all_reduce: bool = False, overlap_wgrad: bool = True):
         if net.flat_parameters is None:
             net.flatten_parameters()
         self.net = net
@@ -36,6 +36,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.lr_dev: Optional[torch.Tensor] = None  # optional device-side learning rate (graph-replay safe)
         self.all_reduce = all_reduce
+        if overlap_wgrad:  # weight-gradient GEMMs run beside the rest of the backward pass; step() joins them
+            net.grad_side = ops.GradSideStream(flat.device)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -44,7 +46,10 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         net = self.net
-        net._check_flat()
+        if net.grad_side is not None:
+            net.grad_side.join()  # the weight-gradient side stream has finished writing the flat gradient buffer
+        if not net._flat_intact():
+            net._check_flat()
         flat_p, flat_g = net.flat_parameters, net.flat_grads
         if flat_p.data_ptr() != getattr(self, "_bound_ptr", flat_p.data_ptr()):
             raise RuntimeError("FusedAdam: the net was re-flattened after the optimizer was created")
