@@ -19,13 +19,22 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const double* __restric
                                                          float* running_mean, float* running_var, float* scale,
                                                          float* shift, float* mean_out, float* invstd_out, int N) {
   const int n = blockIdx.x, lane = threadIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int p = lane; p < parts; p += 64) {
-    s += part[((size_t)p * 2 + 0) * N + n];
-    q += part[((size_t)p * 2 + 1) * N + n];
+  // 4 independent accumulator pairs: 8 loads in flight per lane (a plain loop waits for every load in turn)
+  double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
+  int p = lane;
+  for (; p + 192 < parts; p += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s4[u] += part[((size_t)(p + 64 * u) * 2 + 0) * N + n];
+      q4[u] += part[((size_t)(p + 64 * u) * 2 + 1) * N + n];
+    }
   }
-  s = wave_sum_d(s);
-  q = wave_sum_d(q);
+  for (; p < parts; p += 64) {
+    s4[0] += part[((size_t)p * 2 + 0) * N + n];
+    q4[0] += part[((size_t)p * 2 + 1) * N + n];
+  }
+  double s = wave_sum_d((s4[0] + s4[1]) + (s4[2] + s4[3]));
+  double q = wave_sum_d((q4[0] + q4[1]) + (q4[2] + q4[3]));
   if (lane != 0) return;
   double mean = s / count;
   double var = q / count - mean * mean;
@@ -206,9 +215,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int row
 // dbeta = s1, dgamma = s2 (dgamma2 = s3)
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(BnBwdArgs a, const double* __restrict__ part, int parts) {
   const int n = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
-  double v = 0.0;
-  for (int p = lane; p < parts; p += 64) v += part[((size_t)p * 3 + which) * a.N + n];
-  v = wave_sum_d(v);
+  double v4[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int p = lane;
+  for (; p + 448 < parts; p += 512) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v4[u] += part[((size_t)(p + 64 * u) * 3 + which) * a.N + n];
+  }
+  for (; p < parts; p += 64) v4[0] += part[((size_t)p * 3 + which) * a.N + n];
+  double v = wave_sum_d(((v4[0] + v4[1]) + (v4[2] + v4[3])) + ((v4[4] + v4[5]) + (v4[6] + v4[7])));
   if (lane != 0) return;
   a.sums[(size_t)which * a.N + n] = v;
   if (which == 0) {

@@ -238,17 +238,29 @@ __global__ __launch_bounds__(256) void lfa_moments_kernel(const float4* __restri
   for (int q = 0; q < 65; ++q) acc[q] = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
     const float4 pi = pos4[i];
-    for (int k = 0; k < K; ++k) {
-      int j = idx[i * K + k];
-      if (j < 0) continue;
-      float r[10];
-      rel_pos(pi, pos4[j], r);
-      int o = 10;
+    // 8 neighbours per trip: ids first, then all 8 positions in flight (unconditional loads from a clamped id; a
+    // branch around the load serialises one memory round trip per neighbour)
+    for (int k0 = 0; k0 < K; k0 += 8) {
+      int jj[8];
+      float4 pj[8];
 #pragma unroll
-      for (int p = 0; p < 10; ++p) {
-        acc[p] += (double)r[p];
+      for (int u = 0; u < 8; ++u) jj[u] = k0 + u < K ? idx[i * K + k0 + u] : -1;
 #pragma unroll
-        for (int q = p; q < 10; ++q) acc[o++] += (double)r[p] * (double)r[q];
+      for (int u = 0; u < 8; ++u) pj[u] = pos4[jj[u] < 0 ? 0 : jj[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float r[10];
+        rel_pos(pi, pj[u], r);
+        const float m = jj[u] < 0 ? 0.f : 1.f;  // missing neighbour: contributes nothing
+#pragma unroll
+        for (int p = 0; p < 10; ++p) r[p] *= m;
+        int o = 10;
+#pragma unroll
+        for (int p = 0; p < 10; ++p) {
+          acc[p] += (double)r[p];
+#pragma unroll
+          for (int q = p; q < 10; ++q) acc[o++] += (double)r[p] * (double)r[q];
+        }
       }
     }
   }

@@ -250,9 +250,12 @@ class HipRandLANet(nn.Module):
         return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
-               mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str) -> Tensor:
+               mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str,
+               wait_graph=None) -> Tensor:
         # idx: knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
-        h = self._shared_layer(blk.mlp1, 0, x, train=train)
+        h = self._shared_layer(blk.mlp1, 0, x, train=train)  # does not need the graph: runs while kNN finishes
+        if wait_graph is not None:
+            wait_graph()
         if rec is not None:
             rec[name + ".knn_idx"] = _knn_to_reference_order(idx, index)
             rec[name + ".mlp1"] = h[index.inv.long()]
@@ -381,9 +384,9 @@ class HipRandLANet(nn.Module):
                                self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
         for lvl, blk in enumerate(blocks):
-            geo.wait(1 + 2 * lvl)  # kNN table (+ encoder moments) of this level
             h = self._block(blk, h, pos4[lvl], index[lvl], geo.knn[lvl], geo.mom[lvl], plan.num_edges[lvl], train,
-                            record, f"block{lvl + 1}")
+                            record, f"block{lvl + 1}",
+                            wait_graph=lambda s=1 + 2 * lvl: geo.wait(s))  # kNN table (+ encoder moments) of this level
             feats.append(h)
             geo.wait(2 + 2 * lvl)  # decimation map into the next level
             h = ops.GatherRowsFn.apply(h, geo.src[lvl]) if train else ops.gather_rows(h, geo.src[lvl])

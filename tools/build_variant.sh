@@ -6,6 +6,7 @@ NAME=$1; SRC=$2; shift; shift
 cd $(dirname $0)/../myria3d_amd/csrc
 mkdir -p ../variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-variable "$@" -c $SRC -o /tmp/var_$NAME.o 2>&1 | grep -E "error" || true
-OBJS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
+BASE=${VARIANT_REPLACES:-${SRC%.hip}}   # object of the stock build that this variant source replaces
+OBJS=$(ls *.o | grep -v "^${BASE}.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/var_$NAME.o -o ../variants/libm3d_$NAME.so
 echo built $NAME
