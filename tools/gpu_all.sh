@@ -3,9 +3,9 @@
 set -u
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/pytest_gpu_$TAG.log
+timeout 240 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/pytest_gpu_$TAG.log
 cat $OUT/pytest_gpu_$TAG.log | tail -6
-timeout 600 python bench.py 2> $OUT/bench_$TAG.err | tail -1 > $OUT/bench_$TAG.json
+timeout 200 python bench.py 2> $OUT/bench_$TAG.err | tail -1 > $OUT/bench_$TAG.json
 cat $OUT/bench_$TAG.json; tail -3 $OUT/bench_$TAG.err
 bash tools/gpu_prof.sh $TAG > /dev/null 2>&1
 python - <<PY

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 TAG=$1; CTRS=$2; shift; shift
 rm -rf /tmp/pmc && mkdir -p /tmp/pmc
-( cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --pmc $CTRS --output-format csv -d /tmp/pmc -o pmc -- "$@" ) > $OUT/pmc_$TAG.log 2>&1
+( cd $GRAFT_REPO_ROOT && timeout 200 rocprofv3 --pmc $CTRS --output-format csv -d /tmp/pmc -o pmc -- "$@" ) > $OUT/pmc_$TAG.log 2>&1
 f=$(find /tmp/pmc -name '*counter_collection.csv' | head -1)
 [ -z "$f" ] && { tail -20 $OUT/pmc_$TAG.log; exit 1; }
 python - "$f" "$OUT/pmc_$TAG.csv" <<'PY'

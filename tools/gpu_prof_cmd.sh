@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 TAG=$1; shift
 rm -rf /tmp/prof && mkdir -p /tmp/prof
-( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o trace -- "$@" ) > $OUT/rocprofcmd_$TAG.log 2>&1
+( cd $GRAFT_REPO_ROOT && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o trace -- "$@" ) > $OUT/rocprofcmd_$TAG.log 2>&1
 for f in $(find /tmp/prof -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats_$TAG.csv; done
 python - <<PY
 import csv
