@@ -330,8 +330,12 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
           const int row = (wm * MTW + m) * 16 + lg * 4 + r;
           const float v = acc[m][t][r];
           if (col < D) {
-            const int j = nbr[row];
-            if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
+            if (CHP == 16) {
+              DA[row * STR + col] = v;  // D < 16: only D of 16 lanes hold dx columns -> repacked below
+            } else {
+              const int j = nbr[row];
+              if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
+            }
           } else if (col < CH) {
             const float lse = F[row * STR + col];
             DA[row * STR + col] = v * (lse > 0.f ? 1.f : a.slope);
@@ -339,6 +343,15 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
         }
       }
     __syncthreads();
+    if (CHP == 16) {
+      // dx scatter with every lane busy: lane -> (edge row, column) over the ROWS x D block staged in DA, so one
+      // wave-level atomic covers 64 / D whole rows instead of D of 16 lanes of a 16-column MFMA tile
+      for (int f = tid; f < ROWS * D; f += NTHR) {
+        const int row = f / D, col = f % D;
+        const int j = nbr[row];
+        if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
+      }
+    }
     if (a.dbg & 32) continue;  // timing experiment: phases 1-6
     // ---- phase 7: G[c', q] += sum_e dy[e, c'] * [r|1][e, q]
     if (wid < GT * KSPL4) {

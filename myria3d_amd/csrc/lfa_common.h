@@ -23,10 +23,25 @@ __device__ __forceinline__ void rel_pos(float4 pi, float4 pj, float (&r)[10]) {
   r[9] = sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
-template <int CHP> struct LfaCfg {};
-template <> struct LfaCfg<16> { static constexpr int ROWS = 256; };
-template <> struct LfaCfg<32> { static constexpr int ROWS = 128; };
-template <> struct LfaCfg<64> { static constexpr int ROWS = 64; };
-template <> struct LfaCfg<128> { static constexpr int ROWS = 64; };
-template <> struct LfaCfg<256> { static constexpr int ROWS = 64; };
-
+// edge rows per forward workgroup (256 threads) per padded channel count; overridable for tuning sweeps
+#ifndef FWD_ROWS_16
+#define FWD_ROWS_16 256
+#endif
+#ifndef FWD_ROWS_32
+#define FWD_ROWS_32 128
+#endif
+#ifndef FWD_ROWS_64
+#define FWD_ROWS_64 64
+#endif
+#ifndef FWD_ROWS_128
+#define FWD_ROWS_128 64
+#endif
+#ifndef FWD_ROWS_256
+#define FWD_ROWS_256 64
+#endif
+template <int CHP> struct LfaCfg {};  // ROWS >= 64: a wavefront must not span two encoder channel groups
+template <> struct LfaCfg<16> { static constexpr int ROWS = FWD_ROWS_16; };
+template <> struct LfaCfg<32> { static constexpr int ROWS = FWD_ROWS_32; };
+template <> struct LfaCfg<64> { static constexpr int ROWS = FWD_ROWS_64; };
+template <> struct LfaCfg<128> { static constexpr int ROWS = FWD_ROWS_128; };
+template <> struct LfaCfg<256> { static constexpr int ROWS = FWD_ROWS_256; };
