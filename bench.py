@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=2, help="tiles in the bounded CPU-baseline sample")
+    ap.add_argument("--mode", choices=["train", "predict"], default="train",
+                    help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative)")
     return ap.parse_args()
 
 
@@ -208,6 +210,65 @@ def cpu_baseline(tiles, points, K, budget_s=25.0):
                       "1 warm-up, oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN)"}
 
 
+def predict_bench(args, dev):
+    """BASELINE config 3 (informative, not the contract line): predict.py-shaped inference over a synthetic 1 km^2
+    cloud = 400 tiles of 50 m, batches of 50 tiles (configs/experiment/predict.yaml:21-23).  Per batch: eval forward
+    on the sub-sampled tiles (12 800 points each), knn_interpolate(k=10) of the logits to every point of the full
+    tiles (25 000 each; the reference does this on the CPU, model.py:86-103), scatter_sum into the per-cloud logit
+    accumulator by original index (interpolation.py:116); finally softmax / argmax / entropy over all points."""
+    from myria3d_amd import HipRandLANet, knn_interpolate, make_plan, scatter_sum
+    from myria3d_amd.synthetic import synthetic_tile
+
+    n_full, n_sub, tiles, bs, C = 25000, args.points, 400, 50, 7
+    g = torch.Generator().manual_seed(1)
+    full_pos, sub_sel, feats = [], [], []
+    for tid in range(bs):  # 50 distinct tiles, re-used for the 8 batches of the sweep
+        x, pos, _ = synthetic_tile(n_full, tid, 9, C)
+        sel = torch.randperm(n_full, generator=g)[:n_sub].sort().values
+        full_pos.append(pos), sub_sel.append(sel), feats.append(x)
+    pos_full = torch.cat(full_pos).to(dev)
+    x_full = torch.cat(feats).to(dev)
+    sel = torch.cat([s_ + i * n_full for i, s_ in enumerate(sub_sel)]).to(dev)
+    pos_sub, x_sub = pos_full[sel].contiguous(), x_full[sel].contiguous()
+    ptr_sub = torch.arange(0, (bs + 1) * n_sub, n_sub, dtype=torch.int64, device=dev)
+    batch_sub = torch.arange(bs, device=dev).repeat_interleave(n_sub)
+    batch_full = torch.arange(bs, device=dev).repeat_interleave(n_full)
+    torch.manual_seed(0)
+    net = HipRandLANet(9, C, num_neighbors=args.neighbors, return_logits=True).to(dev).eval()
+    plan = make_plan(ptr_sub.tolist(), 4, args.neighbors, dev)
+    total = tiles * n_full
+    acc = torch.zeros((total, C), device=dev)
+    orig = torch.arange(bs * n_full, dtype=torch.int32, device=dev)
+
+    def sweep():
+        acc.zero_()
+        with torch.no_grad():
+            for b in range(tiles // bs):
+                logits = net(x_sub, pos_sub, None, ptr_sub, plan=plan)
+                dense = knn_interpolate(logits, pos_sub, pos_full, batch_sub, batch_full, k=10)
+                scatter_sum(dense, orig + b * bs * n_full, out=acc)
+            probas = acc.softmax(dim=1)
+            pred = probas.argmax(dim=1)
+            entropy = -(probas * torch.log(probas + 1e-12)).sum(dim=1)
+        return pred, entropy
+
+    for _ in range(max(1, args.warmup // 3)):
+        sweep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = max(1, args.steps // 10)
+    for _ in range(reps):
+        sweep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"metric": "points/sec classified, predict path (fwd + kNN-interpolation k=10 + merge)",
+                      "value": round(total / dt, 1), "unit": "points/s", "n_gpus": 1, "ms_per_sweep": round(dt * 1e3, 2),
+                      "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"BASELINE config 3: {tiles} tiles x {n_full} pts (sub-sampled to {n_sub}), "
+                                             f"batch {bs}, K={args.neighbors}, C={C}, interpolation k=10",
+                                 "launch": "eager"}}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +286,11 @@ def main():
     from myria3d_amd.synthetic import synthetic_batch
 
     _lib.lib()  # no fallback: fail here if the HIP library is missing
+    if args.mode == "predict":
+        if world > 1:
+            raise SystemExit("--mode predict is a single-GPU run (tiles shard without communication)")
+        predict_bench(args, dev)
+        return
     B, N, K = args.tiles, args.points, args.neighbors
     tile_ids = shard_tiles(B * world, rank, world)  # weak scaling: B tiles per rank
     x, pos, batch, ptr, y = synthetic_batch([N] * B, first_tile_id=tile_ids.start)

@@ -41,7 +41,10 @@ def knn_interpolate(x: Tensor, pos_x: Tensor, pos_y: Tensor, batch_x: Optional[T
         elif ptr_x.numel() < ptr_y.numel():
             ptr_x = torch.cat([ptr_x, ptr_x[-1:].expand(ptr_y.numel() - ptr_x.numel())])
         index = ops.KnnIndex(pos_x, ptr_x.contiguous())
-        idx, d2 = index.query(k, pos_qry=pos_y, ptr_qry=ptr_y.contiguous(), want_d2=True)
+        # the queries get a grid of their own: cell-sorted query order keeps every wavefront inside a few grid cells
+        # (rows of the result stay in the caller's order)
+        qindex = ops.KnnIndex(pos_y, ptr_y.contiguous())
+        idx, d2 = index.query(k, qry=qindex, want_d2=True)
         return ops.idw_interpolate(x.to(torch.float32).contiguous(), idx, d2)
 
 
@@ -52,8 +55,16 @@ def scatter_sum(src: Tensor, index: Tensor, dim: int = 0, out: Optional[Tensor] 
         raise NotImplementedError("scatter_sum drop-in covers the reference's use: 2-D src, dim=0")
     if not src.is_cuda:
         raise RuntimeError("myria3d_amd.scatter_sum runs on the HIP device only (no CPU fallback)")
+    src = src.to(torch.float32).contiguous()
+    idx = index.to(src.device, torch.int32).contiguous()
+    if out is not None and out.is_cuda and out.dtype == torch.float32 and out.stride(1) == 1 \
+            and out.shape[1] == src.shape[1]:
+        # accumulate straight into the caller's buffer (the reference's `out=` use, interpolation.py:116)
+        ops.call("m3d_scatter_add_rows", src.data_ptr(), idx.data_ptr(), out.data_ptr(), out.stride(0), src.shape[0],
+                 src.shape[1], torch.cuda.current_stream().cuda_stream)
+        return out
     n = dim_size if dim_size is not None else (out.shape[0] if out is not None else int(index.max().item()) + 1)
-    res = ops.scatter_add_rows(src.to(torch.float32).contiguous(), index.to(src.device, torch.int32).contiguous(), n)
+    res = ops.scatter_add_rows(src, idx, n)
     if out is not None:
         out += res.to(out.dtype)
         return out
