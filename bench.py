@@ -359,30 +359,42 @@ def main():
                     fwd_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g_train, g_fwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            g_train = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_train):
                 if world == 1:
                     train_step()  # no collective: the optimizer launches are part of the graph
                 else:
                     fwd_bwd()
-            with torch.cuda.graph(g_fwd):
-                fwd_step()
 
             def graph_step():
                 g_train.replay()
                 if world > 1:
                     opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
 
-            step_fn, fwd_fn, launch = graph_step, g_fwd.replay, "hipgraph"
+            step_fn, launch = graph_step, "hipgraph"
         except Exception as e:  # capture is an optimisation, never a requirement
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
-            step_fn, fwd_fn, launch = train_step, fwd_step, "eager"
+            step_fn, launch = train_step, "eager"
 
     for _ in range(args.warmup):
         step_fn()
     dt = timed(step_fn, args.steps, world)
+    # eval forward of the trained weights.  The first (eager) pass folds the BatchNorms / packs the attention weights
+    # (cached by the module until the next training phase); the captured graph then holds the per-batch work only
+    fwd_step()
+    if launch == "hipgraph":
+        try:
+            torch.cuda.synchronize()
+            g_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fwd):
+                fwd_step()
+            fwd_fn = g_fwd.replay
+        except Exception as e:
+            if rank == 0:
+                print(f"[bench] eval hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
     for _ in range(max(1, args.warmup // 2)):
         fwd_fn()
     dt_f = timed(fwd_fn, args.steps, world)

@@ -123,6 +123,9 @@ class HipRandLANet(nn.Module):
         self._warned_eval_grad = False
         self._use_sinks = False
         self._streams: Dict = {}
+        # eval-mode derived tensors (folded BatchNorm scale/shift, folded encoder, packed attention weights) depend on
+        # parameters / running statistics only: cached across forwards, dropped whenever those may have changed
+        self._eval_cache: Dict = {}
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
@@ -209,6 +212,29 @@ class HipRandLANet(nn.Module):
     def _sinks(*params):
         return tuple(p.grad for p in params)
 
+    def invalidate_eval_cache(self) -> None:
+        """Call after changing parameters or running statistics behind the module's back (raw-pointer writes)."""
+        self._eval_cache.clear()
+
+    def _cached(self, key, fn):
+        hit = self._eval_cache.get(key)
+        if hit is None:
+            hit = self._eval_cache[key] = fn()
+        return hit
+
+    def train(self, mode: bool = True):
+        if mode or self.training:  # entering or leaving a training phase: weights / running statistics change
+            self._eval_cache.clear()
+        return super().train(mode)
+
+    def _apply(self, fn, recurse=True):
+        self._eval_cache.clear()
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._eval_cache.clear()
+        return super().load_state_dict(*args, **kwargs)
+
     # ------------------------------------------------------------------------------------------
     def plan_for(self, ptr: Tensor) -> LevelPlan:
         """One device->host read of ``ptr`` per forward (the reference syncs 2*B times per level,
@@ -230,7 +256,7 @@ class HipRandLANet(nn.Module):
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
                                                 sk)
-        scale, shift = ops.bn_fold_eval(bn)
+        scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn))
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
                         k1=0 if x1 is None else x1.shape[1], bias=lin.bias, scale=scale, shift=shift, act=mlp.act)
@@ -245,8 +271,9 @@ class HipRandLANet(nn.Module):
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
                                        enc_bn.bias, enc_lin, enc_bn, w_att, sk)
         else:
-            wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
-            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att)
+            wf, bf, wp = self._cached(("lfa", id(p)), lambda: ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)[:2] + (
+                ops.pack_attention_weights(w_att, False)[0] if idx.shape[1] <= 32 else None,))
+            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp)
         return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
@@ -271,8 +298,8 @@ class HipRandLANet(nn.Module):
             out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
                                                 ns.weight, ns.bias, ns, sk2, sks)
         else:
-            sc2, sh2 = ops.bn_fold_eval(n2)
-            scs, shs = ops.bn_fold_eval(ns)
+            sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2))
+            scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns))
             z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias)
             zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias)
             out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
@@ -367,6 +394,8 @@ class HipRandLANet(nn.Module):
         if plan is None:
             plan = self.plan_for(ptr)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
+        if train:
+            self._eval_cache.clear()  # this pass updates the running statistics (and an optimizer step follows)
         if train and self._flat is not None:
             self._nbt_flat += 1
         # weight gradients on a side stream: only with gradient sinks and an optimizer that joins the stream
