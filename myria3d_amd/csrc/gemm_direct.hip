@@ -21,7 +21,8 @@
 // Kernels:
 //   gemm_rowstream_kernel<NT,KQ,MODE,..>   K <= 64, per-wave column slice <= 64: the weight slice lives in registers
 //                                 and the wave streams 16-row tiles (204 800-row layers: pure HBM streaming)
-//   gemm_kloop_kernel<NTW,MODE,..>   any K: weights re-read from L1/L2 every chunk (deep layers: few rows, long K)
+//   gemm_kloop_kernel<MTW,NTW,MODE,..>  any K: operands re-read from L1/L2 every chunk (deep layers: few rows, long
+//                                 K); a wave owns MTW x NTW tiles so that a loaded fragment feeds several MFMAs
 //   wgrad2_kernel<TN,TK>          dW[n][k] = sum_m dZ[m][n] X[m][k]: the reduction runs over the rows; every wave
 //                                 owns one row split and stores its partial to a workspace that wgrad_reduce_kernel
 //                                 sums (no LDS atomics, no same-address global atomics)
@@ -258,8 +259,10 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(GemmArgs g, int cve
 // ------------------------------------------------------------------------------------------
 // any K: weights streamed from L1/L2 chunk by chunk.  grid: (row workgroups, column slices of 16*NTW)
 // ------------------------------------------------------------------------------------------
-template <int NTW, int MODE, bool VEC, bool CAT, bool BCM>
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM>
 __global__ __launch_bounds__(256) void gemm_kloop_kernel(GemmArgs g, int cvec) {
+  // a wave owns MTW x NTW tiles of 16x16: every A / W fragment it loads feeds NTW / MTW MFMAs (these shapes are
+  // L2-bandwidth bound on operand re-reads when MTW = NTW = 1)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int KQ = (K + 15) >> 4;
@@ -274,28 +277,37 @@ __global__ __launch_bounds__(256) void gemm_kloop_kernel(GemmArgs g, int cvec) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.0; ssq[t][r] = 0.0; }
 
-  const int64_t ntiles = (g.M + 15) >> 4;
+  const int64_t ngroups = (g.M + 16 * MTW - 1) / (16 * MTW);
   const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += stride) {
-    const int64_t m = tile * 16 + lr;
-    const ARow row = a_row(g, m);
-    f32x4 acc[NTW];
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wid; grp < ngroups; grp += stride) {
+    ARow row[MTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MTW; ++mt) row[mt] = a_row(g, (grp * MTW + mt) * 16 + lr);
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int q = 0; q < KQ; ++q) {
       const int k = 16 * q + 4 * lg;
-      const float4 a = a_frag<VEC, CAT>(g, ra0, ra1, row, k, K);
-      float4 w[NTW];
+      float4 a[MTW], w[NTW];
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = a_frag<VEC, CAT>(g, ra0, ra1, row[mt], k, K);
 #pragma unroll
       for (int t = 0; t < NTW; ++t) w[t] = w_frag<VEC, BCM>(g, rb, nb + 16 * t + lr, k, K);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = mfma16(f4(w[t], i), f4(a, i), acc[t]);
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma16(f4(w[t], i), f4(a[mt], i), acc[mt][t]);
     }
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) epi_store<MODE>(g, e[t], acc[t], m, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+        epi_store<MODE>(g, e[t], acc[mt][t], (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
   }
   if (MODE == 1) stats_flush<NTW, 4>(g, nb, ssum, ssq);
 }
@@ -330,28 +342,28 @@ static void launch_rowstream(const GemmArgs& g, int mode, int KQ, int variant, d
   else launch_rs_mode<NT, 4>(g, mode, variant, grid, st, cvec);
 }
 
-template <int NTW, int MODE>
+template <int MTW, int NTW, int MODE>
 static void launch_kl(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
   switch (variant) {
-    case 0: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 1: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 2: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
-    case 3: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
-    default: hipLaunchKernelGGL((gemm_kloop_kernel<NTW, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 2: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    case 3: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    default: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
   }
 }
 
-template <int NTW>
+template <int MTW, int NTW>
 static void launch_kloop(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
-  if (mode == 1) launch_kl<NTW, 1>(g, variant, grid, st, cvec);
-  else if (mode == 2) launch_kl<NTW, 2>(g, variant, grid, st, cvec);
-  else launch_kl<NTW, 0>(g, variant, grid, st, cvec);
+  if (mode == 1) launch_kl<MTW, NTW, 1>(g, variant, grid, st, cvec);
+  else if (mode == 2) launch_kl<MTW, NTW, 2>(g, variant, grid, st, cvec);
+  else launch_kl<MTW, NTW, 0>(g, variant, grid, st, cvec);
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // launch geometry of the forward / dgrad kernels (shared with m3d_gemm_direct_stat_parts)
-struct RowPlan { int rowstream, NT, KQ; int64_t wgs, slices; };
+struct RowPlan { int rowstream, NT, MT, KQ; int64_t wgs, slices; };
 static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
   RowPlan p;
   const int64_t ntiles = m3d_cdiv(M, 16);
@@ -364,10 +376,24 @@ static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
     if (mode != 0 && NT == 4 && p.KQ >= 2) NT = 2;      // statistics / affine registers on top: stay <= 128 VGPRs
     p.NT = NT;
   } else {
-    // K > 64: pick the per-wave column slice so that ~4096 waves exist
-    const int64_t units = ntiles * ncol16;
-    p.NT = units >= 16384 ? 4 : (units >= 4096 ? 2 : 1);
+    // K > 64: the largest per-wave tile (MT x NT blocks of 16x16) that still leaves >= ~768 waves for 1024 SIMDs
+    // (4 x 4 tiles were measured slower: too few waves to hide the fragment-load latency)
+    static const int cand[4][2] = {{2, 4}, {2, 2}, {1, 2}, {1, 1}};
+    p.MT = 1; p.NT = 1;
+    for (int c = 0; c < 4; ++c) {
+      const int64_t waves = m3d_cdiv(ntiles, cand[c][0]) * m3d_cdiv(ncol16, cand[c][1]);
+      if (waves >= 768 || c == 3) { p.MT = cand[c][0]; p.NT = cand[c][1]; break; }
+    }
+    p.slices = m3d_cdiv(ncol16, p.NT);
+    const int64_t ngroups = m3d_cdiv(ntiles, p.MT);
+    int64_t wgs = m3d_cdiv(ngroups, 4);
+    int64_t cap = 2048 / p.slices;  // statistics partial rows = wgs: keep them bounded
+    if (cap < 1) cap = 1;
+    if (wgs > cap) wgs = cap;
+    p.wgs = wgs < 1 ? 1 : wgs;
+    return p;
   }
+  p.MT = 1;
   p.slices = m3d_cdiv(ncol16, p.NT);
   // ~4096 waves to fill 1024 SIMDs, at most 16 tiles per wave
   int64_t wgs = m3d_cdiv(ntiles, 4);
@@ -416,9 +442,10 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
     else if (rp.NT == 2) launch_rowstream<2>(g, mode, rp.KQ, variant, grid, st, cvec);
     else launch_rowstream<1>(g, mode, rp.KQ, variant, grid, st, cvec);
   } else {
-    if (rp.NT == 4) launch_kloop<4>(g, mode, variant, grid, st, cvec);
-    else if (rp.NT == 2) launch_kloop<2>(g, mode, variant, grid, st, cvec);
-    else launch_kloop<1>(g, mode, variant, grid, st, cvec);
+    if (rp.MT == 2 && rp.NT == 4) launch_kloop<2, 4>(g, mode, variant, grid, st, cvec);
+    else if (rp.MT == 2) launch_kloop<2, 2>(g, mode, variant, grid, st, cvec);
+    else if (rp.NT == 2) launch_kloop<1, 2>(g, mode, variant, grid, st, cvec);
+    else launch_kloop<1, 1>(g, mode, variant, grid, st, cvec);
   }
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
