@@ -236,41 +236,64 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(BnBwdArgs a, const 
 }
 
 // pass 2: dz = scale*(dact - s1/M - zhat*s2/M);  dz2 likewise with its own zhat2/s2';  dgamma = s2, dbeta = s1
+struct BnCol {  // per-column constants of 4 consecutive columns
+  float4 sc, sh, mu, is, m1, m2;
+};
+
+__device__ __forceinline__ float4 bn_dz(const BnCol& k, float4 g, float4 zv) {
+  float4 o;
+  o.x = k.sc.x * (g.x - k.m1.x - (zv.x - k.mu.x) * k.is.x * k.m2.x);
+  o.y = k.sc.y * (g.y - k.m1.y - (zv.y - k.mu.y) * k.is.y * k.m2.y);
+  o.z = k.sc.z * (g.z - k.m1.z - (zv.z - k.mu.z) * k.is.z * k.m2.z);
+  o.w = k.sc.w * (g.w - k.m1.w - (zv.w - k.mu.w) * k.is.w * k.m2.w);
+  return o;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const int N4 = a.N / 4;
   const int64_t total4 = a.M * N4;
   const double invM = 1.0 / (double)a.M;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % N4) * 4;
-    float4 zv = ((const float4*)a.z)[i];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  // the grid stride is a multiple of N4 for every power-of-two width (all of this network's): a thread then stays on
+  // the same 4 columns and their constants (incl. the fp64 column sums) are loaded once, not per element
+  const bool fixed = (stride % N4) == 0;
+  BnCol k1, k2;
+  auto load_cols = [&](int c) {
+    k1.sc = *(const float4*)(a.scale + c); k1.sh = *(const float4*)(a.shift + c);
+    k1.mu = *(const float4*)(a.mean + c); k1.is = *(const float4*)(a.invstd + c);
+    k1.m1 = make_float4((float)(a.sums[c] * invM), (float)(a.sums[c + 1] * invM), (float)(a.sums[c + 2] * invM),
+                        (float)(a.sums[c + 3] * invM));
+    k1.m2 = make_float4((float)(a.sums[a.N + c] * invM), (float)(a.sums[a.N + c + 1] * invM),
+                        (float)(a.sums[a.N + c + 2] * invM), (float)(a.sums[a.N + c + 3] * invM));
+    if (a.z2) {
+      const size_t o = 2 * (size_t)a.N + c;
+      k2.sc = *(const float4*)(a.scale2 + c); k2.sh = *(const float4*)(a.shift2 + c);
+      k2.mu = *(const float4*)(a.mean2 + c); k2.is = *(const float4*)(a.invstd2 + c);
+      k2.m1 = k1.m1;
+      k2.m2 = make_float4((float)(a.sums[o] * invM), (float)(a.sums[o + 1] * invM), (float)(a.sums[o + 2] * invM),
+                          (float)(a.sums[o + 3] * invM));
+    }
+  };
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (fixed && i < total4) load_cols((int)(i % N4) * 4);
+  for (; i < total4; i += stride) {
+    if (!fixed) load_cols((int)(i % N4) * 4);
+    const float4 zv = ((const float4*)a.z)[i];
+    float4 g = ((const float4*)a.dy)[i];
     float4 z2v = make_float4(0, 0, 0, 0);
     if (a.z2) z2v = ((const float4*)a.z2)[i];
-    float4 g = bn_dact(a, i, c, zv, z2v);
-    float m1[4], m2[4], m3[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      m1[j] = (float)(a.sums[c + j] * invM);
-      m2[j] = (float)(a.sums[a.N + c + j] * invM);
-      m3[j] = a.z2 ? (float)(a.sums[2 * (size_t)a.N + c + j] * invM) : 0.f;
+    if (a.act) {
+      float4 u = make_float4(zv.x * k1.sc.x + k1.sh.x, zv.y * k1.sc.y + k1.sh.y, zv.z * k1.sc.z + k1.sh.z,
+                             zv.w * k1.sc.w + k1.sh.w);
+      if (a.z2) {
+        u.x += z2v.x * k2.sc.x + k2.sh.x; u.y += z2v.y * k2.sc.y + k2.sh.y;
+        u.z += z2v.z * k2.sc.z + k2.sh.z; u.w += z2v.w * k2.sc.w + k2.sh.w;
+      }
+      g.x *= u.x > 0.f ? 1.f : a.slope; g.y *= u.y > 0.f ? 1.f : a.slope;
+      g.z *= u.z > 0.f ? 1.f : a.slope; g.w *= u.w > 0.f ? 1.f : a.slope;
     }
-    {
-      float4 mu = *(const float4*)(a.mean + c), is = *(const float4*)(a.invstd + c), sc = *(const float4*)(a.scale + c);
-      float4 o;
-      o.x = sc.x * (g.x - m1[0] - (zv.x - mu.x) * is.x * m2[0]);
-      o.y = sc.y * (g.y - m1[1] - (zv.y - mu.y) * is.y * m2[1]);
-      o.z = sc.z * (g.z - m1[2] - (zv.z - mu.z) * is.z * m2[2]);
-      o.w = sc.w * (g.w - m1[3] - (zv.w - mu.w) * is.w * m2[3]);
-      ((float4*)a.dz)[i] = o;
-    }
-    if (a.z2) {
-      float4 mu = *(const float4*)(a.mean2 + c), is = *(const float4*)(a.invstd2 + c), sc = *(const float4*)(a.scale2 + c);
-      float4 o;
-      o.x = sc.x * (g.x - m1[0] - (z2v.x - mu.x) * is.x * m3[0]);
-      o.y = sc.y * (g.y - m1[1] - (z2v.y - mu.y) * is.y * m3[1]);
-      o.z = sc.z * (g.z - m1[2] - (z2v.z - mu.z) * is.z * m3[2]);
-      o.w = sc.w * (g.w - m1[3] - (z2v.w - mu.w) * is.w * m3[3]);
-      ((float4*)a.dz2)[i] = o;
-    }
+    ((float4*)a.dz)[i] = bn_dz(k1, g, zv);
+    if (a.z2) ((float4*)a.dz2)[i] = bn_dz(k2, g, z2v);
   }
 }
 
