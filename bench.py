@@ -360,7 +360,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g_train = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_train):
+            with torch.cuda.graph(g_train, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
                 if world == 1:
                     train_step()  # no collective: the optimizer launches are part of the graph
                 else:
@@ -388,7 +388,7 @@ def main():
         try:
             torch.cuda.synchronize()
             g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd):
+            with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
                 fwd_step()
             fwd_fn = g_fwd.replay
         except Exception as e:

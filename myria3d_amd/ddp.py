@@ -57,5 +57,7 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
     """Make every rank start from rank ``src``'s parameters and buffers (what DDP does at construction)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    flat = getattr(module, "flat_parameters", None)
+    tensors = [flat] if flat is not None else [p.data for p in module.parameters()]  # one bucket when flattened
+    for t in tensors + [b.data for b in module.buffers()]:
+        dist.broadcast(t, src=src)
