@@ -141,3 +141,68 @@ def test_train_steps_follow_the_oracle(device):
         # fp32 trajectories drift apart step by step (Adam normalises tiny gradient differences to +-lr)
         assert abs(lr_.item() - lg.item()) < (1e-3 + 2e-3 * step) * max(1.0, abs(lr_.item()))
     assert lg.item() < 3.0
+
+
+def test_hipgraph_replay_matches_eager_steps(device):
+    """bench.py replays the whole step as a hipGraph with parallel branches (position-only work and weight gradients on
+    side streams): two replayed steps must leave the same parameters as two eager steps."""
+    from myria3d_amd import FusedAdam, HipRandLANet, cross_entropy, make_plan
+    from oracle.randla_oracle import fixed_decimation_indices
+
+    sizes = [700, 500]
+    x, pos, batch, ptr = rand_batch(sizes, seed=13)
+    dec = [d.to(device) for d in fixed_decimation_indices(ptr.tolist(), 4, seed=2)]
+    rs = np.random.RandomState(6)
+    mask = torch.from_numpy((rs.uniform(size=(sum(sizes), 32)) > 0.5).astype(np.float32)).to(device)
+    y = torch.from_numpy(rs.randint(0, 6, (sum(sizes),))).to(device)
+    xd, pd, ptrd = x.to(device), pos.to(device), ptr.to(device)
+    plan = make_plan(ptr.tolist(), 4, 16, device)
+    results = []
+    for use_graph in (False, True):
+        net = HipRandLANet(9, 6, return_logits=True)
+        fill_params_deterministic(net, 31)
+        net = net.to(device).flatten_parameters().train()
+        opt = FusedAdam(net, lr=1e-3)
+
+        def step():
+            loss = cross_entropy(net(xd, pd, None, ptrd, decimation_idx=dec, dropout_mask=mask, plan=plan), y, 65)
+            loss.backward()
+            opt.step()
+
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()  # warm-up outside the capture (allocator, lazy inits) ...
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            snapshot = [t.clone() for t in (net.flat_parameters, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
+            bufs = [b.clone() for b in net.buffers()]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                step()
+            # ... then rewind to the initial state and replay twice
+            fresh = HipRandLANet(9, 6, return_logits=True)
+            fill_params_deterministic(fresh, 31)
+            net.load_state_dict(fresh.state_dict())
+            opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.step_count.zero_(), net.flat_grads.zero_()
+            del snapshot, bufs
+            g.replay()
+            g.replay()
+        else:
+            step()
+            step()
+        torch.cuda.synchronize()
+        results.append({k: v.detach().clone() for k, v in net.state_dict().items()})
+    worst = ("", 0.0)
+    for k in results[0]:
+        if k == "fc0.bias" or (".lins." in k and k.endswith("bias")):
+            # gradients that are analytically zero (a bias in front of a train-mode BatchNorm): pure rounding noise that
+            # Adam normalises to +-lr, different in every run (atomic ordering) - not a property of the replay
+            continue
+        a, b = results[0][k].double(), results[1][k].double()
+        err = (a - b).abs().max().item()
+        if err > worst[1]:
+            worst = (k, err)
+        assert torch.allclose(a, b, rtol=5e-3, atol=2e-4), (k, err)
+    print(f"[parity] graph replay vs eager, worst state difference: {worst[0]} {worst[1]:.3e}")
