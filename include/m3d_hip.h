@@ -160,6 +160,13 @@ int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_e
 int m3d_idw_interpolate_fwd(const float* x, int64_t ldx, const int32_t* idx, const float* d2, int64_t n_qry,
                             int32_t k, int32_t C, float* y, void* stream);
 
+/* ---- merged predictions (Interpolator.reduce_predictions_and_save, myria3d/models/interpolation.py:142-169) ----
+ * for i < m:  row = logits[idx ? idx[i] : i];  probas[i, :C] = softmax(row);  preds[i] = argmax(row) (first maximum);
+ * entropy[i] = torch.distributions.Categorical(probs=probas[i]).entropy().  probas / preds / entropy may be NULL.
+ * C <= 64. */
+int m3d_predict_reduce(const float* logits, int64_t ld, const int32_t* idx, int64_t m, int32_t C, float* probas,
+                       int64_t ldp, int32_t* preds, float* entropy, void* stream);
+
 /* ---- training step: loss and optimizer -------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(ignore_index=65, reduction="mean") on the logits (myria3d/models/model.py:118,
  * configs/model/criterion/CrossEntropyLoss.yaml:1-3).  lse: [n] scratch kept for the backward; acc2: fp64 [2]

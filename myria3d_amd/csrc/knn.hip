@@ -14,11 +14,21 @@
 // Distances are computed as (dx*dx + dy*dy) + dz*dz with contraction disabled.
 #include "m3d_common.h"
 #include "../../include/m3d_hip.h"
+#include <stdlib.h>
 
 #define GMAX 64
 #define CELLS_MAX (GMAX * GMAX)
 #define GP_STRIDE 8  // per-cloud grid record, 8 x 4 bytes
 #define M3D_KNN_CELL_TARGET 7.0f
+#ifndef KNN_UNROLL
+#define KNN_UNROLL 4
+#endif
+#ifndef KNN_MIN_BLOCKS
+#define KNN_MIN_BLOCKS 1
+#endif
+#ifndef M3D_KNN_DEFAULT_F64
+#define M3D_KNN_DEFAULT_F64 1
+#endif
 
 struct KnnWs {
   float* gridp;     // [B][8]: xmin, ymin, inv_h, h, eps, (int)Gx, (int)Gy, (int)n
@@ -67,7 +77,8 @@ extern "C" size_t m3d_knn_workspace_offset(int64_t n_src, int32_t num_clouds, in
 // grid build: one 1024-thread workgroup per cloud
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void knn_build_kernel(const float* __restrict__ pos, int pstride,
-                                                         const int64_t* __restrict__ ptr, KnnWs w) {
+                                                         const int64_t* __restrict__ ptr, KnnWs w,
+                                                         float cell_target) {
   __shared__ float red[4][16];
   __shared__ int cnt[CELLS_MAX];
   __shared__ int wsum[16];
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(1024) void knn_build_kernel(const float* __restrict
       h = 1.f;
     } else {
       float area = fmaxf(wx, wmax * 1e-3f) * fmaxf(wy, wmax * 1e-3f);
-      h = sqrtf(area * M3D_KNN_CELL_TARGET / (float)n);
+      h = sqrtf(area * cell_target / (float)n);
       h = fmaxf(h, wmax / (float)GMAX * 1.0001f);
     }
     int Gx = min(GMAX, (int)(wx / h) + 1), Gy = min(GMAX, (int)(wy / h) + 1);
@@ -176,17 +187,61 @@ __global__ __launch_bounds__(1024) void knn_build_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
 
-template <int KMAX>
-__device__ __forceinline__ void topk_insert(u64 (&best)[KMAX], u64 key) {
-  if (key < best[KMAX - 1]) {
-#pragma unroll
-    for (int j = KMAX - 1; j > 0; --j) {
-      u64 prev = best[j - 1];
-      best[j] = key < prev ? prev : (key < best[j] ? key : best[j]);
-    }
-    best[0] = key < best[0] ? key : best[0];
+// The running top-k of a lane is a sorted register array of 64-bit keys (d2 bits, original row): two key policies
+// with the SAME total order, selected at launch (M3D_KNN_KEYS=u64|f64).
+//
+// KeyU64: the key is an integer; insertion = compare + select per slot (~6 32-bit VALU instructions per slot).
+struct KeyU64 {
+  typedef u64 T;
+  static __device__ __forceinline__ T make(float d2, int row) {
+    return ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)row;
   }
-}
+  static __device__ __forceinline__ T empty() { return ~0ull; }
+  static __device__ __forceinline__ bool is_empty(T k) { return k == ~0ull; }
+  static __device__ __forceinline__ unsigned d2bits(T k) { return (unsigned)(k >> 32); }
+  static __device__ __forceinline__ int row(T k) { return (int)(unsigned)(k & 0xffffffffull); }
+  template <int KMAX>
+  static __device__ __forceinline__ void insert(T (&best)[KMAX], T key) {
+    if (key < best[KMAX - 1]) {
+#pragma unroll
+      for (int j = KMAX - 1; j > 0; --j) {
+        u64 prev = best[j - 1];
+        best[j] = key < prev ? prev : (key < best[j] ? key : best[j]);
+      }
+      best[0] = key < best[0] ? key : best[0];
+    }
+  }
+};
+
+// KeyF64: the same 64 bits read as an IEEE double.  For sign bit 0 the order of doubles IS the order of their bit
+// patterns, so a sorted insertion is a chain of v_min_f64 / v_max_f64 — 2 full-rate VALU instructions per slot.
+// The high word is biased by one double-exponent step (0x00100000): every finite / inf / NaN fp32 d2 then maps to a
+// NORMAL finite double (no denormal or NaN operand ever reaches min/max, so the bits pass through unchanged), and
+// +inf (0x7FF00000'00000000) is the "empty slot" sentinel, above every key.
+struct KeyF64 {
+  typedef double T;
+  static constexpr unsigned BIAS = 0x00100000u;
+  static __device__ __forceinline__ T make(float d2, int row) {
+    return __hiloint2double((int)(__float_as_uint(d2) + BIAS), row);
+  }
+  static __device__ __forceinline__ T empty() { return __hiloint2double(0x7FF00000, 0); }
+  static __device__ __forceinline__ bool is_empty(T k) { return (unsigned)__double2hiint(k) == 0x7FF00000u; }
+  static __device__ __forceinline__ unsigned d2bits(T k) { return (unsigned)__double2hiint(k) - BIAS; }
+  static __device__ __forceinline__ int row(T k) { return __double2loint(k); }
+  template <int KMAX>
+  static __device__ __forceinline__ void insert(T (&best)[KMAX], T key) {
+    if (key < best[KMAX - 1]) {
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        // raw instructions: fmin()/fmax() would add a canonicalising v_max_f64 per operand in IEEE mode
+        T hi;
+        asm("v_max_f64 %0, %1, %2" : "=&v"(hi) : "v"(best[j]), "v"(key));
+        asm("v_min_f64 %0, %0, %1" : "+v"(best[j]) : "v"(key));  // in place: no register copies at the join
+        key = hi;
+      }
+    }
+  }
+};
 
 __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float4 s) {
 #pragma clang fp contract(off)
@@ -198,29 +253,30 @@ __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float
   return ab + c;
 }
 
-template <int KMAX>
-__device__ __forceinline__ void scan_range(u64 (&best)[KMAX], const float4* __restrict__ sorted, int p0, int p1,
-                                           float qx, float qy, float qz) {
-  // 4 candidates per trip: four independent 16-byte loads in flight per lane (the loop is latency-bound otherwise)
-  for (int p = p0; p < p1; p += 4) {
+template <int KMAX, class KP>
+__device__ __forceinline__ void scan_range(typename KP::T (&best)[KMAX], const float4* __restrict__ sorted, int p0,
+                                           int p1, float qx, float qy, float qz) {
+  // KNN_UNROLL candidates per trip: that many independent 16-byte loads in flight per lane (the loop is latency-bound
+  // otherwise)
+  for (int p = p0; p < p1; p += KNN_UNROLL) {
     const int last = p1 - 1;
-    float4 s[4];
+    float4 s[KNN_UNROLL];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] = sorted[min(p + u, last)];
+    for (int u = 0; u < KNN_UNROLL; ++u) s[u] = sorted[min(p + u, last)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < KNN_UNROLL; ++u) {
       float d2 = dist2_exact(qx, qy, qz, s[u]);
-      u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)__float_as_int(s[u].w);
-      if (p + u > last) key = ~0ull;
-      topk_insert<KMAX>(best, key);
+      typename KP::T key = KP::make(d2, __float_as_int(s[u].w));
+      if (p + u > last) key = KP::empty();
+      KP::template insert<KMAX>(best, key);
     }
   }
 }
 
 // qmode 0: queries are pos_qry rows (row index = output row)
 // qmode 1: queries are the float4 records of qsorted (output row = record.w) — cell-sorted, wave-coherent
-template <int KMAX>
-__global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* __restrict__ ptr_src, int B,
+template <int KMAX, class KP>
+__global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w, const int64_t* __restrict__ ptr_src, int B,
                                                         const float* __restrict__ pos_qry, int qstride,
                                                         const float4* __restrict__ qsorted,
                                                         const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
@@ -250,9 +306,9 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
   const int* cs = w.cell_start + (size_t)b * (CELLS_MAX + 1);
   const float4* sorted = w.sorted + ptr_src[b];
 
-  u64 best[KMAX];
+  typename KP::T best[KMAX];
 #pragma unroll
-  for (int j = 0; j < KMAX; ++j) best[j] = ~0ull;
+  for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
 
   if (n > 0) {
     const int cx = min(Gx - 1, max(0, (int)((qx - gx0) * inv_h)));
@@ -263,10 +319,10 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
         if (yy < 0 || yy >= Gy) continue;
         if (dy == -R || dy == R) {
           int x0 = max(cx - R, 0), x1 = min(cx + R, Gx - 1);
-          scan_range<KMAX>(best, sorted, cs[yy * Gx + x0], cs[yy * Gx + x1 + 1], qx, qy, qz);
+          scan_range<KMAX, KP>(best, sorted, cs[yy * Gx + x0], cs[yy * Gx + x1 + 1], qx, qy, qz);
         } else {
-          if (cx - R >= 0) scan_range<KMAX>(best, sorted, cs[yy * Gx + cx - R], cs[yy * Gx + cx - R + 1], qx, qy, qz);
-          if (cx + R < Gx) scan_range<KMAX>(best, sorted, cs[yy * Gx + cx + R], cs[yy * Gx + cx + R + 1], qx, qy, qz);
+          if (cx - R >= 0) scan_range<KMAX, KP>(best, sorted, cs[yy * Gx + cx - R], cs[yy * Gx + cx - R + 1], qx, qy, qz);
+          if (cx + R < Gx) scan_range<KMAX, KP>(best, sorted, cs[yy * Gx + cx + R], cs[yy * Gx + cx + R + 1], qx, qy, qz);
         }
       }
       const bool covers = (cx - R <= 0) && (cx + R >= Gx - 1) && (cy - R <= 0) && (cy + R >= Gy - 1);
@@ -277,12 +333,12 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
       if (cy - R > 0) bound = fminf(bound, qy - (gy0 + (float)(cy - R) * h));
       if (cy + R < Gy - 1) bound = fminf(bound, (gy0 + (float)(cy + R + 1) * h) - qy);
       bound = fmaxf(bound - eps, 0.f);
-      // NaN (unfilled slot) compares false -> keep searching
-      u64 kb = best[KMAX - 1];
+      typename KP::T kb = best[KMAX - 1];
 #pragma unroll
       for (int j = 0; j < KMAX - 1; ++j)
         if (j == k - 1) kb = best[j];
-      float kth = __uint_as_float((unsigned)(kb >> 32));
+      // an unfilled slot reads as NaN (u64 keys) or as a huge value (f64 keys): either way the search continues
+      float kth = KP::is_empty(kb) ? __builtin_nanf("") : __uint_as_float(KP::d2bits(kb));
       if (kth <= bound * bound) break;
     }
   }
@@ -290,11 +346,11 @@ __global__ __launch_bounds__(256) void knn_query_kernel(KnnWs w, const int64_t* 
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
     if (j < k) {
-      bool ok = best[j] != ~0ull;
-      int id = ok ? (int)(unsigned)(best[j] & 0xffffffffull) : -1;
+      bool ok = !KP::is_empty(best[j]);
+      int id = ok ? KP::row(best[j]) : -1;
       if (sorted_io && ok) id = w.inv[id];  // neighbours selected by (d2, original row); reported as cell-sorted slots
       io[j] = id;
-      if (d2_out) d2_out[orow * k + j] = ok ? __uint_as_float((unsigned)(best[j] >> 32)) : __builtin_inff();
+      if (d2_out) d2_out[orow * k + j] = ok ? __uint_as_float(KP::d2bits(best[j])) : __builtin_inff();
     }
   }
 }
@@ -305,10 +361,23 @@ extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int
   if (num_clouds == 0) return M3D_OK;
   if (!pos_src && n_src > 0) return M3D_ERR_INVALID;
   KnnWs w = ws_carve(ws, num_clouds, n_src);
+  // points per grid column the cell size aims at (tuning knob; any positive value gives the same exact result)
+  static const float cell_target = [] {
+    const char* e = getenv("M3D_KNN_CELL_TARGET");
+    float v = e ? (float)atof(e) : M3D_KNN_CELL_TARGET;
+    return v > 0.f ? v : M3D_KNN_CELL_TARGET;
+  }();
   hipLaunchKernelGGL(knn_build_kernel, dim3(num_clouds), dim3(1024), 0, (hipStream_t)stream, pos_src, pos_stride,
-                     ptr_src, w);
+                     ptr_src, w, cell_target);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
+}
+
+// key policy of the top-k registers: M3D_KNN_KEYS=u64 (integer compare/select chain) | f64 (v_min/v_max_f64 chain)
+static bool knn_f64_keys() {
+  const char* e = getenv("M3D_KNN_KEYS");
+  if (!e) return M3D_KNN_DEFAULT_F64 != 0;
+  return e[0] == 'f';
 }
 
 extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds,
@@ -325,9 +394,15 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   const float4* qs = qry_ws ? ws_carve((void*)qry_ws, num_clouds, n_qry).sorted : nullptr;
   dim3 grid((unsigned)m3d_cdiv(n_qry, 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(KM)                                                                                              \
-  hipLaunchKernelGGL(knn_query_kernel<KM>, grid, block, 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, qs, \
-                     ptr_qry, n_qry, k, idx_out, d2_out, sorted_io)
+  static const bool f64_keys = knn_f64_keys();
+#define LAUNCH_KP(KM, KP)                                                                                      \
+  hipLaunchKernelGGL((knn_query_kernel<KM, KP>), grid, block, 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, \
+                     qs, ptr_qry, n_qry, k, idx_out, d2_out, sorted_io)
+#define LAUNCH(KM)                      \
+  do {                                  \
+    if (f64_keys) LAUNCH_KP(KM, KeyF64); \
+    else LAUNCH_KP(KM, KeyU64);          \
+  } while (0)
   if (k == 1) LAUNCH(1);
   else if (k <= 4) LAUNCH(4);
   else if (k <= 8) LAUNCH(8);
@@ -335,6 +410,7 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   else if (k <= 32) LAUNCH(32);
   else LAUNCH(64);
 #undef LAUNCH
+#undef LAUNCH_KP
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

@@ -5,10 +5,12 @@
   the logits to the CPU for it; here kNN + inverse-squared-distance weighting stay on the MI355X.
 * ``torch_scatter.scatter_sum(src, index, out=..., dim=0)`` as called by ``Interpolator.reduce_predicted_logits``
   (``/root/reference/myria3d/models/interpolation.py:116``).
+* ``DeviceInterpolator``: the arithmetic of ``Interpolator`` (``interpolation.py:94-169``: store, scatter-sum merge,
+  softmax / argmax / entropy) kept on the device; the LAS reading / writing around it (pdal) stays with the caller.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 from torch import Tensor
@@ -69,3 +71,76 @@ def scatter_sum(src: Tensor, index: Tensor, dim: int = 0, out: Optional[Tensor] 
         out += res.to(out.dtype)
         return out
     return res
+
+
+def predict_reduce(logits: Tensor, index: Optional[Tensor] = None, want_probas: bool = True, want_preds: bool = True,
+                   want_entropy: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+    """``(Softmax(dim=1)(rows), argmax(rows, dim=1), Categorical(probs=probas).entropy())`` of
+    ``rows = logits[index]`` (``index=None``: all rows) in one HIP launch (``interpolation.py:145-164``)."""
+    if not logits.is_cuda:
+        raise RuntimeError("myria3d_amd.predict_reduce runs on the HIP device only (no CPU fallback)")
+    if logits.dim() != 2:
+        raise ValueError("logits must be [points, classes]")
+    logits = logits.to(torch.float32)
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    dev = logits.device
+    idx = None if index is None else index.to(dev, torch.int32).contiguous()
+    m, C = (logits.shape[0] if idx is None else idx.shape[0]), logits.shape[1]
+    probas = torch.empty((m, C), dtype=torch.float32, device=dev) if want_probas else None
+    preds = torch.empty((m,), dtype=torch.int32, device=dev) if want_preds else None
+    entropy = torch.empty((m,), dtype=torch.float32, device=dev) if want_entropy else None
+    ops.call("m3d_predict_reduce", logits.data_ptr(), logits.stride(0), None if idx is None else idx.data_ptr(), m, C,
+             None if probas is None else probas.data_ptr(), C, None if preds is None else preds.data_ptr(),
+             None if entropy is None else entropy.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return probas, (None if preds is None else preds.to(torch.int64)), entropy
+
+
+class DeviceInterpolator:
+    """Device-resident mirror of the arithmetic of ``myria3d.models.interpolation.Interpolator``
+    (``interpolation.py:94-169``): same method names and meaning for ``store_predictions`` and
+    ``reduce_predicted_logits``; ``reduce_predictions`` returns what ``reduce_predictions_and_save`` writes into
+    the LAS dimensions (probabilities, predicted class, entropy) instead of writing a file."""
+
+    def __init__(self, reverse_mapper: Optional[Dict[int, int]] = None):
+        self.reverse_mapper = reverse_mapper  # class index -> LAS classification code (interpolation.py:52-56)
+        self.logits: List[Tensor] = []
+        self.idx_in_full_cloud_list: List[Tensor] = []
+
+    def store_predictions(self, logits: Tensor, idx_in_original_cloud: Union[Tensor, Sequence]) -> None:
+        """Keep the (already interpolated) logits of one batch and where their points sit in the full cloud."""
+        if not logits.is_cuda:
+            raise RuntimeError("DeviceInterpolator keeps predictions on the HIP device (no CPU fallback)")
+        self.logits.append(logits)
+        if isinstance(idx_in_original_cloud, Tensor):
+            self.idx_in_full_cloud_list.append(idx_in_original_cloud.to(logits.device))
+        else:  # the reference collates a list of numpy arrays, one per tile (interpolation.py:96)
+            self.idx_in_full_cloud_list += [torch.as_tensor(a).to(logits.device) for a in idx_in_original_cloud]
+
+    @torch.no_grad()
+    def reduce_predicted_logits(self, nb_points: int) -> Tuple[Tensor, Tensor]:
+        """Sum the logits of points predicted more than once (overlapping tiles) and return them per stored
+        prediction, in stored order, with the index vector (``interpolation.py:98-121``)."""
+        logits = torch.cat(self.logits)
+        idx = torch.cat([i.reshape(-1) for i in self.idx_in_full_cloud_list])
+        self.logits, self.idx_in_full_cloud_list = [], []
+        reduced = torch.zeros((nb_points, logits.shape[1]), dtype=torch.float32, device=logits.device)
+        scatter_sum(logits, idx, out=reduced, dim=0)
+        return ops.gather_rows(reduced, idx.to(torch.int32)), idx
+
+    @torch.no_grad()
+    def reduce_predictions(self, nb_points: int) -> Dict[str, Tensor]:
+        """``probas`` [M, C], ``preds`` [M] (mapped through ``reverse_mapper`` if given), ``entropy`` [M] and
+        ``idx_in_full_cloud`` [M] for the M stored predictions (``interpolation.py:142-164``)."""
+        logits = torch.cat(self.logits)
+        idx = torch.cat([i.reshape(-1) for i in self.idx_in_full_cloud_list])
+        self.logits, self.idx_in_full_cloud_list = [], []
+        reduced = torch.zeros((nb_points, logits.shape[1]), dtype=torch.float32, device=logits.device)
+        scatter_sum(logits, idx, out=reduced, dim=0)
+        probas, preds, entropy = predict_reduce(reduced, idx)
+        if self.reverse_mapper is not None:
+            lut = torch.zeros(max(self.reverse_mapper) + 1, dtype=torch.int64, device=preds.device)
+            for k, v in self.reverse_mapper.items():
+                lut[k] = v
+            preds = lut[preds]
+        return {"probas": probas, "preds": preds, "entropy": entropy, "idx_in_full_cloud": idx}

@@ -173,6 +173,23 @@ def knn_interpolate(
     return num / den
 
 
+def interpolator_reduce(logits_list: Sequence[Tensor], idx_list: Sequence[Tensor], nb_points: int):
+    """Arithmetic of ``Interpolator.reduce_predicted_logits`` + ``reduce_predictions_and_save``
+    (myria3d/models/interpolation.py:98-121, 142-164) without the LAS I/O: concatenate the stored logits, sum the
+    predictions that land on the same point of the full cloud, read them back per stored prediction, then
+    ``Softmax(dim=1)``, ``argmax(dim=1)`` and ``Categorical(probs=probas).entropy()``.
+    Returns ``(reduced_logits[idx], probas, preds, entropy, idx)``."""
+    logits = torch.cat([l.cpu() for l in logits_list])
+    idx = torch.cat([torch.as_tensor(i).reshape(-1).to(torch.int64) for i in idx_list])
+    reduced = torch.zeros((nb_points, logits.size(1)))
+    reduced = reduced + scatter_sum(logits, idx, nb_points)          # scatter_sum(..., out=reduced, dim=0)
+    rows = reduced[idx]
+    probas = torch.nn.Softmax(dim=1)(rows)
+    preds = torch.argmax(rows, dim=1)
+    entropy = torch.distributions.Categorical(probs=probas).entropy()
+    return rows, probas, preds, entropy, idx
+
+
 # --------------------------------------------------------------------------------------
 # PyG MLP / SharedMLP restated (pyg_randla_net.py:97-109; Appendix A.1)
 # --------------------------------------------------------------------------------------

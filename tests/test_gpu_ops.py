@@ -384,3 +384,52 @@ def test_knn_interpolate_dropin(device, k):
     out = myria3d_amd.scatter_sum(got, index.to(device), dim=0, out=torch.zeros(300, 7, device=device))
     ref_s = torch.zeros(300, 7, dtype=torch.float64).index_add_(0, index, got.cpu().double())
     _close("scatter_sum", out, ref_s, 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize("C", [6, 7, 12, 40])
+def test_device_interpolator_matches_reference_arithmetic(device, C):
+    """Interpolator.reduce_predicted_logits / reduce_predictions_and_save (interpolation.py:98-164) on the device:
+    overlapping tiles (points predicted twice), points never predicted, exact ties for argmax, saturated rows."""
+    import myria3d_amd
+    from oracle.randla_oracle import interpolator_reduce
+
+    rs = np.random.RandomState(C)
+    nb_points = 5000
+    sizes = [1200, 900, 1500]
+    logits_list = [torch.from_numpy(rs.normal(0, 3, (m, C)).astype(np.float32)) for m in sizes]
+    logits_list[0][:40] = 0.0                      # all classes tie: argmax must take the first
+    logits_list[1][:40, 1] = 60.0                  # saturated softmax: p = 1 -> entropy clamp path
+    logits_list[2][:40, 2] = logits_list[2][:40, 4] = 9.5   # two-way tie
+    idx_list = [rs.choice(nb_points, m, replace=False) for m in sizes]   # overlaps across tiles, none inside one
+    rows, probas, preds, entropy, idx = interpolator_reduce(logits_list, idx_list, nb_points)
+
+    itp = myria3d_amd.DeviceInterpolator()
+    for l, i in zip(logits_list[:2], idx_list[:2]):
+        itp.store_predictions(l.to(device), [i])               # list of numpy arrays, as the reference collates
+    itp.store_predictions(logits_list[2].to(device), torch.from_numpy(idx_list[2]))
+    got_rows, got_idx = itp.reduce_predicted_logits(nb_points)
+    assert torch.equal(got_idx.cpu(), idx)
+    _close("reduced logits", got_rows, rows.double(), 1e-6, 1e-6)
+
+    for l, i in zip(logits_list, idx_list):
+        itp.store_predictions(l.to(device), [i])
+    out = itp.reduce_predictions(nb_points)
+    _close("probas", out["probas"], probas.double(), 1e-6, 1e-5)
+    _close("entropy", out["entropy"], entropy.double(), 2e-6, 1e-5)
+    # argmax: identical wherever the reference's maximum is unique at fp32 resolution of the merged logits
+    top2 = rows.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(out["preds"].cpu()[clear], preds[clear])
+    once = torch.bincount(idx, minlength=nb_points)[idx] == 1          # single prediction: merged logits are bit-equal
+    ties = (top2[:, 0] == top2[:, 1]) & once
+    assert ties.sum() >= 40
+    assert torch.equal(out["preds"].cpu()[ties], preds[ties]), "exact ties: first maximum, like torch.argmax"
+    assert torch.equal(out["idx_in_full_cloud"].cpu(), idx)
+    # function-level: all rows, no index; and the class-code mapping of the reference (interpolation.py:52-56)
+    p2, c2, e2 = myria3d_amd.predict_reduce(got_rows)
+    _close("probas (no index)", p2, probas.double(), 1e-6, 1e-5)
+    mapper = {c: 10 * c + 1 for c in range(C)}
+    itp2 = myria3d_amd.DeviceInterpolator(reverse_mapper=mapper)
+    itp2.store_predictions(logits_list[0].to(device), [idx_list[0]])
+    out2 = itp2.reduce_predictions(nb_points)
+    assert torch.equal(out2["preds"].cpu(), torch.argmax(logits_list[0], dim=1) * 10 + 1)

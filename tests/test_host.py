@@ -40,6 +40,15 @@ def test_constructor_and_forward_surface():
     bad = HipRandLANet(9, 6, decimation=0.5)
     with pytest.raises(ValueError, match="higher than"):
         bad(torch.rand(10, 9), torch.rand(10, 3), None, torch.tensor([0, 10]))
+    # the function-level drop-ins of the predict path refuse host tensors too
+    import myria3d_amd
+    for fn, args in [(myria3d_amd.knn_interpolate, (torch.rand(4, 2), torch.rand(4, 3), torch.rand(6, 3))),
+                     (myria3d_amd.scatter_sum, (torch.rand(4, 2), torch.zeros(4, dtype=torch.long))),
+                     (myria3d_amd.predict_reduce, (torch.rand(4, 6),))]:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fn(*args)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        myria3d_amd.DeviceInterpolator().store_predictions(torch.rand(4, 6), [np.arange(4)])
 
 
 def test_level_plan_matches_reference_decimation_rule():

@@ -131,3 +131,22 @@ def test_golden_vectors_pin_the_oracle():
                      (net.block1.lfa1.mlp_attention.lins[0].weight.grad, "grad_block1_lfa1_att")):
         ref = torch.from_numpy(g[key])
         assert (got - ref).norm() / ref.norm() < 1e-2, key
+
+
+def test_interpolator_reduce_by_hand():
+    """interpolation.py:98-164 restated: overlapping predictions are summed, rows come back in stored order, entropy
+    is the Shannon entropy of the softmax (natural log)."""
+    from oracle.randla_oracle import interpolator_reduce
+
+    a = torch.tensor([[1.0, 2.0, 0.5], [0.0, 0.0, 0.0]])
+    b = torch.tensor([[0.5, -1.0, 3.0]])
+    rows, probas, preds, entropy, idx = interpolator_reduce([a, b], [np.array([4, 2]), np.array([4])], nb_points=6)
+    assert idx.tolist() == [4, 2, 4]
+    merged = a[0] + b[0]
+    assert torch.allclose(rows, torch.stack([merged, a[1], merged]))
+    p = torch.exp(merged) / torch.exp(merged).sum()
+    assert torch.allclose(probas[0], p, atol=1e-6) and torch.allclose(probas[2], p, atol=1e-6)
+    assert torch.allclose(probas[1], torch.full((3,), 1 / 3), atol=1e-6)
+    assert preds.tolist() == [2, 0, 2]                     # uniform row: first maximum
+    assert abs(entropy[1].item() - np.log(3.0)) < 1e-6
+    assert abs(entropy[0].item() + (p * p.log()).sum().item()) < 1e-6
