@@ -107,7 +107,8 @@ int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64
 int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64_t n, void* stream);
 /* decimation_indices(): slot r of cloud b <- ptr[b] + P_b(r), P_b a keyed pseudo-random permutation of
  * [0, n_b); ptr_out is the decimated ptr (computed by the caller: max(1, n_b // factor) per cloud);
- * seed: device uint64[1]. */
+ * seed: device uint64[1].  A cloud may ask for MORE slots than it has points (MinimumNumNodes,
+ * myria3d/pctl/transforms/transforms.py:66-84): slots n_b.. continue with further independent permutations. */
 int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds, const uint64_t* seed,
                            uint32_t level, int32_t* idx_out, int64_t m, void* stream);
 
@@ -166,6 +167,28 @@ int m3d_idw_interpolate_fwd(const float* x, int64_t ldx, const int32_t* idx, con
  * C <= 64. */
 int m3d_predict_reduce(const float* logits, int64_t ld, const int32_t* idx, int64_t m, int32_t C, float* probas,
                        int64_t ldp, int32_t* preds, float* entropy, void* stream);
+
+/* ---- data preparation (next row after the net): torch_geometric.transforms.GridSampling(size) as configured in
+ * configs/datamodule/transforms/preparations/points_budget.yaml:14-17 — voxel_grid + consecutive_cluster + per-voxel
+ * mean of pos / x and majority vote of y — for all tiles of a batch at once, every tile with its own bounding box
+ * (= the reference's per-tile application).  Outputs have capacity n rows; the number of voxels of tile b is
+ * out_ptr[b+1] - out_ptr[b] (device int64 [num_clouds + 1]; the caller reads out_ptr[num_clouds] to slice).
+ * x / y (and out_x / out_y) may be NULL.  Rows come out in ascending voxel id per tile, like consecutive_cluster. */
+size_t m3d_grid_sampling_workspace_bytes(int64_t n, int32_t num_clouds);
+int m3d_grid_sampling(const float* pos, int32_t pos_stride, const float* x, int64_t ldx, int32_t F, const int64_t* y,
+                      const int64_t* ptr, int32_t num_clouds, int64_t n, float size, void* ws, float* out_pos,
+                      float* out_x, int64_t* out_y, int64_t* out_ptr, void* stream);
+/* status_dev_out: device int32 [1] <- 0 ok | 1 some tile's voxel grid has >= 2^40 cells (results invalid) */
+int m3d_grid_sampling_status(const void* ws, int64_t n, int32_t num_clouds, int32_t* status_dev_out, void* stream);
+
+/* Per-tile normalisations, in place, for a whole batch (two launches): Center (pos -= mean), NullifyLowestZ
+ * (z -= min z; myria3d/pctl/transforms/transforms.py:141-146), NormalizePos (pos *= pos_scale; :149-162) and
+ * StandardizeRGBAndIntensity (:115-138) on columns intensity_col (log(v + 1) first) and rgb_col of x (-1 = skip):
+ * s = std_unbiased + 1e-6 (1 if NaN), v <- clamp((v - mean) / s, -clamp_sigma * s, clamp_sigma * s).
+ * stats_ws: fp64 [num_clouds][8] scratch. */
+int m3d_tile_normalize(float* pos, int32_t pos_stride, float* x, int64_t ldx, int32_t intensity_col, int32_t rgb_col,
+                       const int64_t* ptr, int32_t num_clouds, int64_t n, int32_t center, int32_t nullify_z,
+                       float pos_scale, float clamp_sigma, double* stats_ws, void* stream);
 
 /* ---- training step: loss and optimizer -------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(ignore_index=65, reduction="mean") on the logits (myria3d/models/model.py:118,

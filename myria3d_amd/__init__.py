@@ -2,12 +2,14 @@
 
 Only what the path needs: ``csrc/`` (HIP kernels + the C ABI of ``include/m3d_hip.h``), the ctypes binding, and
 the host-side mirror of the reference's operator interface (``HipRandLANet``, ``knn_interpolate``,
-``scatter_sum``, ``DeviceInterpolator``, ``register_in_model_zoo``).
+``scatter_sum``, ``DeviceInterpolator``, ``register_in_model_zoo``) plus the device-side data preparation that feeds
+it (``transforms``: GridSampling, node budget, normalisations).
 """
 from .randla import HipRandLANet, make_plan  # noqa: F401
 from .interpolation import DeviceInterpolator, knn_interpolate, predict_reduce, scatter_sum  # noqa: F401
 from .registration import register_in_model_zoo  # noqa: F401
 from .train import FusedAdam, cross_entropy  # noqa: F401
+from . import transforms  # noqa: F401
 
 __all__ = ["HipRandLANet", "make_plan", "knn_interpolate", "scatter_sum", "predict_reduce", "DeviceInterpolator",
-           "register_in_model_zoo", "FusedAdam", "cross_entropy"]
+           "register_in_model_zoo", "FusedAdam", "cross_entropy", "transforms"]

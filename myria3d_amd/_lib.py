@@ -51,6 +51,10 @@ SIGNATURES = {
     "m3d_lfa_enc_bwd_finalize": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
     "m3d_idw_interpolate_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
     "m3d_predict_reduce": (_i32, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p]),
+    "m3d_grid_sampling_workspace_bytes": (C.c_size_t, [_i64, _i32]),
+    "m3d_grid_sampling": (_i32, [_p, _i32, _p, _i64, _i32, _p, _p, _i32, _i64, _f32, _p, _p, _p, _p, _p, _p]),
+    "m3d_grid_sampling_status": (_i32, [_p, _i64, _i32, _p, _p]),
+    "m3d_tile_normalize": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _i32, _i64, _i32, _i32, _f32, _f32, _p, _p]),
     "m3d_ce_loss_fwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p]),
     "m3d_ce_loss_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p]),
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),

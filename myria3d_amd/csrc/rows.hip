@@ -137,10 +137,16 @@ __global__ __launch_bounds__(256) void decimation_kernel(const int64_t* __restri
     if (ptr_out[mid] <= t) lo = mid; else hi = mid;
   }
   const int b = lo;
-  const uint32_t r = (uint32_t)(t - ptr_out[b]);
+  uint32_t r = (uint32_t)(t - ptr_out[b]);
   const uint32_t n = (uint32_t)(ptr[b + 1] - ptr[b]);
   const uint64_t s = seed[0];
   uint32_t key = mix32((uint32_t)s ^ mix32((uint32_t)(s >> 32) + 0x85ebca6bu * (level + 1u)) ^ mix32((uint32_t)b * 0xc2b2ae35u + 1u));
+  if (r >= n && n > 0) {
+    // more slots than points (MinimumNumNodes, transforms.py:66-84): concatenated independent permutations
+    const uint32_t rep = r / n;
+    r -= rep * n;
+    key = mix32(key ^ (rep * 0x27d4eb2fu));
+  }
   idx_out[t] = (int32_t)(ptr[b] + (int64_t)feistel_perm(r, n, key));
 }
 

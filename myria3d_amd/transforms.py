@@ -1,0 +1,244 @@
+"""Device-side data preparation: the per-tile transforms the reference runs on the CPU in its
+dataloader workers, here as HIP kernels over a whole batch of tiles that is already resident in HBM.
+
+Same class names, constructor arguments and ``__call__(data) -> data`` protocol as the reference's Hydra targets
+(``/root/reference/configs/datamodule/transforms/preparations/points_budget.yaml``,
+``.../normalizations/default.yaml``):
+
+=============================  ==========================================================================
+``GridSampling(size)``          ``torch_geometric.transforms.GridSampling`` (voxel mean / label majority)
+``MinimumNumNodes(num)``        ``myria3d.pctl.transforms.transforms.MinimumNumNodes`` (transforms.py:66-87)
+``MaximumNumNodes(num)``        ``myria3d.pctl.transforms.transforms.MaximumNumNodes`` (transforms.py:48-63)
+``Center()``                    ``torch_geometric.transforms.Center``
+``NullifyLowestZ()``            transforms.py:141-146
+``NormalizePos(subtile_width)`` transforms.py:149-162
+``StandardizeRGBAndIntensity``  transforms.py:115-138
+=============================  ==========================================================================
+
+``data`` is anything with ``pos`` / ``x`` / ``y`` attributes (a PyG ``Data`` / ``Batch`` works); it may hold ONE tile
+or a collated batch (``ptr`` or a sorted ``batch`` vector) — every tile is treated on its own, exactly as if the
+reference transform had been applied before collating.  Tensors must live on the HIP device (no CPU fallback).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+__all__ = ["grid_sampling", "node_budget", "normalize_tiles", "GridSampling", "MinimumNumNodes", "MaximumNumNodes",
+           "Center", "NullifyLowestZ", "NormalizePos", "StandardizeRGBAndIntensity"]
+
+
+def _need_device(t: Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"myria3d_amd.transforms.{what} runs on the HIP device only (no CPU fallback)")
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# functional layer
+# --------------------------------------------------------------------------------------------------
+def grid_sampling(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tensor, size: float
+                  ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor]:
+    """GridSampling(size) of every tile of a batch: ``(pos', x', y', ptr')``, rows in ascending voxel id per tile."""
+    _need_device(pos, "grid_sampling")
+    dev = pos.device
+    pos = _f32(pos)
+    n, B = pos.shape[0], ptr.numel() - 1
+    ptr = ptr.to(dev, torch.int64).contiguous()
+    F = 0 if x is None else x.shape[1]
+    xin = None if x is None else _f32(x.to(dev))
+    yin = None if y is None else y.to(dev, torch.int64).contiguous()
+    ws = torch.empty(ops.lib().m3d_grid_sampling_workspace_bytes(n, B), dtype=torch.uint8, device=dev)
+    out_pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    out_x = None if x is None else torch.empty((n, F), dtype=torch.float32, device=dev)
+    out_y = None if y is None else torch.empty((n,), dtype=torch.int64, device=dev)
+    out_ptr = torch.empty((B + 1,), dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    dp = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    ops.call("m3d_grid_sampling", pos.data_ptr(), 3, dp(xin), F if xin is not None else 0, F, dp(yin), ptr.data_ptr(), B,
+             n, float(size), ws.data_ptr(), out_pos.data_ptr(), dp(out_x), dp(out_y), out_ptr.data_ptr(), _st())
+    ops.call("m3d_grid_sampling_status", ws.data_ptr(), n, B, status.data_ptr(), _st())
+    m = int(out_ptr[-1].item()) if B > 0 else 0  # the only host sync: the number of voxels sizes the outputs
+    if int(status.item()) != 0:
+        raise ValueError("GridSampling: a tile's voxel grid has >= 2**40 cells (size too small for its extent)")
+    return (out_pos[:m], None if out_x is None else out_x[:m], None if out_y is None else out_y[:m], out_ptr)
+
+
+def node_budget(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tensor, minimum: int = 0,
+                maximum: Optional[int] = None, seed: int = 0):
+    """MinimumNumNodes(minimum) then MaximumNumNodes(maximum) for every tile of a batch: tiles with fewer points are
+    filled with further random permutations of themselves, tiles with more keep the head of one random permutation
+    (the reference's scheme; the pseudo-random permutations are keyed by ``seed`` and the tile number).
+    Returns ``(pos', x', y', ptr', idx)`` with ``idx`` the kept rows (int32, into the input)."""
+    _need_device(pos, "node_budget")
+    dev = pos.device
+    ptr_c = ptr.cpu().to(torch.int64)
+    counts = ptr_c[1:] - ptr_c[:-1]
+    out = counts.clone()
+    if minimum:
+        out = torch.where((counts > 0) & (counts < minimum), torch.full_like(out, minimum), out)
+    if maximum is not None:
+        out = out.clamp(max=maximum)
+    ptr_d = ptr.to(dev, torch.int64).contiguous()
+    ptr_out = torch.cat([out.new_zeros(1), out.cumsum(0)]).to(torch.int64)
+    m, B = int(ptr_out[-1]), counts.numel()
+    if bool((out == counts).all()):
+        return pos, x, y, ptr_d, torch.arange(pos.shape[0], dtype=torch.int32, device=dev)
+    ptr_out_d = ptr_out.to(dev)
+    idx = torch.empty((m,), dtype=torch.int32, device=dev)
+    seed_t = torch.tensor([seed & ((1 << 63) - 1)], dtype=torch.int64, device=dev)
+    ops.call("m3d_decimation_indices", ptr_d.data_ptr(), ptr_out_d.data_ptr(), B, seed_t.data_ptr(), 0x5a17, idx.data_ptr(), m,
+             _st())
+    # tiles that keep all their points keep them in order (the reference returns such tiles untouched)
+    same = (out == counts)
+    if bool(same.any()):
+        ident = torch.cat([torch.arange(int(ptr_c[b]), int(ptr_c[b + 1]), dtype=torch.int32) if bool(same[b])
+                           else torch.full((int(out[b]),), -1, dtype=torch.int32) for b in range(B)]).to(dev)
+        idx = torch.where(ident >= 0, ident, idx)
+    pos_o = ops.gather_rows(_f32(pos), idx)
+    x_o = None if x is None else ops.gather_rows(_f32(x), idx)
+    y_o = None if y is None else y.to(dev)[idx.long()]
+    return pos_o, x_o, y_o, ptr_out_d, idx
+
+
+def normalize_tiles(pos: Tensor, x: Optional[Tensor], ptr: Tensor, center: bool = True, nullify_z: bool = True,
+                    subtile_width: Optional[float] = 50, intensity_col: int = -1, rgb_col: int = -1,
+                    clamp_sigma: float = 3.0) -> Tuple[Tensor, Optional[Tensor]]:
+    """Center, NullifyLowestZ, NormalizePos and StandardizeRGBAndIntensity of every tile in two launches.
+    Returns new tensors ``(pos', x')`` (inputs untouched)."""
+    _need_device(pos, "normalize_tiles")
+    dev = pos.device
+    pos_o = _f32(pos).clone()
+    x_o = None if x is None else _f32(x.to(dev)).clone()
+    ptr = ptr.to(dev, torch.int64).contiguous()
+    B, n = ptr.numel() - 1, pos_o.shape[0]
+    stats = torch.empty((max(B, 1), 8), dtype=torch.float64, device=dev)
+    scale = 1.0 if subtile_width is None else 1.0 / (subtile_width / 2)
+    ops.call("m3d_tile_normalize", pos_o.data_ptr(), 3, None if x_o is None else x_o.data_ptr(),
+             0 if x_o is None else x_o.stride(0), intensity_col if x_o is not None else -1,
+             rgb_col if x_o is not None else -1, ptr.data_ptr(), B, n, int(center), int(nullify_z), float(scale),
+             float(clamp_sigma), stats.data_ptr(), _st())
+    return pos_o, x_o
+
+
+# --------------------------------------------------------------------------------------------------
+# transform objects with the reference's names and call protocol
+# --------------------------------------------------------------------------------------------------
+def _tile_ptr(data) -> Tensor:
+    pos = data.pos
+    ptr = getattr(data, "ptr", None)
+    if ptr is not None:
+        return ptr.to(pos.device, torch.int64)
+    batch = getattr(data, "batch", None)
+    if batch is not None:
+        counts = torch.bincount(batch.to(pos.device), minlength=int(batch.max().item()) + 1 if batch.numel() else 0)
+        return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int64)
+    return torch.tensor([0, pos.shape[0]], dtype=torch.int64, device=pos.device)
+
+
+def _store(data, pos, x, y, ptr) -> None:
+    had_ptr, had_batch = getattr(data, "ptr", None) is not None, getattr(data, "batch", None) is not None
+    data.pos = pos
+    if x is not None:
+        data.x = x
+    if y is not None:
+        data.y = y
+    if had_ptr:
+        data.ptr = ptr
+    if had_batch:
+        counts = ptr[1:] - ptr[:-1]
+        data.batch = torch.repeat_interleave(torch.arange(counts.numel(), device=ptr.device), counts)
+    if hasattr(data, "num_nodes"):
+        try:
+            data.num_nodes = pos.shape[0]
+        except AttributeError:  # read-only property on some containers
+            pass
+
+
+class GridSampling:
+    def __init__(self, size: float):
+        self.size = float(size)
+
+    def __call__(self, data):
+        pos, x, y, ptr = grid_sampling(data.pos, getattr(data, "x", None), getattr(data, "y", None), _tile_ptr(data),
+                                       self.size)
+        _store(data, pos, x, y, ptr)
+        return data
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(size={self.size})"
+
+
+class _Budget:
+    minimum, maximum = 0, None
+
+    def __init__(self, num: int, seed: int = 0):
+        self.num, self.seed, self._calls = int(num), int(seed), 0
+
+    def __call__(self, data):
+        self._calls += 1  # a fresh permutation per call, like torch.randperm
+        pos, x, y, ptr, _ = node_budget(data.pos, getattr(data, "x", None), getattr(data, "y", None), _tile_ptr(data),
+                                        minimum=self.num if self.minimum else 0,
+                                        maximum=self.num if self.maximum else None,
+                                        seed=self.seed * 1000003 + self._calls)
+        _store(data, pos, x, y, ptr)
+        return data
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}({self.num})"
+
+
+class MinimumNumNodes(_Budget):
+    minimum, maximum = 1, None
+
+
+class MaximumNumNodes(_Budget):
+    minimum, maximum = 0, 1
+
+
+class _Normalize:
+    kw: dict = {}
+
+    def __call__(self, data):
+        kw = dict(center=False, nullify_z=False, subtile_width=None)
+        kw.update(self.kw)
+        cols = {}
+        if kw.pop("standardize", False):
+            names = list(data.x_features_names)
+            cols = dict(intensity_col=names.index("Intensity"), rgb_col=names.index("rgb_avg"))
+        pos, x = normalize_tiles(data.pos, getattr(data, "x", None) if cols else None, _tile_ptr(data), **kw, **cols)
+        data.pos = pos
+        if cols:
+            data.x = x
+        return data
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}()"
+
+
+class Center(_Normalize):
+    kw = dict(center=True)
+
+
+class NullifyLowestZ(_Normalize):
+    kw = dict(nullify_z=True)
+
+
+class NormalizePos(_Normalize):
+    def __init__(self, subtile_width: float = 50):
+        self.kw = dict(subtile_width=float(subtile_width))
+
+
+class StandardizeRGBAndIntensity(_Normalize):
+    kw = dict(standardize=True)

@@ -49,6 +49,16 @@ def test_constructor_and_forward_surface():
             fn(*args)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         myria3d_amd.DeviceInterpolator().store_predictions(torch.rand(4, 6), [np.arange(4)])
+    T = myria3d_amd.transforms
+    ptr = torch.tensor([0, 4])
+    for fn, args in [(T.grid_sampling, (torch.rand(4, 3), None, None, ptr, 0.25)),
+                     (T.node_budget, (torch.rand(4, 3), None, None, ptr, 300, 40000)),
+                     (T.normalize_tiles, (torch.rand(4, 3), None, ptr))]:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            fn(*args)
+    # same Hydra-facing names and constructor arguments as the reference's transform targets
+    assert repr(T.GridSampling(0.25)) == "GridSampling(size=0.25)" and T.MinimumNumNodes(300).num == 300
+    assert T.MaximumNumNodes(40000).num == 40000 and T.NormalizePos(subtile_width=50).kw["subtile_width"] == 50.0
 
 
 def test_level_plan_matches_reference_decimation_rule():

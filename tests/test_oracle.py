@@ -150,3 +150,29 @@ def test_interpolator_reduce_by_hand():
     assert preds.tolist() == [2, 0, 2]                     # uniform row: first maximum
     assert abs(entropy[1].item() - np.log(3.0)) < 1e-6
     assert abs(entropy[0].item() + (p * p.log()).sum().item()) < 1e-6
+
+
+def test_prep_oracle_grid_sampling_by_hand():
+    """GridSampling restated (PyG voxel_grid + consecutive_cluster + scatter mean / label majority)."""
+    from oracle import prep_oracle as P
+
+    pos = torch.tensor([[0.0, 0.0, 0.0], [0.1, 0.1, 0.1], [0.3, 0.0, 0.0], [0.0, 0.3, 0.0], [0.2, 0.2, 0.2],
+                        [0.26, 0.01, 0.01]])
+    x = torch.arange(12, dtype=torch.float32).reshape(6, 2)
+    y = torch.tensor([2, 1, 4, 0, 1, 3])
+    p, xx, yy, inv = P.grid_sampling(pos, x, y, 0.25)
+    # voxels (x fastest): (0,0,0) <- points 0,1,4 ; (1,0,0) <- points 2,5 ; (0,1,0) <- point 3
+    assert inv.tolist() == [0, 0, 1, 2, 0, 1]
+    assert torch.allclose(p[0], pos[[0, 1, 4]].mean(0)) and torch.allclose(p[1], pos[[2, 5]].mean(0))
+    assert torch.allclose(xx[0], x[[0, 1, 4]].mean(0)) and torch.allclose(xx[2], x[3])
+    assert yy.tolist() == [1, 3, 0]            # majority 1; tie between 4 and 3 -> first maximum = 3; single 0
+    # node budget bookkeeping and the standardisation quirk (clamp bound = 3 * std of the raw channel)
+    assert [P.budget_counts(n, 300, 40000) for n in (0, 1, 299, 300, 40000, 50000)] == [0, 300, 300, 300, 40000, 40000]
+    c = P.minimum_num_nodes_choice(7, 20, torch.Generator().manual_seed(0))
+    assert c.shape == (20,) and sorted(c[:7].tolist()) == list(range(7)) and sorted(c[7:14].tolist()) == list(range(7))
+    ch = torch.tensor([0.0, 0.1, 0.2, 50.0])
+    s = P.standardize_channel(ch)
+    assert torch.allclose(s, (ch - ch.mean()) / (ch.std() + 1e-6))     # |z| < 3 * std here: no clamping
+    assert torch.equal(P.standardize_channel(torch.tensor([5.0])), torch.tensor([0.0]))   # std NaN -> 1
+    q = P.normalize_pos(P.nullify_lowest_z(P.center(pos)), 50)
+    assert float(q[:, 2].min()) == 0.0 and torch.allclose(q[:, :2].mean(0), torch.zeros(2), atol=1e-7)
