@@ -292,6 +292,14 @@ def predict_bench(args, dev):
                                  "launch": "eager"}}), flush=True)
 
 
+def _baseline_config(points: int, neighbors: int) -> str:
+    if (points, neighbors) == (12800, 16):
+        return "BASELINE config 2"
+    if (points, neighbors) == (40000, 32):
+        return "BASELINE config 5, RandLA part"
+    return "non-BASELINE size"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -401,7 +409,7 @@ def main():
 
     total_points = B * N * world
     res = {
-        "metric": "points/sec fwd+bwd, RandLA-Net, 12 800-pt tiles",
+        "metric": f"points/sec fwd+bwd, RandLA-Net, {N // 1000} {N % 1000:03d}-pt tiles",
         "value": round(total_points * args.steps / dt, 1),
         "unit": "points/s",
         "n_gpus": world,
@@ -414,7 +422,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"RandLA-Net train step (fwd + CE + bwd + grad all-reduce + Adam), {B} tiles x {N} pts per GPU, "
-                               f"K={K}, F=9, C=6, decimation 4 (BASELINE config 2, fp32)",
+                               f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, fp32)",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
                    "launch": launch},
         "fwd_only": {"value": round(total_points * args.steps / dt_f, 1), "unit": "points/s",
