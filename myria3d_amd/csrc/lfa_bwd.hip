@@ -38,14 +38,26 @@ struct LfaBwdArgs {
 
 // tile geometry of the backward kernel per padded channel count: edge rows per workgroup iteration, waves per
 // workgroup, cap on resident (persistent) workgroups.  Overridable at compile time for tuning sweeps.
+#ifndef BWD_PIPE_8
+#define BWD_PIPE_8 1
+#endif
+#ifndef BWD_PIPE_16
+#define BWD_PIPE_16 1
+#endif
+#ifndef BWD_PIPE_32
+#define BWD_PIPE_32 1
+#endif
+#ifndef BWD_PIPE_64
+#define BWD_PIPE_64 1
+#endif
 #ifndef BWD_ROWS_16
-#define BWD_ROWS_16 256
+#define BWD_ROWS_16 128  // with MINW 4: four 4-wave workgroups per CU instead of two (ch=16: 334 -> 244 us, ch=8: 290 -> 240)
 #endif
 #ifndef BWD_ROWS_32
-#define BWD_ROWS_32 128
+#define BWD_ROWS_32 64   // with MINW 4: four workgroups per CU (154 -> 121 us)
 #endif
 #ifndef BWD_ROWS_64
-#define BWD_ROWS_64 128
+#define BWD_ROWS_64 64   // 4-wave workgroups, four per CU (286 -> 270 us at level 2)
 #endif
 #ifndef BWD_ROWS_128
 #define BWD_ROWS_128 64
@@ -60,10 +72,10 @@ struct LfaBwdArgs {
 #define BWD_NW_32 4
 #endif
 #ifndef BWD_NW_64
-#define BWD_NW_64 8
+#define BWD_NW_64 4
 #endif
 #ifndef BWD_NW_128
-#define BWD_NW_128 4
+#define BWD_NW_128 8   // with MINW 4: two 8-wave workgroups per CU (277 -> 255 us at level 3)
 #endif
 #ifndef BWD_NW_256
 #define BWD_NW_256 8
@@ -75,7 +87,7 @@ struct LfaBwdArgs {
 #define BWD_CAP_32 1024
 #endif
 #ifndef BWD_CAP_64
-#define BWD_CAP_64 512
+#define BWD_CAP_64 1024
 #endif
 #ifndef BWD_CAP_128
 #define BWD_CAP_128 512
@@ -83,15 +95,31 @@ struct LfaBwdArgs {
 #ifndef BWD_CAP_256
 #define BWD_CAP_256 256
 #endif
+// MINW: wavefronts per SIMD the register allocator must leave room for (2nd argument of __launch_bounds__ in HIP)
+#ifndef BWD_MINW_16
+#define BWD_MINW_16 4
+#endif
+#ifndef BWD_MINW_32
+#define BWD_MINW_32 4
+#endif
+#ifndef BWD_MINW_64
+#define BWD_MINW_64 4  // 128 VGPRs: 385 -> 293 us at level 2 with the former 8-wave workgroups
+#endif
+#ifndef BWD_MINW_128
+#define BWD_MINW_128 4
+#endif
+#ifndef BWD_MINW_256
+#define BWD_MINW_256 1
+#endif
 template <int CHP> struct BwdCfg {};
-template <> struct BwdCfg<16> { static constexpr int ROWS = BWD_ROWS_16, NW = BWD_NW_16, CAP = BWD_CAP_16; };
-template <> struct BwdCfg<32> { static constexpr int ROWS = BWD_ROWS_32, NW = BWD_NW_32, CAP = BWD_CAP_32; };
-template <> struct BwdCfg<64> { static constexpr int ROWS = BWD_ROWS_64, NW = BWD_NW_64, CAP = BWD_CAP_64; };
-template <> struct BwdCfg<128> { static constexpr int ROWS = BWD_ROWS_128, NW = BWD_NW_128, CAP = BWD_CAP_128; };
-template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = BWD_NW_256, CAP = BWD_CAP_256; };
+template <> struct BwdCfg<16> { static constexpr int ROWS = BWD_ROWS_16, NW = BWD_NW_16, CAP = BWD_CAP_16, MINW = BWD_MINW_16; };
+template <> struct BwdCfg<32> { static constexpr int ROWS = BWD_ROWS_32, NW = BWD_NW_32, CAP = BWD_CAP_32, MINW = BWD_MINW_32; };
+template <> struct BwdCfg<64> { static constexpr int ROWS = BWD_ROWS_64, NW = BWD_NW_64, CAP = BWD_CAP_64, MINW = BWD_MINW_64; };
+template <> struct BwdCfg<128> { static constexpr int ROWS = BWD_ROWS_128, NW = BWD_NW_128, CAP = BWD_CAP_128, MINW = BWD_MINW_128; };
+template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = BWD_NW_256, CAP = BWD_CAP_256, MINW = BWD_MINW_256; };
 
 template <int CH, int KP>
-__global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_kernel(LfaBwdArgs a) {
+__global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
   constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
@@ -385,6 +413,374 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64) void lfa_bwd_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// software-pipelined variant for ch <= 64 (M3D_LFA_BWD_PIPE): identical arithmetic, different load schedule
+// ------------------------------------------------------------------------------------------
+template <int CH, int KP>
+__global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_pipe_kernel(LfaBwdArgs a) {
+  constexpr int CHP = CH < 16 ? 16 : CH;
+  constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
+  constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
+  constexpr int ROWS = BwdCfg<CHP>::ROWS;
+  constexpr int TC = ROWS / KP, KT = KP / 16;
+  constexpr int STR = CHP + 2, RSTR = 18;
+  constexpr int MT = ROWS / 16, NT = CHP / 16;
+  constexpr int WN = NT < NW ? NT : NW, WM = NW / WN;
+  constexpr int NTW = NT / WN, MTW = MT / WM;
+  constexpr int S4 = CHP / 16;
+  static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
+  // GEMM-3 (dW_att) tile ownership
+  constexpr int T3 = NT * NT;
+  constexpr int KSPL3 = T3 >= NW ? 1 : NW / T3;
+  constexpr int TPW3 = T3 >= NW ? T3 / NW : 1;
+  constexpr int KTW3 = TPW3 < NT ? TPW3 : NT;
+  constexpr int CTW3 = TPW3 / KTW3;
+  // GEMM-4 (G) tile ownership: GT tiles of 16 encoder channels
+  constexpr int DP = CHP / 2 < 16 ? 16 : CHP / 2;  // padded encoder width
+  constexpr int GT = DP / 16;
+  constexpr int KSPL4 = GT >= NW ? 1 : NW / GT;
+  static_assert(GT <= NW, "one G tile per wave at most");
+  constexpr int D4 = D >> 2;
+  constexpr int GPT = (ROWS * D4 + NTHR - 1) / NTHR;  // prefetched x_j segments (float4) per thread
+  constexpr int NCW = MTW / KT;                       // centres per wave in the softmax phase
+  static_assert(ROWS <= NTHR, "one neighbour id per thread");
+  static_assert(S4 * NTW <= 8, "B fragments of one GEMM are held in registers");
+
+  __shared__ float F[ROWS * STR];
+  __shared__ float DA[ROWS * STR];
+  __shared__ float RT[ROWS * RSTR];
+  __shared__ int nbr2[2][ROWS];  // neighbour ids of the current and of the next group
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int K = a.K;
+  const int wn = wid % WN, wm = wid / WN;
+
+  // persistent accumulators
+  f32x4 acc3[CTW3][KTW3];
+#pragma unroll
+  for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+    for (int k = 0; k < KTW3; ++k) acc3[c][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 accg = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int t0 = (wid / KSPL3) * TPW3;
+  const int ct0 = t0 / NT, kt0 = t0 % NT, ks3 = wid % KSPL3;
+  const int gt = wid / KSPL4, ks4 = wid % KSPL4;
+
+  const int64_t ngroups = (a.n + TC - 1) / TC;
+  const int64_t nlast = a.n - 1;
+  // ---- software pipeline over the persistent loop: everything a group needs from HBM (neighbour ids, x_j rows,
+  // positions, dout) is loaded one group ahead into registers, so the loads fly during the MFMA phases of the
+  // previous group.  All prefetch loads are unconditional (clamped addresses); validity is applied on use.
+  float4 xg[GPT], ppi, ppj;
+  float dgp[NCW][NTW], dgc[NCW][NTW];
+  int jn = -1;
+  auto load_idx = [&](int64_t g) -> int {
+    int j = -1;
+    if (tid < ROWS && g < ngroups) {
+      const int ci = tid / KP, k = tid % KP;
+      const int64_t i = g * TC + ci;
+      if (i < a.n && k < K) j = a.idx[i * K + k];
+    }
+    return j;
+  };
+  auto prefetch = [&](int64_t g, const int* nb) {
+    const int64_t c0 = g * TC;
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+      const int f = tid + u * NTHR;
+      const int e = (f / D4) % ROWS, c4 = f % D4;  // (f >= ROWS*D4 only in a padded last trip: harmless extra load)
+      const int j = nb[e];
+      xg[u] = *(const float4*)(a.x + (int64_t)(j < 0 ? 0 : j) * D + c4 * 4);
+    }
+    {
+      const int e = tid % ROWS;
+      const int j = nb[e];
+      const int64_t i = c0 + e / KP;
+      ppi = a.pos4[i < a.n ? i : nlast];
+      ppj = a.pos4[j < 0 ? 0 : j];
+    }
+#pragma unroll
+    for (int cc = 0; cc < NCW; ++cc) {
+      const int64_t i = c0 + (wm * MTW + cc * KT) / KT;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wn * NTW + t) * 16 + lr;
+        dgp[cc][t] = a.dout[(i < a.n ? i : nlast) * CH + (col < CH ? col : CH - 1)];
+      }
+    }
+  };
+  int cur = 0;
+  if ((int64_t)blockIdx.x < ngroups) {
+    const int j0 = load_idx(blockIdx.x);
+    if (tid < ROWS) nbr2[0][tid] = j0;
+    __syncthreads();
+    prefetch(blockIdx.x, nbr2[0]);
+    jn = load_idx((int64_t)blockIdx.x + gridDim.x);
+  }
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, cur ^= 1) {
+    const int64_t c0 = grp * TC;
+    const int* nbr = nbr2[cur];
+    // ---- phase 1 (from the prefetched registers): x_j -> F[:, 0:D]
+    {
+#pragma unroll
+      for (int u = 0; u < GPT; ++u) {
+        const int f = tid + u * NTHR;
+        if (f < ROWS * D4) {
+          const int e = f / D4, c4 = f % D4;
+          float4 v = xg[u];
+          if (nbr[e] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          float* d = &F[e * STR + c4 * 4];
+          *(float2*)d = make_float2(v.x, v.y);
+          *(float2*)(d + 2) = make_float2(v.z, v.w);
+        }
+      }
+      if (CH < CHP) {
+        constexpr int P = CHP - CH;
+        for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
+      }
+    }
+    // ---- phase 1c: r, folded encoder -> F[:, D:2D];  [r | 1 | 0...] -> RT
+    {
+      constexpr int NG = NTHR / ROWS;
+      const int e = tid % ROWS;
+      const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
+      constexpr int DG = D / NG;
+      const int j = nbr[e];
+      float r[10];
+      rel_pos(ppi, ppj, r);
+      if (j < 0) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) r[q] = 0.f;
+      }
+      if (grp_c == 0) {
+        float* rt = &RT[e * RSTR];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) rt[q] = r[q];
+        rt[10] = j >= 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 11; q < 16; ++q) rt[q] = 0.f;
+      }
+      for (int c = grp_c * DG; c < (grp_c + 1) * DG; ++c) {
+        const float* w = a.wf + c * 10;
+        float v = a.bf[c];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+        F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < NCW; ++cc)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) dgc[cc][t] = dgp[cc][t];
+    if (tid < ROWS) nbr2[cur ^ 1][tid] = jn;  // ids of the next group (all -1 past the end)
+    __syncthreads();
+
+    if (a.dbg & 2) continue;   // timing experiment: phase 1 only
+    // ---- phase 2: A = F * W_att^T
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+      float4 b[S4][NTW];  // every B fragment of this wave's column tiles: one latency exposure, not one per k-step
+#pragma unroll
+      for (int s4 = 0; s4 < S4; ++s4)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[s4][t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#pragma unroll
+      for (int s4 = 0; s4 < S4; ++s4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float av[MTW];
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const float bv = i == 0 ? b[s4][t].x : (i == 1 ? b[s4][t].y : (i == 2 ? b[s4][t].z : b[s4][t].w));
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+          }
+        }
+      }
+    }
+    // B fragments of GEMM-2 (W_att^T): issued now, they arrive during the softmax phase
+    float4 b4[S4][NTW];
+#pragma unroll
+    for (int s4 = 0; s4 < S4; ++s4)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) b4[s4][t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+
+    if (a.dbg & 4) continue;   // timing experiment: phases 1-2
+    // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
+#pragma unroll
+    for (int cc = 0; cc < MTW / KT; ++cc) {
+      const int mt0 = wm * MTW + cc * KT;
+      const int64_t i = c0 + mt0 / KT;
+      bool vr[KT][4];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vr[kt][r] = nbr[(mt0 + kt) * 16 + lg * 4 + r] >= 0;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wn * NTW + t) * 16 + lr;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (vr[kt][r]) mx = fmaxf(mx, acc[cc * KT + kt][t][r]);
+        mx = xgroup_max(mx);
+        float num = 0.f, den = 0.f;
+        float fv[KT][4];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = 0.f, f = 0.f;
+            if (vr[kt][r]) {
+              p = __expf(acc[cc * KT + kt][t][r] - mx);
+              f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
+            }
+            num += p * f;
+            den += p;
+            acc[cc * KT + kt][t][r] = p;
+            fv[kt][r] = f;
+          }
+        num = xgroup_sum(num);
+        den = xgroup_sum(den);
+        const float inv = 1.f / (den + 1e-16f);
+        const float o = num * inv;
+        const float g = (i < a.n && col < CH) ? dgc[cc][t] : 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float s = acc[cc * KT + kt][t][r] * inv;
+            DA[((mt0 + kt) * 16 + lg * 4 + r) * STR + col] = s * g * (fv[kt][r] - o);
+            acc[cc * KT + kt][t][r] = g * s;
+          }
+      }
+    }
+    __syncthreads();
+
+    if (a.dbg & 8) continue;   // timing experiment: phases 1-3
+    // ---- phase 4: dF = dout*s + DA * W_att
+    {
+      // next group's loads go out here: the last in-iteration global load has been consumed before the first MFMA
+      // below, so waiting for it (vmcnt is in order) no longer drags these along
+      const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
+      bool first = true;
+#pragma unroll
+      for (int s4 = 0; s4 < S4; ++s4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float av[MTW];
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const float bv = i == 0 ? b4[s4][t].x : (i == 1 ? b4[s4][t].y : (i == 2 ? b4[s4][t].z : b4[s4][t].w));
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+          }
+        }
+        if (first) {
+          first = false;
+          if (grp + gridDim.x < ngroups) {
+            prefetch(grp + gridDim.x, nbr2[cur ^ 1]);
+            jn = load_idx(grp + 2 * (int64_t)gridDim.x);
+          }
+        }
+      }
+    }
+    // ---- phase 5: dW_att[c, k] += sum_e DA[e, c] * F[e, k]
+    {
+#pragma unroll 2
+      for (int s = ks3; s < ROWS / 4; s += KSPL3) {
+        const int eo = (4 * s + lg) * STR + lr;
+        float av[CTW3], bv[KTW3];
+#pragma unroll
+        for (int c = 0; c < CTW3; ++c) av[c] = DA[eo + (ct0 + c) * 16];
+#pragma unroll
+        for (int k = 0; k < KTW3; ++k) bv[k] = F[eo + (kt0 + k) * 16];
+#pragma unroll
+        for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+          for (int k = 0; k < KTW3; ++k) acc3[c][k] = mfma16(av[c], bv[k], acc3[c][k]);
+      }
+    }
+    __syncthreads();
+    if (a.dbg & 16) continue;  // timing experiment: phases 1-5
+    // ---- phase 6: scatter dx; dy -> DA[:, D:2D]
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wn * NTW + t) * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (wm * MTW + m) * 16 + lg * 4 + r;
+          const float v = acc[m][t][r];
+          if (col < D) {
+            if (CHP == 16) {
+              DA[row * STR + col] = v;  // D < 16: only D of 16 lanes hold dx columns -> repacked below
+            } else {
+              const int j = nbr[row];
+              if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
+            }
+          } else if (col < CH) {
+            const float lse = F[row * STR + col];
+            DA[row * STR + col] = v * (lse > 0.f ? 1.f : a.slope);
+          }
+        }
+      }
+    __syncthreads();
+    if (CHP == 16) {
+      // dx scatter with every lane busy: lane -> (edge row, column) over the ROWS x D block staged in DA, so one
+      // wave-level atomic covers 64 / D whole rows instead of D of 16 lanes of a 16-column MFMA tile
+      for (int f = tid; f < ROWS * D; f += NTHR) {
+        const int row = f / D, col = f % D;
+        const int j = nbr[row];
+        if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
+      }
+    }
+    if (a.dbg & 32) continue;  // timing experiment: phases 1-6
+    // ---- phase 7: G[c', q] += sum_e dy[e, c'] * [r|1][e, q]
+    if (wid < GT * KSPL4) {
+      const bool crow = gt * 16 + lr < D;
+#pragma unroll 4
+      for (int s = ks4; s < ROWS / 4; s += KSPL4) {
+        const int e = 4 * s + lg;
+        const float av = crow ? DA[e * STR + D + gt * 16 + lr] : 0.f;
+        const float bv = RT[e * RSTR + lr];
+        accg = mfma16(av, bv, accg);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write this workgroup's partials
+  {
+    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPL3 + ks3) * (CHP * CHP);
+#pragma unroll
+    for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+      for (int k = 0; k < KTW3; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dst[((ct0 + c) * 16 + lg * 4 + r) * CHP + (kt0 + k) * 16 + lr] = acc3[c][k][r];
+    if (wid < GT * KSPL4) {
+      float* gd = a.g_part + ((size_t)blockIdx.x * KSPL4 + ks4) * (DP * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gd[(gt * 16 + lg * 4 + r) * 16 + lr] = accg[r];
+    }
+  }
+}
+
 // sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64).  blockIdx.x owns 256 consecutive
 // elements, blockIdx.y a contiguous chunk of the partials; chunks are combined with one atomic per element per
 // chunk into the (pre-zeroed) outputs, so the pass runs at HBM speed instead of one block walking every partial.
@@ -452,6 +848,18 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
 template <int CH>
 static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
+  // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*); M3D_LFA_BWD_PIPE=0/1
+  // forces it off / on for every ch <= 64
+  static const int pipe_env = getenv("M3D_LFA_BWD_PIPE") ? atoi(getenv("M3D_LFA_BWD_PIPE")) : -1;
+  constexpr bool pipe_default = CH == 8 ? BWD_PIPE_8 : (CH == 16 ? BWD_PIPE_16 : (CH == 32 ? BWD_PIPE_32 : BWD_PIPE_64));
+  const bool pipe = pipe_env < 0 ? pipe_default : pipe_env != 0;
+  if constexpr (CH <= 64) {
+    if (pipe && !a.dbg) {
+      if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_pipe_kernel<CH, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((lfa_bwd_pipe_kernel<CH, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+    }
+  }
   if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
   else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
