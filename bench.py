@@ -85,29 +85,33 @@ def _time_launch(launch, reps=20):
     return sum(a.elapsed_time(b) for a, b in evs) / reps
 
 
-def _pmc_traffic(kernel_prefix):
+def _pmc_traffic(*kernel_prefixes):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*pmc_fetch_size.csv and
     *pmc_write_size.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_target.py, per-kernel means in
     KB).  FETCH_SIZE is reported raw: MI355X_MICROARCH.md calibrates a x2 correction for wide streaming reads only;
-    these kernels mostly gather.  Returns None when the passes are not in the tree."""
+    these kernels mostly gather.  ``kernel_prefixes``: the kernel's name in the newest pass first, older names after
+    (kernels were renamed when variants were added).  Returns None when no pass in the tree lists the kernel."""
     import csv
     import glob
 
-    tot, found = 0.0, 0
-    for pat, col in (("*pmc_fetch_size.csv", "FETCH_SIZE"), ("*pmc_write_size.csv", "WRITE_SIZE")):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
-        if not files:
-            return None
-        for row in csv.DictReader(open(files[-1])):
-            if row["kernel"].startswith(kernel_prefix):
-                tot += float(row[col]) * 1024.0
-                found += 1
-    return int(tot) if found == 2 else None
+    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_size.csv")), reverse=True)
+    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_write_size.csv")), reverse=True)
+
+    def lookup(files, col):
+        for f in files:                      # newest pass first
+            for prefix in kernel_prefixes:
+                for row in csv.DictReader(open(f)):
+                    if row["kernel"].startswith(prefix):
+                        return float(row[col]) * 1024.0
+        return None
+
+    r, w = lookup(fetch, "FETCH_SIZE"), lookup(write, "WRITE_SIZE")
+    return None if r is None or w is None else int(r + w)
 
 
 def stage_rooflines(net, pos, plan):
     """Roofline entries, timed live.  ``dominant``: the kernel with the largest share of the training step —
-    lfa_bwd_kernel<64,16> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an fp32-MFMA kernel:
+    lfa_bwd_pipe_kernel<64,16> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an fp32-MFMA kernel:
     3 x 2 x n x K x (ch^2 + 10 ch/2) flop per launch (recomputed attention GEMM + its two backward GEMMs).
     ``knn_lse``: the HBM-class kernels of the kNN + LSE-gather stage at level 1 (204 800 points), algorithmic bytes
     per launch from SURVEY 8d: kNN read 12 n + write 4 n K; LFA(ch) read n (12 + 4 ch/2 + 4 K), write 4 n ch."""
@@ -139,10 +143,10 @@ def stage_rooflines(net, pos, plan):
             0, G.data_ptr(), ws.data_ptr(), st))
         flop = 3 * 2 * n2 * K * (ch * ch + 10 * D)
         tf = flop / (ms * 1e-3) / 1e12
-        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
+        out["dominant"] = {"kernel": f"lfa_bwd_pipe_kernel<64,16> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
                            "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-                           "traffic": _pmc_traffic("void lfa_bwd_kernel<64, 16>"),
+                           "traffic": _pmc_traffic("void lfa_bwd_pipe_kernel<64, 16>", "void lfa_bwd_kernel<64, 16>"),
                            "algorithmic_flop_per_launch": flop, "avg_launch_ms": round(ms, 4)}
         # ---- kNN + LSE gather stage at level 1
         n1 = geo.pos4[0].shape[0]
@@ -166,7 +170,7 @@ def stage_rooflines(net, pos, plan):
             {"kernel": f"knn_query_kernel<16> (level 1, n={n1}, K={K})", "bound": "hbm",
              "achieved": round(b_knn / (ms_knn * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(b_knn / (ms_knn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_knn,
-             "traffic": _pmc_traffic("void knn_query_kernel<16>"),
+             "traffic": _pmc_traffic("void knn_query_kernel<16, KeyF64>", "void knn_query_kernel<16>"),
              "avg_launch_ms": round(ms_knn, 4)},
             {"kernel": f"lfa_fwd_kernel<16,16> (block1.lfa2, ch={ch1}, n={n1}, K={K})", "bound": "hbm",
              "achieved": round(b_lfa / (ms_lfa * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
