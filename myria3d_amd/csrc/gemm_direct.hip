@@ -30,6 +30,19 @@
 // then across lanes / waves (LDS); every workgroup stores its partial row and m3d_bn_finalize sums the rows.
 #include <stdlib.h>
 #include "gemm_common.h"
+
+// wavefronts per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument in HIP).  hipcc sizes
+// registers to the launch bounds only; the LFA backward gained 20-30 % from such caps.  1 = no cap:
+// untuned knobs for same-box A/B runs (tools/build_variant.sh NAME gemm_direct.hip -DGEMM_RS_MINW=4 ...).
+#ifndef GEMM_RS_MINW
+#define GEMM_RS_MINW 1
+#endif
+#ifndef GEMM_KL_MINW
+#define GEMM_KL_MINW 1
+#endif
+#ifndef WGRAD_MINW
+#define WGRAD_MINW 1
+#endif
 #include "../../include/m3d_hip.h"
 
 __device__ __forceinline__ float f4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -214,7 +227,7 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
 // grid: (row workgroups, column slices); 4 waves per workgroup take interleaved 16-row tiles.
 // ------------------------------------------------------------------------------------------
 template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM>
-__global__ __launch_bounds__(256) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
+__global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * NT;
@@ -260,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_rowstream_kernel(GemmArgs g, int cve
 // any K: weights streamed from L1/L2 chunk by chunk.  grid: (row workgroups, column slices of 16*NTW)
 // ------------------------------------------------------------------------------------------
 template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM>
-__global__ __launch_bounds__(256) void gemm_kloop_kernel(GemmArgs g, int cvec) {
+__global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
   // a wave owns MTW x NTW tiles of 16x16: every A / W fragment it loads feeds NTW / MTW MFMAs (these shapes are
   // L2-bandwidth bound on operand re-reads when MTW = NTW = 1)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
@@ -504,7 +517,7 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 // every WAVE is one row split (no LDS, no barrier: LDS float atomics run at ~1 lane per 3 clocks on gfx950 and
 // made a cross-wave reduction the dominant cost); its [16*TN, 16*TK] partial goes from the accumulators to ws
 template <int TN, int TK>
-__global__ __launch_bounds__(256) void wgrad2_kernel(WgradArgs g) {
+__global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * TN, kb = blockIdx.z * 16 * TK;
