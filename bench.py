@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=2, help="tiles in the bounded CPU-baseline sample")
-    ap.add_argument("--mode", choices=["train", "predict"], default="train",
-                    help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative)")
+    ap.add_argument("--mode", choices=["train", "predict", "prepare"], default="train",
+                    help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative).  "
+                         "prepare: the data-preparation chain in front of the net (informative)")
     return ap.parse_args()
 
 
@@ -243,7 +244,7 @@ def predict_bench(args, dev):
     on the sub-sampled tiles (12 800 points each), knn_interpolate(k=10) of the logits to every point of the full
     tiles (25 000 each; the reference does this on the CPU, model.py:86-103), scatter_sum into the per-cloud logit
     accumulator by original index (interpolation.py:116); finally softmax / argmax / entropy over all points."""
-    from myria3d_amd import HipRandLANet, knn_interpolate, make_plan, scatter_sum
+    from myria3d_amd import HipRandLANet, knn_interpolate, make_plan, predict_reduce, scatter_sum
     from myria3d_amd.synthetic import synthetic_tile
 
     n_full, n_sub, tiles, bs, C = 25000, args.points, 400, 50, 7
@@ -274,9 +275,7 @@ def predict_bench(args, dev):
                 logits = net(x_sub, pos_sub, None, ptr_sub, plan=plan)
                 dense = knn_interpolate(logits, pos_sub, pos_full, batch_sub, batch_full, k=10)
                 scatter_sum(dense, orig + b * bs * n_full, out=acc)
-            probas = acc.softmax(dim=1)
-            pred = probas.argmax(dim=1)
-            entropy = -(probas * torch.log(probas + 1e-12)).sum(dim=1)
+            probas, pred, entropy = predict_reduce(acc)  # softmax / argmax / entropy in one launch (interp.hip)
         return pred, entropy
 
     for _ in range(max(1, args.warmup // 3)):
@@ -294,6 +293,62 @@ def predict_bench(args, dev):
                       "config": {"workload": f"BASELINE config 3: {tiles} tiles x {n_full} pts (sub-sampled to {n_sub}), "
                                              f"batch {bs}, K={args.neighbors}, C={C}, interpolation k=10",
                                  "launch": "eager"}}), flush=True)
+
+
+def prepare_bench(args, dev):
+    """Data preparation in front of the net (informative, not the contract line): raw tiles of
+    ~80 000 points (a 50 m Lidar-HD tile at ~30 pts/m^2) through GridSampling(0.25) -> MinimumNumNodes(300) ->
+    MaximumNumNodes(40000) -> Center -> NullifyLowestZ -> NormalizePos -> StandardizeRGBAndIntensity
+    (configs/datamodule/transforms/preparations/points_budget.yaml, normalizations/default.yaml) as ONE batch on the
+    device, next to the oracle's per-tile CPU chain (oracle/prep_oracle.py) on a bounded sample of the same tiles."""
+    import numpy as np
+
+    from myria3d_amd import transforms as T
+
+    n_raw, B = 80000, args.tiles
+    rs = np.random.RandomState(0)
+    pos = torch.from_numpy((rs.uniform(0, 1, (B * n_raw, 3)) * np.array([50.0, 50.0, 6.0])).astype(np.float32))
+    pos += torch.arange(B).repeat_interleave(n_raw)[:, None].float() * torch.tensor([50.0, 0.0, 0.0])
+    x = torch.from_numpy(rs.uniform(0, 1, (B * n_raw, 9)).astype(np.float32))
+    x[:, 0] = torch.from_numpy(rs.gamma(2.0, 300.0, B * n_raw).astype(np.float32))
+    x[:, 7] = torch.from_numpy(rs.uniform(0, 255, B * n_raw).astype(np.float32))
+    y = torch.from_numpy(rs.randint(0, 6, B * n_raw).astype(np.int64))
+    ptr = torch.arange(0, (B + 1) * n_raw, n_raw, dtype=torch.int64)
+    pos_d, x_d, y_d, ptr_d = pos.to(dev), x.to(dev), y.to(dev), ptr.to(dev)
+
+    def chain():
+        p, xx, yy, pt = T.grid_sampling(pos_d, x_d, y_d, ptr_d, 0.25)
+        p, xx, yy, pt, _ = T.node_budget(p, xx, yy, pt, minimum=300, maximum=40000, seed=1)
+        p, xx = T.normalize_tiles(p, xx, pt, center=True, nullify_z=True, subtile_width=50, intensity_col=0, rgb_col=7)
+        return p, xx, yy, pt
+
+    for _ in range(max(1, args.warmup // 2)):
+        out = chain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = max(1, args.steps // 2)
+    for _ in range(reps):
+        out = chain()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    res = {"metric": "raw points/sec through the data preparation (GridSampling + node budget + normalisations)",
+           "value": round(B * n_raw / dt, 1), "unit": "points/s", "n_gpus": 1, "ms_per_batch": round(dt * 1e3, 3),
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{B} raw tiles x {n_raw} pts, voxel 0.25 m -> {int(out[3][-1])} points kept",
+                      "launch": "eager (one host sync per batch: the voxel count)"}}
+    if not args.skip_cpu_baseline:
+        sys.path.insert(0, ROOT)
+        from oracle import prep_oracle as O  # checker / baseline only
+
+        k = min(args.cpu_tiles, B)
+        torch.set_num_threads(1)  # the reference runs these transforms in single-threaded dataloader workers
+        t0 = time.perf_counter()
+        O.prepare_tiles(pos[:k * n_raw], x[:k * n_raw], y[:k * n_raw], ptr[:k + 1].tolist(), 0.25, 50, 0, 7)
+        dt_c = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(k * n_raw / dt_c, 1), "unit": "points/s", "cores": 1, "kind": "port",
+                               "sample": f"{k} tile(s) x {n_raw} raw pts, oracle/prep_oracle.py (torch CPU ops, one "
+                                         "thread = one dataloader worker; the reference uses 3 workers)"}
+    print(json.dumps(res), flush=True)
 
 
 def _baseline_config(points: int, neighbors: int) -> str:
@@ -325,6 +380,11 @@ def main():
         if world > 1:
             raise SystemExit("--mode predict is a single-GPU run (tiles shard without communication)")
         predict_bench(args, dev)
+        return
+    if args.mode == "prepare":
+        if world > 1:
+            raise SystemExit("--mode prepare is a single-GPU run (tiles shard without communication)")
+        prepare_bench(args, dev)
         return
     B, N, K = args.tiles, args.points, args.neighbors
     tile_ids = shard_tiles(B * world, rank, world)  # weak scaling: B tiles per rank
