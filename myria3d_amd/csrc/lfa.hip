@@ -27,6 +27,11 @@
 #include "lfa_common.h"
 #include "../../include/m3d_hip.h"
 
+// 1: double-buffer the attention-weight fragments of the MFMA loop (untuned knob for a same-box A/B; default off)
+#ifndef LFA_B_PREFETCH
+#define LFA_B_PREFETCH 0
+#endif
+
 // CH is a template parameter: with a runtime channel count the index arithmetic of the gather / encoder loops
 // (f / D4, f % D4, ...) compiled to integer divisions and made the ch <= 32 kernels VALU-issue-bound
 // (rocprofv3 SQ_INSTS_VALU: 650 VALU instructions per wave of 64 edges at ch = 16).
@@ -108,11 +113,27 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+#if LFA_B_PREFETCH
+  // B fragments double-buffered: the loads of k-step group s4+1 are in flight during the MFMAs of group s4
+  float4 bn[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+#endif
 #pragma unroll 1
   for (int s4 = 0; s4 < S4; ++s4) {
     float4 b[NTW];
+#if LFA_B_PREFETCH
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) b[t] = bn[t];
+    {
+      const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+    }
+#else
 #pragma unroll
     for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float av[MTW];

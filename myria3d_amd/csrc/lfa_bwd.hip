@@ -38,6 +38,10 @@ struct LfaBwdArgs {
 
 // tile geometry of the backward kernel per padded channel count: edge rows per workgroup iteration, waves per
 // workgroup, cap on resident (persistent) workgroups.  Overridable at compile time for tuning sweeps.
+// 1: double-buffer the weight fragments of GEMM-1 / GEMM-2 in the non-pipelined kernel (ch >= 128): untuned A/B knob
+#ifndef BWD_B_PREFETCH
+#define BWD_B_PREFETCH 0
+#endif
 #ifndef BWD_PIPE_8
 #define BWD_PIPE_8 1
 #endif
@@ -232,11 +236,26 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+#if BWD_B_PREFETCH
+      float4 bn[NTW];  // B fragments double-buffered: group s4+1 is in flight during the MFMAs of group s4
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+#endif
 #pragma unroll 1
       for (int s4 = 0; s4 < S4; ++s4) {
         float4 b[NTW];
+#if BWD_B_PREFETCH
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = bn[t];
+        {
+          const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+        }
+#else
 #pragma unroll
         for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float av[MTW];
@@ -310,11 +329,26 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     // ---- phase 4: dF = dout*s + DA * W_att
     {
       const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
+#if BWD_B_PREFETCH
+      float4 bn[NTW];  // B fragments double-buffered: group s4+1 is in flight during the MFMAs of group s4
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+#endif
 #pragma unroll 1
       for (int s4 = 0; s4 < S4; ++s4) {
         float4 b[NTW];
+#if BWD_B_PREFETCH
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t] = bn[t];
+        {
+          const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+        }
+#else
 #pragma unroll
         for (int t = 0; t < NTW; ++t) b[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float av[MTW];
