@@ -112,7 +112,7 @@ def _pmc_traffic(*kernel_prefixes):
 
 def stage_rooflines(net, pos, plan):
     """Roofline entries, timed live.  ``dominant``: the kernel with the largest share of the training step —
-    lfa_bwd_pipe_kernel<64,16> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an fp32-MFMA kernel:
+    lfa_bwd_kernel<64,16,PIPE=true> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an fp32-MFMA kernel:
     3 x 2 x n x K x (ch^2 + 10 ch/2) flop per launch (recomputed attention GEMM + its two backward GEMMs).
     ``knn_lse``: the HBM-class kernels of the kNN + LSE-gather stage at level 1 (204 800 points), algorithmic bytes
     per launch from SURVEY 8d: kNN read 12 n + write 4 n K; LFA(ch) read n (12 + 4 ch/2 + 4 K), write 4 n ch."""
@@ -144,10 +144,11 @@ def stage_rooflines(net, pos, plan):
             0, G.data_ptr(), ws.data_ptr(), st))
         flop = 3 * 2 * n2 * K * (ch * ch + 10 * D)
         tf = flop / (ms * 1e-3) / 1e12
-        out["dominant"] = {"kernel": f"lfa_bwd_pipe_kernel<64,16> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
+        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16,pipelined> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
                            "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-                           "traffic": _pmc_traffic("void lfa_bwd_pipe_kernel<64, 16>", "void lfa_bwd_kernel<64, 16>"),
+                           "traffic": _pmc_traffic("void lfa_bwd_kernel<64, 16, true>", "void lfa_bwd_pipe_kernel<64, 16>",
+                                                    "void lfa_bwd_kernel<64, 16>"),
                            "algorithmic_flop_per_launch": flop, "avg_launch_ms": round(ms, 4)}
         # ---- kNN + LSE gather stage at level 1
         n1 = geo.pos4[0].shape[0]

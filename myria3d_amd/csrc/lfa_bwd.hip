@@ -122,336 +122,11 @@ template <> struct BwdCfg<64> { static constexpr int ROWS = BWD_ROWS_64, NW = BW
 template <> struct BwdCfg<128> { static constexpr int ROWS = BWD_ROWS_128, NW = BWD_NW_128, CAP = BWD_CAP_128, MINW = BWD_MINW_128; };
 template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = BWD_NW_256, CAP = BWD_CAP_256, MINW = BWD_MINW_256; };
 
-template <int CH, int KP>
+// PIPE (ch <= 64): software-pipelined load schedule — neighbour ids, x_j rows, positions and dout of the NEXT group
+// are loaded into registers while the current group's GEMMs run, and all B fragments of a GEMM are fetched up front.
+// Identical arithmetic either way; the launcher picks per channel count (BWD_PIPE_*, M3D_LFA_BWD_PIPE).
+template <int CH, int KP, bool PIPE>
 __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_kernel(LfaBwdArgs a) {
-  constexpr int CHP = CH < 16 ? 16 : CH;
-  constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
-  constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
-  constexpr int ROWS = BwdCfg<CHP>::ROWS;
-  constexpr int TC = ROWS / KP, KT = KP / 16;
-  constexpr int STR = CHP + 2, RSTR = 18;
-  constexpr int MT = ROWS / 16, NT = CHP / 16;
-  constexpr int WN = NT < NW ? NT : NW, WM = NW / WN;
-  constexpr int NTW = NT / WN, MTW = MT / WM;
-  constexpr int S4 = CHP / 16;
-  static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
-  // GEMM-3 (dW_att) tile ownership
-  constexpr int T3 = NT * NT;
-  constexpr int KSPL3 = T3 >= NW ? 1 : NW / T3;
-  constexpr int TPW3 = T3 >= NW ? T3 / NW : 1;
-  constexpr int KTW3 = TPW3 < NT ? TPW3 : NT;
-  constexpr int CTW3 = TPW3 / KTW3;
-  // GEMM-4 (G) tile ownership: GT tiles of 16 encoder channels
-  constexpr int DP = CHP / 2 < 16 ? 16 : CHP / 2;  // padded encoder width
-  constexpr int GT = DP / 16;
-  constexpr int KSPL4 = GT >= NW ? 1 : NW / GT;
-  static_assert(GT <= NW, "one G tile per wave at most");
-
-  __shared__ float F[ROWS * STR];
-  __shared__ float DA[ROWS * STR];
-  __shared__ float RT[ROWS * RSTR];
-  __shared__ int nbr[ROWS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int K = a.K;
-  const int wn = wid % WN, wm = wid / WN;
-
-  // persistent accumulators
-  f32x4 acc3[CTW3][KTW3];
-#pragma unroll
-  for (int c = 0; c < CTW3; ++c)
-#pragma unroll
-    for (int k = 0; k < KTW3; ++k) acc3[c][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 accg = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int t0 = (wid / KSPL3) * TPW3;
-  const int ct0 = t0 / NT, kt0 = t0 % NT, ks3 = wid % KSPL3;
-  const int gt = wid / KSPL4, ks4 = wid % KSPL4;
-
-  const int64_t ngroups = (a.n + TC - 1) / TC;
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t c0 = grp * TC;
-    // ---- phase 1a: neighbour ids
-    for (int e = tid; e < ROWS; e += NTHR) {
-      int ci = e / KP, k = e % KP;
-      int64_t i = c0 + ci;
-      int j = -1;
-      if (i < a.n && k < K) j = a.idx[i * K + k];
-      nbr[e] = j;
-    }
-    __syncthreads();
-    // ---- phase 1b: gather x_j
-    {
-      constexpr int D4 = D >> 2;
-      for (int f = tid; f < ROWS * D4; f += NTHR) {
-        int e = f / D4, c4 = f % D4;
-        int j = nbr[e];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
-        float* d = &F[e * STR + c4 * 4];
-        *(float2*)d = make_float2(v.x, v.y);
-        *(float2*)(d + 2) = make_float2(v.z, v.w);
-      }
-      if (CH < CHP) {
-        constexpr int P = CHP - CH;
-        for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
-      }
-    }
-    // ---- phase 1c: r, folded encoder -> F[:, D:2D];  [r | 1 | 0...] -> RT
-    {
-      constexpr int NG = NTHR / ROWS;
-      const int e = tid % ROWS;
-      const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
-      constexpr int DG = D / NG;
-      const int j = nbr[e];
-      const int64_t i = c0 + e / KP;
-      float r[10];
-#pragma unroll
-      for (int q = 0; q < 10; ++q) r[q] = 0.f;
-      if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
-      if (grp_c == 0) {
-        float* rt = &RT[e * RSTR];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) rt[q] = r[q];
-        rt[10] = j >= 0 ? 1.f : 0.f;
-#pragma unroll
-        for (int q = 11; q < 16; ++q) rt[q] = 0.f;
-      }
-      for (int c = grp_c * DG; c < (grp_c + 1) * DG; ++c) {
-        const float* w = a.wf + c * 10;
-        float v = a.bf[c];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) v += w[q] * r[q];
-        F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
-      }
-    }
-    __syncthreads();
-
-    if (a.dbg & 2) continue;   // timing experiment: phase 1 only
-    // ---- phase 2: A = F * W_att^T
-    f32x4 acc[MTW][NTW];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
-      const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
-#if BWD_B_PREFETCH
-      float4 bn[NTW];  // B fragments double-buffered: group s4+1 is in flight during the MFMAs of group s4
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
-#endif
-#pragma unroll 1
-      for (int s4 = 0; s4 < S4; ++s4) {
-        float4 b[NTW];
-#if BWD_B_PREFETCH
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t] = bn[t];
-        {
-          const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
-        }
-#else
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float av[MTW];
-#pragma unroll
-          for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
-          }
-        }
-      }
-    }
-
-    if (a.dbg & 4) continue;   // timing experiment: phases 1-2
-    // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
-#pragma unroll
-    for (int cc = 0; cc < MTW / KT; ++cc) {
-      const int mt0 = wm * MTW + cc * KT;
-      const int64_t i = c0 + mt0 / KT;
-      bool vr[KT][4];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vr[kt][r] = nbr[(mt0 + kt) * 16 + lg * 4 + r] >= 0;
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const int col = (wn * NTW + t) * 16 + lr;
-        float mx = -__builtin_inff();
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (vr[kt][r]) mx = fmaxf(mx, acc[cc * KT + kt][t][r]);
-        mx = xgroup_max(mx);
-        float num = 0.f, den = 0.f;
-        float fv[KT][4];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = 0.f, f = 0.f;
-            if (vr[kt][r]) {
-              p = __expf(acc[cc * KT + kt][t][r] - mx);
-              f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
-            }
-            num += p * f;
-            den += p;
-            acc[cc * KT + kt][t][r] = p;
-            fv[kt][r] = f;
-          }
-        num = xgroup_sum(num);
-        den = xgroup_sum(den);
-        const float inv = 1.f / (den + 1e-16f);
-        const float o = num * inv;
-        const float g = (i < a.n && col < CH) ? a.dout[i * CH + col] : 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float s = acc[cc * KT + kt][t][r] * inv;
-            DA[((mt0 + kt) * 16 + lg * 4 + r) * STR + col] = s * g * (fv[kt][r] - o);
-            acc[cc * KT + kt][t][r] = g * s;
-          }
-      }
-    }
-    __syncthreads();
-
-    if (a.dbg & 8) continue;   // timing experiment: phases 1-3
-    // ---- phase 4: dF = dout*s + DA * W_att
-    {
-      const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
-#if BWD_B_PREFETCH
-      float4 bn[NTW];  // B fragments double-buffered: group s4+1 is in flight during the MFMAs of group s4
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4) * 64 + lane];
-#endif
-#pragma unroll 1
-      for (int s4 = 0; s4 < S4; ++s4) {
-        float4 b[NTW];
-#if BWD_B_PREFETCH
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t] = bn[t];
-        {
-          const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
-        }
-#else
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float av[MTW];
-#pragma unroll
-          for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
-          }
-        }
-      }
-    }
-    // ---- phase 5: dW_att[c, k] += sum_e DA[e, c] * F[e, k]
-    {
-#pragma unroll 2
-      for (int s = ks3; s < ROWS / 4; s += KSPL3) {
-        const int eo = (4 * s + lg) * STR + lr;
-        float av[CTW3], bv[KTW3];
-#pragma unroll
-        for (int c = 0; c < CTW3; ++c) av[c] = DA[eo + (ct0 + c) * 16];
-#pragma unroll
-        for (int k = 0; k < KTW3; ++k) bv[k] = F[eo + (kt0 + k) * 16];
-#pragma unroll
-        for (int c = 0; c < CTW3; ++c)
-#pragma unroll
-          for (int k = 0; k < KTW3; ++k) acc3[c][k] = mfma16(av[c], bv[k], acc3[c][k]);
-      }
-    }
-    __syncthreads();
-    if (a.dbg & 16) continue;  // timing experiment: phases 1-5
-    // ---- phase 6: scatter dx; dy -> DA[:, D:2D]
-#pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const int col = (wn * NTW + t) * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (wm * MTW + m) * 16 + lg * 4 + r;
-          const float v = acc[m][t][r];
-          if (col < D) {
-            if (CHP == 16) {
-              DA[row * STR + col] = v;  // D < 16: only D of 16 lanes hold dx columns -> repacked below
-            } else {
-              const int j = nbr[row];
-              if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
-            }
-          } else if (col < CH) {
-            const float lse = F[row * STR + col];
-            DA[row * STR + col] = v * (lse > 0.f ? 1.f : a.slope);
-          }
-        }
-      }
-    __syncthreads();
-    if (CHP == 16) {
-      // dx scatter with every lane busy: lane -> (edge row, column) over the ROWS x D block staged in DA, so one
-      // wave-level atomic covers 64 / D whole rows instead of D of 16 lanes of a 16-column MFMA tile
-      for (int f = tid; f < ROWS * D; f += NTHR) {
-        const int row = f / D, col = f % D;
-        const int j = nbr[row];
-        if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
-      }
-    }
-    if (a.dbg & 32) continue;  // timing experiment: phases 1-6
-    // ---- phase 7: G[c', q] += sum_e dy[e, c'] * [r|1][e, q]
-    if (wid < GT * KSPL4) {
-      const bool crow = gt * 16 + lr < D;
-#pragma unroll 4
-      for (int s = ks4; s < ROWS / 4; s += KSPL4) {
-        const int e = 4 * s + lg;
-        const float av = crow ? DA[e * STR + D + gt * 16 + lr] : 0.f;
-        const float bv = RT[e * RSTR + lr];
-        accg = mfma16(av, bv, accg);
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- write this workgroup's partials
-  {
-    float* dst = a.dw_part + ((size_t)blockIdx.x * KSPL3 + ks3) * (CHP * CHP);
-#pragma unroll
-    for (int c = 0; c < CTW3; ++c)
-#pragma unroll
-      for (int k = 0; k < KTW3; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          dst[((ct0 + c) * 16 + lg * 4 + r) * CHP + (kt0 + k) * 16 + lr] = acc3[c][k][r];
-    if (wid < GT * KSPL4) {
-      float* gd = a.g_part + ((size_t)blockIdx.x * KSPL4 + ks4) * (DP * 16);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gd[(gt * 16 + lg * 4 + r) * 16 + lr] = accg[r];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// software-pipelined variant for ch <= 64 (M3D_LFA_BWD_PIPE): identical arithmetic, different load schedule
-// ------------------------------------------------------------------------------------------
-template <int CH, int KP>
-__global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_pipe_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
   constexpr int NW = BwdCfg<CHP>::NW, NTHR = NW * 64;
@@ -477,13 +152,13 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   constexpr int D4 = D >> 2;
   constexpr int GPT = (ROWS * D4 + NTHR - 1) / NTHR;  // prefetched x_j segments (float4) per thread
   constexpr int NCW = MTW / KT;                       // centres per wave in the softmax phase
-  static_assert(ROWS <= NTHR, "one neighbour id per thread");
-  static_assert(S4 * NTW <= 8, "B fragments of one GEMM are held in registers");
+  static_assert(!PIPE || ROWS <= NTHR, "one neighbour id per thread");
+  static_assert(!PIPE || S4 * NTW <= 8, "B fragments of one GEMM are held in registers");
 
   __shared__ float F[ROWS * STR];
   __shared__ float DA[ROWS * STR];
   __shared__ float RT[ROWS * RSTR];
-  __shared__ int nbr2[2][ROWS];  // neighbour ids of the current and of the next group
+  __shared__ int nbr2[PIPE ? 2 : 1][ROWS];  // neighbour ids of the current (and, pipelined, of the next) group
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -545,70 +220,128 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     }
   };
   int cur = 0;
-  if ((int64_t)blockIdx.x < ngroups) {
+  if (PIPE && (int64_t)blockIdx.x < ngroups) {
     const int j0 = load_idx(blockIdx.x);
     if (tid < ROWS) nbr2[0][tid] = j0;
     __syncthreads();
     prefetch(blockIdx.x, nbr2[0]);
     jn = load_idx((int64_t)blockIdx.x + gridDim.x);
   }
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, cur ^= 1) {
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, cur ^= (PIPE ? 1 : 0)) {
     const int64_t c0 = grp * TC;
-    const int* nbr = nbr2[cur];
-    // ---- phase 1 (from the prefetched registers): x_j -> F[:, 0:D]
-    {
+    int* nbr = nbr2[cur];
+    if constexpr (PIPE) {
+      // ---- phase 1 (from the prefetched registers): x_j -> F[:, 0:D]
+      {
 #pragma unroll
-      for (int u = 0; u < GPT; ++u) {
-        const int f = tid + u * NTHR;
-        if (f < ROWS * D4) {
-          const int e = f / D4, c4 = f % D4;
-          float4 v = xg[u];
-          if (nbr[e] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < GPT; ++u) {
+          const int f = tid + u * NTHR;
+          if (f < ROWS * D4) {
+            const int e = f / D4, c4 = f % D4;
+            float4 v = xg[u];
+            if (nbr[e] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* d = &F[e * STR + c4 * 4];
+            *(float2*)d = make_float2(v.x, v.y);
+            *(float2*)(d + 2) = make_float2(v.z, v.w);
+          }
+        }
+        if (CH < CHP) {
+          constexpr int P = CHP - CH;
+          for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
+        }
+      }
+      // ---- phase 1c: r, folded encoder -> F[:, D:2D];  [r | 1 | 0...] -> RT
+      {
+        constexpr int NG = NTHR / ROWS;
+        const int e = tid % ROWS;
+        const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
+        constexpr int DG = D / NG;
+        const int j = nbr[e];
+        float r[10];
+        rel_pos(ppi, ppj, r);
+        if (j < 0) {
+#pragma unroll
+          for (int q = 0; q < 10; ++q) r[q] = 0.f;
+        }
+        if (grp_c == 0) {
+          float* rt = &RT[e * RSTR];
+#pragma unroll
+          for (int q = 0; q < 10; ++q) rt[q] = r[q];
+          rt[10] = j >= 0 ? 1.f : 0.f;
+#pragma unroll
+          for (int q = 11; q < 16; ++q) rt[q] = 0.f;
+        }
+        for (int c = grp_c * DG; c < (grp_c + 1) * DG; ++c) {
+          const float* w = a.wf + c * 10;
+          float v = a.bf[c];
+#pragma unroll
+          for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+          F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCW; ++cc)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) dgc[cc][t] = dgp[cc][t];
+      if (tid < ROWS) nbr2[cur ^ 1][tid] = jn;  // ids of the next group (all -1 past the end)
+      __syncthreads();
+    } else {
+      // ---- phase 1a: neighbour ids
+      for (int e = tid; e < ROWS; e += NTHR) {
+        int ci = e / KP, k = e % KP;
+        int64_t i = c0 + ci;
+        int j = -1;
+        if (i < a.n && k < K) j = a.idx[i * K + k];
+        nbr[e] = j;
+      }
+      __syncthreads();
+      // ---- phase 1b: gather x_j
+      {
+        constexpr int D4 = D >> 2;
+        for (int f = tid; f < ROWS * D4; f += NTHR) {
+          int e = f / D4, c4 = f % D4;
+          int j = nbr[e];
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
           float* d = &F[e * STR + c4 * 4];
           *(float2*)d = make_float2(v.x, v.y);
           *(float2*)(d + 2) = make_float2(v.z, v.w);
         }
+        if (CH < CHP) {
+          constexpr int P = CHP - CH;
+          for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
+        }
       }
-      if (CH < CHP) {
-        constexpr int P = CHP - CH;
-        for (int f = tid; f < ROWS * P; f += NTHR) F[(f / P) * STR + CH + (f % P)] = 0.f;
-      }
-    }
-    // ---- phase 1c: r, folded encoder -> F[:, D:2D];  [r | 1 | 0...] -> RT
-    {
-      constexpr int NG = NTHR / ROWS;
-      const int e = tid % ROWS;
-      const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
-      constexpr int DG = D / NG;
-      const int j = nbr[e];
-      float r[10];
-      rel_pos(ppi, ppj, r);
-      if (j < 0) {
+      // ---- phase 1c: r, folded encoder -> F[:, D:2D];  [r | 1 | 0...] -> RT
+      {
+        constexpr int NG = NTHR / ROWS;
+        const int e = tid % ROWS;
+        const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
+        constexpr int DG = D / NG;
+        const int j = nbr[e];
+        const int64_t i = c0 + e / KP;
+        float r[10];
 #pragma unroll
         for (int q = 0; q < 10; ++q) r[q] = 0.f;
-      }
-      if (grp_c == 0) {
-        float* rt = &RT[e * RSTR];
+        if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
+        if (grp_c == 0) {
+          float* rt = &RT[e * RSTR];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) rt[q] = r[q];
-        rt[10] = j >= 0 ? 1.f : 0.f;
+          for (int q = 0; q < 10; ++q) rt[q] = r[q];
+          rt[10] = j >= 0 ? 1.f : 0.f;
 #pragma unroll
-        for (int q = 11; q < 16; ++q) rt[q] = 0.f;
-      }
-      for (int c = grp_c * DG; c < (grp_c + 1) * DG; ++c) {
-        const float* w = a.wf + c * 10;
-        float v = a.bf[c];
+          for (int q = 11; q < 16; ++q) rt[q] = 0.f;
+        }
+        for (int c = grp_c * DG; c < (grp_c + 1) * DG; ++c) {
+          const float* w = a.wf + c * 10;
+          float v = a.bf[c];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) v += w[q] * r[q];
-        F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+          for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+          F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+        }
       }
+      __syncthreads();
     }
-#pragma unroll
-    for (int cc = 0; cc < NCW; ++cc)
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) dgc[cc][t] = dgp[cc][t];
-    if (tid < ROWS) nbr2[cur ^ 1][tid] = jn;  // ids of the next group (all -1 past the end)
-    __syncthreads();
 
     if (a.dbg & 2) continue;   // timing experiment: phase 1 only
     // ---- phase 2: A = F * W_att^T
@@ -617,35 +350,76 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
-      const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
-      float4 b[S4][NTW];  // every B fragment of this wave's column tiles: one latency exposure, not one per k-step
+    if constexpr (PIPE) {
+      {
+        const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+        float4 b[S4][NTW];  // every B fragment of this wave's column tiles: one latency exposure, not one per k-step
 #pragma unroll
-      for (int s4 = 0; s4 < S4; ++s4)
+        for (int s4 = 0; s4 < S4; ++s4)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) b[s4][t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+          for (int t = 0; t < NTW; ++t) b[s4][t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
 #pragma unroll
-      for (int s4 = 0; s4 < S4; ++s4) {
+        for (int s4 = 0; s4 < S4; ++s4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float av[MTW];
+          for (int i = 0; i < 4; ++i) {
+            float av[MTW];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+            for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const float bv = i == 0 ? b[s4][t].x : (i == 1 ? b[s4][t].y : (i == 2 ? b[s4][t].z : b[s4][t].w));
+            for (int t = 0; t < NTW; ++t) {
+              const float bv = i == 0 ? b[s4][t].x : (i == 1 ? b[s4][t].y : (i == 2 ? b[s4][t].z : b[s4][t].w));
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+              for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+            }
+          }
+        }
+      }
+    } else {
+      {
+        const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+#if BWD_B_PREFETCH
+        float4 bn[NTW];  // B fragments double-buffered: group s4+1 is in flight during the MFMAs of group s4
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+#endif
+#pragma unroll 1
+        for (int s4 = 0; s4 < S4; ++s4) {
+          float4 b[NTW];
+#if BWD_B_PREFETCH
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) b[t] = bn[t];
+          {
+            const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+          }
+#else
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#endif
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float av[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+              const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+#pragma unroll
+              for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+            }
           }
         }
       }
     }
     // B fragments of GEMM-2 (W_att^T): issued now, they arrive during the softmax phase
-    float4 b4[S4][NTW];
+    float4 b4[PIPE ? S4 : 1][NTW];
+    if constexpr (PIPE) {
 #pragma unroll
-    for (int s4 = 0; s4 < S4; ++s4)
+      for (int s4 = 0; s4 < S4; ++s4)
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) b4[s4][t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+        for (int t = 0; t < NTW; ++t) b4[s4][t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+    }
 
     if (a.dbg & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
@@ -688,7 +462,11 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         den = xgroup_sum(den);
         const float inv = 1.f / (den + 1e-16f);
         const float o = num * inv;
-        const float g = (i < a.n && col < CH) ? dgc[cc][t] : 0.f;
+        float g = 0.f;
+        if (i < a.n && col < CH) {
+          if constexpr (PIPE) g = dgc[cc][t];
+          else g = a.dout[i * CH + col];
+        }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -703,30 +481,69 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 
     if (a.dbg & 8) continue;   // timing experiment: phases 1-3
     // ---- phase 4: dF = dout*s + DA * W_att
-    {
-      // next group's loads go out here: the last in-iteration global load has been consumed before the first MFMA
-      // below, so waiting for it (vmcnt is in order) no longer drags these along
-      const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
-      bool first = true;
+    if constexpr (PIPE) {
+      {
+        // next group's loads go out here: the last in-iteration global load has been consumed before the first MFMA
+        // below, so waiting for it (vmcnt is in order) no longer drags these along
+        const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
+        bool first = true;
 #pragma unroll
-      for (int s4 = 0; s4 < S4; ++s4) {
+        for (int s4 = 0; s4 < S4; ++s4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float av[MTW];
+          for (int i = 0; i < 4; ++i) {
+            float av[MTW];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
+            for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const float bv = i == 0 ? b4[s4][t].x : (i == 1 ? b4[s4][t].y : (i == 2 ? b4[s4][t].z : b4[s4][t].w));
+            for (int t = 0; t < NTW; ++t) {
+              const float bv = i == 0 ? b4[s4][t].x : (i == 1 ? b4[s4][t].y : (i == 2 ? b4[s4][t].z : b4[s4][t].w));
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+              for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+            }
+          }
+          if (first) {
+            first = false;
+            if (grp + gridDim.x < ngroups) {
+              prefetch(grp + gridDim.x, nbr2[cur ^ 1]);
+              jn = load_idx(grp + 2 * (int64_t)gridDim.x);
+            }
           }
         }
-        if (first) {
-          first = false;
-          if (grp + gridDim.x < ngroups) {
-            prefetch(grp + gridDim.x, nbr2[cur ^ 1]);
-            jn = load_idx(grp + 2 * (int64_t)gridDim.x);
+      }
+    } else {
+      {
+        const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
+#if BWD_B_PREFETCH
+        float4 bn[NTW];  // B fragments double-buffered: group s4+1 is in flight during the MFMAs of group s4
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+#endif
+#pragma unroll 1
+        for (int s4 = 0; s4 < S4; ++s4) {
+          float4 b[NTW];
+#if BWD_B_PREFETCH
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) b[t] = bn[t];
+          {
+            const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+          }
+#else
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) b[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+#endif
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float av[MTW];
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+              const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+#pragma unroll
+              for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+            }
           }
         }
       }
@@ -889,13 +706,13 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st)
   const bool pipe = pipe_env < 0 ? pipe_default : pipe_env != 0;
   if constexpr (CH <= 64) {
     if (pipe && !a.dbg) {
-      if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_pipe_kernel<CH, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
-      else hipLaunchKernelGGL((lfa_bwd_pipe_kernel<CH, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
       return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
     }
   }
-  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16>), dim3(p.grid), dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, false>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, false>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
 
