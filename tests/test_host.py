@@ -179,3 +179,32 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
         capture_output=True, text=True, env=env, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_knn_f64_key_trick_preserves_the_total_order():
+    """knn.hip keeps the top-k keys (fp32 d2 bits << 32 | row) as IEEE doubles so that a sorted insertion is a
+    v_min_f64 / v_max_f64 chain.  The high word is biased by 0x00100000: every fp32 pattern up to 0x7FEFFFFF (zero,
+    denormals, normals, inf, the canonical NaN 0x7FC00000 the hardware produces) must map to a finite NORMAL double, and the doubles must order exactly like the
+    64-bit integers; +inf is the empty-slot sentinel above all of them."""
+    rs = np.random.RandomState(0)
+    d2 = np.concatenate([
+        np.array([0.0, 1e-45, 1e-39, 1.17549435e-38, 1.0, 3.4028235e38, np.inf], np.float32),
+        np.abs(rs.standard_cauchy(5000)).astype(np.float32), rs.uniform(0, 1e-30, 2000).astype(np.float32),
+        np.repeat(np.float32(0.25), 64)])                       # ties in distance: the row decides
+    bits = d2.view(np.uint32).astype(np.uint64)
+    bits = np.concatenate([bits, np.array([0x7FC00000, 0x7FEFFFFF], np.uint64)])   # canonical NaN; largest pattern covered
+    rows = rs.randint(0, 2 ** 31 - 1, bits.shape[0]).astype(np.uint64)
+    ukey = (bits << np.uint64(32)) | rows
+    dkey = (((bits + np.uint64(0x00100000)) << np.uint64(32)) | rows).view(np.float64)
+    assert np.isfinite(dkey).all()
+    exp = (dkey.view(np.uint64) >> np.uint64(52)) & np.uint64(0x7FF)
+    assert (exp > 0).all() and (exp < 0x7FF).all(), "normal doubles only: min/max return their operands unchanged"
+    order_u, order_d = np.argsort(ukey, kind="stable"), np.argsort(dkey, kind="stable")
+    assert np.array_equal(order_u, order_d)
+    assert len(np.unique(ukey)) == len(np.unique(dkey))
+    empty = np.array([0x7FF0000000000000], np.uint64).view(np.float64)[0]
+    assert np.isinf(empty) and (dkey < empty).all()
+    # decoding gives back the distance bits and the row
+    back = dkey.view(np.uint64)
+    assert np.array_equal((back >> np.uint64(32)) - np.uint64(0x00100000), bits)
+    assert np.array_equal(back & np.uint64(0xFFFFFFFF), rows)
