@@ -216,7 +216,7 @@ struct KeyU64 {
 // KeyF64: the same 64 bits read as an IEEE double.  For sign bit 0 the order of doubles IS the order of their bit
 // patterns, so a sorted insertion is a chain of v_min_f64 / v_max_f64 — 2 full-rate VALU instructions per slot.
 // The high word is biased by one double-exponent step (0x00100000): every finite / inf / canonical-NaN fp32 d2 (bit
-// patterns up to 0x7FEFFFFF; tests/test_host.py pins the mapping) then maps to a
+// patterns up to 0x7FDFFFFF; tests/test_host.py pins the mapping) then maps to a
 // NORMAL finite double (no denormal or NaN operand ever reaches min/max, so the bits pass through unchanged), and
 // +inf (0x7FF00000'00000000) is the "empty slot" sentinel, above every key.
 struct KeyF64 {

@@ -183,7 +183,7 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
 
 def test_knn_f64_key_trick_preserves_the_total_order():
     """knn.hip keeps the top-k keys (fp32 d2 bits << 32 | row) as IEEE doubles so that a sorted insertion is a
-    v_min_f64 / v_max_f64 chain.  The high word is biased by 0x00100000: every fp32 pattern up to 0x7FEFFFFF (zero,
+    v_min_f64 / v_max_f64 chain.  The high word is biased by 0x00100000: every fp32 pattern up to 0x7FDFFFFF (zero,
     denormals, normals, inf, the canonical NaN 0x7FC00000 the hardware produces) must map to a finite NORMAL double, and the doubles must order exactly like the
     64-bit integers; +inf is the empty-slot sentinel above all of them."""
     rs = np.random.RandomState(0)
@@ -192,7 +192,7 @@ def test_knn_f64_key_trick_preserves_the_total_order():
         np.abs(rs.standard_cauchy(5000)).astype(np.float32), rs.uniform(0, 1e-30, 2000).astype(np.float32),
         np.repeat(np.float32(0.25), 64)])                       # ties in distance: the row decides
     bits = d2.view(np.uint32).astype(np.uint64)
-    bits = np.concatenate([bits, np.array([0x7FC00000, 0x7FEFFFFF], np.uint64)])   # canonical NaN; largest pattern covered
+    bits = np.concatenate([bits, np.array([0x7FC00000, 0x7FDFFFFF], np.uint64)])   # canonical NaN; largest pattern covered
     rows = rs.randint(0, 2 ** 31 - 1, bits.shape[0]).astype(np.uint64)
     ukey = (bits << np.uint64(32)) | rows
     dkey = (((bits + np.uint64(0x00100000)) << np.uint64(32)) | rows).view(np.float64)
