@@ -163,3 +163,30 @@ def test_transform_objects_compose_like_the_reference_pipeline(device):
     with torch.no_grad():
         logits = net(data.x, data.pos, data.batch, data.ptr)
     assert logits.shape == (rptr[-1], 6) and bool(torch.isfinite(logits).all())
+
+
+def test_golden_fixture_prep_and_merge(device):
+    """Committed vectors (tests/golden/prep_small.npz, generated by the CPU oracles): the kernels against the files,
+    without running the oracle."""
+    import os
+
+    import myria3d_amd
+    from myria3d_amd import transforms as T
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prep_small.npz"))
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    p, xx, yy, ptr = T.grid_sampling(t("pos").to(device), t("x").to(device), t("y").to(device), t("ptr").to(device), 0.25)
+    assert ptr.cpu().tolist() == g["prep_ptr"].tolist() and torch.equal(yy.cpu(), t("prep_y"))
+    p, xx = T.normalize_tiles(p, xx, ptr, center=True, nullify_z=True, subtile_width=50, intensity_col=0, rgb_col=7)
+    assert torch.allclose(p.cpu(), t("prep_pos"), rtol=0, atol=1e-4)
+    assert torch.allclose(xx.cpu(), t("prep_x"), rtol=1e-4, atol=1e-4)
+    itp = myria3d_amd.DeviceInterpolator()
+    for i in range(3):
+        itp.store_predictions(t(f"logits{i}").to(device), [g[f"idx{i}"]])
+    out = itp.reduce_predictions(int(g["nb_points"]))
+    assert torch.equal(out["idx_in_full_cloud"].cpu(), t("cat_idx"))
+    assert torch.allclose(out["probas"].cpu(), t("probas"), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(out["entropy"].cpu(), t("entropy"), rtol=2e-6, atol=1e-5)
+    top2 = t("rows").topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(out["preds"].cpu()[clear], t("preds")[clear])

@@ -176,3 +176,24 @@ def test_prep_oracle_grid_sampling_by_hand():
     assert torch.equal(P.standardize_channel(torch.tensor([5.0])), torch.tensor([0.0]))   # std NaN -> 1
     q = P.normalize_pos(P.nullify_lowest_z(P.center(pos)), 50)
     assert float(q[:, 2].min()) == 0.0 and torch.allclose(q[:, :2].mean(0), torch.zeros(2), atol=1e-7)
+
+
+def test_golden_vectors_pin_the_prep_and_interpolator_oracles():
+    """tests/golden/prep_small.npz (tests/golden/make_golden_prep.py): data preparation chain + merged predictions."""
+    from oracle import prep_oracle as P
+    from oracle.randla_oracle import interpolator_reduce
+
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "prep_small.npz"))
+    p, xx, yy, optr = P.prepare_tiles(torch.from_numpy(g["pos"]), torch.from_numpy(g["x"]), torch.from_numpy(g["y"]),
+                                      g["ptr"].tolist(), 0.25, 50, 0, 7)
+    assert optr == g["prep_ptr"].tolist()
+    assert torch.allclose(p, torch.from_numpy(g["prep_pos"]), rtol=0, atol=1e-6)
+    assert torch.allclose(xx, torch.from_numpy(g["prep_x"]), rtol=1e-5, atol=1e-5)
+    assert torch.equal(yy, torch.from_numpy(g["prep_y"]))
+    logits = [torch.from_numpy(g[f"logits{i}"]) for i in range(3)]
+    idx = [g[f"idx{i}"] for i in range(3)]
+    rows, probas, preds, entropy, cat_idx = interpolator_reduce(logits, idx, int(g["nb_points"]))
+    assert torch.equal(cat_idx, torch.from_numpy(g["cat_idx"])) and torch.equal(rows, torch.from_numpy(g["rows"]))
+    assert torch.allclose(probas, torch.from_numpy(g["probas"]), rtol=1e-6, atol=1e-7)
+    assert torch.equal(preds, torch.from_numpy(g["preds"]))
+    assert torch.allclose(entropy, torch.from_numpy(g["entropy"]), rtol=1e-6, atol=1e-6)
