@@ -181,6 +181,50 @@ def test_gradient_allreduce_world_size_2_gloo(tmp_path):
     assert res.stdout.count("ok") == 2
 
 
+_FLAT_DDP_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from myria3d_amd import HipRandLANet
+from myria3d_amd.ddp import broadcast_module_state, shard_tiles
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(rank)                                   # different initial weights per rank
+net = HipRandLANet(9, 6, return_logits=True).flatten_parameters()
+keys = list(net.state_dict().keys())
+assert net.flat_parameters.numel() >= 1113686 and "block1.lfa1.mlp_attention.lins.0.weight" in keys
+assert all(p.data_ptr() >= net.flat_parameters.data_ptr() for p in net.parameters())     # views of ONE bucket
+broadcast_module_state(net)                               # one broadcast of the flat bucket (+ the BN buffers)
+got = [torch.zeros_like(net.flat_parameters) for _ in range(world)]
+dist.all_gather(got, net.flat_parameters)
+assert torch.equal(got[0], got[1]) and torch.equal(net.fc0.weight.reshape(-1), got[0][:net.fc0.weight.numel()])
+# what FusedAdam.step(all_reduce=True) does before its single launch: ONE all-reduce(SUM) of the flat gradient,
+# scaled by 1/world inside the update
+for i, p in enumerate(net.parameters()):
+    p.grad.fill_(float(rank + 1) * (i + 1))               # p.grad is a view of net.flat_grads
+local = net.flat_grads.clone()
+dist.all_reduce(net.flat_grads, op=dist.ReduceOp.SUM)
+for i, p in enumerate(net.parameters()):
+    assert torch.all(p.grad == 3.0 * (i + 1)), i          # ranks 1 + 2
+assert torch.equal(net.flat_grads, local * 3.0 / (rank + 1))
+assert list(shard_tiles(32, rank, world)) == list(range(16 * rank, 16 * rank + 16))
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_flat_bucket_broadcast_and_allreduce_world_size_2_gloo(tmp_path):
+    """The N > 1 host logic on the real module: flat parameter / gradient buckets, one broadcast, one all-reduce."""
+    script = tmp_path / "flat_ddp_check.py"
+    script.write_text(_FLAT_DDP_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29533", str(script), ROOT],
+        capture_output=True, text=True, env=env, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2
+
+
 def test_knn_f64_key_trick_preserves_the_total_order():
     """knn.hip keeps the top-k keys (fp32 d2 bits << 32 | row) as IEEE doubles so that a sorted insertion is a
     v_min_f64 / v_max_f64 chain.  The high word is biased by 0x00100000: every fp32 pattern up to 0x7FDFFFFF (zero,
