@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--points", type=int, default=12800, help="points per tile")
     ap.add_argument("--neighbors", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="EXPERIMENTAL: build the position-only tables of step i+1 beside step i "
+                         "(HipRandLANet.prefetch_geometry); off by default")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=2, help="tiles in the bounded CPU-baseline sample")
@@ -400,13 +403,19 @@ def main():
     plan = make_plan(ptr.tolist(), 4, K, dev)
     opt = FusedAdam(net, lr=0.003933709606504788, all_reduce=True)  # lr: configs/model/pyg_randla_net_model.yaml:4
 
+    look = args.lookahead
+
     def fwd_bwd():
         net.train()
         out = net(x, pos, None, ptr, plan=plan)
+        if look:  # the next step's kNN tables / decimation are built beside this step's kernels
+            net.prefetch_geometry(pos, ptr, plan, train=True)
         loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
         loss.backward()
         if net.grad_side is not None:
             net.grad_side.join()  # weight-gradient side stream rejoins (must happen inside a captured region)
+        if look:
+            net.join_geometry()
 
     def train_step():
         fwd_bwd()
@@ -416,6 +425,9 @@ def main():
         net.eval()
         with torch.no_grad():
             net(x, pos, None, ptr, plan=plan)
+            if look:
+                net.prefetch_geometry(pos, ptr, plan, train=False)
+                net.join_geometry()
 
     launch = "eager"
     step_fn, fwd_fn = train_step, fwd_step
@@ -489,7 +501,7 @@ def main():
         "config": {"workload": f"RandLA-Net train step (fwd + CE + bwd + grad all-reduce + Adam), {B} tiles x {N} pts per GPU, "
                                f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, fp32)",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
-                   "launch": launch},
+                   "launch": launch, **({"geometry_lookahead": True} if look else {})},
         "fwd_only": {"value": round(total_points * args.steps / dt_f, 1), "unit": "points/s",
                      "ms_per_step": round(dt_f / args.steps * 1e3, 4), "mode": "eval, no_grad"},
     }

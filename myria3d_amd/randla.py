@@ -129,6 +129,7 @@ class HipRandLANet(nn.Module):
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
+        self._look: Optional["_Lookahead"] = None  # geometry of the NEXT forward, see prefetch_geometry()
 
     # ------------------------------------------------------------------------------------------
     # flat parameter / gradient buffers (opt-in): every parameter becomes a view of ONE fp32 buffer and every
@@ -339,7 +340,7 @@ class HipRandLANet(nn.Module):
             return self._forward(x, pos, ptr.to(torch.int64).contiguous(), decimation_idx, dropout_mask, plan,
                                  record, train)
 
-    def _geometry(self, pos: Tensor, plan: LevelPlan, decimation_idx, train: bool) -> "_Geometry":
+    def _geometry(self, pos: Tensor, plan: LevelPlan, decimation_idx, train: bool, wait_main: bool = True) -> "_Geometry":
         """Everything that depends on positions only — kNN grids and tables of the 4 levels, encoder moments, random
         decimation, the decoder's 1-NN tables — enqueued on a SIDE stream: these kernels are latency / VALU-bound
         and overlap with the MFMA- and HBM-bound feature kernels of the main stream (under hipGraph capture the two
@@ -347,7 +348,7 @@ class HipRandLANet(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_stream(pos.device) if self.overlap_geometry else main
         g = _Geometry(main, side)
-        if side is not main:
+        if side is not main and wait_main:
             side.wait_stream(main)
         K = self.num_neighbors
         with torch.cuda.stream(side):
@@ -381,6 +382,79 @@ class HipRandLANet(nn.Module):
             g.mark()                                                            # stage 9
         return g
 
+    # ------------------------------------------------------------------------------------------
+    # geometry lookahead (opt-in, EXPERIMENTAL: not yet run on hardware).  The position-only work of a forward pass
+    # depends on nothing the previous step produces, so it can be enqueued one step ahead:
+    #     net.prefetch_geometry(pos_next, ptr_next, plan)      # side stream, returns at once
+    #     ... the current step's backward / optimizer run meanwhile ...
+    #     net(x_next, pos_next, None, ptr_next, plan=plan)     # finds its tables ready: nothing to wait for
+    # hipGraph-friendly: results live in PERSISTENT buffers (``Y``: written by the side stream; ``X``: read by the
+    # network), refreshed by one device copy Y -> X at the head of the consuming forward, so a captured step always
+    # reads and writes the same addresses and the tables computed by replay r are consumed by replay r + 1.
+    # ------------------------------------------------------------------------------------------
+    def prefetch_geometry(self, pos: Tensor, ptr: Tensor, plan: Optional[LevelPlan] = None,
+                          train: Optional[bool] = None) -> None:
+        if not pos.is_cuda:
+            raise RuntimeError("HipRandLANet runs on an MI355X (cuda/HIP device) only; there is no CPU fallback")
+        pos = pos.to(torch.float32).contiguous()
+        ptr = ptr.to(torch.int64).contiguous()
+        if plan is None:
+            plan = self.plan_for(ptr)
+        train = self.training if train is None else train
+        look = self._look
+        key = (tuple(pos.shape), id(plan), bool(train))
+        if look is None or look.key != key:
+            look = self._look = _Lookahead(key)
+        side = self._side_stream(pos.device)
+        first = look.x_free is None
+        if not first:
+            # the only dependency: the Y -> X copy of the consuming forward (Y may be overwritten after it).  Called
+            # right after that forward has been enqueued, the tables are built beside its kernels and its backward
+            side.wait_event(look.x_free)
+        with torch.cuda.stream(side):
+            self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
+        geo = self._geometry(pos, plan, None, train, wait_main=first)
+        with torch.cuda.stream(side):
+            fresh = geo.tensors()
+            if look.y is None:
+                look.y = [t.clone() for t in fresh]
+            else:
+                for dst, src in zip(look.y, fresh):
+                    dst.copy_(src)
+            look.ready = torch.cuda.Event()
+            look.ready.record(side)
+            look.ready_captured = torch.cuda.is_current_stream_capturing()
+        look.template = geo if look.template is None else look.template
+        look.pos_ptr = pos.data_ptr()
+        look.pending = True
+
+    def join_geometry(self) -> None:
+        """Make the current stream wait for an outstanding ``prefetch_geometry`` (end of a captured step: every stream
+        of a hipGraph capture must be joined before the capture ends)."""
+        if self._look is not None and self._look.ready is not None:
+            torch.cuda.current_stream().wait_event(self._look.ready)
+
+    def _consume_lookahead(self, pos: Tensor, plan: LevelPlan, train: bool) -> Optional["_Geometry"]:
+        look = self._look
+        if look is None or not look.pending or look.key != (tuple(pos.shape), id(plan), bool(train)) \
+                or look.pos_ptr != pos.data_ptr():
+            return None
+        main = torch.cuda.current_stream()
+        if torch.cuda.is_current_stream_capturing() and not look.ready_captured:
+            look.ready.synchronize()  # recorded before the capture began: settle it on the host, nothing to capture
+        else:
+            main.wait_event(look.ready)
+        if look.x is None:  # persistent copies the network reads + a _Geometry that points at them
+            look.x = [t.clone() for t in look.y]
+            look.geo_x = look.template.rebound(look.x, main)
+        else:
+            for dst, src in zip(look.x, look.y):
+                dst.copy_(src)
+        look.x_free = torch.cuda.Event()
+        look.x_free.record(main)
+        look.pending = False
+        return look.geo_x
+
     def _side_stream(self, device) -> "torch.cuda.Stream":
         st = self._streams.get(device)
         if st is None:
@@ -403,9 +477,11 @@ class HipRandLANet(nn.Module):
         # weight gradients on a side stream: only with gradient sinks and an optimizer that joins the stream
         ops._grad_side = self.grad_side if self._use_sinks else None
         blocks = (self.block1, self.block2, self.block3, self.block4)
-        if decimation_idx is None:
-            self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
-        geo = self._geometry(pos, plan, decimation_idx, train)
+        geo = self._consume_lookahead(pos, plan, train) if (self._look is not None and decimation_idx is None) else None
+        if geo is None:
+            if decimation_idx is None:
+                self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
+            geo = self._geometry(pos, plan, decimation_idx, train)
         index, pos4, dec_ref = geo.index, geo.pos4, geo.dec_ref
         feats: List[Tensor] = []
         hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
@@ -481,6 +557,45 @@ class _Geometry:
     def wait(self, stage: int) -> None:
         if self.side is not self.main:
             self.main.wait_event(self.events[stage])
+
+    def tensors(self) -> List[Tensor]:
+        """Every device buffer of this geometry, in a fixed order (``pos4`` / ``perm`` / ``inv`` are views of the
+        index workspaces and come along with them)."""
+        return [ix.ws for ix in self.index] + self.knn + [m for m in self.mom if m is not None] + self.src + \
+            self.dec_ref + self.nn
+
+    def rebound(self, buffers: List[Tensor], main) -> "_Geometry":
+        """A geometry with the same structure whose buffers are ``buffers`` (same order as ``tensors()``); complete
+        by construction, so ``wait`` is a no-op."""
+        g = _Geometry(main, main)
+        it = iter(buffers)
+        for ix in self.index:
+            cp = ops.KnnIndex.__new__(ops.KnnIndex)
+            cp.n, cp.num_clouds, cp.ptr, cp.ws = ix.n, ix.num_clouds, ix.ptr, next(it)
+            g.index.append(cp)
+        g.pos4 = [ix.sorted_pos4 for ix in g.index]
+        g.knn = [next(it) for _ in self.knn]
+        g.mom = [next(it) if m is not None else None for m in self.mom]
+        g.src = [next(it) for _ in self.src]
+        g.dec_ref = [next(it) for _ in self.dec_ref]
+        g.nn = [next(it) for _ in self.nn]
+        return g
+
+
+class _Lookahead:
+    """State of ``HipRandLANet.prefetch_geometry``: persistent Y (side stream writes) and X (network reads) buffers."""
+
+    def __init__(self, key):
+        self.key = key
+        self.y: Optional[List[Tensor]] = None
+        self.x: Optional[List[Tensor]] = None
+        self.template: Optional[_Geometry] = None
+        self.geo_x: Optional[_Geometry] = None
+        self.ready = None     # event: Y holds the prefetched geometry
+        self.ready_captured = False
+        self.x_free = None    # event: the last Y -> X copy has been enqueued (Y may be overwritten after it)
+        self.pending = False
+        self.pos_ptr = 0
 
 
 def _knn_to_reference_order(idx: Tensor, index: "ops.KnnIndex") -> Tensor:
