@@ -444,6 +444,10 @@ def main():
                     fwd_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if look:  # the captured step must CONSUME prefetched tables: leave one pending for the training key
+                net.prefetch_geometry(pos, ptr, plan, train=True)
+                train_step()
+                torch.cuda.synchronize()
             g_train = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_train, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
                 if world == 1:
@@ -468,6 +472,8 @@ def main():
     dt = timed(step_fn, args.steps, world)
     # eval forward of the trained weights.  The first (eager) pass folds the BatchNorms / packs the attention weights
     # (cached by the module until the next training phase); the captured graph then holds the per-batch work only
+    if look:
+        net.prefetch_geometry(pos, ptr, plan, train=False)
     fwd_step()
     if launch == "hipgraph":
         try:
