@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Benchmark of the RandLA-Net hot path on MI355X (BASELINE.json metric: points/sec fwd+bwd on 12 800-pt tiles).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller launches it under ``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`` (the driver does), or — when WORLD_SIZE is not in the environment —
+``python bench.py --gpus N`` re-executes itself under torch.distributed.run with N ranks.  The world size that comes
+up must equal ``--gpus`` (and fit ``torch.cuda.device_count()``), otherwise the run aborts.
 
 One "step" = one pass of the hot path over one batch of synthetic tiles already resident in HBM:
 train-mode forward (BatchNorm batch statistics, dropout, device-side random decimation) + cross-entropy +
@@ -47,7 +52,15 @@ def parse():
                          "(HipRandLANet.prefetch_geometry); off by default")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=2, help="tiles in the bounded CPU-baseline sample")
+    ap.add_argument("--skip-extras", action="store_true",
+                    help="skip the informative extra legs of the N=1 line (eager step, predict sweep, dense tiles)")
+    ap.add_argument("--cpu-tiles", type=int, default=16, help="tiles in the CPU-baseline sample (BASELINE.md 3: 16)")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="BASELINE.md 3 protocol in full: 3 warm-up + 10 timed iterations, at the probe-picked thread "
+                         "count AND on all cores (several minutes of CPU time)")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="launch check without GPUs: bring the N ranks up over gloo, exchange one all-reduce, print the "
+                         "rank census (used by the CPU tests)")
     ap.add_argument("--mode", choices=["train", "predict", "prepare"], default="train",
                     help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative).  "
                          "prepare: the data-preparation chain in front of the net (informative)")
@@ -145,14 +158,22 @@ def stage_rooflines(net, pos, plan):
             "m3d_lfa_bwd", xin.data_ptr(), geo.pos4[1].data_ptr(), geo.knn[1].data_ptr(), n2, K, ch, wf.data_ptr(),
             bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(),
             0, G.data_ptr(), ws.data_ptr(), st))
-        flop = 3 * 2 * n2 * K * (ch * ch + 10 * D)
-        tf = flop / (ms * 1e-3) / 1e12
-        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16,pipelined> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
+        # ALGORITHMIC flops of this backward (backward = 2 x forward: dF = dA W and dW = dA^T F, plus the
+        # encoder's two transposes) vs the flops the kernel EXECUTES (it recomputes the forward attention GEMM
+        # A = F W^T instead of saving [E, ch] logits: a third GEMM)
+        flop_alg = 2 * 2 * n2 * K * (ch * ch + 10 * D)
+        flop_exe = 3 * 2 * n2 * K * (ch * ch + 10 * D)
+        tf = flop_alg / (ms * 1e-3) / 1e12
+        tf_exe = flop_exe / (ms * 1e-3) / 1e12
+        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
                            "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+                           "frac_algorithmic": round(tf / FP32_MFMA_PEAK_TF, 4),
+                           "frac_executed": round(tf_exe / FP32_MFMA_PEAK_TF, 4),
                            "traffic": _pmc_traffic("void lfa_bwd_kernel<64, 16, true>", "void lfa_bwd_pipe_kernel<64, 16>",
                                                     "void lfa_bwd_kernel<64, 16>"),
-                           "algorithmic_flop_per_launch": flop, "avg_launch_ms": round(ms, 4)}
+                           "algorithmic_flop_per_launch": flop_alg, "executed_flop_per_launch": flop_exe,
+                           "avg_launch_ms": round(ms, 4)}
         # ---- kNN + LSE gather stage at level 1
         n1 = geo.pos4[0].shape[0]
         ix = geo.index[0]
@@ -203,55 +224,82 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(tiles, points, K, budget_s=25.0):
+def cpu_baseline(tiles, points, K, full=False):
     """The CPU oracle (op-for-op restatement of the reference path; kNN through cKDTree like torch_cluster's CPU
-    path), fwd+bwd in train mode on all host cores, on a BOUNDED sample: a short probe on a 1 600-point tile sizes
-    the sample (whole 12 800-point tiles when the host manages them inside the budget, else one smaller tile), then
-    as many iterations as fit in ~`budget_s` seconds of CPU work."""
+    path) on the SAME workload as the GPU line (B = 16 tiles x 12 800 points; fewer tiles only when
+    the host has too little free memory), fwd+bwd in train mode (CE loss) and fwd-only in eval mode, median of the
+    timed iterations.  Default (bounded to ~30 s of CPU work so the driver's default run stays short): 1 warm-up + 3
+    timed iterations at the thread count a micro-probe picks.  ``full`` = BASELINE.md 3 to the letter: 3 warm-up + 10
+    timed, at the probe-picked count AND on every host core."""
+    import statistics
+
     from oracle.randla_oracle import RandLANetOracle
     from myria3d_amd.synthetic import synthetic_batch
 
-    cores = _pick_threads()
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2**30
+    except Exception:
+        free_gb = 16.0
+    tiles = max(1, min(tiles, int(free_gb // 1.5)))  # ~0.7 GB of autograd intermediates per 12 800-point tile
+    picked = _pick_threads()
     torch.manual_seed(0)
-    net = RandLANetOracle(9, 6, num_neighbors=K, return_logits=True, knn="kdtree").train()
+    net = RandLANetOracle(9, 6, num_neighbors=K, return_logits=True, knn="kdtree")
+    x, pos, batch, ptr, y = synthetic_batch([points] * tiles)
+    warm, reps = (3, 10) if full else (1, 3)
 
-    def run(sizes, max_s, max_reps):
-        x, pos, batch, ptr, y = synthetic_batch(sizes)
+    def leg(threads):
+        torch.set_num_threads(threads)
 
-        def step():
+        def train_step():
+            net.train()
             net.zero_grad(set_to_none=True)
             torch.nn.functional.cross_entropy(net(x, pos, batch, ptr), y).backward()
 
-        step()  # warm-up (page-faults the allocator arenas)
-        t0, reps = time.perf_counter(), 0
-        while reps < 1 or (time.perf_counter() - t0 < max_s and reps < max_reps):
-            step()
-            reps += 1
-        return sum(sizes) * reps / (time.perf_counter() - t0), reps
+        def fwd_step():
+            net.eval()
+            with torch.no_grad():
+                net(x, pos, batch, ptr)
 
-    rate, _ = run([1600], 2.0, 3)
-    n_budget = rate * budget_s / 3.0  # points per step so that warm-up + >=2 iterations fit the budget
-    if n_budget >= points:
-        sizes = [points] * max(1, min(tiles, int(n_budget // points)))
-    else:
-        sizes = [max(1600, int(n_budget) // 400 * 400)]
-    rate, reps = run(sizes, budget_s * 2.0 / 3.0, 10)
-    return {"value": round(rate, 1), "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": f"{len(sizes)} tile(s) x {sizes[0]} pts, fwd+bwd (train mode, CE loss), {reps} timed iteration(s) after "
-                      "1 warm-up, oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN)"}
+        res = {}
+        for name, fn in (("fwd_bwd", train_step), ("fwd_only", fwd_step)):
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            res[name] = tiles * points / statistics.median(ts)
+        return res
+
+    main = leg(picked)
+    out = {"value": round(main["fwd_bwd"], 1), "unit": "points/s", "cores": picked, "kind": "port",
+           "fwd_only": round(main["fwd_only"], 1), "host_cores": ncpu,
+           "sample": f"{tiles} tiles x {points} pts (the GPU line's batch), median of {reps} timed iteration(s) after "
+                     f"{warm} warm-up; fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
+                     f"oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN); threads = {picked} (fastest of "
+                     f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
+    if full and picked != ncpu:
+        allc = leg(ncpu)
+        out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1), "fwd_only": round(allc["fwd_only"], 1)}
+    return out
 
 
-def predict_bench(args, dev):
+def predict_bench(args, dev, world=1, rank=0, reps=None):
     """BASELINE config 3 (informative, not the contract line): predict.py-shaped inference over a synthetic 1 km^2
     cloud = 400 tiles of 50 m, batches of 50 tiles (configs/experiment/predict.yaml:21-23).  Per batch: eval forward
     on the sub-sampled tiles (12 800 points each), knn_interpolate(k=10) of the logits to every point of the full
     tiles (25 000 each; the reference does this on the CPU, model.py:86-103), scatter_sum into the per-cloud logit
-    accumulator by original index (interpolation.py:116); finally softmax / argmax / entropy over all points."""
+    accumulator by original index (interpolation.py:116); finally softmax / argmax / entropy over all points.
+    N > 1: the 8 batches shard over the ranks (independent units: NO collective on the data path; every rank merges
+    and classifies its own tiles, as when each rank writes its own LAS files)."""
     from myria3d_amd import HipRandLANet, knn_interpolate, make_plan, predict_reduce, scatter_sum
+    from myria3d_amd.ddp import shard_tiles
     from myria3d_amd.synthetic import synthetic_tile
 
-    n_full, n_sub, tiles, bs, C = 25000, args.points, 400, 50, 7
+    n_full, n_sub, tiles, bs, C = 25000, 12800, 400, 50, 7
     g = torch.Generator().manual_seed(1)
     full_pos, sub_sel, feats = [], [], []
     for tid in range(bs):  # 50 distinct tiles, re-used for the 8 batches of the sweep
@@ -266,16 +314,17 @@ def predict_bench(args, dev):
     batch_sub = torch.arange(bs, device=dev).repeat_interleave(n_sub)
     batch_full = torch.arange(bs, device=dev).repeat_interleave(n_full)
     torch.manual_seed(0)
-    net = HipRandLANet(9, C, num_neighbors=args.neighbors, return_logits=True).to(dev).eval()
-    plan = make_plan(ptr_sub.tolist(), 4, args.neighbors, dev)
+    net = HipRandLANet(9, C, num_neighbors=16, return_logits=True).to(dev).eval()
+    plan = make_plan(ptr_sub.tolist(), 4, 16, dev)
+    mine = shard_tiles(tiles // bs, rank, world)  # batches of this rank
     total = tiles * n_full
-    acc = torch.zeros((total, C), device=dev)
+    acc = torch.zeros((max(1, len(mine)) * bs * n_full, C), device=dev)
     orig = torch.arange(bs * n_full, dtype=torch.int32, device=dev)
 
     def sweep():
         acc.zero_()
         with torch.no_grad():
-            for b in range(tiles // bs):
+            for b in range(len(mine)):
                 logits = net(x_sub, pos_sub, None, ptr_sub, plan=plan)
                 dense = knn_interpolate(logits, pos_sub, pos_full, batch_sub, batch_full, k=10)
                 scatter_sum(dense, orig + b * bs * n_full, out=acc)
@@ -284,19 +333,15 @@ def predict_bench(args, dev):
 
     for _ in range(max(1, args.warmup // 3)):
         sweep()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = max(1, args.steps // 10)
-    for _ in range(reps):
-        sweep()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print(json.dumps({"metric": "points/sec classified, predict path (fwd + kNN-interpolation k=10 + merge)",
-                      "value": round(total / dt, 1), "unit": "points/s", "n_gpus": 1, "ms_per_sweep": round(dt * 1e3, 2),
-                      "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": f"BASELINE config 3: {tiles} tiles x {n_full} pts (sub-sampled to {n_sub}), "
-                                             f"batch {bs}, K={args.neighbors}, C={C}, interpolation k=10",
-                                 "launch": "eager"}}), flush=True)
+    reps = reps if reps is not None else max(1, args.steps // 10)
+    dt = timed(sweep, reps, world) / reps
+    return {"metric": "points/sec classified, predict path (fwd + kNN-interpolation k=10 + merge)",
+            "value": round(total / dt, 1), "unit": "points/s", "n_gpus": world, "ms_per_sweep": round(dt * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3: {tiles} tiles x {n_full} pts (sub-sampled to {n_sub}), "
+                                   f"batch {bs}, K=16, C={C}, interpolation k=10; batches sharded over {world} rank(s), "
+                                   "no data-path collective",
+                       "launch": "eager"}}
 
 
 def prepare_bench(args, dev):
@@ -363,34 +408,45 @@ def _baseline_config(points: int, neighbors: int) -> str:
     return "non-BASELINE size"
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+def _respawn(args):
+    """``python bench.py --gpus N`` without a launcher: re-execute under torch.distributed.run with N ranks."""
+    import socket
+    import subprocess
 
-    from myria3d_amd import FusedAdam, HipRandLANet, _lib, cross_entropy, make_plan
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _dry_run_gloo(args, world, rank):
+    """Launch check without GPUs: the N ranks rendezvous over gloo, one all-reduce, rank 0 prints the census."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    pids = [None] * world
+    dist.all_gather_object(pids, os.getpid())
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "backend": "gloo", "n_gpus": world, "ranks": int(t.item()), "pids": pids}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False):
+    """The contract measurement: ``steps`` training steps (fwd + CE + bwd + [all-reduce] + Adam) and ``steps`` eval
+    forwards over B tiles x N points per rank.  Returns (record, net, pos, plan)."""
+    from myria3d_amd import FusedAdam, HipRandLANet, cross_entropy, make_plan
     from myria3d_amd.ddp import broadcast_module_state, shard_tiles
     from myria3d_amd.synthetic import synthetic_batch
 
-    _lib.lib()  # no fallback: fail here if the HIP library is missing
-    if args.mode == "predict":
-        if world > 1:
-            raise SystemExit("--mode predict is a single-GPU run (tiles shard without communication)")
-        predict_bench(args, dev)
-        return
-    if args.mode == "prepare":
-        if world > 1:
-            raise SystemExit("--mode prepare is a single-GPU run (tiles shard without communication)")
-        prepare_bench(args, dev)
-        return
-    B, N, K = args.tiles, args.points, args.neighbors
     tile_ids = shard_tiles(B * world, rank, world)  # weak scaling: B tiles per rank
     x, pos, batch, ptr, y = synthetic_batch([N] * B, first_tile_id=tile_ids.start)
     x, pos, ptr, y = x.to(dev), pos.to(dev), ptr.to(dev), y.to(dev)
@@ -431,9 +487,14 @@ def main():
 
     launch = "eager"
     step_fn, fwd_fn = train_step, fwd_step
-    # hipGraph: the forward+loss+backward launch sequence (~600 kernels, parallel branches for the position-only work
-    # and the weight gradients) is captured once and replayed (eager launching is host-bound at ~10 us per kernel).
-    # With N > 1 the optimizer (all-reduce + 2 launches) stays outside the graph so that no collective is captured
+    eager_ms = None
+    if with_eager:  # what a Lightning loop (no capture, model.py:79) sees: host-bound launching of the same kernels
+        for _ in range(3):
+            train_step()
+        eager_ms = timed(train_step, 5, world) / 5 * 1e3
+    # hipGraph: the forward+loss+backward launch sequence (parallel branches for the position-only work and the weight
+    # gradients) is captured once and replayed.  With N > 1 the optimizer (all-reduce + 2 launches) stays outside the
+    # graph so that no collective is captured
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -467,9 +528,9 @@ def main():
             torch.cuda.synchronize()
             step_fn, launch = train_step, "eager"
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step_fn()
-    dt = timed(step_fn, args.steps, world)
+    dt = timed(step_fn, steps, world)
     # eval forward of the trained weights.  The first (eager) pass folds the BatchNorms / packs the attention weights
     # (cached by the module until the next training phase); the captured graph then holds the per-batch work only
     if look:
@@ -486,19 +547,19 @@ def main():
             if rank == 0:
                 print(f"[bench] eval hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
-    for _ in range(max(1, args.warmup // 2)):
+    for _ in range(max(1, warmup // 2)):
         fwd_fn()
-    dt_f = timed(fwd_fn, args.steps, world)
+    dt_f = timed(fwd_fn, steps, world)
 
     total_points = B * N * world
     res = {
         "metric": f"points/sec fwd+bwd, RandLA-Net, {N // 1000} {N % 1000:03d}-pt tiles",
-        "value": round(total_points * args.steps / dt, 1),
+        "value": round(total_points * steps / dt, 1),
         "unit": "points/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -507,21 +568,91 @@ def main():
         "config": {"workload": f"RandLA-Net train step (fwd + CE + bwd + grad all-reduce + Adam), {B} tiles x {N} pts per GPU, "
                                f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, fp32)",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
+                   "collective": "one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" if world > 1 else "none (1 rank)",
                    "launch": launch, **({"geometry_lookahead": True} if look else {})},
-        "fwd_only": {"value": round(total_points * args.steps / dt_f, 1), "unit": "points/s",
-                     "ms_per_step": round(dt_f / args.steps * 1e3, 4), "mode": "eval, no_grad"},
+        "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
+                     "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad"},
     }
-    if rank == 0:
-        if not args.skip_roofline:
+    if eager_ms is not None:
+        res["eager_ms_per_step"] = round(eager_ms, 4)
+    return res, net, pos, plan
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _respawn(args)  # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or drop the launcher: `python bench.py --gpus N` starts its own ranks)")
+    if args.dry_run_gloo:
+        _dry_run_gloo(args, world, rank)
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) are visible")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL came up with {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from myria3d_amd import _lib
+
+    _lib.lib()  # no fallback: fail here if the HIP library is missing
+    if args.mode == "predict":
+        res = predict_bench(args, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+    elif args.mode == "prepare":
+        if world > 1:
+            raise SystemExit("--mode prepare is a single-GPU run")
+        prepare_bench(args, dev)
+    else:
+        B, N, K = args.tiles, args.points, args.neighbors
+        extras = world == 1 and not args.skip_extras
+        res, net, pos, plan = train_bench(args, dev, world, rank, B, N, K, args.steps, args.warmup, with_eager=extras)
+        if world > 1:
+            res["rccl_ranks"] = dist.get_world_size()
+        if rank == 0:
+            if not args.skip_roofline:
+                try:
+                    rl = stage_rooflines(net, pos, plan)
+                    res["roofline"] = rl["dominant"]
+                    res["roofline_knn_lse_stage"] = rl["knn_lse"]
+                except Exception as e:
+                    res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
+        del net, pos, plan
+        if extras:
+            # informative extra legs of the N=1 line (BASELINE configs 3 and 5), short: they share the driver's clock
             try:
-                rl = stage_rooflines(net, pos, plan)
-                res["roofline"] = rl["dominant"]
-                res["roofline_knn_lse_stage"] = rl["knn_lse"]
+                torch.cuda.empty_cache()
+                pr = predict_bench(args, dev, reps=2)
+                res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
             except Exception as e:
-                res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.skip_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_tiles, N, K)
-        print(json.dumps(res), flush=True)
+                res["predict_config3"] = {"error": f"{type(e).__name__}: {e}"}
+            if (N, K) == (12800, 16):
+                try:
+                    torch.cuda.empty_cache()
+                    d5, *_ = train_bench(args, dev, 1, 0, 16, 40000, 32, 5, 2)
+                    res["dense_tiles_config5"] = {"value": d5["value"], "unit": "points/s", "ms_per_step": d5["ms_per_step"],
+                                                  "fwd_only": d5["fwd_only"], "workload": d5["config"]["workload"]}
+                except Exception as e:
+                    res["dense_tiles_config5"] = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            if world == 1 and not args.skip_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(args.cpu_tiles, N, K, full=args.cpu_baseline_full)
+            print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -30,9 +30,15 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const float l = mx + logf(s);
     lse[i] = l;
     const int64_t t = target[i];
-    if (t != ignore_index && t >= 0 && t < C) {
-      ls += (double)(l - row[t]);
-      cnt += 1.0;
+    if (t != ignore_index) {
+      if (t >= 0 && t < C) {
+        ls += (double)(l - row[t]);
+        cnt += 1.0;
+      } else {
+        // a class code outside [0, C) that is not ignore_index (e.g. an unmapped LAS code): torch's CrossEntropyLoss
+        // raises / device-asserts; here the loss is poisoned with NaN so the mistake cannot pass silently
+        ls += (double)__builtin_nanf("");
+      }
     }
   }
   ls = wave_sum_d(ls);

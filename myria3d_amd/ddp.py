@@ -3,14 +3,13 @@
 Under Lightning the reference gets this from ``strategy: ddp_find_unused_parameters_false``
 (``/root/reference/configs/experiment/RandLaNet_base_run_FR-MultiGPU.yaml:9-13``) and ``HipRandLANet`` works under
 ``torch.nn.parallel.DistributedDataParallel`` unchanged (its gradients come from ordinary autograd nodes).  For the
-stand-alone bench / training loops this module provides the same thing in its MI355X-friendly form: ONE flat
-fp32 bucket (1 113 686 parameters = 4.45 MB) all-reduced over RCCL/xGMI per step — a single collective sized for
-the 7 point-to-point links instead of DDP's default 25 MB bucketing logic.  BatchNorm statistics stay per rank,
+stand-alone bench / training loops the same thing comes in its MI355X-friendly form from ``FusedAdam(all_reduce=True)``
+(``train.py``): ONE flat fp32 bucket (1 113 686 parameters = 4.45 MB) all-reduced over RCCL/xGMI per step — a single
+collective sized for the 7 point-to-point links instead of DDP's default 25 MB bucketing logic.  This module holds
+the two pieces around it: which tiles a rank owns, and the start-up broadcast.  BatchNorm statistics stay per rank,
 as in the reference (no SyncBatchNorm).
 """
 from __future__ import annotations
-
-from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
@@ -20,37 +19,6 @@ def shard_tiles(num_tiles: int, rank: int, world_size: int) -> range:
     """Contiguous block of tile ids owned by ``rank`` (independent units; no data-path exchange)."""
     per = (num_tiles + world_size - 1) // world_size
     return range(min(num_tiles, rank * per), min(num_tiles, (rank + 1) * per))
-
-
-class FlatGradAllReduce:
-    """Average gradients across ranks through one flat bucket (allocated once, reused every step)."""
-
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        if not self.params:
-            raise ValueError("no trainable parameters")
-        dev, dt = self.params[0].device, self.params[0].dtype
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
-
-    @torch.no_grad()
-    def __call__(self) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:  # ddp_find_unused_parameters_false: every parameter must have a gradient
-                raise RuntimeError("parameter without gradient in data-parallel step")
-            self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad.copy_(self.flat[off:off + n].view_as(p.grad))
-            off += n
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:

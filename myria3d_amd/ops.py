@@ -130,12 +130,15 @@ def linear_dgrad(dz: Tensor, w: Tensor) -> Tensor:
 
 class GradSideStream:
     """Weight-gradient kernels are leaves of the backward pass (nothing downstream reads dW before the optimizer), so
-    with gradient sinks they can run on a side stream next to the dgrad / BatchNorm / LFA chain.  The owner
-    (``FusedAdam``) calls ``join()`` before it reads the gradients; operand tensors are kept alive until then."""
+    with gradient sinks they can run on a side stream next to the dgrad / BatchNorm / LFA chain.  The stream rejoins the
+    main stream at the END of every backward pass (an autograd-engine callback queued by the first kernel sent here), so
+    whatever reads ``p.grad`` after ``backward()`` — gradient clipping, logging, an all-reduce, any optimizer — is
+    ordered behind the weight-gradient kernels.  Operand tensors are kept alive until that join."""
 
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self.keep: list = []
+        self._join_queued = False
 
     def run(self, fn, *tensors):
         main = torch.cuda.current_stream()
@@ -143,21 +146,30 @@ class GradSideStream:
         with torch.cuda.stream(self.stream):
             fn()
         self.keep.append(tensors)      # their memory must not be recycled by the main stream before join()
+        if not self._join_queued:
+            try:  # inside a backward pass: join when the engine has run its last node
+                torch.autograd.Variable._execution_engine.queue_callback(self.join)
+                self._join_queued = True
+            except RuntimeError:  # called outside a backward pass (direct use of the op): the caller joins
+                pass
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
+        self._join_queued = False
 
 
-_grad_side: Optional[GradSideStream] = None  # set by HipRandLANet while a flat-gradient backward may run
+# the side stream of the net whose forward pass is being recorded; every autograd Function below copies it into its own
+# ctx at forward time, so a backward pass always uses the stream of the net (and optimizer) it belongs to
+_grad_side: Optional[GradSideStream] = None
 
 
 def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None, x1: Optional[Tensor] = None,
-                 k1: int = 0, out: Optional[Tensor] = None) -> Optional[Tensor]:
+                 k1: int = 0, out: Optional[Tensor] = None, side: Optional[GradSideStream] = None) -> Optional[Tensor]:
     """dW[N, k0+k1] = dZ^T [X0[rows] | X1] (``m3d_linear_wgrad_f32``): the reduction over the M rows is split across
     waves whose partials meet in a workspace.  ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a slice of the
     flat gradient buffer) that is added to; nothing is returned then (and the kernels may run on the gradient side
-    stream)."""
+    stream ``side``)."""
     M, N = dz.shape
     K = k0 + k1
     sink = out is not None
@@ -169,8 +181,8 @@ def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None,
         call("m3d_linear_wgrad_f32", _p(dz), dz.stride(0), _p(x0), x0.stride(0), _p(rows), k0, _p(x1),
              x1.stride(0) if x1 is not None else 0, k1, M, N, _p(dw), dw.stride(0), int(sink), _p(ws), _st())
 
-    if sink and _grad_side is not None:
-        _grad_side.run(launch, dz, x0, x1, rows, ws)
+    if sink and side is not None:
+        side.run(launch, dz, x0, x1, rows, ws)
     else:
         launch()
     return None if sink else dw
@@ -291,6 +303,7 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.sinks = sinks
+        ctx.side = _grad_side if sinks is not None else None
         return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=b)
 
     @staticmethod
@@ -299,7 +312,7 @@ class LinearFn(torch.autograd.Function):
         sk = ctx.sinks
         dy = dy.contiguous()
         dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dy, x, x.shape[1], out=sk[0] if sk else None)
+        dw = linear_wgrad(dy, x, x.shape[1], out=sk[0] if sk else None, side=ctx.side)
         return dx, dw, colsum(dy, out=sk[1] if sk else None), None
 
 
@@ -312,6 +325,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
     def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None):
         # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None
         ctx.sinks = sinks
+        ctx.side = _grad_side if sinks is not None else None
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         N = w.shape[0]
         k0 = x0.shape[1]
@@ -343,7 +357,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
                     dx0 = dx0.contiguous()
             if x1 is not None and ctx.needs_input_grad[1]:
                 dx1 = dxc[:, k0:].contiguous()
-        dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None)
+        dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
         return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None
 
@@ -353,6 +367,7 @@ class ResidualTailTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None):
         ctx.sinks = (sinks2, sinkss) if sinks2 is not None else None
+        ctx.side = _grad_side if sinks2 is not None else None
         M, N = x2.shape[0], w2.shape[0]
         st2 = stat_buffer(M, N, x2.shape[1], w2.device)
         sts = stat_buffer(M, N, xs.shape[1], w2.device)
@@ -372,8 +387,8 @@ class ResidualTailTrainFn(torch.autograd.Function):
                                               sinks=(sk[0][2], sk[0][3], sk[1][2], sk[1][3]) if sk else None)
         dx2 = linear_dgrad(dz2, w2)
         dxs = linear_dgrad(dzs, ws)
-        dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None)
-        dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None)
+        dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None, side=ctx.side)
+        dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None, side=ctx.side)
         z0_2 = None if sk else torch.zeros_like(db2)
         z0_s = None if sk else torch.zeros_like(dbs)
         return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None)

@@ -117,8 +117,12 @@ class HipRandLANet(nn.Module):
         self.fp1 = FPParams(SharedMLPParams([32 + 32, d_bottleneck]))
         self.mlp_classif = SharedMLPParams([d_bottleneck, 64, 32], dropout=[0.0, 0.5])
         self.fc_classif = nn.Linear(32, num_classes)
-        # device-side RNG state for decimation (bumped every forward; hipGraph-replay safe)
+        # device-side RNG state for decimation (bumped every forward; hipGraph-replay safe).  Seeded lazily, on the
+        # first forward, from torch's global seed (``torch.manual_seed`` / ``seed_everything``) mixed with the rank —
+        # the reference draws its ``torch.randperm`` from the global generator (pyg_randla_net.py:221), so there too
+        # the seed controls decimation and every DDP rank draws its own permutations
         self.register_buffer("_decim_seed", torch.tensor([0x5DEECE66D], dtype=torch.int64), persistent=False)
+        self._decim_seeded = False
         self._plans: Dict[tuple, LevelPlan] = {}
         self._warned_eval_grad = False
         self._use_sinks = False
@@ -130,6 +134,26 @@ class HipRandLANet(nn.Module):
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
         self._look: Optional["_Lookahead"] = None  # geometry of the NEXT forward, see prefetch_geometry()
+        # a parent module's load_state_dict() reaches this module through _load_from_state_dict only
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._eval_cache.clear())
+
+    def set_decimation_seed(self, seed: int) -> None:
+        """Fix the device-side decimation RNG state (otherwise derived from ``torch.initial_seed()`` and the rank on the
+        first forward)."""
+        seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x5DEECE66D) & ((1 << 63) - 1)
+        with torch.no_grad():
+            self._decim_seed.fill_(seed)
+        self._decim_seeded = True
+
+    def _seed_decimation(self) -> None:
+        if self._decim_seeded:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return  # a fill recorded into a graph would reset the state at every replay: keep the current value
+        import torch.distributed as dist
+
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.set_decimation_seed((torch.initial_seed() & 0xFFFFFFFFFFFF) * 1024 + rank)
 
     # ------------------------------------------------------------------------------------------
     # flat parameter / gradient buffers (opt-in): every parameter becomes a view of ONE fp32 buffer and every
@@ -219,11 +243,20 @@ class HipRandLANet(nn.Module):
         """Call after changing parameters or running statistics behind the module's back (raw-pointer writes)."""
         self._eval_cache.clear()
 
-    def _cached(self, key, fn):
+    def _cached(self, key, fn, deps=()):
+        """``deps``: the parameters / buffers the cached value was derived from.  Their autograd version counters are
+        part of the entry, so in-place updates through torch (``load_state_dict`` of a parent module, an optimizer
+        step, EMA / SWA swaps with ``copy_``) are noticed; writes through ``.data`` or raw pointers are not —
+        ``invalidate_eval_cache()`` is for those (``FusedAdam.step`` calls it)."""
+        stamp = tuple((t.data_ptr(), t._version) for t in deps)
         hit = self._eval_cache.get(key)
-        if hit is None:
-            hit = self._eval_cache[key] = fn()
-        return hit
+        if hit is None or hit[0] != stamp:
+            hit = self._eval_cache[key] = (stamp, fn())
+        return hit[1]
+
+    @staticmethod
+    def _bn_deps(bn):
+        return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
     def train(self, mode: bool = True):
         if mode or self.training:  # entering or leaving a training phase: weights / running statistics change
@@ -259,7 +292,7 @@ class HipRandLANet(nn.Module):
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
                                                 sk)
-        scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn))
+        scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
                         k1=0 if x1 is None else x1.shape[1], bias=lin.bias, scale=scale, shift=shift, act=mlp.act)
@@ -275,7 +308,8 @@ class HipRandLANet(nn.Module):
                                        enc_bn.bias, enc_lin, enc_bn, w_att, sk)
         else:
             wf, bf, wp = self._cached(("lfa", id(p)), lambda: ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)[:2] + (
-                ops.pack_attention_weights(w_att, False)[0] if idx.shape[1] <= 32 else None,))
+                ops.pack_attention_weights(w_att, False)[0] if idx.shape[1] <= 32 else None,),
+                (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
             agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp)
         return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
 
@@ -301,8 +335,8 @@ class HipRandLANet(nn.Module):
             out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
                                                 ns.weight, ns.bias, ns, sk2, sks)
         else:
-            sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2))
-            scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns))
+            sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2), self._bn_deps(n2))
+            scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns), self._bn_deps(ns))
             z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias)
             zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias)
             out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
@@ -412,6 +446,7 @@ class HipRandLANet(nn.Module):
             # right after that forward has been enqueued, the tables are built beside its kernels and its backward
             side.wait_event(look.x_free)
         with torch.cuda.stream(side):
+            self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
         geo = self._geometry(pos, plan, None, train, wait_main=first)
         with torch.cuda.stream(side):
@@ -480,6 +515,7 @@ class HipRandLANet(nn.Module):
         geo = self._consume_lookahead(pos, plan, train) if (self._look is not None and decimation_idx is None) else None
         if geo is None:
             if decimation_idx is None:
+                self._seed_decimation()
                 self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # device-side bump, hipGraph-replay safe
             geo = self._geometry(pos, plan, decimation_idx, train)
         index, pos4, dec_ref = geo.index, geo.pos4, geo.dec_ref

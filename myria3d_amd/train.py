@@ -22,22 +22,102 @@ class FusedAdam(torch.optim.Optimizer):
     """Adam over ``net.flat_parameters`` / ``net.flat_grads`` (same update rule and defaults as ``torch.optim.Adam``,
     ``amsgrad=False``).  ``step()`` also clears the gradient buffer (``zero_grad`` is then free), and under
     ``torch.distributed`` all-reduces the flat gradient first when ``all_reduce=True`` — one RCCL collective on
-    the 4.45 MB bucket, no packing copies."""
+    the 4.45 MB bucket, no packing copies.
+
+    ``state_dict()`` / ``load_state_dict()`` speak ``torch.optim.Adam``'s format (per-parameter ``step`` /
+    ``exp_avg`` / ``exp_avg_sq``), so Lightning checkpoints (``ckpt_path`` resume, ``/root/reference/myria3d/train.py:145``)
+    keep the Adam moments and the bias-correction step, and a run started with the reference's ``torch.optim.Adam``
+    can be resumed here (and the other way round).  One parameter group, every parameter trainable: the single
+    launch updates the whole flat buffer."""
 
     def __init__(self, net, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  all_reduce: bool = False, overlap_wgrad: bool = True):
         if net.flat_parameters is None:
             net.flatten_parameters()
         self.net = net
-        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        params = list(net.parameters())
+        if any(not p.requires_grad for p in params):
+            raise ValueError("FusedAdam updates the whole flat parameter buffer: frozen parameters "
+                             "(requires_grad=False) are not supported — use torch.optim.Adam for partial fine-tuning")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         flat = net.flat_parameters
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.lr_dev: Optional[torch.Tensor] = None  # optional device-side learning rate (graph-replay safe)
         self.all_reduce = all_reduce
-        if overlap_wgrad:  # weight-gradient GEMMs run beside the rest of the backward pass; step() joins them
+        if overlap_wgrad and flat.is_cuda:  # weight-gradient GEMMs run beside the rest of the backward pass
             net.grad_side = ops.GradSideStream(flat.device)
+
+    def add_param_group(self, param_group):
+        if len(self.param_groups) >= 1:
+            raise ValueError("FusedAdam supports exactly one parameter group (one launch over the flat buffer)")
+        super().add_param_group(param_group)
+
+    # ------------------------------------------------------------------------------------------
+    def _slices(self):
+        off = 0
+        for p in self.net.parameters():
+            n = p.numel()
+            yield p, off, n
+            off += (n + 3) // 4 * 4
+
+    def state_dict(self):
+        """``torch.optim.Adam``'s layout: ``state[i] = {step, exp_avg, exp_avg_sq}`` per parameter index."""
+        step = self.step_count.detach().reshape(()).clone().cpu()
+        state = {}
+        for i, (p, off, n) in enumerate(self._slices()):
+            state[i] = {"step": step.clone(),
+                        "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        groups = [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]
+        groups[0]["params"] = list(range(len(state)))
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != 1:
+            raise ValueError("FusedAdam supports exactly one parameter group")
+        slices = list(self._slices())
+        if len(groups[0]["params"]) != len(slices):
+            raise ValueError("loaded state dict has a different number of parameters")
+        if groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise ValueError("FusedAdam implements amsgrad=False, maximize=False only")
+        state = state_dict["state"]
+        steps = set()
+        with torch.no_grad():
+            self.exp_avg.zero_(), self.exp_avg_sq.zero_()
+            for key, (p, off, n) in zip(groups[0]["params"], slices):
+                st = state.get(key, state.get(str(key)))
+                if st is None:  # torch.optim.Adam has no entry for a parameter that was never stepped
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of parameter {key} has shape {tuple(st['exp_avg'].shape)}, "
+                                     f"expected {tuple(p.shape)}")
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(float(st["step"]))
+            if len(steps) > 1:
+                raise ValueError(f"FusedAdam keeps ONE step counter; the loaded state has {sorted(steps)}")
+            self.step_count.fill_(steps.pop() if steps else 0.0)
+        for k, v in groups[0].items():
+            if k != "params" and k in self.param_groups[0]:
+                self.param_groups[0][k] = v
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reduce_gradients(self) -> float:
+        """Joins the weight-gradient side stream and, with ``all_reduce`` under ``torch.distributed``, sums the flat
+        gradient bucket over the ranks with ONE collective.  Returns the scale (1 / world size) the update applies."""
+        net = self.net
+        if net.grad_side is not None:
+            net.grad_side.join()  # the weight-gradient side stream has finished writing the flat gradient buffer
+        if not net._flat_intact():
+            net._check_flat()
+        if self.all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(net.flat_grads, op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -46,24 +126,18 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         net = self.net
-        if net.grad_side is not None:
-            net.grad_side.join()  # the weight-gradient side stream has finished writing the flat gradient buffer
-        if not net._flat_intact():
-            net._check_flat()
+        scale = self.reduce_gradients()
         flat_p, flat_g = net.flat_parameters, net.flat_grads
         if flat_p.data_ptr() != getattr(self, "_bound_ptr", flat_p.data_ptr()):
             raise RuntimeError("FusedAdam: the net was re-flattened after the optimizer was created")
         self._bound_ptr = flat_p.data_ptr()
-        scale = 1.0
-        if self.all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
-            scale = 1.0 / dist.get_world_size()
         g = self.param_groups[0]
         call("m3d_adam_step", flat_p.data_ptr(), flat_g.data_ptr(), self.exp_avg.data_ptr(),
              self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(),
              None if self.lr_dev is None else self.lr_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
              float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), scale, 1, flat_p.numel(),
              torch.cuda.current_stream().cuda_stream)
+        net.invalidate_eval_cache()  # the weights changed behind the module's back (raw-pointer update)
         return loss
 
     def zero_grad(self, set_to_none: bool = False):  # gradients are views of the flat buffer: never detach them

@@ -308,15 +308,29 @@ def test_lfa_eval_forward(device, ch, k):
     _close(f"lfa_unfused(ch={ch},k={k})", got_u, ref, 2e-5, 2e-5)
 
 
-@pytest.mark.parametrize("ch,k,fused", [(8, 16, True), (16, 16, True), (32, 16, True), (64, 16, True), (128, 16, True),
-                                        (256, 16, True), (16, 32, True), (128, 32, True), (8, 16, False),
-                                        (64, 16, False), (32, 40, True)])
-def test_lfa_train_forward_backward(device, ch, k, fused):
-    """fused=True: m3d_lfa_bwd; fused=False: the materialising fallback (also what K > 32 uses)."""
+def _relclose(name, got, ref, rel):
+    """Reduced quantities (sums over all edges): relative L2 error of the whole tensor."""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    den = ref.norm().item()
+    err = (got - ref).norm().item()
+    print(f"[parity] {name}: rel_l2_err={err / max(den, 1e-30):.3e} ref_norm={den:.3e}")
+    assert err <= rel * den + 1e-7, f"{name}: relative L2 error {err / max(den, 1e-30):.3e} > {rel}"
+
+
+def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False):
+    """m3d_lfa_fwd + m3d_lfa_bwd (train mode: encoder BatchNorm on batch statistics) vs the fp64 oracle
+    (LocalFeatureAggregation.aggregate + autograd).  ``big``: kNN table through cKDTree (any valid table serves an
+    op-level check), reduced gradients compared by relative L2 norm."""
     from myria3d_amd import ops
+    from oracle.randla_oracle import LocalFeatureAggregation, dense_to_edge_index, knn_exact, knn_kdtree
 
     ops.LFATrainFn.force_unfused_backward = not fused
-    x, pos, ptr, lfa, idx, ei = _lfa_setup(ch, [200, 11, 90], k, seed=ch)
+    x, pos, _, ptr = rand_batch(sizes, num_features=ch // 2, seed=seed)
+    x = x * 2 - 1
+    lfa = LocalFeatureAggregation(ch)
+    fill_params_deterministic(lfa, seed)
+    idx, _ = (knn_kdtree if big else knn_exact)(pos, ptr.tolist(), pos, ptr.tolist(), k)
+    ei = dense_to_edge_index(idx)
     lfa = lfa.double().train()
     xr = x.double().requires_grad_(True)
     ref = lfa.aggregate(ei, xr, pos.double())
@@ -324,16 +338,13 @@ def test_lfa_train_forward_backward(device, ch, k, fused):
     ref.backward(gy)
     enc_lin_r, enc_bn_r = lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module
 
-    import copy
-    from oracle.randla_oracle import LocalFeatureAggregation
     g = LocalFeatureAggregation(ch)
-    fill_params_deterministic(g, ch)
+    fill_params_deterministic(g, seed)
     g = g.to(device).train()
     enc_lin, enc_bn = g.mlp_encoder.lins[0], g.mlp_encoder.norms[0].module
     w_att = g.mlp_attention.lins[0].weight
     pos4 = ops.pad_pos(pos.to(device))
     idx32 = idx.to(torch.int32).to(device)
-    sizes = (ptr[1:] - ptr[:-1]).tolist()
     num_edges = sum(n * min(k, n) for n in sizes)
     mom = ops.lfa_moments(pos4, idx32)
     xg = x.to(device).requires_grad_(True)
@@ -342,24 +353,85 @@ def test_lfa_train_forward_backward(device, ch, k, fused):
     out.backward(gy.float().to(device))
     sc = max(1.0, gy.abs().max().item())
     checks = [
-        (f"lfa_train.out(ch={ch})", out, ref, 1e-4, 1e-4),
-        ("lfa_train.running_mean", enc_bn.running_mean, enc_bn_r.running_mean, 1e-4, 1e-5),
-        ("lfa_train.running_var", enc_bn.running_var, enc_bn_r.running_var, 1e-4, 1e-5),
-        ("lfa_train.dx", xg.grad, xr.grad, 1e-3, 1e-4 * sc),
-        ("lfa_train.dW_att", w_att.grad, lfa.mlp_attention.lins[0].weight.grad, 1e-3, 1e-3),
-        ("lfa_train.dW_enc", enc_lin.weight.grad, enc_lin_r.weight.grad, 2e-3, 2e-3),
-        ("lfa_train.dgamma_enc", enc_bn.weight.grad, enc_bn_r.weight.grad, 2e-3, 2e-3),
-        ("lfa_train.dbeta_enc", enc_bn.bias.grad, enc_bn_r.bias.grad, 2e-3, 2e-3),
-        ("lfa_train.db_enc", enc_lin.bias.grad, enc_lin_r.bias.grad, 0, 2e-3),
+        (_close, f"lfa_train.out(ch={ch})", out, ref, 1e-4, 1e-4),
+        (_close, "lfa_train.running_mean", enc_bn.running_mean, enc_bn_r.running_mean, 1e-4, 1e-5),
+        (_close, "lfa_train.running_var", enc_bn.running_var, enc_bn_r.running_var, 1e-4, 1e-5),
+        (_close, "lfa_train.dx", xg.grad, xr.grad, 1e-3, 1e-4 * sc),
     ]
+    if big:
+        checks += [
+            (_relclose, "lfa_train.dW_att", w_att.grad, lfa.mlp_attention.lins[0].weight.grad, 1e-3),
+            (_relclose, "lfa_train.dW_enc", enc_lin.weight.grad, enc_lin_r.weight.grad, 2e-3),
+            (_relclose, "lfa_train.dgamma_enc", enc_bn.weight.grad, enc_bn_r.weight.grad, 2e-3),
+            (_relclose, "lfa_train.dbeta_enc", enc_bn.bias.grad, enc_bn_r.bias.grad, 2e-3),
+        ]
+    else:
+        checks += [
+            (_close, "lfa_train.dW_att", w_att.grad, lfa.mlp_attention.lins[0].weight.grad, 1e-3, 1e-3),
+            (_close, "lfa_train.dW_enc", enc_lin.weight.grad, enc_lin_r.weight.grad, 2e-3, 2e-3),
+            (_close, "lfa_train.dgamma_enc", enc_bn.weight.grad, enc_bn_r.weight.grad, 2e-3, 2e-3),
+            (_close, "lfa_train.dbeta_enc", enc_bn.bias.grad, enc_bn_r.bias.grad, 2e-3, 2e-3),
+            (_close, "lfa_train.db_enc", enc_lin.bias.grad, enc_lin_r.bias.grad, 0, 2e-3),
+        ]
     failures = []
-    for c in checks:
+    for fn, *c in checks:
         try:
-            _close(*c)
+            fn(*c)
         except AssertionError as e:
             failures.append(str(e))
     ops.LFATrainFn.force_unfused_backward = False
     assert not failures, failures
+
+
+@pytest.mark.parametrize("ch,k,fused", [(8, 16, True), (16, 16, True), (32, 16, True), (64, 16, True), (128, 16, True),
+                                        (256, 16, True), (16, 32, True), (128, 32, True), (8, 16, False),
+                                        (64, 16, False), (32, 40, True)])
+def test_lfa_train_forward_backward(device, ch, k, fused):
+    """fused=True: m3d_lfa_bwd; fused=False: the materialising fallback (also what K > 32 uses)."""
+    _lfa_train_parity(device, ch, k, [200, 11, 90], seed=ch, fused=fused)
+
+
+# sizes at which EVERY persistent workgroup of lfa_bwd_kernel walks >= 4 groups (its grid is capped at
+# 1024 / 1024 / 1024 / 512 / 256 workgroups of 8 / 4 / 4 / 4 / 4 centres for ch <= 16 / 32 / 64 / 128 / 256 at K = 16,
+# half as many centres per group at K = 32), so the grid-stride loop, the register prefetch of the NEXT group and the
+# double-buffered neighbour ids (PIPE, ch <= 64) are all compared with the oracle, not only the first trip
+_PERSISTENT_CASES = [(8, 16, 34000), (16, 16, 34000), (32, 16, 17000), (64, 16, 17000), (128, 16, 8500),
+                     (256, 16, 4300), (16, 32, 17000), (64, 32, 8500), (256, 32, 2200)]
+
+
+@pytest.mark.parametrize("ch,k,n", _PERSISTENT_CASES)
+def test_lfa_backward_persistent_loop(device, ch, k, n):
+    """The launch shape the bench times (many groups per workgroup) against the fp64 oracle."""
+    from myria3d_amd import _lib
+
+    kp = 16 if k <= 16 else 32
+    chp = max(ch, 16)
+    rows = 128 if chp == 16 else 64
+    cap = {16: 1024, 32: 1024, 64: 1024, 128: 512, 256: 256}[chp]
+    groups = -(-n // (rows // kp))
+    assert groups >= 4 * cap, "test sizes must keep every workgroup in its loop for >= 4 trips"
+    # the workspace query reports the grid the launcher will use: parts = grid * kspl3
+    assert _lib.lib().m3d_lfa_bwd_workspace_bytes(n, k, ch) > 0
+    third = n // 3
+    _lfa_train_parity(device, ch, k, [third, third + 7, n - 2 * third - 7], seed=ch + k, big=True)
+
+
+@pytest.mark.parametrize("ch,k,n", [(16, 16, 34000), (64, 16, 17000)])
+def test_lfa_backward_persistent_loop_without_pipelining(ch, k, n):
+    """Same check with the software-pipelined variant switched off (M3D_LFA_BWD_PIPE=0 is read once per process, so
+    the case runs in a child interpreter)."""
+    import os
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    env = dict(os.environ, M3D_LFA_BWD_PIPE="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_ops.py"),
+                          "-k", f"test_lfa_backward_persistent_loop and {ch}-{k}-{n} and not without"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "1 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
 
 
 # ----------------------------------------------------------------------------------------------- interpolation

@@ -206,3 +206,74 @@ def test_hipgraph_replay_matches_eager_steps(device):
             worst = (k, err)
         assert torch.allclose(a, b, rtol=5e-3, atol=2e-4), (k, err)
     print(f"[parity] graph replay vs eager, worst state difference: {worst[0]} {worst[1]:.3e}")
+
+
+def test_fused_adam_resume_matches_torch_adam(device):
+    """save -> load -> step: a FusedAdam restored from a checkpoint (its own, or one written by the reference's
+    torch.optim.Adam) continues exactly like torch.optim.Adam does (moments AND bias-correction step survive)."""
+    from myria3d_amd import FusedAdam
+
+    plain, flat = _nets(device, 13)
+    opt_t = torch.optim.Adam(plain.parameters(), lr=3.9e-3)
+    opt_f = FusedAdam(flat, lr=3.9e-3)
+    rs = np.random.RandomState(1)
+
+    def step_both(of):
+        for p, q in zip(plain.parameters(), of.net.parameters()):
+            g = torch.from_numpy(rs.normal(0, 1, tuple(p.shape)).astype(np.float32)).to(device)
+            p.grad = g.clone()
+            q.grad.copy_(g)
+        opt_t.step()
+        of.step()
+
+    for _ in range(3):
+        step_both(opt_f)
+    # resume into a NEW optimizer over a new net from (a) FusedAdam's and (b) torch.optim.Adam's state_dict
+    for source in ("fused", "torch"):
+        _, again = _nets(device, 13)
+        again.load_state_dict(flat.state_dict())
+        opt_r = FusedAdam(again, lr=1.0)
+        opt_r.load_state_dict(opt_f.state_dict() if source == "fused" else opt_t.state_dict())
+        assert float(opt_r.step_count) == 3.0 and opt_r.param_groups[0]["lr"] == 3.9e-3
+        assert torch.allclose(opt_r.exp_avg, opt_f.exp_avg, rtol=2e-5, atol=1e-7)
+    for _ in range(2):
+        step_both(opt_r)          # (plain/opt_t keep stepping in lock-step with the last restored optimizer)
+    for (name, p), (_, q) in zip(plain.named_parameters(), again.named_parameters()):
+        assert torch.allclose(p.detach(), q.detach(), rtol=5e-5, atol=5e-6), name
+
+
+def test_cross_entropy_poisons_the_loss_on_out_of_range_targets(device):
+    """torch raises / device-asserts on a class code outside [0, C) that is not ignore_index; the HIP loss turns NaN."""
+    from myria3d_amd import cross_entropy
+
+    logits = torch.zeros(16, 6, device=device)
+    y = torch.arange(16, device=device) % 6
+    assert torch.isfinite(cross_entropy(logits, y, ignore_index=65))
+    y[3] = 9
+    assert torch.isnan(cross_entropy(logits, y, ignore_index=65))
+    y[3] = 65
+    assert torch.isfinite(cross_entropy(logits, y, ignore_index=65))
+
+
+def test_gradients_are_ready_when_backward_returns(device):
+    """with FusedAdam's weight-gradient side stream, anything that reads ``p.grad`` right after
+    ``backward()`` (clipping, logging, an all-reduce) must see the finished gradients: the side stream rejoins the
+    main stream at the end of the backward pass, without an explicit join by the caller."""
+    from myria3d_amd import FusedAdam, cross_entropy
+    from oracle.randla_oracle import fixed_decimation_indices, synthetic_batch
+
+    plain, flat = _nets(device, 14)
+    FusedAdam(flat, lr=1e-3)              # creates flat.grad_side
+    assert flat.grad_side is not None
+    x, pos, batch, ptr, y = synthetic_batch([6000, 5000])
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=3)
+    mask = torch.ones(11000, 32, device=device)
+    args = (x.to(device), pos.to(device), None, ptr.to(device))
+    plain.train(), flat.train()
+    cross_entropy(plain(*args, decimation_idx=dec, dropout_mask=mask), y.to(device), 65).backward()
+    for rep in range(3):
+        flat.flat_grads.zero_()
+        cross_entropy(flat(*args, decimation_idx=dec, dropout_mask=mask), y.to(device), 65).backward()
+        total = torch.nn.utils.clip_grad_norm_(flat.parameters(), 1e9)     # reads every p.grad on the main stream
+        ref = torch.nn.utils.clip_grad_norm_(plain.parameters(), 1e9)
+        assert abs(total.item() - ref.item()) <= 2e-4 * ref.item(), (rep, total.item(), ref.item())

@@ -137,54 +137,29 @@ def test_tile_sharding_is_a_partition():
         assert got == list(range(tiles))
 
 
-_DDP_SCRIPT = r"""
-import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, sys.argv[1])
-from myria3d_amd.ddp import FlatGradAllReduce, broadcast_module_state
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-torch.manual_seed(rank)            # different initial weights per rank ...
-net = torch.nn.Sequential(torch.nn.Linear(9, 32), torch.nn.BatchNorm1d(32), torch.nn.Linear(32, 6))
-broadcast_module_state(net)       # ... made identical, like DDP's constructor broadcast
-w0 = [p.detach().clone() for p in net.parameters()]
-gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
-dist.all_gather(gathered, w0[0])
-assert all(torch.equal(g, gathered[0]) for g in gathered)
-red = FlatGradAllReduce(net.parameters())
-torch.manual_seed(100 + rank)     # every rank owns its own tiles
-x, y = torch.randn(64, 9), torch.randint(0, 6, (64,))
-torch.nn.functional.cross_entropy(net(x), y).backward()
-local = [p.grad.clone() for p in net.parameters()]
-red()
-for p, l in zip(net.parameters(), local):
-    parts = [torch.zeros_like(l) for _ in range(world)]
-    dist.all_gather(parts, l)
-    assert torch.allclose(p.grad, sum(parts) / world, atol=1e-6)
-# BatchNorm statistics stay per rank (no SyncBatchNorm in the reference)
-rm = [torch.zeros(32) for _ in range(world)]
-dist.all_gather(rm, net[1].running_mean)
-assert not torch.equal(rm[0], rm[1])
-dist.destroy_process_group()
-print("ok", rank)
-"""
-
-
-def test_gradient_allreduce_world_size_2_gloo(tmp_path):
-    script = tmp_path / "ddp_check.py"
-    script.write_text(_DDP_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    res = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29531", str(script), ROOT],
-        capture_output=True, text=True, env=env, timeout=240)
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """``python bench.py --gpus 2`` (no launcher, no WORLD_SIZE) must come up as TWO processes in one process group;
+    --dry-run-gloo does the launch + rendezvous + one all-reduce without touching a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-gloo"],
+                         capture_output=True, text=True, env=env, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    assert res.stdout.count("ok") == 2
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = __import__("json").loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and len(set(rec["pids"])) == 2
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run-gloo"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stdout + res.stderr)
 
 
 _FLAT_DDP_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from myria3d_amd import HipRandLANet
+from myria3d_amd import FusedAdam, HipRandLANet
 from myria3d_amd.ddp import broadcast_module_state, shard_tiles
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -202,7 +177,9 @@ assert torch.equal(got[0], got[1]) and torch.equal(net.fc0.weight.reshape(-1), g
 for i, p in enumerate(net.parameters()):
     p.grad.fill_(float(rank + 1) * (i + 1))               # p.grad is a view of net.flat_grads
 local = net.flat_grads.clone()
-dist.all_reduce(net.flat_grads, op=dist.ReduceOp.SUM)
+opt = FusedAdam(net, lr=1e-3, all_reduce=True)            # the product path's collective: FusedAdam.reduce_gradients()
+scale = opt.reduce_gradients()                            # = what step() does before its single update launch
+assert scale == 1.0 / world
 for i, p in enumerate(net.parameters()):
     assert torch.all(p.grad == 3.0 * (i + 1)), i          # ranks 1 + 2
 assert torch.equal(net.flat_grads, local * 3.0 / (rank + 1))
@@ -252,3 +229,75 @@ def test_knn_f64_key_trick_preserves_the_total_order():
     back = dkey.view(np.uint64)
     assert np.array_equal((back >> np.uint64(32)) - np.uint64(0x00100000), bits)
     assert np.array_equal(back & np.uint64(0xFFFFFFFF), rows)
+
+
+def test_fused_adam_state_dict_speaks_torch_adam(tmp_path):
+    """Adam moments and the step counter must survive ``state_dict()`` -> ``load_state_dict()`` (Lightning
+    checkpoints / ``ckpt_path`` resume), in ``torch.optim.Adam``'s own layout so that either optimizer can resume the
+    other's run.  Host-side logic only (the update kernel itself is covered by tests/test_gpu_train.py)."""
+    import torch
+    from myria3d_amd import FusedAdam, HipRandLANet
+
+    torch.manual_seed(0)
+    net = HipRandLANet(9, 6, return_logits=True).flatten_parameters()
+    opt = FusedAdam(net, lr=2e-3, betas=(0.8, 0.95))
+    opt.exp_avg.copy_(torch.randn_like(opt.exp_avg))
+    opt.exp_avg_sq.copy_(torch.rand_like(opt.exp_avg_sq))
+    opt.step_count.fill_(7.0)
+    sd = opt.state_dict()
+    n_params = len(list(net.parameters()))
+    assert sorted(sd["state"].keys()) == list(range(n_params)) and sd["param_groups"][0]["params"] == list(range(n_params))
+    assert float(sd["state"][3]["step"]) == 7.0 and sd["param_groups"][0]["betas"] == (0.8, 0.95)
+    torch.save(sd, tmp_path / "opt.pt")
+    # (a) torch.optim.Adam accepts it verbatim
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in net.parameters()], lr=1.0)
+    ref.load_state_dict(torch.load(tmp_path / "opt.pt"))
+    for i, (p, q) in enumerate(zip(ref.param_groups[0]["params"], net.parameters())):
+        assert torch.equal(ref.state[p]["exp_avg"], sd["state"][i]["exp_avg"]) and float(ref.state[p]["step"]) == 7.0
+    assert ref.param_groups[0]["lr"] == 2e-3
+    # (b) a fresh FusedAdam restores moments + step from torch.optim.Adam's own state_dict
+    net2 = HipRandLANet(9, 6, return_logits=True).flatten_parameters()
+    opt2 = FusedAdam(net2, lr=1.0)
+    opt2.load_state_dict(ref.state_dict())
+    assert float(opt2.step_count) == 7.0 and opt2.param_groups[0]["lr"] == 2e-3
+    for (p, off, n) in opt._slices():
+        assert torch.equal(opt2.exp_avg[off:off + n], opt.exp_avg[off:off + n])
+        assert torch.equal(opt2.exp_avg_sq[off:off + n], opt.exp_avg_sq[off:off + n])
+    # one group, no frozen parameters
+    with pytest.raises(ValueError):
+        opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(1))]})
+    net3 = HipRandLANet(9, 6)
+    net3.fc0.weight.requires_grad_(False)
+    with pytest.raises(ValueError):
+        FusedAdam(net3)
+
+
+def test_eval_cache_notices_parameter_updates_through_a_parent_module():
+    """folded-BatchNorm / packed-weight caches of the eval path must not survive a parent module's
+    ``load_state_dict`` (Lightning: ``Model.model``), an optimizer step or an in-place copy."""
+    import torch
+    from myria3d_amd import HipRandLANet
+
+    class Shell(torch.nn.Module):          # stands in for myria3d.models.model.Model
+        def __init__(self):
+            super().__init__()
+            self.model = HipRandLANet(9, 6)
+
+    shell = Shell().eval()
+    net = shell.model
+    bn = net.block1.mlp1.norms[0].module
+    calls = []
+    fold = lambda: calls.append(1) or ("folded", len(calls))
+    deps = net._bn_deps(bn)
+    assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 1)
+    assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 1)          # hit
+    shell.load_state_dict(shell.state_dict())                               # parent-level load -> post hook
+    assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 2)
+    with torch.no_grad():
+        bn.running_var.mul_(2.0)                                            # in-place update: version counter moves
+    assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 3)
+    torch.optim.SGD([bn.weight], lr=0.1)                                    # an optimizer step in eval mode
+    with torch.no_grad():
+        bn.weight.add_(1.0)
+    assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 4)
+    assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 4)
