@@ -8,8 +8,9 @@ it (``transforms``: GridSampling, node budget, normalisations).
 from .randla import HipRandLANet, make_plan  # noqa: F401
 from .interpolation import DeviceInterpolator, knn_interpolate, predict_reduce, scatter_sum  # noqa: F401
 from .registration import register_in_model_zoo  # noqa: F401
+from .model_forward import SimpleBatch, collate_tiles, forward_like_model  # noqa: F401
 from .train import FusedAdam, cross_entropy  # noqa: F401
 from . import transforms  # noqa: F401
 
 __all__ = ["HipRandLANet", "make_plan", "knn_interpolate", "scatter_sum", "predict_reduce", "DeviceInterpolator",
-           "register_in_model_zoo", "FusedAdam", "cross_entropy", "transforms"]
+           "register_in_model_zoo", "forward_like_model", "collate_tiles", "SimpleBatch", "FusedAdam", "cross_entropy", "transforms"]

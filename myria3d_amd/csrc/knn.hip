@@ -29,6 +29,20 @@
 #ifndef M3D_KNN_DEFAULT_F64
 #define M3D_KNN_DEFAULT_F64 1
 #endif
+// deferred-insertion query kernel (k > 4): depth of the per-lane LDS candidate queue, register cap (waves per SIMD)
+#ifndef KNNQ_DEPTH
+#define KNNQ_DEPTH 16
+#endif
+#ifndef KNNQ_MINW
+#define KNNQ_MINW 4
+#endif
+#ifndef KNNQ_UNROLL
+#define KNNQ_UNROLL 4
+#endif
+#ifndef KNNQ_DRAIN
+#define KNNQ_DRAIN 2
+#endif
+static_assert((KNNQ_DEPTH & (KNNQ_DEPTH - 1)) == 0, "queue depth must be a power of two");
 
 struct KnnWs {
   float* gridp;     // [B][8]: xmin, ymin, inv_h, h, eps, (int)Gx, (int)Gy, (int)n
@@ -193,12 +207,15 @@ typedef unsigned long long u64;
 // KeyU64: the key is an integer; insertion = compare + select per slot (~6 32-bit VALU instructions per slot).
 struct KeyU64 {
   typedef u64 T;
+  static constexpr bool IS_F64 = false;
   static __device__ __forceinline__ T make(float d2, int row) {
     return ((u64)__float_as_uint(d2) << 32) | (u64)(unsigned)row;
   }
   static __device__ __forceinline__ T empty() { return ~0ull; }
   static __device__ __forceinline__ bool is_empty(T k) { return k == ~0ull; }
   static __device__ __forceinline__ unsigned d2bits(T k) { return (unsigned)(k >> 32); }
+  static __device__ __forceinline__ unsigned hi32(T k) { return (unsigned)(k >> 32); }
+  static __device__ __forceinline__ unsigned d2bits_of_hi(unsigned hw) { return hw; }
   static __device__ __forceinline__ int row(T k) { return (int)(unsigned)(k & 0xffffffffull); }
   template <int KMAX>
   static __device__ __forceinline__ void insert(T (&best)[KMAX], T key) {
@@ -221,6 +238,7 @@ struct KeyU64 {
 // +inf (0x7FF00000'00000000) is the "empty slot" sentinel, above every key.
 struct KeyF64 {
   typedef double T;
+  static constexpr bool IS_F64 = true;
   static constexpr unsigned BIAS = 0x00100000u;
   static __device__ __forceinline__ T make(float d2, int row) {
     return __hiloint2double((int)(__float_as_uint(d2) + BIAS), row);
@@ -228,6 +246,8 @@ struct KeyF64 {
   static __device__ __forceinline__ T empty() { return __hiloint2double(0x7FF00000, 0); }
   static __device__ __forceinline__ bool is_empty(T k) { return (unsigned)__double2hiint(k) == 0x7FF00000u; }
   static __device__ __forceinline__ unsigned d2bits(T k) { return (unsigned)__double2hiint(k) - BIAS; }
+  static __device__ __forceinline__ unsigned hi32(T k) { return (unsigned)__double2hiint(k); }
+  static __device__ __forceinline__ unsigned d2bits_of_hi(unsigned hw) { return hw - BIAS; }
   static __device__ __forceinline__ int row(T k) { return __double2loint(k); }
   template <int KMAX>
   static __device__ __forceinline__ void insert(T (&best)[KMAX], T key) {
@@ -356,6 +376,205 @@ __global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// query, deferred insertion (the default for k > 4)
+//
+// Same search (per-lane ring walk over the xy grid, same keys, same total order => bit-identical results), different
+// inner loop.  The direct kernel above runs its 2*KMAX-instruction sorted insertion whenever ANY of the 64 lanes
+// improves its list — measured ~200 times per wavefront at K = 16 although a lane improves only ~55 times — and
+// every candidate slot pays key construction, a 64-bit compare and a divergent branch.  Here a candidate costs a
+// distance, one fp32 compare against the lane's current k-th distance and, if it passes, an 8-byte append to a
+// per-lane queue in LDS ([slot][lane]: conflict-free).  Queues are drained into the sorted register list together —
+// when a queue is about to fill and at the end of every ring, where the termination test needs the exact k-th
+// distance — so the insertion chain runs (max queue length over the lanes) times per drain instead of once per
+// improving slot of any lane, and the threshold tightens after every drain.  One wavefront per workgroup: no
+// barriers, the hardware balances 3 200 independent wavefronts over the CUs.
+// ------------------------------------------------------------------------------------------
+template <int KMAX, class KP, int QD>
+__global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
+    KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float* __restrict__ pos_qry, int qstride,
+    const float4* __restrict__ qsorted, const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
+    int* __restrict__ idx_out, float* __restrict__ d2_out, int flags) {
+  const int sorted_io = flags & 1;  // bit 1: idx_out / d2_out are 16-byte aligned (vector stores allowed)
+  typedef typename KP::T KT;
+  __shared__ KT queue[QD][64];
+  const int lane = threadIdx.x;
+  // XCD-aware order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (observed; affects speed
+  // only), so workgroup b takes the queries of chunk (b % 8): every XCD then walks one contiguous eighth of the
+  // (cell-sorted) queries — two whole tiles at BASELINE config 2 — and its private L2 holds just those tiles' records
+  // instead of all of them (memory waits were ~50 % of the wave cycles with the plain order, profiles/r02c_*)
+  int64_t wg = blockIdx.x;
+  {
+    const int64_t nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+    const int64_t xcd = wg & 7, i8 = wg >> 3;
+    wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
+  }
+  const int64_t t = wg * 64 + lane;
+  if (t >= n_qry) return;  // (the drains below are per-lane loops: lanes that leave early are simply inactive)
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (ptr_qry[mid] <= t) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  float qx, qy, qz;
+  int64_t orow;
+  if (qsorted) {
+    float4 q = qsorted[t];
+    qx = q.x; qy = q.y; qz = q.z; orow = sorted_io ? t : (int64_t)__float_as_int(q.w);
+  } else {
+    const float* p = pos_qry + t * qstride;
+    qx = p[0]; qy = p[1]; qz = p[2]; orow = t;
+  }
+  const float* gp = w.gridp + (size_t)b * GP_STRIDE;
+  const float gx0 = gp[0], gy0 = gp[1], inv_h = gp[2], h = gp[3], eps = gp[4];
+  const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6], n = ((const int*)gp)[7];
+  const int* cs = w.cell_start + (size_t)b * (CELLS_MAX + 1);
+  const float4* sorted = w.sorted + ptr_src[b];
+
+  KT best[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
+  int cnt = 0;                       // entries in this lane's queue
+  float kth = __builtin_inff();      // this lane's current k-th squared distance (+inf while the list is not full)
+
+  auto chain = [&](KT key) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if constexpr (KP::IS_F64) {
+        KT hi2;
+        asm("v_max_f64 %0, %1, %2" : "=&v"(hi2) : "v"(best[j]), "v"(key));
+        asm("v_min_f64 %0, %0, %1" : "+v"(best[j]) : "v"(key));
+        key = hi2;
+      } else {
+        const KT cur = best[j];
+        const bool lt = key < cur;
+        best[j] = lt ? key : cur;
+        key = lt ? cur : key;
+      }
+    }
+  };
+  auto drain = [&]() {
+    // divergent trip count: the wavefront runs max(cnt) insertion chains, all lanes in step.  KNNQ_DRAIN keys per
+    // trip: their chains are independent up to a one-slot skew, so the scheduler can interleave them (a lone chain
+    // is KMAX dependent v_max_f64 long)
+    for (int i = 0; i < cnt; i += KNNQ_DRAIN) {
+      KT key[KNNQ_DRAIN];
+#pragma unroll
+      for (int u = 0; u < KNNQ_DRAIN; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
+#pragma unroll
+      for (int u = 0; u < KNNQ_DRAIN; ++u) chain(u == 0 || i + u < cnt ? key[u] : KP::empty());
+    }
+    cnt = 0;
+    // k-th key = the largest of the first k (the list is ascending; empty slots sort above every key).  Written as
+    // a max over the high words so that a run-time k costs KMAX selects, not a register array spilled to scratch
+    // for dynamic indexing
+    unsigned hw = KP::hi32(best[KMAX - 1]);
+    if (k < KMAX) {
+      hw = 0u;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const unsigned v = j < k ? KP::hi32(best[j]) : 0u;
+        hw = v > hw ? v : hw;
+      }
+    }
+    kth = hw == KP::hi32(KP::empty()) ? __builtin_inff() : __uint_as_float(KP::d2bits_of_hi(hw));
+  };
+
+  if (n > 0) {
+    const int cx = min(Gx - 1, max(0, (int)((qx - gx0) * inv_h)));
+    const int cy = min(Gy - 1, max(0, (int)((qy - gy0) * inv_h)));
+    for (int R = 0;; ++R) {
+      for (int dy = -R; dy <= R; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= Gy) continue;
+        const bool edge = (dy == -R || dy == R);
+        for (int sg = 0; sg < (edge ? 1 : 2); ++sg) {
+          int xa, xb;
+          if (edge) {
+            xa = max(cx - R, 0); xb = min(cx + R, Gx - 1);
+          } else {
+            xa = xb = (sg == 0 ? cx - R : cx + R);
+            if (xa < 0 || xa >= Gx) continue;
+          }
+          const int p0 = cs[yy * Gx + xa], p1 = cs[yy * Gx + xb + 1];
+          // (reads run up to 2*KNNQ_UNROLL-1 records past p1: still inside the workspace — the sorted array is
+          // followed by the perm / inv arrays — and masked out below).  The loads of batch i+1 are issued before batch
+          // i is consumed: two batches of 16-byte loads in flight per lane
+          float4 nx[KNNQ_UNROLL];
+#pragma unroll
+          for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[p0 + u];
+          for (int p = p0; p < p1; p += KNNQ_UNROLL) {
+            float4 s[KNNQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < KNNQ_UNROLL; ++u) s[u] = nx[u];
+#pragma unroll
+            for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[p + KNNQ_UNROLL + u];
+#pragma unroll
+            for (int u = 0; u < KNNQ_UNROLL; ++u) asm volatile("" : "+v"(nx[u].w));  // whole 16-byte loads, issued together
+            if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
+#pragma unroll
+            for (int u = 0; u < KNNQ_UNROLL; ++u) {
+              const float d2 = dist2_exact(qx, qy, qz, s[u]);
+              // !(d2 > kth): ties with the current k-th distance go through the exact (d2, row) order in the drain
+              if (p + u < p1 && !(d2 > kth)) {
+                queue[cnt][lane] = KP::make(d2, __float_as_int(s[u].w));
+                ++cnt;
+              }
+            }
+          }
+        }
+      }
+      drain();
+      const bool covers = (cx - R <= 0) && (cx + R >= Gx - 1) && (cy - R <= 0) && (cy + R >= Gy - 1);
+      if (covers) break;
+      float bound = 3.4e38f;
+      if (cx - R > 0) bound = fminf(bound, qx - (gx0 + (float)(cx - R) * h));
+      if (cx + R < Gx - 1) bound = fminf(bound, (gx0 + (float)(cx + R + 1) * h) - qx);
+      if (cy - R > 0) bound = fminf(bound, qy - (gy0 + (float)(cy - R) * h));
+      if (cy + R < Gy - 1) bound = fminf(bound, (gy0 + (float)(cy + R + 1) * h) - qy);
+      bound = fmaxf(bound - eps, 0.f);
+      if (kth <= bound * bound) break;  // (kth = +inf while fewer than k neighbours are known: keeps searching)
+    }
+  }
+  // ---- results: all slot translations (w.inv) in flight together, rows stored 16 bytes at a time when k == KMAX
+  int ids[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) ids[j] = KP::is_empty(best[j]) ? -1 : KP::row(best[j]);
+  if (sorted_io) {  // neighbours selected by (d2, original row); reported as cell-sorted slots
+    int tr[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) tr[j] = w.inv[ids[j] < 0 ? 0 : ids[j]];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? -1 : tr[j];
+  }
+  int* io = idx_out + orow * k;
+  if (k == KMAX && KMAX % 4 == 0 && (flags & 2)) {
+#pragma unroll
+    for (int j = 0; j < KMAX; j += 4) *(int4*)(io + j) = make_int4(ids[j], ids[j + 1], ids[j + 2], ids[j + 3]);
+    if (d2_out) {
+      float* dq = d2_out + orow * k;
+#pragma unroll
+      for (int j = 0; j < KMAX; j += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = KP::is_empty(best[j + u]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j + u]));
+        *(float4*)(dq + j) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < k) {
+        io[j] = ids[j];
+        if (d2_out)
+          d2_out[orow * k + j] = KP::is_empty(best[j]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j]));
+      }
+    }
+  }
+}
+
 extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int64_t* ptr_src, int32_t num_clouds,
                              int64_t n_src, void* ws, void* stream) {
   if (!ptr_src || !ws || num_clouds < 0 || n_src < 0 || pos_stride < 3) return M3D_ERR_INVALID;
@@ -396,21 +615,39 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   dim3 grid((unsigned)m3d_cdiv(n_qry, 256)), block(256);
   hipStream_t st = (hipStream_t)stream;
   static const bool f64_keys = knn_f64_keys();
+  // M3D_KNN_QUEUE=0: the direct-insertion kernel for every k (cross-check of the deferred-insertion kernel);
+  const int qflags = (sorted_io ? 1 : 0) | (((((uintptr_t)idx_out) | ((uintptr_t)d2_out)) & 15) == 0 ? 2 : 0);
+  // M3D_KNN_QUEUE=1: always, unset: where it measured faster — large query sets (>= 1M (query, neighbour) pairs: level
+  // 1 of BASELINE config 2 189 vs 224 us; the K = 32 tiles), while the small deep-level launches (a few waves per CU,
+  // latency-bound) stay on the direct kernel (profiles/r02d_knn_ab.log)
+  static const int queue_env = getenv("M3D_KNN_QUEUE") ? atoi(getenv("M3D_KNN_QUEUE")) : -1;
+  const bool use_queue = queue_env < 0 ? n_qry * (int64_t)k >= (1 << 20) : queue_env != 0;
 #define LAUNCH_KP(KM, KP)                                                                                      \
   hipLaunchKernelGGL((knn_query_kernel<KM, KP>), grid, block, 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, \
                      qs, ptr_qry, n_qry, k, idx_out, d2_out, sorted_io)
-#define LAUNCH(KM)                      \
-  do {                                  \
+#define LAUNCH_Q(KM, KP)                                                                                          \
+  hipLaunchKernelGGL((knn_query_queue_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
+                     w, ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags)
+#define LAUNCH(KM)                       \
+  do {                                   \
     if (f64_keys) LAUNCH_KP(KM, KeyF64); \
     else LAUNCH_KP(KM, KeyU64);          \
   } while (0)
+#define LAUNCHQ(KM)                      \
+  do {                                   \
+    if (!use_queue) LAUNCH(KM);          \
+    else if (f64_keys) LAUNCH_Q(KM, KeyF64); \
+    else LAUNCH_Q(KM, KeyU64);           \
+  } while (0)
   if (k == 1) LAUNCH(1);
   else if (k <= 4) LAUNCH(4);
-  else if (k <= 8) LAUNCH(8);
-  else if (k <= 16) LAUNCH(16);
-  else if (k <= 32) LAUNCH(32);
-  else LAUNCH(64);
+  else if (k <= 8) LAUNCHQ(8);
+  else if (k <= 16) LAUNCHQ(16);
+  else if (k <= 32) LAUNCHQ(32);
+  else LAUNCHQ(64);
 #undef LAUNCH
+#undef LAUNCHQ
+#undef LAUNCH_Q
 #undef LAUNCH_KP
   M3D_CHECK_LAUNCH();
   return M3D_OK;

@@ -402,9 +402,11 @@ class HipRandLANet(nn.Module):
                     assert d_ref.numel() == plan.totals[lvl + 1]
                     d_int = ops.gather_i32(ix.inv, d_ref)
                 else:
-                    d_int = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
+                    # drawn in REFERENCE rows (like the reference's randperm, pyg_randla_net.py:221): which points
+                    # survive depends on the seed only, not on the (arbitrary) order of points inside a grid cell
+                    d_ref = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
                                                    self._decim_seed, lvl)
-                    d_ref = ops.gather_i32(ix.perm, d_int)
+                    d_int = ops.gather_i32(ix.inv, d_ref)
                 g.dec_ref.append(d_ref)
                 nxt = ops.KnnIndex(ops.gather_rows(g.pos4[lvl], d_int), plan.ptrs[lvl + 1])
                 g.src.append(ops.gather_i32(d_int, nxt.perm))  # sorted slot of level lvl+1 -> sorted slot of level lvl

@@ -1,0 +1,128 @@
+"""Pins the oracle to the REAL reference — runs only where the reference's third-party stack is importable.
+
+    python tests/golden/make_golden_from_reference.py  [/path/to/myria3d checkout, default /root/reference]
+
+Needs ``torch_geometric`` (pyg 2.4), ``torch_cluster``, ``torch_scatter``, ``torchmetrics`` (environment.yml:14-22 of
+the reference).  None of them is installed in the build image of rounds 1-2, so this script has NOT been run yet and
+``tests/golden/randla_reference.npz`` does not exist: the oracle's parity with the reference stays UNPINNED until it
+does (oracle/__init__.py).  The day the wheels exist:
+
+  1. this script imports ``PyGRandLANet`` from ``myria3d/models/modules/pyg_randla_net.py`` of the checkout (by file
+     path: the package ``__init__`` pulls in Lightning / hydra, which the net itself does not need),
+  2. loads the same deterministic weights as ``tests/_util.fill_params_deterministic`` (state_dict keys are shared by
+     construction), injects the same decimation indices by replacing the module-level
+     ``decimation_indices`` (pyg_randla_net.py:192-231) and switches the classifier dropout off (PyG ``MLP.dropout``
+     is a plain list) because torch's dropout stream cannot be injected,
+  3. writes the reference's OWN outputs — eval logits, train-mode logits, loss, a handful of parameter gradients,
+     running statistics, the level-1 kNN edge list as sorted per-centre squared distances — to
+     ``tests/golden/randla_reference.npz``.
+
+``tests/test_reference_pin.py`` then compares ``oracle.randla_oracle.RandLANetOracle`` with that file on every run
+(and, where the stack is importable, with the live reference as well).
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests._util import fill_params_deterministic, rand_batch  # noqa: E402
+
+SIZES = [700, 333, 50]
+PARAM_SEED = 77
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "randla_reference.npz")
+GRAD_KEYS = ["fc0.weight", "block1.lfa1.mlp_attention.lins.0.weight", "block1.lfa2.mlp_encoder.lins.0.weight",
+             "block2.mlp2.norms.0.module.weight", "block4.lfa2.mlp_encoder.lins.0.weight", "fp2.nn.lins.0.weight",
+             "fc_classif.weight"]
+
+
+def load_reference_module(ref_root: str):
+    """The reference's net module, imported by file path.  Raises ImportError when its dependencies are missing."""
+    path = os.path.join(ref_root, "myria3d", "models", "modules", "pyg_randla_net.py")
+    if not os.path.exists(path):
+        raise ImportError(f"no reference checkout at {ref_root}")
+    spec = importlib.util.spec_from_file_location("_m3d_reference_pyg_randla_net", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)  # ImportError here = torch_geometric / torch_cluster / torch_scatter missing
+    return mod
+
+
+def fixed_decimation(ptr, factor, levels, seed):
+    """Same indices as oracle.randla_oracle.fixed_decimation_indices, without importing the oracle."""
+    g = torch.Generator().manual_seed(seed)
+    out, p = [], [int(v) for v in ptr]
+    for _ in range(levels):
+        idx, new = [], [0]
+        for b in range(len(p) - 1):
+            n = p[b + 1] - p[b]
+            m = max(1, n // factor)
+            idx.append(p[b] + torch.randperm(n, generator=g)[:m])
+            new.append(new[-1] + m)
+        out.append(torch.cat(idx))
+        p = new
+    return out
+
+
+def run_reference(mod, x, pos, batch, ptr, dec, y, param_seed=PARAM_SEED):
+    """Eval logits, train logits (dropout off), loss, gradients, running statistics of the REAL PyGRandLANet."""
+    net = mod.PyGRandLANet(9, 6, decimation=4, num_neighbors=16, return_logits=True)
+    fill_params_deterministic(net, param_seed)
+    net.mlp_classif.dropout = [0.0, 0.0]
+    calls = {"i": 0}
+    orig = mod.decimation_indices
+
+    def injected(ptr_in, factor):
+        idx = dec[calls["i"] % len(dec)]
+        calls["i"] += 1
+        _, ptr_out = orig(ptr_in, factor)  # the reference's own ptr arithmetic (deterministic)
+        assert idx.numel() == int(ptr_out[-1])
+        return idx, ptr_out
+
+    mod.decimation_indices = injected
+    try:
+        net.eval()
+        with torch.no_grad():
+            logits_eval = net(x, pos, batch, ptr)
+        net.train()
+        logits_train = net(x, pos, batch, ptr)
+        loss = torch.nn.functional.cross_entropy(logits_train, y)
+        loss.backward()
+    finally:
+        mod.decimation_indices = orig
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    bufs = {k: b.detach().clone() for k, b in net.named_buffers() if k.endswith(("running_mean", "running_var"))}
+    # level-1 graph through the reference's own knn_graph (torch_cluster): per-centre ascending squared distances
+    edge = mod.knn_graph(pos, 16, batch=batch, loop=True)
+    d2 = ((pos[edge[0]] - pos[edge[1]]) ** 2).sum(1)
+    return dict(logits_eval=logits_eval, logits_train=logits_train.detach(), loss=loss.detach(), grads=grads, bufs=bufs,
+                knn_src=edge[0], knn_dst=edge[1], knn_d2=d2)
+
+
+def main():
+    ref_root = sys.argv[1] if len(sys.argv) > 1 else os.environ.get("M3D_REFERENCE_ROOT", "/root/reference")
+    mod = load_reference_module(ref_root)
+    torch.set_num_threads(1)
+    x, pos, batch, ptr = rand_batch(SIZES, seed=2025)
+    dec = fixed_decimation(ptr.tolist(), 4, 4, seed=8)
+    y = torch.from_numpy(np.random.RandomState(3).randint(0, 6, (sum(SIZES),)))
+    r = run_reference(mod, x, pos, batch, ptr, dec, y)
+    out = dict(x=x.numpy(), pos=pos.numpy(), ptr=ptr.numpy(), y=y.numpy(), param_seed=np.int64(PARAM_SEED),
+               logits_eval=r["logits_eval"].numpy(), logits_train=r["logits_train"].numpy(),
+               loss_train=np.float64(r["loss"].item()), knn_src=r["knn_src"].numpy(), knn_dst=r["knn_dst"].numpy(),
+               knn_d2=r["knn_d2"].numpy())
+    for i, d in enumerate(dec):
+        out[f"dec{i}"] = d.numpy().astype(np.int64)
+    for k in GRAD_KEYS:
+        out["grad:" + k] = r["grads"][k].numpy()
+    for k, b in r["bufs"].items():
+        if k.startswith(("block1.lfa1.mlp_encoder", "block3.mlp2", "mlp_summit")):
+            out["buf:" + k] = b.numpy()
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes — generated from the reference at", ref_root)
+
+
+if __name__ == "__main__":
+    main()

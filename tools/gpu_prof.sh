@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 TAG=${1:-r01}; shift
 rm -rf /tmp/prof && mkdir -p /tmp/prof
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-graph --steps 5 --warmup 2 --skip-cpu-baseline "$@" ) > $OUT/rocprof_$TAG.log 2>&1
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-graph --steps 5 --warmup 2 --skip-cpu-baseline --skip-extras "$@" ) > $OUT/rocprof_$TAG.log 2>&1
 find /tmp/prof -type f | head -20
 for f in $(find /tmp/prof -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats_$TAG.csv; done
 for f in $(find /tmp/prof -name '*kernel_trace.csv'); do python - "$f" "$OUT/kernel_trace_${TAG}_summary.csv" <<'PY'

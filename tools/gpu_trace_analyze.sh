@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 TAG=${1:-t}
 rm -rf /tmp/prof && mkdir -p /tmp/prof
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --skip-roofline ) > $OUT/trace_$TAG.log 2>&1
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --skip-roofline --skip-extras ) > $OUT/trace_$TAG.log 2>&1
 f=$(find /tmp/prof -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
