@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 2
+#define M3D_ABI_VERSION 3
 int m3d_abi_version(void);
 
 /* ---- k nearest neighbours -----------------------------------------------------------------------------
@@ -180,6 +180,20 @@ int m3d_grid_sampling(const float* pos, int32_t pos_stride, const float* x, int6
                       float* out_x, int64_t* out_y, int64_t* out_ptr, void* stream);
 /* status_dev_out: device int32 [1] <- 0 ok | 1 some tile's voxel grid has >= 2^40 cells (results invalid) */
 int m3d_grid_sampling_status(const void* ws, int64_t n, int32_t num_clouds, int32_t* status_dev_out, void* stream);
+
+/* Tiling of a whole cloud into square samples: the selection of split_cloud_into_samples()
+ * (myria3d/pctl/dataset/utils.py:126-158: cKDTree.query_ball_point(centre, r = subtile_width // 2, p = inf) per centre
+ * of get_mosaic_of_centers(), utils.py:29-39) for ALL centres at once.  centers_dev: fp64 [centers_per_axis] lattice
+ * coordinates (identical for x and y); sample s = ix * centers_per_axis + iy (the reference's x-major order); a point
+ * belongs to sample s iff |x - xmin - c[ix]| <= radius and |y - ymin - c[iy]| <= radius, evaluated like the reference
+ * (float32 shift by the per-cloud minimum, float64 compare).  Two calls: count_only = 1 fills sample_ptr (int64
+ * [S + 1], CSR offsets; sample_ptr[S] = total memberships), count_only = 0 writes idx_out (int32 [total], point
+ * indices, ascending inside each sample; the reference returns them in tree order — the set is the contract).
+ * start / step: first lattice coordinate and lattice pitch (candidate pre-selection only). */
+size_t m3d_tile_select_workspace_bytes(int64_t n, int32_t centers_per_axis);
+int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, const double* centers_dev,
+                    int32_t centers_per_axis, double radius, double start, double step, void* ws, int32_t count_only,
+                    int64_t* sample_ptr, int32_t* idx_out, void* stream);
 
 /* Per-tile normalisations, in place, for a whole batch (two launches): Center (pos -= mean), NullifyLowestZ
  * (z -= min z; myria3d/pctl/transforms/transforms.py:141-146), NormalizePos (pos *= pos_scale; :149-162) and

@@ -490,3 +490,172 @@ extern "C" int m3d_tile_normalize(float* pos, int32_t pos_stride, float* x, int6
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Tiling of a whole cloud into square receptive fields
+//
+// Replaces the selection loop of split_cloud_into_samples()
+// (/root/reference/myria3d/pctl/dataset/utils.py:126-158): a cKDTree over the xy coordinates shifted by their minimum
+// and, per centre of the mosaic (get_mosaic_of_centers, utils.py:29-39), query_ball_point(centre, r=subtile_width // 2,
+// p=inf) = every point whose Chebyshev distance to the centre is <= r (closed ball) — one CPU tree query per 50 m
+// sample.  Here all samples of a cloud are produced in three launches: each point finds the few mosaic cells it can
+// belong to arithmetically (the centres form a regular lattice) and tests them with the reference's own arithmetic
+// (float32 shift by the minimum, then float64 |d| <= r); a wavefront walks its chunk of points IN ORDER and ranks the
+// members of each sample with ballots, so every sample's index list comes out ascending and deterministic (the tree
+// returns them in traversal order: the SET is the contract).  Layout: CSR (sample_ptr, idx).
+// ------------------------------------------------------------------------------------------
+#define TS_CHUNK 2048     // points per wavefront (one workgroup)
+#define TS_MAX_SAMPLES 8192
+
+struct TileSelArgs {
+  const float* pos; int pstride; int64_t n;
+  const double* centers;  // [nc] mosaic coordinates along one axis (the same values are used for x and y)
+  int nc; double r; double start, step;
+  float xmin, ymin;       // unused when minxy != nullptr
+  const float* minxy;     // device [2]
+  int32_t* hist;          // [nc*nc][nwg]: pass 0 writes counts, the host scans it in place, pass 1 reads offsets
+  int nwg;
+  int32_t* out_idx;
+};
+
+// partial xy minima: one float2 per workgroup, combined by tile_sel_min_final
+__global__ __launch_bounds__(256) void tile_sel_min_kernel(const float* __restrict__ pos, int pstride, int64_t n,
+                                                           float* __restrict__ part) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float mx = 3.4e38f, my = 3.4e38f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+    mx = fminf(mx, pos[i * pstride]);
+    my = fminf(my, pos[i * pstride + 1]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fminf(mx, __shfl_xor(mx, o, 64)); my = fminf(my, __shfl_xor(my, o, 64)); }
+  if (lane == 0) { red[0][wid] = mx; red[1][wid] = my; }
+  __syncthreads();
+  if (tid == 0) {
+    part[2 * blockIdx.x] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    part[2 * blockIdx.x + 1] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+  }
+}
+__global__ __launch_bounds__(64) void tile_sel_min_final(const float* __restrict__ part, int nparts, float* __restrict__ out) {
+  float mx = 3.4e38f, my = 3.4e38f;
+  for (int i = threadIdx.x; i < nparts; i += 64) { mx = fminf(mx, part[2 * i]); my = fminf(my, part[2 * i + 1]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fminf(mx, __shfl_xor(mx, o, 64)); my = fminf(my, __shfl_xor(my, o, 64)); }
+  if (threadIdx.x == 0) { out[0] = mx; out[1] = my; }
+}
+
+// candidate lattice range of one coordinate: every centre index i with |v - c[i]| <= r lies in [lo, hi]
+__device__ __forceinline__ void ts_range(double v, const TileSelArgs& a, int& lo, int& hi) {
+  lo = (int)floor((v - a.r - a.start) / a.step) - 1;
+  hi = (int)ceil((v + a.r - a.start) / a.step) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > a.nc - 1 ? a.nc - 1 : hi;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void tile_select_kernel(TileSelArgs a) {
+  __shared__ int cnt[TS_MAX_SAMPLES];
+  const int lane = threadIdx.x, wg = blockIdx.x;
+  const int S = a.nc * a.nc;
+  for (int s = lane; s < S; s += 64) cnt[s] = WRITE ? a.hist[(size_t)s * a.nwg + wg] : 0;
+  __syncthreads();
+  const float xmin = a.minxy[0], ymin = a.minxy[1];
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t base = (int64_t)wg * TS_CHUNK;
+  for (int i0 = 0; i0 < TS_CHUNK; i0 += 64) {
+    const int64_t p = base + i0 + lane;
+    const bool live = p < a.n;
+    double xs = 0.0, ys = 0.0;
+    int ilo = 0, ihi = -1, jlo = 0, jhi = -1;
+    if (live) {
+      // the reference's arithmetic: float32 subtraction of the minimum, then float64 distances (cKDTree data is f64)
+      xs = (double)(a.pos[p * a.pstride] - xmin);
+      ys = (double)(a.pos[p * a.pstride + 1] - ymin);
+      ts_range(xs, a, ilo, ihi);
+      ts_range(ys, a, jlo, jhi);
+    }
+    int ni = ihi - ilo + 1, nj = jhi - jlo + 1;
+    ni = ni < 0 ? 0 : ni; nj = nj < 0 ? 0 : nj;
+    int mi = ni, mj = nj;  // wave-uniform loop bounds
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mi = max(mi, __shfl_xor(mi, o, 64)); mj = max(mj, __shfl_xor(mj, o, 64)); }
+    for (int di = 0; di < mi; ++di) {
+      const int i = ilo + di;
+      const bool okx = live && di < ni && fabs(xs - a.centers[i]) <= a.r;
+      for (int dj = 0; dj < mj; ++dj) {
+        const int j = jlo + dj;
+        const bool member = okx && dj < nj && fabs(ys - a.centers[j]) <= a.r;
+        const int s = member ? i * a.nc + j : -1;  // sample order of get_mosaic_of_centers: x-major
+        unsigned long long todo = __ballot(member);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const int s0 = __shfl(s, leader, 64);
+          const unsigned long long mask = __ballot(member && s == s0);
+          const int c0 = cnt[s0];
+          if (WRITE && member && s == s0) a.out_idx[c0 + __popcll(mask & lt)] = (int32_t)p;
+          __syncthreads();  // (one wavefront: orders the LDS read above before the leader's update)
+          if (lane == leader) cnt[s0] = c0 + __popcll(mask);
+          __syncthreads();
+          todo &= ~mask;
+        }
+      }
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    for (int s = lane; s < S; s += 64) a.hist[(size_t)s * a.nwg + wg] = cnt[s];
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_sel_ptr_kernel(const int32_t* __restrict__ scanned, int S, int nwg,
+                                                           int64_t* __restrict__ sample_ptr) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s <= S) sample_ptr[s] = (int64_t)scanned[(size_t)s * nwg];  // s == S: the grand total stored behind the table
+}
+
+extern "C" size_t m3d_tile_select_workspace_bytes(int64_t n, int32_t centers_per_axis) {
+  if (n < 0 || centers_per_axis < 1) return 0;
+  const int64_t nwg = m3d_cdiv(n > 0 ? n : 1, TS_CHUNK);
+  const int64_t S = (int64_t)centers_per_axis * centers_per_axis;
+  return al256((size_t)(S * nwg + 1) * 4) + al256(2 * 1024 * 4) + 256;
+}
+
+// pass 0 (count_only != 0): fills the histogram, scans it, writes sample_ptr[S + 1] (int64) — the caller reads
+// sample_ptr[S] to size idx_out; pass 1: writes idx_out (int32 point indices, ascending inside each sample).
+extern "C" int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, const double* centers_dev,
+                               int32_t centers_per_axis, double radius, double start, double step, void* ws,
+                               int32_t count_only, int64_t* sample_ptr, int32_t* idx_out, void* stream) {
+  if (n < 0 || pos_stride < 2 || centers_per_axis < 1 || !ws || !sample_ptr || !centers_dev) return M3D_ERR_INVALID;
+  if (!(step > 0.0) || !(radius >= 0.0)) return M3D_ERR_INVALID;
+  const int64_t S = (int64_t)centers_per_axis * centers_per_axis;
+  if (S > TS_MAX_SAMPLES) return M3D_ERR_UNSUPPORTED;
+  if (n > 0 && !pos) return M3D_ERR_INVALID;
+  if (!count_only && !idx_out && n > 0) return M3D_ERR_INVALID;
+  if (n >= (1ll << 31)) return M3D_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nwg = m3d_cdiv(n > 0 ? n : 1, TS_CHUNK);
+  if (S * nwg + 1 >= (1ll << 31)) return M3D_ERR_UNSUPPORTED;
+  char* p = (char*)ws;
+  int32_t* hist = (int32_t*)p; p += al256((size_t)(S * nwg + 1) * 4);
+  float* part = (float*)p;  // [1024][2] partial minima, then [2] final at part + 2048
+  TileSelArgs a;
+  a.pos = pos; a.pstride = pos_stride; a.n = n; a.centers = centers_dev; a.nc = centers_per_axis; a.r = radius;
+  a.start = start; a.step = step; a.xmin = a.ymin = 0.f; a.minxy = part + 2048 - 2; a.hist = hist; a.nwg = (int)nwg;
+  a.out_idx = idx_out;
+  if (count_only) {
+    int nparts = (int)(n / 4096 + 1);
+    if (nparts > 1023) nparts = 1023;
+    hipLaunchKernelGGL(tile_sel_min_kernel, dim3(nparts), dim3(256), 0, st, pos, pos_stride, n, part);
+    hipLaunchKernelGGL(tile_sel_min_final, dim3(1), dim3(64), 0, st, (const float*)part, nparts, part + 2048 - 2);
+    hipLaunchKernelGGL((tile_select_kernel<false>), dim3((unsigned)nwg), dim3(64), 0, st, a);
+    // exclusive scan in sample-major order: hist[s][wg] -> first output slot of (sample s, chunk wg); total at the end
+    hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, hist, S * nwg, hist + S * nwg);
+    hipLaunchKernelGGL(tile_sel_ptr_kernel, dim3((unsigned)m3d_cdiv(S + 1, 256)), dim3(256), 0, st, (const int32_t*)hist,
+                       (int)S, (int)nwg, sample_ptr);
+  } else {
+    hipLaunchKernelGGL((tile_select_kernel<true>), dim3((unsigned)nwg), dim3(64), 0, st, a);
+  }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

@@ -27,6 +27,7 @@ from __future__ import annotations
 import math
 from typing import Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -130,3 +131,32 @@ def prepare_tiles(pos: Tensor, x: Tensor, y: Optional[Tensor], ptr: Sequence[int
         P.append(p), X.append(xx), Y.append(yy)
         out_ptr.append(out_ptr[-1] + p.shape[0])
     return torch.cat(P), torch.cat(X), (None if y is None else torch.cat(Y)), out_ptr
+
+
+# --------------------------------------------------------------------------------------
+# tiling of a whole cloud into square samples (myria3d/pctl/dataset/utils.py:29-39, 126-158)
+# --------------------------------------------------------------------------------------
+def get_mosaic_of_centers(tile_width, subtile_width, subtile_overlap=0):
+    """utils.py:29-39."""
+    if subtile_overlap < 0:
+        raise ValueError("datamodule.subtile_overlap must be positive.")
+    xy_range = np.arange(subtile_width / 2, tile_width + (subtile_width / 2) - subtile_overlap,
+                         step=subtile_width - subtile_overlap)
+    return [np.array([x, y]) for x in xy_range for y in xy_range]
+
+
+def split_cloud_into_samples(pos, tile_width, subtile_width, subtile_overlap=0):
+    """utils.py:139-158 without the pdal read: the SAME third-party call as the reference (scipy's cKDTree is
+    installed here, so this part of the oracle is pinned to the reference's own arithmetic).  ``pos``: float32
+    ``[N, 3]`` numpy array.  Yields ``(sample number in the mosaic, sample_idx)`` for the non-empty samples; the order
+    inside ``sample_idx`` is the tree's traversal order, as in the reference."""
+    from scipy.spatial import cKDTree
+
+    pos = np.asarray(pos, dtype=np.float32)
+    kd_tree = cKDTree(pos[:, :2] - pos[:, :2].min(axis=0))
+    for s, center in enumerate(get_mosaic_of_centers(tile_width, subtile_width, subtile_overlap=subtile_overlap)):
+        radius = subtile_width // 2  # Square receptive field.
+        sample_idx = np.array(kd_tree.query_ball_point(center, r=radius, p=np.inf))
+        if not len(sample_idx):
+            continue
+        yield s, sample_idx
