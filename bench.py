@@ -440,7 +440,7 @@ def _dry_run_gloo(args, world, rank):
     dist.destroy_process_group()
 
 
-def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False):
+def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False, precision="fp32"):
     """The contract measurement: ``steps`` training steps (fwd + CE + bwd + [all-reduce] + Adam) and ``steps`` eval
     forwards over B tiles x N points per rank.  Returns (record, net, pos, plan)."""
     from myria3d_amd import FusedAdam, HipRandLANet, cross_entropy, make_plan
@@ -452,6 +452,7 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     x, pos, ptr, y = x.to(dev), pos.to(dev), ptr.to(dev), y.to(dev)
     torch.manual_seed(0)
     net = HipRandLANet(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev)
+    net.matmul_precision = precision
     # every parameter / gradient becomes a view of one flat buffer: the backward kernels accumulate into it, RCCL
     # all-reduces it as ONE 4.45 MB bucket, m3d_adam_step updates (and clears) it in one launch
     net.flatten_parameters()
@@ -463,9 +464,10 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
 
     def fwd_bwd():
         net.train()
-        out = net(x, pos, None, ptr, plan=plan)
-        if look:  # the next step's kNN tables / decimation are built beside this step's kernels
-            net.prefetch_geometry(pos, ptr, plan, train=True)
+        out = net(x, pos, None, ptr, plan=plan)  # (lookahead: consumes the tables the previous step prefetched)
+        if look:  # the NEXT step's kNN tables / decimation: enqueued (and, in the graph, submitted) behind the forward's
+            # kernels, dependent on the forward's START only, so they run beside the forward tail and the backward pass
+            net.prefetch_geometry(pos, ptr, plan, train=True, after="forward_start")
         loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
         loss.backward()
         if net.grad_side is not None:
@@ -482,7 +484,7 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
         with torch.no_grad():
             net(x, pos, None, ptr, plan=plan)
             if look:
-                net.prefetch_geometry(pos, ptr, plan, train=False)
+                net.prefetch_geometry(pos, ptr, plan, train=False, after="forward_start")
                 net.join_geometry()
 
     launch = "eager"
@@ -505,19 +507,24 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                     fwd_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            if look:  # the captured step must CONSUME prefetched tables: leave one pending for the training key
-                net.prefetch_geometry(pos, ptr, plan, train=True)
+            if look:  # the captured steps must CONSUME tables prefetched one step earlier: leave one pending
                 train_step()
                 torch.cuda.synchronize()
-            g_train = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_train, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
-                if world == 1:
-                    train_step()  # no collective: the optimizer launches are part of the graph
-                else:
-                    fwd_bwd()
+            # with the lookahead the prefetched tables live in two buffer sets used in turn: one captured step per set
+            g_train = []
+            for _ in range(2 if look else 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
+                    if world == 1:
+                        train_step()  # no collective: the optimizer launches are part of the graph
+                    else:
+                        fwd_bwd()
+                g_train.append(g)
+            turn = [0]
 
             def graph_step():
-                g_train.replay()
+                g_train[turn[0] % len(g_train)].replay()
+                turn[0] += 1
                 if world > 1:
                     opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
 
@@ -533,16 +540,24 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     dt = timed(step_fn, steps, world)
     # eval forward of the trained weights.  The first (eager) pass folds the BatchNorms / packs the attention weights
     # (cached by the module until the next training phase); the captured graph then holds the per-batch work only
-    if look:
-        net.prefetch_geometry(pos, ptr, plan, train=False)
     fwd_step()
+    fwd_step()  # (lookahead: the second call consumes what the first one prefetched and leaves an eval-mode slot pending)
     if launch == "hipgraph":
         try:
             torch.cuda.synchronize()
-            g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fwd, capture_error_mode="thread_local"):
-                fwd_step()
-            fwd_fn = g_fwd.replay
+            g_fwd = []
+            for _ in range(2 if look else 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    fwd_step()
+                g_fwd.append(g)
+            fturn = [0]
+
+            def fwd_graph():
+                g_fwd[fturn[0] % len(g_fwd)].replay()
+                fturn[0] += 1
+
+            fwd_fn = fwd_graph
         except Exception as e:
             if rank == 0:
                 print(f"[bench] eval hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -641,6 +656,16 @@ def main():
                 res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
             except Exception as e:
                 res["predict_config3"] = {"error": f"{type(e).__name__}: {e}"}
+            try:  # BASELINE config 2 names bf16: the same step with the matrix-bound layers on bf16 matrix cores (fp32
+                # accumulate; parity bar of SURVEY 8c: logits within 3e-2 of the fp32 oracle, tests/test_gpu_net.py)
+                torch.cuda.empty_cache()
+                b16, *_ = train_bench(args, dev, 1, 0, B, N, K, args.steps, args.warmup, precision="bf16")
+                res["bf16"] = {"value": b16["value"], "unit": "points/s", "ms_per_step": b16["ms_per_step"],
+                               "fwd_only": b16["fwd_only"],
+                               "what": "LFA attention GEMMs (ch >= 64, fwd + bwd) on v_mfma_f32_16x16x32_bf16, fp32 "
+                                       "accumulate; storage / kNN / softmax / BatchNorm / other GEMMs fp32"}
+            except Exception as e:
+                res["bf16"] = {"error": f"{type(e).__name__}: {e}"}
             if (N, K) == (12800, 16):
                 try:
                     torch.cuda.empty_cache()

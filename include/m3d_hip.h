@@ -28,6 +28,13 @@ extern "C" {
 #define M3D_ABI_VERSION 3
 int m3d_abi_version(void);
 
+/* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
+ * dst / src / bytes are HOST arrays read at call time (the pointers travel as kernel arguments). */
+int m3d_copy_many(void* const* dst, const void* const* src, const int64_t* bytes, int32_t count, void* stream);
+
+/* *id_out <- id of the hipGraph capture `stream` is part of, 0 when it is not capturing (host pointer). */
+int m3d_stream_capture_id(void* stream, uint64_t* id_out);
+
 /* ---- k nearest neighbours -----------------------------------------------------------------------------
  * torch_cluster.knn as called by knn_graph(pos, K, batch, loop=True)
  * (myria3d/models/modules/pyg_randla_net.py:180), knn_interpolate(k=1) (pyg_randla_net.py:250) and
@@ -122,6 +129,23 @@ int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, const float* w 
                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                          float* running_var, float* w_folded, float* b_folded, float* mean_out, float* invstd_out,
                          int32_t D, void* stream);
+
+/* m3d_lfa_enc_finalize + m3d_lfa_pack_att (bf16 = 0: fp32 fragments of W_att in `packed`, of W_att^T in `packed_t`,
+ * each max(CH,16)^2 floats) or + m3d_lfa_pack_att_bf16 (bf16 != 0: CH^2 bf16 each, CH % 32 == 0) in ONE launch. */
+int m3d_lfa_prepare(const double* mom65, int64_t num_edges, const float* w, const float* b, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                    float* w_folded, float* b_folded, float* mean_out, float* invstd_out, int32_t D,
+                    const float* w_att, int32_t CH, void* packed, void* packed_t, int32_t bf16, void* stream);
+
+/* bf16 matrix-core variant of m3d_lfa_fwd (CH in {32, 64, 128, 256}): the attention GEMM takes bf16 operands
+ * (v_mfma_f32_16x16x32_bf16, fp32 accumulate; BASELINE config 2's "bf16"), everything else stays fp32.
+ * att_w_packed_bf16: m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1) output `packed`. */
+int m3d_lfa_fwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                     const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16, float slope,
+                     float* out, void* stream);
+/* W_att [CH, CH] fp32 -> bf16 operand fragments [CH/16][CH/32][64 lanes][8]:
+ * packed: element i of lane l = W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + i]; packed_t (optional): the same of W^T. */
+int m3d_lfa_pack_att_bf16(const float* w, int32_t CH, void* packed, void* packed_t, void* stream);
 /* fused forward: out[n, CH] = sum_k softmax_k(W_att f_k) * f_k,  f_k = [x[j_k] | LeakyReLU(wf r_k + bf)].
  * CH in {8,16,32,64,128,256}, K <= 32.  att_w_packed: W_att ([CH,CH] row-major, zero-padded to
  * CHP = max(CH,16)) re-laid as [CHP/16][CHP/16][64 lanes][4]:
@@ -139,8 +163,14 @@ size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH);
 int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                 const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
                 const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
-                int32_t accumulate_dw /* != 0: add into dw_att instead of overwriting */, double* G, void* ws,
-                void* stream);
+                int32_t flags /* bit 0: add into dw_att instead of overwriting; bit 1: G is already zero */, double* G,
+                void* ws, void* stream);
+/* bf16 matrix-core variant (CH in {64, 128, 256}): the recomputed attention logits, dF and dW_att GEMMs take bf16
+ * operands (fp32 accumulate); att_w*_packed_bf16 from m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1). */
+int m3d_lfa_bwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                     const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16,
+                     const void* att_wt_packed_bf16, float slope, const float* dout, float* dx, float* dw_att,
+                     int32_t flags, double* G, void* ws, void* stream);
 /* unfused pieces (fallback for K > 32, cross-check of the fused kernels): F[n*K, CH] edge features */
 int m3d_lfa_edge_features(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                           const float* enc_w_folded, const float* enc_b_folded, float slope, float* F, void* stream);
@@ -187,7 +217,8 @@ int m3d_grid_sampling_status(const void* ws, int64_t n, int32_t num_clouds, int3
  * coordinates (identical for x and y); sample s = ix * centers_per_axis + iy (the reference's x-major order); a point
  * belongs to sample s iff |x - xmin - c[ix]| <= radius and |y - ymin - c[iy]| <= radius, evaluated like the reference
  * (float32 shift by the per-cloud minimum, float64 compare).  Two calls: count_only = 1 fills sample_ptr (int64
- * [S + 1], CSR offsets; sample_ptr[S] = total memberships), count_only = 0 writes idx_out (int32 [total], point
+ * [S + 1], CSR offsets; sample_ptr[S] = total memberships, or -1 when some point lies in more than 64 samples —
+ * an overlap beyond what the kernel lists), count_only = 0 writes idx_out (int32 [total], point
  * indices, ascending inside each sample; the reference returns them in tree order — the set is the contract).
  * start / step: first lattice coordinate and lattice pitch (candidate pre-selection only). */
 size_t m3d_tile_select_workspace_bytes(int64_t n, int32_t centers_per_axis);

@@ -18,6 +18,8 @@ _p, _i32, _i64, _f32, _u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_ui
 # name -> (restype, argtypes): must mirror include/m3d_hip.h exactly (tests/test_abi.py checks the symbol list)
 SIGNATURES = {
     "m3d_abi_version": (_i32, []),
+    "m3d_stream_capture_id": (_i32, [_p, _p]),
+    "m3d_copy_many": (_i32, [_p, _p, _p, _i32, _p]),
     "m3d_knn_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_knn_build": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p]),
     "m3d_knn_workspace_offset": (C.c_size_t, [_i64, _i32, _i32]),
@@ -41,9 +43,14 @@ SIGNATURES = {
     "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_lfa_pack_att": (_i32, [_p, _i32, _p, _p, _p]),
+    "m3d_lfa_prepare": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _i32,
+                               _p]),
+    "m3d_lfa_fwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
+    "m3d_lfa_pack_att_bf16": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
     "m3d_lfa_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
+    "m3d_lfa_bwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
     "m3d_lfa_edge_features": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p]),
     "m3d_lfa_edge_softmax_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "m3d_lfa_edge_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),

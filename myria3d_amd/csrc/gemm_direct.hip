@@ -514,16 +514,26 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
   return f;
 }
 
-// every WAVE is one row split (no LDS, no barrier: LDS float atomics run at ~1 lane per 3 clocks on gfx950 and
-// made a cross-wave reduction the dominant cost); its [16*TN, 16*TK] partial goes from the accumulators to ws
+// Every WAVE owns a contiguous row range; the four waves of a workgroup then add their [16*TN, 16*TK] accumulators
+// through LDS (plain stores + one barrier; LDS float atomics run at ~1 lane per 3 clocks on gfx950) and the workgroup
+// stores ONE partial to ws, so the chip can be filled with waves (HBM streaming needs bytes in flight: with 2 048 waves
+// = 2 per SIMD and 8 loads each the level-1 layers sat at 2 TB/s) without multiplying the partial traffic.
+// WGRAD_DEPTH 4-row steps are in flight per trip.
+#ifndef WGRAD_DEPTH
+#define WGRAD_DEPTH 4
+#endif
 template <int TN, int TK>
 __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
+  // big tiles (16 accumulator quads: the deep, few-row layers) keep one partial per WAVE and two steps in flight: their
+  // register budget has no room for four, and their LDS reduction would take 48 KB
+  constexpr bool WGR = TN * TK < 16;
+  constexpr int DEPTH = TN * TK < 8 ? WGRAD_DEPTH : 2;
+  __shared__ float red[WGR ? 3 : 1][WGR ? TN * TK * 256 : 1];  // accumulators of waves 1..3 (wave 0 keeps its own)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * TN, kb = blockIdx.z * 16 * TK;
   const int64_t steps_total = (g.M + 3) >> 2;
-  const int64_t split = (int64_t)blockIdx.x * 4 + wid;
-  if (split >= g.S) return;
+  const int64_t split = (int64_t)blockIdx.x * 4 + wid;           // wave-level row split
   const int64_t s0 = split * g.steps_per_split;
   const int64_t s1 = s0 + g.steps_per_split < steps_total ? s0 + g.steps_per_split : steps_total;
   f32x4 acc[TN][TK];
@@ -533,18 +543,42 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
     for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const rsrc_t rz = mk_rsrc(g.dz), rx0 = mk_rsrc(g.x0), rx1 = mk_rsrc(g.x1);
 
-  // two 4-row steps per trip: 2*(TN+TK) independent loads in flight per lane
-  for (int64_t s = s0; s < s1; s += 2) {
-    const WgradFrag<TN, TK> f0 = wgrad_load<TN, TK>(g, rz, rx0, rx1, s, true, nb, kb, lr, lg, K);
-    const WgradFrag<TN, TK> f1 = wgrad_load<TN, TK>(g, rz, rx0, rx1, s + 1, s + 1 < s1, nb, kb, lr, lg, K);
+  for (int64_t s = s0; s < s1; s += DEPTH) {
+    WgradFrag<TN, TK> f[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) f[d] = wgrad_load<TN, TK>(g, rz, rx0, rx1, s + d, s + d < s1, nb, kb, lr, lg, K);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f[d].a[a], f[d].b[b], acc[a][b]);
+  }
+  int64_t part = split;
+  if constexpr (WGR) {
+    // ---- the workgroup's four accumulators meet in LDS (same lane layout: element (a, b, r) of lane l <-> l)
+    if (wid > 0) {
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wid - 1][((a * TK + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (wid > 0) return;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-      for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f0.a[a], f0.b[b], acc[a][b]);
+      for (int b = 0; b < TK; ++b)
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f1.a[a], f1.b[b], acc[a][b]);
+        for (int r = 0; r < 4; ++r) {
+          const int o = ((a * TK + b) * 4 + r) * 64 + lane;
+          acc[a][b][r] += (red[0][o] + red[1][o]) + red[2][o];
+        }
+    part = blockIdx.x;
+  } else {
+    if (s0 >= steps_total) return;  // (no rows: this wave has no partial slot either)
   }
   // D layout: row n = 16a + 4lg + r, col k = 16b + lr  (16 lanes = 64 contiguous bytes per store)
 #pragma unroll
@@ -556,7 +590,7 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
         const int n = nb + 16 * a + 4 * lg + r, k = kb + 16 * b + lr;
         if (n < g.N && k < K) {
           if (g.S > 1) {
-            g.ws[((size_t)split * g.N + n) * K + k] = acc[a][b][r];
+            g.ws[((size_t)part * g.N + n) * K + k] = acc[a][b][r];
           } else {
             float* cp = g.dw + (int64_t)n * g.lddw + k;
             *cp = g.accumulate ? *cp + acc[a][b][r] : acc[a][b][r];
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, i
   if (e < N * K) p[(int64_t)(e / K) * ld + (e % K)] = 0.f;
 }
 
-struct WgradPlan { int TN, TK; int64_t by, bz, S, spw; };
+struct WgradPlan { int TN, TK; int64_t by, bz, S, spw, wgs; };  // S: partials in ws, spw: 4-row steps per WAVE, wgs: grid.x
 static WgradPlan wgrad_plan(int64_t M, int N, int K) {
   WgradPlan p;
   const int tn = (int)m3d_cdiv(N, 16), tk = (int)m3d_cdiv(K, 16);
@@ -601,13 +635,23 @@ static WgradPlan wgrad_plan(int64_t M, int N, int K) {
   p.TK = tk >= 4 ? 4 : (tk >= 2 ? 2 : 1);
   p.by = m3d_cdiv(N, 16 * p.TN);
   p.bz = m3d_cdiv(K, 16 * p.TK);
-  const int64_t steps_total = m3d_cdiv(M, 4);
-  static const int target = getenv("M3D_WGRAD_WAVES") ? atoi(getenv("M3D_WGRAD_WAVES")) : 2048;
-  int64_t S = m3d_cdiv(target, p.by * p.bz);  // ~2048 waves, each one row split
-  if (S > steps_total / 8) S = steps_total / 8;  // >= 8 steps (32 rows) per wave
-  if (S < 1) S = 1;
-  p.spw = m3d_cdiv(steps_total > 0 ? steps_total : 1, S);
-  p.S = m3d_cdiv(steps_total > 0 ? steps_total : 1, p.spw);
+  const bool wgr = p.TN * p.TK < 16;  // workgroup-level partials (see wgrad2_kernel)
+  const int64_t steps_total = m3d_cdiv(M > 0 ? M : 1, 4);
+  static const int target_env = getenv("M3D_WGRAD_WAVES") ? atoi(getenv("M3D_WGRAD_WAVES")) : 0;
+  const int target = target_env > 0 ? target_env : (wgr ? 8192 : 2048);
+  int64_t waves = m3d_cdiv(target, p.by * p.bz);  // streaming tiles: ~8 waves per SIMD over the chip
+  if (waves > steps_total / 8) waves = steps_total / 8;  // >= 8 steps (32 rows) per wave
+  if (waves < 1) waves = 1;
+  if (wgr) {
+    p.wgs = m3d_cdiv(waves, 4);
+    p.spw = m3d_cdiv(steps_total, p.wgs * 4);
+    p.wgs = m3d_cdiv(steps_total, p.spw * 4);
+    p.S = p.wgs;
+  } else {
+    p.spw = m3d_cdiv(steps_total, waves);
+    p.S = m3d_cdiv(steps_total, p.spw);  // one partial per wave that owns rows
+    p.wgs = m3d_cdiv(p.S, 4);
+  }
   return p;
 }
 
@@ -652,7 +696,7 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
   g.dz = dz; g.lddz = lddz; g.x0 = x0; g.ldx0 = ldx0; g.rows = x0_rows; g.k0 = k0; g.x1 = x1; g.ldx1 = ldx1; g.k1 = k1;
   g.M = M; g.N = N; g.dw = dw; g.lddw = lddw; g.accumulate = accumulate; g.ws = (float*)ws; g.S = (int)p.S;
   g.steps_per_split = p.spw;
-  dim3 grid((unsigned)m3d_cdiv(p.S, 4), (unsigned)p.by, (unsigned)p.bz);
+  dim3 grid((unsigned)p.wgs, (unsigned)p.by, (unsigned)p.bz);
   if (p.TN == 4) launch_wgrad2<4>(g, p.TK, grid, st);
   else if (p.TN == 2) launch_wgrad2<2>(g, p.TK, grid, st);
   else launch_wgrad2<1>(g, p.TK, grid, st);

@@ -35,7 +35,10 @@
 // CH is a template parameter: with a runtime channel count the index arithmetic of the gather / encoder loops
 // (f / D4, f % D4, ...) compiled to integer divisions and made the ch <= 32 kernels VALU-issue-bound
 // (rocprofv3 SQ_INSTS_VALU: 650 VALU instructions per wave of 64 edges at ch = 16).
-template <int CH, int KP>
+// BF: the attention GEMM runs on bf16 matrix cores (operands rounded to bf16 when the fragments are built from the fp32
+// LDS tile / pre-packed as bf16, fp32 accumulate): BASELINE config 2's "bf16" arithmetic (torch autocast semantics);
+// everything else — gathers, encoder, softmax, the pooled sum, all storage — stays fp32.  CH >= 32 only.
+template <int CH, int KP, bool BF = false>
 __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;
@@ -112,38 +115,57 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
-#if LFA_B_PREFETCH
-  // B fragments double-buffered: the loads of k-step group s4+1 are in flight during the MFMAs of group s4
-  float4 bn[NTW];
+  if constexpr (BF) {
+    static_assert(CHP % 32 == 0, "bf16 tiles are 32 deep");
+    constexpr int KS = CHP / 32;
+    const uint4* wpb = (const uint4*)a.wp;  // [NT][KS][64 lanes] x 8 bf16: W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + i]
+    const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg * 8];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
-#endif
-#pragma unroll 1
-  for (int s4 = 0; s4 < S4; ++s4) {
-    float4 b[NTW];
-#if LFA_B_PREFETCH
+    for (int ks = 0; ks < KS; ++ks) {
+      Bf16Frag b[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) b[t] = bn[t];
-    {
-      const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+      for (int t = 0; t < NTW; ++t) b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+      for (int m = 0; m < MTW; ++m) {
+        const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+      }
     }
-#else
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
-#endif
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float av[MTW];
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+  } else {
+    const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+  #if LFA_B_PREFETCH
+    // B fragments double-buffered: the loads of k-step group s4+1 are in flight during the MFMAs of group s4
+    float4 bn[NTW];
+  #pragma unroll
+    for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+  #endif
+  #pragma unroll 1
+    for (int s4 = 0; s4 < S4; ++s4) {
+      float4 b[NTW];
+  #if LFA_B_PREFETCH
+  #pragma unroll
+      for (int t = 0; t < NTW; ++t) b[t] = bn[t];
+      {
+        const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
+  #pragma unroll
+        for (int t = 0; t < NTW; ++t) bn[t] = a.wp[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
+      }
+  #else
+  #pragma unroll
+      for (int t = 0; t < NTW; ++t) b[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
+  #endif
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float av[MTW];
+  #pragma unroll
+        for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+  #pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+  #pragma unroll
+          for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+        }
       }
     }
   }
@@ -186,13 +208,13 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   }
 }
 
-template <int CH>
+template <int CH, bool BF = false>
 static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st) {
   constexpr int ROWS = LfaCfg<(CH < 16 ? 16 : CH)>::ROWS;
   if (a.K <= 16) {
-    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 32>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 32, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
   return M3D_OK;
@@ -219,6 +241,51 @@ extern "C" int m3d_lfa_fwd(const float* x, const float* pos4, const int32_t* idx
     case 128: return launch_lfa_fwd<128>(a, st);
     default: return launch_lfa_fwd<256>(a, st);
   }
+}
+
+extern "C" int m3d_lfa_fwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                                const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16,
+                                float slope, float* out, void* stream) {
+  if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed_bf16 || !out) return M3D_ERR_INVALID;
+  if (K > 32) return M3D_ERR_UNSUPPORTED;
+  if (CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (((uintptr_t)pos4) & 15) || (((uintptr_t)att_w_packed_bf16) & 15)) return M3D_ERR_INVALID;
+  LfaArgs a;
+  a.x = x; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded;
+  a.wp = (const float4*)att_w_packed_bf16; a.out = out; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
+  hipStream_t st = (hipStream_t)stream;
+  switch (CH) {
+    case 32: return launch_lfa_fwd<32, true>(a, st);
+    case 64: return launch_lfa_fwd<64, true>(a, st);
+    case 128: return launch_lfa_fwd<128, true>(a, st);
+    default: return launch_lfa_fwd<256, true>(a, st);
+  }
+}
+
+// W_att [CH,CH] fp32 -> bf16 operand fragments of v_mfma_f32_16x16x32_bf16 (CH a multiple of 32):
+//   packed  [NT][KS][64][8]: element i of lane l = W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + i]     (B of F * W^T)
+//   packed_t, same shape:     element i of lane l = W[32 ks + 8 (l >> 4) + i][16 nt + (l & 15)]     (B of dA * W)
+__global__ __launch_bounds__(256) void lfa_pack_att_bf16_kernel(const float* __restrict__ w, int CH,
+                                                                unsigned short* __restrict__ packed,
+                                                                unsigned short* __restrict__ packed_t) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= CH * CH) return;
+  const int KS = CH / 32;
+  const int i = t & 7, lane = (t >> 3) & 63, ks = (t >> 9) % KS, nt = (t >> 9) / KS;
+  const int r = 16 * nt + (lane & 15), c = 32 * ks + 8 * (lane >> 4) + i;
+  packed[t] = (unsigned short)(pack_bf16(w[r * CH + c], 0.f) & 0xffffu);
+  if (packed_t) packed_t[t] = (unsigned short)(pack_bf16(w[c * CH + r], 0.f) & 0xffffu);
+}
+
+extern "C" int m3d_lfa_pack_att_bf16(const float* w, int32_t CH, void* packed, void* packed_t, void* stream) {
+  if (CH < 32 || !w || !packed) return M3D_ERR_INVALID;
+  if (CH % 32) return M3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(lfa_pack_att_bf16_kernel, dim3((CH * CH + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, CH,
+                     (unsigned short*)packed, (unsigned short*)packed_t);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -372,6 +439,90 @@ extern "C" int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, cons
   hipLaunchKernelGGL(lfa_enc_finalize_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, mom65,
                      (double)num_edges, w, b, gamma, beta, eps, momentum, running_mean, running_var, w_folded,
                      b_folded, mean_out, invstd_out, D);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// Everything one LocalFeatureAggregation needs before its fused kernels, in ONE launch (the training step is a chain
+// of ~400 graph nodes and every tiny node costs 5-9 us of it): the encoder fold of m3d_lfa_enc_finalize (blocks
+// [0, D)) and the attention-weight fragments of m3d_lfa_pack_att — fp32 W / W^T, or with bf16 != 0 the bf16 operand
+// fragments of m3d_lfa_pack_att_bf16 — in the remaining blocks.
+__global__ __launch_bounds__(64) void lfa_prepare_kernel(const double* __restrict__ mom, double E,
+                                                         const float* __restrict__ w, const float* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float momentum, float* running_mean,
+                                                         float* running_var, float* wf, float* bf, float* mean_out,
+                                                         float* invstd_out, int D, const float* __restrict__ w_att, int CH,
+                                                         int CHP, void* packed, void* packed_t, int bf16) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= D) {
+    const int t = ((int)blockIdx.x - D) * 64 + lane;
+    if (bf16) {
+      if (t >= CH * CH) return;
+      const int KS = CH / 32;
+      const int i = t & 7, ln = (t >> 3) & 63, ks = (t >> 9) % KS, nt = (t >> 9) / KS;
+      const int r = 16 * nt + (ln & 15), c = 32 * ks + 8 * (ln >> 4) + i;
+      ((unsigned short*)packed)[t] = (unsigned short)(pack_bf16(w_att[r * CH + c], 0.f) & 0xffffu);
+      if (packed_t) ((unsigned short*)packed_t)[t] = (unsigned short)(pack_bf16(w_att[c * CH + r], 0.f) & 0xffffu);
+    } else {
+      if (t >= CHP * CHP) return;
+      const int S4 = CHP / 16;
+      const int i = t & 3, ln = (t >> 2) & 63, s4 = (t >> 8) % S4, nt = (t >> 8) / S4;
+      const int row = 16 * nt + (ln & 15), col = 4 * (4 * s4 + i) + (ln >> 4);
+      const bool ok = row < CH && col < CH;
+      ((float*)packed)[t] = ok ? w_att[row * CH + col] : 0.f;
+      if (packed_t) ((float*)packed_t)[t] = ok ? w_att[col * CH + row] : 0.f;
+    }
+    return;
+  }
+  const int c = blockIdx.x;
+  double mean, var;
+  if (mom) {
+    double pv = 0.0, pm = 0.0;
+    for (int t = lane; t < 100; t += 64) {
+      const int p = t / 10, q = t % 10;
+      pv += (double)w[c * 10 + p] * (double)w[c * 10 + q] * (mom2(mom, p, q) / E - (mom[p] / E) * (mom[q] / E));
+    }
+    if (lane < 10) pm = (double)w[c * 10 + lane] * (mom[lane] / E);
+    var = wave_sum_d(pv);
+    mean = wave_sum_d(pm) + (double)b[c];
+    if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * invstd;
+  if (lane < 10) wf[c * 10 + lane] = (float)(sc * (double)w[c * 10 + lane]);
+  if (lane != 0) return;
+  if (mom) {
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+    if (running_var) {
+      double unb = E > 1.0 ? var * E / (E - 1.0) : var;
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+  }
+  bf[c] = (float)(sc * ((double)b[c] - mean) + (double)beta[c]);
+  if (mean_out) mean_out[c] = (float)mean;
+  if (invstd_out) invstd_out[c] = (float)invstd;
+}
+
+extern "C" int m3d_lfa_prepare(const double* mom65, int64_t num_edges, const float* w, const float* b,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* w_folded, float* b_folded, float* mean_out,
+                               float* invstd_out, int32_t D, const float* w_att, int32_t CH, void* packed,
+                               void* packed_t, int32_t bf16, void* stream) {
+  if (D < 1 || CH < 1) return M3D_ERR_INVALID;
+  if (!w || !b || !gamma || !beta || !w_folded || !b_folded || !w_att || !packed) return M3D_ERR_INVALID;
+  if (mom65 && num_edges < 1) return M3D_ERR_INVALID;
+  if (!mom65 && (!running_mean || !running_var)) return M3D_ERR_INVALID;
+  const int CHP = CH < 16 ? 16 : CH;
+  if (CHP % 16) return M3D_ERR_UNSUPPORTED;
+  if (bf16 && (CH % 32)) return M3D_ERR_UNSUPPORTED;
+  const int elems = bf16 ? CH * CH : CHP * CHP;
+  hipLaunchKernelGGL(lfa_prepare_kernel, dim3(D + (elems + 63) / 64), dim3(64), 0, (hipStream_t)stream, mom65,
+                     (double)num_edges, w, b, gamma, beta, eps, momentum, running_mean, running_var, w_folded, b_folded,
+                     mean_out, invstd_out, D, w_att, CH, CHP, packed, packed_t, bf16);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

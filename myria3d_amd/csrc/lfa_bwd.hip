@@ -125,7 +125,10 @@ template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = 
 // PIPE (ch <= 64): software-pipelined load schedule — neighbour ids, x_j rows, positions and dout of the NEXT group
 // are loaded into registers while the current group's GEMMs run, and all B fragments of a GEMM are fetched up front.
 // Identical arithmetic either way; the launcher picks per channel count (BWD_PIPE_*, M3D_LFA_BWD_PIPE).
-template <int CH, int KP, bool PIPE>
+// BF (ch >= 64): the three attention GEMMs (recomputed logits, dF, dW_att) take bf16 operands on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation — fragments are rounded when they are built from the fp32 LDS tiles
+// (a.wp / a.wpt then hold the bf16 fragments of m3d_lfa_pack_att_bf16); everything else is unchanged fp32.
+template <int CH, int KP, bool PIPE, bool BF = false>
 __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
@@ -350,7 +353,23 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (PIPE) {
+    if constexpr (BF) {
+      constexpr int KS = CHP / 32;
+      const uint4* wpb = (const uint4*)a.wp;
+      const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg * 8];
+#pragma unroll(KS <= 2 ? KS : 1)
+      for (int ks = 0; ks < KS; ++ks) {
+        Bf16Frag b[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+        }
+      }
+    } else     if constexpr (PIPE) {
       {
         const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
         float4 b[S4][NTW];  // every B fragment of this wave's column tiles: one latency exposure, not one per k-step
@@ -413,8 +432,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
     }
     // B fragments of GEMM-2 (W_att^T): issued now, they arrive during the softmax phase
-    float4 b4[PIPE ? S4 : 1][NTW];
-    if constexpr (PIPE) {
+    float4 b4[(PIPE && !BF) ? S4 : 1][NTW];
+    if constexpr (PIPE && !BF) {
 #pragma unroll
       for (int s4 = 0; s4 < S4; ++s4)
 #pragma unroll
@@ -481,7 +500,29 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 
     if (a.dbg & 8) continue;   // timing experiment: phases 1-3
     // ---- phase 4: dF = dout*s + DA * W_att
-    if constexpr (PIPE) {
+    if constexpr (BF) {
+      constexpr int KS = CHP / 32;
+      const uint4* wptb = (const uint4*)a.wpt;
+      const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg * 8];
+#pragma unroll(KS <= 2 ? KS : 1)
+      for (int ks = 0; ks < KS; ++ks) {
+        Bf16Frag b[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[t].q = wptb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          const bf16x8 av = lds_row_to_bf16(da + m * 16 * STR + ks * 32);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+        }
+        if constexpr (PIPE) {
+          if (ks == 0 && grp + gridDim.x < ngroups) {  // next group's loads (see the fp32 branch below)
+            prefetch(grp + gridDim.x, nbr2[cur ^ 1]);
+            jn = load_idx(grp + 2 * (int64_t)gridDim.x);
+          }
+        }
+      }
+    } else if constexpr (PIPE) {
       {
         // next group's loads go out here: the last in-iteration global load has been consumed before the first MFMA
         // below, so waiting for it (vmcnt is in order) no longer drags these along
@@ -549,7 +590,27 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
     }
     // ---- phase 5: dW_att[c, k] += sum_e DA[e, c] * F[e, k]
-    {
+    if constexpr (BF) {
+      static_assert(!BF || KSPL3 == 1, "bf16 variant: one wave owns whole (c, k) tiles");
+#pragma unroll
+      for (int sr = 0; sr < ROWS / 32; ++sr) {
+        const int eo = (32 * sr + 8 * lg) * STR + lr;
+        constexpr int KB = KTW3 < 4 ? KTW3 : 4;  // F fragments in flight (a [16, 8] bf16 fragment is 4 VGPRs)
+        bf16x8 av[CTW3];
+#pragma unroll
+        for (int c = 0; c < CTW3; ++c) av[c] = lds_col_to_bf16(&DA[eo + (ct0 + c) * 16], STR);
+#pragma unroll
+        for (int k0 = 0; k0 < KTW3; k0 += KB) {
+          bf16x8 bv[KB];
+#pragma unroll
+          for (int k = 0; k < KB; ++k) bv[k] = lds_col_to_bf16(&F[eo + (kt0 + k0 + k) * 16], STR);
+#pragma unroll
+          for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+            for (int k = 0; k < KB; ++k) acc3[c][k0 + k] = mfma_bf16(av[c], bv[k], acc3[c][k0 + k]);
+        }
+      }
+    } else {
 #pragma unroll 2
       for (int s = ks3; s < ROWS / 4; s += KSPL3) {
         const int eo = (4 * s + lg) * STR + lr;
@@ -697,13 +758,22 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
 }
 
 template <int CH>
-static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st) {
+static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
   // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*); M3D_LFA_BWD_PIPE=0/1
   // forces it off / on for every ch <= 64
   static const int pipe_env = getenv("M3D_LFA_BWD_PIPE") ? atoi(getenv("M3D_LFA_BWD_PIPE")) : -1;
   constexpr bool pipe_default = CH == 8 ? BWD_PIPE_8 : (CH == 16 ? BWD_PIPE_16 : (CH == 32 ? BWD_PIPE_32 : BWD_PIPE_64));
   const bool pipe = pipe_env < 0 ? pipe_default : pipe_env != 0;
+  if constexpr (CH >= 64) {
+    if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
+      constexpr bool P = CH == 64;
+      if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+    }
+  }
+  if (bf16) return M3D_ERR_UNSUPPORTED;
   if constexpr (CH <= 64) {
     if (pipe && !a.dbg) {
       if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
@@ -716,16 +786,18 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st)
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
 
-extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
-                           const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
-                           const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
-                           int32_t accumulate_dw, double* G, void* ws, void* stream) {
+static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                        const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed,
+                        const void* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
+                        int32_t flags, double* G, void* ws, void* stream, bool bf16) {
   if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
   if (K > 32) return M3D_ERR_UNSUPPORTED;
   if (CH != 8 && CH != 16 && CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
+  if (bf16 && CH < 64) return M3D_ERR_UNSUPPORTED;
   if (!dw_att || !G || !ws) return M3D_ERR_INVALID;
   if (n > 0 && (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed || !att_wt_packed || !dout || !dx))
     return M3D_ERR_INVALID;
+  const int accumulate_dw = flags & 1, g_is_zero = flags & 2;
   hipStream_t st = (hipStream_t)stream;
   BwdPlan p = bwd_plan(n, K, CH);
   LfaBwdArgs a;
@@ -738,12 +810,12 @@ extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx
   a.dbg = dbg;
   int rc;
   switch (CH) {
-    case 8: rc = launch_lfa_bwd<8>(a, p, st); break;
-    case 16: rc = launch_lfa_bwd<16>(a, p, st); break;
-    case 32: rc = launch_lfa_bwd<32>(a, p, st); break;
-    case 64: rc = launch_lfa_bwd<64>(a, p, st); break;
-    case 128: rc = launch_lfa_bwd<128>(a, p, st); break;
-    default: rc = launch_lfa_bwd<256>(a, p, st); break;
+    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16); break;
+    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16); break;
+    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16); break;
+    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16); break;
+    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16); break;
+    default: rc = launch_lfa_bwd<256>(a, p, st, bf16); break;
   }
   if (rc != M3D_OK) return rc;
   const int total = p.chp * p.chp + p.dp * 16;
@@ -754,9 +826,27 @@ extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx
   if (gy < 1) gy = 1;
   if (!accumulate_dw && hipMemsetAsync(dw_att, 0, sizeof(float) * (size_t)CH * CH, st) != hipSuccess)
     return M3D_ERR_LAUNCH;
-  if (hipMemsetAsync(G, 0, sizeof(double) * 11 * (size_t)(CH / 2), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  if (!g_is_zero && hipMemsetAsync(G, 0, sizeof(double) * 11 * (size_t)(CH / 2), st) != hipSuccess) return M3D_ERR_LAUNCH;
   hipLaunchKernelGGL(lfa_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, a.dw_part, parts, p.chp, CH, dw_att,
                      a.g_part, p.grid * p.kspl4, p.dp, CH / 2, G);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
+}
+
+// flags: bit 0 = add into dw_att (gradient sink) instead of overwriting it, bit 1 = G is already zero (skips a memset)
+extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                           const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                           const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
+                           int32_t flags, double* G, void* ws, void* stream) {
+  return lfa_bwd_impl(x, pos4, idx, n, K, CH, enc_w_folded, enc_b_folded, att_w_packed, att_wt_packed, slope, dout, dx,
+                      dw_att, flags, G, ws, stream, false);
+}
+
+// bf16 matrix-core variant (CH in {64, 128, 256}; att_w*_packed: m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1))
+extern "C" int m3d_lfa_bwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                                const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16,
+                                const void* att_wt_packed_bf16, float slope, const float* dout, float* dx, float* dw_att,
+                                int32_t flags, double* G, void* ws, void* stream) {
+  return lfa_bwd_impl(x, pos4, idx, n, K, CH, enc_w_folded, enc_b_folded, att_w_packed_bf16, att_wt_packed_bf16, slope,
+                      dout, dx, dw_att, flags, G, ws, stream, true);
 }

@@ -161,3 +161,47 @@ extern "C" int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// many small device-to-device copies in ONE launch.  A hipGraph replays its nodes at ~5-10 us apiece when they are
+// tiny (memcpy nodes ~9 us: profiles/r02f_step_timeline.csv), so the ~25 buffer copies that move a prefetched geometry
+// into its persistent slot cost more submission time than the kernels they follow.  dst / src are 16-byte aligned.
+// ------------------------------------------------------------------------------------------
+#define M3D_COPY_MANY_MAX 48
+struct CopyManyArgs {
+  void* dst[M3D_COPY_MANY_MAX];
+  const void* src[M3D_COPY_MANY_MAX];
+  int64_t bytes[M3D_COPY_MANY_MAX];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyManyArgs a) {
+  const int e = blockIdx.y;
+  const int64_t nb = a.bytes[e];
+  const int64_t n16 = nb >> 4;
+  const uint4* s = (const uint4*)a.src[e];
+  uint4* d = (uint4*)a.dst[e];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+  if (blockIdx.x == 0) {
+    const int64_t tail = nb & 15;
+    if ((int64_t)threadIdx.x < tail) ((char*)a.dst[e])[(n16 << 4) + threadIdx.x] = ((const char*)a.src[e])[(n16 << 4) + threadIdx.x];
+  }
+}
+
+extern "C" int m3d_copy_many(void* const* dst, const void* const* src, const int64_t* bytes, int32_t count, void* stream) {
+  if (count < 0 || count > M3D_COPY_MANY_MAX) return M3D_ERR_UNSUPPORTED;
+  if (count == 0) return M3D_OK;
+  if (!dst || !src || !bytes) return M3D_ERR_INVALID;
+  CopyManyArgs a;
+  int64_t mx = 0;
+  for (int i = 0; i < count; ++i) {
+    if (bytes[i] < 0 || (bytes[i] > 0 && (!dst[i] || !src[i]))) return M3D_ERR_INVALID;
+    if ((((uintptr_t)dst[i]) | ((uintptr_t)src[i])) & 15) return M3D_ERR_INVALID;
+    a.dst[i] = dst[i]; a.src[i] = src[i]; a.bytes[i] = bytes[i];
+    if (bytes[i] > mx) mx = bytes[i];
+  }
+  int64_t gx = m3d_cdiv(mx, 256 * 16 * 4);  // ~4 x 16 bytes per thread for the largest buffer
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)gx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}

@@ -516,6 +516,7 @@ struct TileSelArgs {
   int32_t* hist;          // [nc*nc][nwg]: pass 0 writes counts, the host scans it in place, pass 1 reads offsets
   int nwg;
   int32_t* out_idx;
+  int* err;                // device int: set when a point belongs to more than TS_MAX_MEMB samples
 };
 
 // partial xy minima: one float2 per workgroup, combined by tile_sel_min_final
@@ -553,9 +554,12 @@ __device__ __forceinline__ void ts_range(double v, const TileSelArgs& a, int& lo
   hi = hi > a.nc - 1 ? a.nc - 1 : hi;
 }
 
+#define TS_MAX_MEMB 64  // samples one point may belong to (overlapping mosaics: (floor(2r / step) + 1)^2)
+
 template <bool WRITE>
 __global__ __launch_bounds__(64) void tile_select_kernel(TileSelArgs a) {
   __shared__ int cnt[TS_MAX_SAMPLES];
+  __shared__ int memb[TS_MAX_MEMB][64];  // per lane: the samples of its point, ascending
   const int lane = threadIdx.x, wg = blockIdx.x;
   const int S = a.nc * a.nc;
   for (int s = lane; s < S; s += 64) cnt[s] = WRITE ? a.hist[(size_t)s * a.nwg + wg] : 0;
@@ -563,62 +567,66 @@ __global__ __launch_bounds__(64) void tile_select_kernel(TileSelArgs a) {
   const float xmin = a.minxy[0], ymin = a.minxy[1];
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int64_t base = (int64_t)wg * TS_CHUNK;
+  bool overflow = false;
   for (int i0 = 0; i0 < TS_CHUNK; i0 += 64) {
     const int64_t p = base + i0 + lane;
-    const bool live = p < a.n;
-    double xs = 0.0, ys = 0.0;
-    int ilo = 0, ihi = -1, jlo = 0, jhi = -1;
-    if (live) {
+    int nm = 0;
+    if (p < a.n) {
       // the reference's arithmetic: float32 subtraction of the minimum, then float64 distances (cKDTree data is f64)
-      xs = (double)(a.pos[p * a.pstride] - xmin);
-      ys = (double)(a.pos[p * a.pstride + 1] - ymin);
+      const double xs = (double)(a.pos[p * a.pstride] - xmin);
+      const double ys = (double)(a.pos[p * a.pstride + 1] - ymin);
+      int ilo, ihi, jlo, jhi;
       ts_range(xs, a, ilo, ihi);
       ts_range(ys, a, jlo, jhi);
-    }
-    int ni = ihi - ilo + 1, nj = jhi - jlo + 1;
-    ni = ni < 0 ? 0 : ni; nj = nj < 0 ? 0 : nj;
-    int mi = ni, mj = nj;  // wave-uniform loop bounds
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { mi = max(mi, __shfl_xor(mi, o, 64)); mj = max(mj, __shfl_xor(mj, o, 64)); }
-    for (int di = 0; di < mi; ++di) {
-      const int i = ilo + di;
-      const bool okx = live && di < ni && fabs(xs - a.centers[i]) <= a.r;
-      for (int dj = 0; dj < mj; ++dj) {
-        const int j = jlo + dj;
-        const bool member = okx && dj < nj && fabs(ys - a.centers[j]) <= a.r;
-        const int s = member ? i * a.nc + j : -1;  // sample order of get_mosaic_of_centers: x-major
-        unsigned long long todo = __ballot(member);
-        while (todo) {
-          const int leader = __ffsll((long long)todo) - 1;
-          const int s0 = __shfl(s, leader, 64);
-          const unsigned long long mask = __ballot(member && s == s0);
-          const int c0 = cnt[s0];
-          if (WRITE && member && s == s0) a.out_idx[c0 + __popcll(mask & lt)] = (int32_t)p;
-          __syncthreads();  // (one wavefront: orders the LDS read above before the leader's update)
-          if (lane == leader) cnt[s0] = c0 + __popcll(mask);
-          __syncthreads();
-          todo &= ~mask;
+      for (int i = ilo; i <= ihi; ++i) {  // x-major = ascending sample number
+        if (!(fabs(xs - a.centers[i]) <= a.r)) continue;
+        for (int j = jlo; j <= jhi; ++j) {
+          if (!(fabs(ys - a.centers[j]) <= a.r)) continue;
+          if (nm < TS_MAX_MEMB) memb[nm++][lane] = i * a.nc + j;
+          else overflow = true;
         }
       }
+    }
+    // every sample that has members among these 64 points, in ascending sample order; inside a sample the members
+    // are ranked by lane = by point index, so each sample's list stays ascending whatever route a point took to it
+    int k = 0;
+    for (;;) {
+      const int cur = k < nm ? memb[k][lane] : 0x7fffffff;
+      int s0 = cur;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s0 = min(s0, __shfl_xor(s0, o, 64));
+      if (s0 == 0x7fffffff) break;
+      const bool mine = cur == s0;
+      const unsigned long long mask = __ballot(mine);
+      const int c0 = cnt[s0];
+      if (WRITE && mine) a.out_idx[c0 + __popcll(mask & lt)] = (int32_t)p;
+      __syncthreads();  // (one wavefront: orders the LDS read above before the update below)
+      if (lane == 0) cnt[s0] = c0 + __popcll(mask);
+      __syncthreads();
+      k += mine ? 1 : 0;
     }
   }
   if (!WRITE) {
     __syncthreads();
     for (int s = lane; s < S; s += 64) a.hist[(size_t)s * a.nwg + wg] = cnt[s];
+    if (__ballot(overflow) != 0 && lane == 0) atomicExch(a.err, 1);
   }
 }
 
 __global__ __launch_bounds__(256) void tile_sel_ptr_kernel(const int32_t* __restrict__ scanned, int S, int nwg,
-                                                           int64_t* __restrict__ sample_ptr) {
+                                                           int64_t* __restrict__ sample_ptr, const int* __restrict__ err) {
   const int s = blockIdx.x * 256 + threadIdx.x;
-  if (s <= S) sample_ptr[s] = (int64_t)scanned[(size_t)s * nwg];  // s == S: the grand total stored behind the table
+  if (s > S) return;
+  int64_t v = (int64_t)scanned[(size_t)s * nwg];  // s == S: the grand total stored behind the table
+  if (s == S && *err) v = -1;  // a point belongs to more than TS_MAX_MEMB samples: the lists are incomplete
+  sample_ptr[s] = v;
 }
 
 extern "C" size_t m3d_tile_select_workspace_bytes(int64_t n, int32_t centers_per_axis) {
   if (n < 0 || centers_per_axis < 1) return 0;
   const int64_t nwg = m3d_cdiv(n > 0 ? n : 1, TS_CHUNK);
   const int64_t S = (int64_t)centers_per_axis * centers_per_axis;
-  return al256((size_t)(S * nwg + 1) * 4) + al256(2 * 1024 * 4) + 256;
+  return al256((size_t)(S * nwg + 1) * 4) + al256(2 * 1024 * 4) + 512;
 }
 
 // pass 0 (count_only != 0): fills the histogram, scans it, writes sample_ptr[S + 1] (int64) — the caller reads
@@ -643,7 +651,9 @@ extern "C" int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, 
   a.pos = pos; a.pstride = pos_stride; a.n = n; a.centers = centers_dev; a.nc = centers_per_axis; a.r = radius;
   a.start = start; a.step = step; a.xmin = a.ymin = 0.f; a.minxy = part + 2048 - 2; a.hist = hist; a.nwg = (int)nwg;
   a.out_idx = idx_out;
+  a.err = (int*)(part + 2048);
   if (count_only) {
+    if (hipMemsetAsync(a.err, 0, sizeof(int), st) != hipSuccess) return M3D_ERR_LAUNCH;
     int nparts = (int)(n / 4096 + 1);
     if (nparts > 1023) nparts = 1023;
     hipLaunchKernelGGL(tile_sel_min_kernel, dim3(nparts), dim3(256), 0, st, pos, pos_stride, n, part);
@@ -652,7 +662,7 @@ extern "C" int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, 
     // exclusive scan in sample-major order: hist[s][wg] -> first output slot of (sample s, chunk wg); total at the end
     hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, hist, S * nwg, hist + S * nwg);
     hipLaunchKernelGGL(tile_sel_ptr_kernel, dim3((unsigned)m3d_cdiv(S + 1, 256)), dim3(256), 0, st, (const int32_t*)hist,
-                       (int)S, (int)nwg, sample_ptr);
+                       (int)S, (int)nwg, sample_ptr, (const int*)a.err);
   } else {
     hipLaunchKernelGGL((tile_select_kernel<true>), dim3((unsigned)nwg), dim3(64), 0, st, a);
   }

@@ -26,6 +26,73 @@ def _st():
     return torch.cuda.current_stream().cuda_stream
 
 
+def capture_id(stream) -> int:
+    """Id of the hipGraph capture ``stream`` is part of, 0 when it is not capturing."""
+    import ctypes
+
+    out = ctypes.c_uint64(0)
+    call("m3d_stream_capture_id", stream.cuda_stream, ctypes.byref(out))
+    return int(out.value)
+
+
+class ZeroArena:
+    """ONE zero-filled device buffer per training step, cut into the accumulation targets of the backward pass (the dx
+    of every LFA layer, the outputs of the row scatter-adds, the fp64 encoder sums): a replayed hipGraph pays 5-9 us per
+    tiny fill / memset node and the step had ~45 of them.  The size is learned from the previous step (the first step
+    falls back to individual ``torch.zeros``)."""
+
+    def __init__(self):
+        self.buf: Optional[Tensor] = None
+        self.off = 0
+        self.grew = 0
+        self.need = 0
+        self.active = False
+
+    def begin(self, device) -> None:
+        self.need = max(self.need, self.off + self.grew) if self.active else self.need
+        self.off = self.grew = 0
+        self.active = True
+        self.buf = torch.zeros(self.need, dtype=torch.uint8, device=device) if self.need else None
+
+    def stop(self) -> None:
+        self.active = False
+        self.buf = None
+
+    def zeros(self, shape, dtype, device) -> Tensor:
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        span = (nbytes + 255) // 256 * 256
+        if self.active and self.buf is not None and self.buf.device == device and self.off + span <= self.buf.numel():
+            v = self.buf[self.off:self.off + nbytes].view(dtype).view(*shape)
+            self.off += span
+            return v
+        if self.active:
+            self.grew += span
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+
+arena = ZeroArena()
+
+
+def copy_many(dsts, srcs) -> None:
+    """``dst.copy_(src)`` for up to 48 contiguous same-size device buffers in ONE launch (``m3d_copy_many``)."""
+    import ctypes
+
+    n = len(dsts)
+    assert n == len(srcs)
+    for i0 in range(0, n, 48):
+        d, s_ = dsts[i0:i0 + 48], srcs[i0:i0 + 48]
+        m = len(d)
+        for a, b in zip(d, s_):
+            assert a.is_contiguous() and b.is_contiguous() and a.numel() * a.element_size() == b.numel() * b.element_size()
+        dp = (ctypes.c_void_p * m)(*[t.data_ptr() for t in d])
+        sp = (ctypes.c_void_p * m)(*[t.data_ptr() for t in s_])
+        nb = (ctypes.c_int64 * m)(*[t.numel() * t.element_size() for t in d])
+        call("m3d_copy_many", dp, sp, nb, m, _st())
+
+
 def _chk(t: Tensor, dtype=torch.float32):
     assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
     return t
@@ -214,7 +281,7 @@ def gather_i32(src: Tensor, idx: Tensor) -> Tensor:
 
 
 def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int) -> Tensor:
-    out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
+    out = arena.zeros((n_out, src.shape[1]), torch.float32, src.device)
     call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], _st())
     return out
 
@@ -454,13 +521,47 @@ def lfa_enc_fold(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int):
     return wf, bf, mean, invstd
 
 
+def lfa_bf16_ok(ch: int, K: int) -> bool:
+    """The bf16 matrix-core variants exist where the layer is matrix-bound: ch >= 64 (and K <= 32)."""
+    return ch >= 64 and K <= 32
+
+
+def lfa_prepare(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int, w_att: Tensor, bf16: bool, want_t: bool):
+    """``lfa_enc_fold`` + ``pack_attention_weights`` (fp32 fragments, or the bf16 operand fragments) in ONE launch
+    (``m3d_lfa_prepare``).  Returns ``(wf, bf, mean, invstd, wp, wpt)``."""
+    D = enc_lin.weight.shape[0]
+    ch = w_att.shape[0]
+    dev = enc_lin.weight.device
+    if mom is not None and num_edges < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [{num_edges}, {D}]")
+    wf = torch.empty((D, 10), dtype=torch.float32, device=dev)
+    bf, mean, invstd = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
+    if bf16:
+        wp = torch.empty(ch * ch, dtype=torch.int16, device=dev)
+    else:
+        wp = torch.empty(max(ch, 16) ** 2, dtype=torch.float32, device=dev)
+    wpt = torch.empty_like(wp) if want_t else None
+    call("m3d_lfa_prepare", _p(mom), num_edges, _p(enc_lin.weight), _p(enc_lin.bias), _p(enc_bn.weight), _p(enc_bn.bias),
+         float(enc_bn.eps), float(enc_bn.momentum), _p(enc_bn.running_mean), _p(enc_bn.running_var), _p(wf), _p(bf),
+         _p(mean), _p(invstd), D, _p(_chk(w_att)), ch, _p(wp), _p(wpt), int(bf16), _st())
+    if mom is not None and not getattr(enc_bn, "_m3d_flat_counter", False):
+        enc_bn.num_batches_tracked += 1
+    return wf, bf, mean, invstd, wp, wpt
+
+
 def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor,
-                wp: Optional[Tensor] = None) -> Tensor:
+                wp: Optional[Tensor] = None, bf16: bool = False) -> Tensor:
+    """``bf16``: ``wp`` holds the bf16 operand fragments and the attention GEMM runs on bf16 matrix cores."""
     n, K = idx.shape
     ch = w_att.shape[0]
     if K > 32:  # the fused kernels tile one centre's neighbours onto <= 2 MFMA row tiles
         return lfa_forward_unfused(x, pos4, idx, wf, bf, w_att)
     out = torch.empty((n, ch), dtype=torch.float32, device=x.device)
+    if bf16:
+        assert wp is not None and wp.dtype == torch.int16
+        call("m3d_lfa_fwd_bf16", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out),
+             _st())
+        return out
     if wp is None:
         wp, _ = pack_attention_weights(w_att, False)  # named local: stays alive until the launch is enqueued
     call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), _st())
@@ -486,14 +587,20 @@ class LFATrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att,
-                sinks=None):
+                sinks=None, bf16=False):
         # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
         ctx.sinks = sinks
         x = x.contiguous()
-        wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
-        wp, wpt = pack_attention_weights(w_att, True) if idx.shape[1] <= 32 else (None, None)
-        out = lfa_forward(x, pos4, idx, wf, bf, w_att, wp)
+        K = idx.shape[1]
+        bf16 = bool(bf16) and lfa_bf16_ok(w_att.shape[0], K)
+        if K <= 32:  # encoder fold + both weight packings: one launch
+            wf, bf, mean, invstd, wp, wpt = lfa_prepare(enc_lin, enc_bn, mom, num_edges, w_att, bf16, True)
+        else:
+            wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
+            wp = wpt = None
+        out = lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16)
         ctx.packed = (wp, wpt)
+        ctx.bf16 = bf16
         ctx.save_for_backward(x, pos4, idx, mom, wf, bf, mean, invstd, enc_w, enc_b, enc_gamma, w_att)
         ctx.num_edges = num_edges
         return out
@@ -507,15 +614,17 @@ class LFATrainFn(torch.autograd.Function):
         dev = x.device
         sk = ctx.sinks
         dout = dout.contiguous()
-        dx = torch.zeros((n, D), dtype=torch.float32, device=dev)
-        G = torch.empty(11 * D, dtype=torch.float64, device=dev)
+        dx = arena.zeros((n, D), torch.float32, dev)
         if K <= 32 and not LFATrainFn.force_unfused_backward:
+            G = arena.zeros((11 * D,), torch.float64, dev)  # (pre-zeroed: flag bit 1 below skips the memset)
             dw_att = sk[4] if sk else torch.empty((ch, ch), dtype=torch.float32, device=dev)
             ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
             wp, wpt = ctx.packed  # packed in the forward pass (one launch for both orientations)
-            call("m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
-                 _p(dout), _p(dx), _p(dw_att), int(sk is not None), _p(G), _p(ws), _st())
+            call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
+                 _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2, _p(G),
+                 _p(ws), _st())
         else:
+            G = torch.empty(11 * D, dtype=torch.float64, device=dev)
             dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
             if sk:
                 sk[4].add_(dw_att)
@@ -527,8 +636,8 @@ class LFATrainFn(torch.autograd.Function):
         call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
              _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, int(sk is not None), _st())
         if sk:
-            return (dx,) + (None,) * 12
-        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None
+            return (dx,) + (None,) * 13
+        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None
 
 
 def _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G):

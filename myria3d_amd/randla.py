@@ -130,10 +130,20 @@ class HipRandLANet(nn.Module):
         # eval-mode derived tensors (folded BatchNorm scale/shift, folded encoder, packed attention weights) depend on
         # parameters / running statistics only: cached across forwards, dropped whenever those may have changed
         self._eval_cache: Dict = {}
+        # "fp32": the reference's arithmetic.  "bf16": the matrix-bound layers (LFA attention GEMMs at ch >= 64) take bf16
+        # operands on the matrix cores with fp32 accumulation (BASELINE config 2); storage, positions, kNN, softmax and
+        # the statistics stay fp32.  Also switched on by torch.autocast(dtype=bfloat16) around the call (Lightning's
+        # ``trainer.precision: bf16-mixed``), like any autocast-aware module.
+        self.matmul_precision = "fp32"
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
-        self._look: Optional["_Lookahead"] = None  # geometry of the NEXT forward, see prefetch_geometry()
+        # geometry of the NEXT forward (see prefetch_geometry()): two persistent slots used in turn
+        self._look_slots: List[Optional["_GeoSlot"]] = [None, None]
+        self._look_queue: List[int] = []  # slots holding prefetched geometry nobody has consumed yet, oldest first
+        self._look_turn = 1
+        self._fwd_start = None  # event: start of the most recent forward (prefetch_geometry(after="forward_start"))
+        self._bf16 = False
         # a parent module's load_state_dict() reaches this module through _load_from_state_dict only
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._eval_cache.clear())
 
@@ -301,16 +311,22 @@ class HipRandLANet(nn.Module):
              train: bool) -> Tensor:
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
+        bf16 = self._bf16 and ops.lfa_bf16_ok(w_att.shape[0], idx.shape[1])
         if train:
             sk = self._sinks(enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, w_att) if self._use_sinks \
                 else None
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk)
+                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16)
         else:
-            wf, bf, wp = self._cached(("lfa", id(p)), lambda: ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)[:2] + (
-                ops.pack_attention_weights(w_att, False)[0] if idx.shape[1] <= 32 else None,),
-                (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
-            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp)
+            if idx.shape[1] <= 32:
+                wf, bf, wp = self._cached(("lfa", id(p), bf16),
+                                          lambda: (lambda r: (r[0], r[1], r[4]))(
+                                              ops.lfa_prepare(enc_lin, enc_bn, None, 0, w_att, bf16, False)),
+                                          (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
+            else:
+                wf, bf, wp = self._cached(("lfa", id(p), False), lambda: ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)[:2]
+                                          + (None,), (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
+            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16)
         return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
@@ -419,17 +435,27 @@ class HipRandLANet(nn.Module):
         return g
 
     # ------------------------------------------------------------------------------------------
-    # geometry lookahead (opt-in, EXPERIMENTAL: not yet run on hardware).  The position-only work of a forward pass
-    # depends on nothing the previous step produces, so it can be enqueued one step ahead:
-    #     net.prefetch_geometry(pos_next, ptr_next, plan)      # side stream, returns at once
-    #     ... the current step's backward / optimizer run meanwhile ...
-    #     net(x_next, pos_next, None, ptr_next, plan=plan)     # finds its tables ready: nothing to wait for
-    # hipGraph-friendly: results live in PERSISTENT buffers (``Y``: written by the side stream; ``X``: read by the
-    # network), refreshed by one device copy Y -> X at the head of the consuming forward, so a captured step always
-    # reads and writes the same addresses and the tables computed by replay r are consumed by replay r + 1.
+    # geometry lookahead.  The position-only work of a forward pass (kNN grids and tables, encoder moments, random
+    # decimation, decoder 1-NN tables: ~0.9 ms of kernels at BASELINE config 2, ~0.25 ms of them in front of the
+    # first feature kernel that needs a table) depends on nothing the previous step produces — in training the next
+    # batch's positions are in the dataloader's prefetch queue — so it can be enqueued one step ahead:
+    #     net.prefetch_geometry(pos_next, ptr_next)            # side stream, returns at once
+    #     out = net(x, pos, None, ptr)                         # consumes the tables prefetched for THIS batch earlier
+    #     loss(out).backward(); optimizer.step()               # ... all of it runs beside the side stream's kernels
+    # Results live in two persistent buffer sets ("slots") used in turn: the slot written during step i is read by step
+    # i + 1 (forward AND backward) and rewritten during step i + 2.  hipGraph: capture two steps (one per slot) and
+    # replay them in turn; every captured step ends with join_geometry().
     # ------------------------------------------------------------------------------------------
     def prefetch_geometry(self, pos: Tensor, ptr: Tensor, plan: Optional[LevelPlan] = None,
-                          train: Optional[bool] = None) -> None:
+                          train: Optional[bool] = None, after: str = "now") -> None:
+        """Enqueue the position-only work for a batch the network will see later (at most two may be outstanding:
+        the one the next ``forward`` consumes and the one after it).
+
+        ``after="now"``: ordered behind everything enqueued on the current stream so far (always safe).
+        ``after="forward_start"``: ordered behind the START of the most recent forward only — for callers whose ``pos``
+        was resident before that forward began (a dataloader prefetch queue, the benchmark's static batch).  Call it
+        right after ``net(...)``: the feature kernels of the step are then enqueued (and, in a captured hipGraph,
+        submitted) first, and the position-only kernels run beside them and beside the backward pass."""
         if not pos.is_cuda:
             raise RuntimeError("HipRandLANet runs on an MI355X (cuda/HIP device) only; there is no CPU fallback")
         pos = pos.to(torch.float32).contiguous()
@@ -437,60 +463,64 @@ class HipRandLANet(nn.Module):
         if plan is None:
             plan = self.plan_for(ptr)
         train = self.training if train is None else train
-        look = self._look
         key = (tuple(pos.shape), id(plan), bool(train))
-        if look is None or look.key != key:
-            look = self._look = _Lookahead(key)
+        turn = self._look_turn = self._look_turn ^ 1
+        slot = self._look_slots[turn]
         side = self._side_stream(pos.device)
-        first = look.x_free is None
-        if not first:
-            # the only dependency: the Y -> X copy of the consuming forward (Y may be overwritten after it).  Called
-            # right after that forward has been enqueued, the tables are built beside its kernels and its backward
-            side.wait_event(look.x_free)
+        main = torch.cuda.current_stream()
+        # what comes first: the producer of ``pos`` and the step that last read the slot rewritten here (two prefetches
+        # ago: complete before the most recent forward began)
+        if after == "forward_start" and self._fwd_start is not None:
+            side.wait_event(self._fwd_start)
+        else:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
-        geo = self._geometry(pos, plan, None, train, wait_main=first)
+        geo = self._geometry(pos, plan, None, train, wait_main=False)
         with torch.cuda.stream(side):
             fresh = geo.tensors()
-            if look.y is None:
-                look.y = [t.clone() for t in fresh]
+            if slot is None or slot.key != key:
+                slot = self._look_slots[turn] = _GeoSlot(key, [t.clone() for t in fresh], geo, main)
             else:
-                for dst, src in zip(look.y, fresh):
-                    dst.copy_(src)
-            look.ready = torch.cuda.Event()
-            look.ready.record(side)
-            look.ready_captured = torch.cuda.is_current_stream_capturing()
-        look.template = geo if look.template is None else look.template
-        look.pos_ptr = pos.data_ptr()
-        look.pending = True
+                ops.copy_many(slot.bufs, fresh)  # one launch (a replayed graph pays ~9 us per memcpy node)
+            slot.ready = torch.cuda.Event()
+            slot.ready.record(side)
+            slot.ready_capture = ops.capture_id(side)
+        slot.pos_ptr = pos.data_ptr()
+        if turn in self._look_queue:
+            self._look_queue.remove(turn)  # a prefetch nobody consumed: its slot has just been rewritten
+        self._look_queue.append(turn)
 
     def join_geometry(self) -> None:
-        """Make the current stream wait for an outstanding ``prefetch_geometry`` (end of a captured step: every stream
-        of a hipGraph capture must be joined before the capture ends)."""
-        if self._look is not None and self._look.ready is not None:
-            torch.cuda.current_stream().wait_event(self._look.ready)
+        """Make the current stream wait for every outstanding ``prefetch_geometry`` (end of a captured step: all
+        streams of a hipGraph capture must be joined before the capture ends)."""
+        main = torch.cuda.current_stream()
+        cap = ops.capture_id(main)
+        for turn in self._look_queue:
+            slot = self._look_slots[turn]
+            if slot.ready_capture == cap:
+                main.wait_event(slot.ready)
+            elif cap == 0:  # recorded inside a finished capture: not a waitable event in eager mode
+                main.wait_stream(self._side_stream(main.device))
 
     def _consume_lookahead(self, pos: Tensor, plan: LevelPlan, train: bool) -> Optional["_Geometry"]:
-        look = self._look
-        if look is None or not look.pending or look.key != (tuple(pos.shape), id(plan), bool(train)) \
-                or look.pos_ptr != pos.data_ptr():
-            return None
-        main = torch.cuda.current_stream()
-        if torch.cuda.is_current_stream_capturing() and not look.ready_captured:
-            look.ready.synchronize()  # recorded before the capture began: settle it on the host, nothing to capture
-        else:
-            main.wait_event(look.ready)
-        if look.x is None:  # persistent copies the network reads + a _Geometry that points at them
-            look.x = [t.clone() for t in look.y]
-            look.geo_x = look.template.rebound(look.x, main)
-        else:
-            for dst, src in zip(look.x, look.y):
-                dst.copy_(src)
-        look.x_free = torch.cuda.Event()
-        look.x_free.record(main)
-        look.pending = False
-        return look.geo_x
+        want = (tuple(pos.shape), id(plan), bool(train))
+        while self._look_queue:
+            turn = self._look_queue.pop(0)  # oldest first
+            slot = self._look_slots[turn]
+            if slot.key != want or slot.pos_ptr != pos.data_ptr():
+                continue  # prefetched for another batch / mode: dropped (falls back to the in-place path if none fits)
+            main = torch.cuda.current_stream()
+            cap = ops.capture_id(main)
+            if slot.ready_capture == cap:
+                main.wait_event(slot.ready)  # same capture (becomes a graph edge) or plain eager execution
+            elif cap == 0:
+                main.wait_stream(self._side_stream(pos.device))  # written by a replayed graph: order behind the side stream
+            # else: capturing, and the tables were written before this graph starts (eager warm-up, or the previously
+            # replayed graph, whose side branch joined at its end): graphs replay in stream order, nothing to wait for
+            return slot.geo
+        return None
 
     def _side_stream(self, device) -> "torch.cuda.Stream":
         st = self._streams.get(device)
@@ -507,6 +537,14 @@ class HipRandLANet(nn.Module):
         if plan is None:
             plan = self.plan_for(ptr)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
+        if self.matmul_precision not in ("fp32", "bf16"):
+            raise ValueError(f"matmul_precision must be 'fp32' or 'bf16', got {self.matmul_precision!r}")
+        self._bf16 = self.matmul_precision == "bf16" or (
+            torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+        if train and torch.is_grad_enabled():
+            ops.arena.begin(pos.device)  # one zero fill for every accumulation target of the coming backward pass
+        else:
+            ops.arena.stop()
         if train:
             self._eval_cache.clear()  # this pass updates the running statistics (and an optimizer step follows)
         if train and self._flat is not None:
@@ -514,7 +552,10 @@ class HipRandLANet(nn.Module):
         # weight gradients on a side stream: only with gradient sinks and an optimizer that joins the stream
         ops._grad_side = self.grad_side if self._use_sinks else None
         blocks = (self.block1, self.block2, self.block3, self.block4)
-        geo = self._consume_lookahead(pos, plan, train) if (self._look is not None and decimation_idx is None) else None
+        if self._look_slots[0] is not None or self._look_queue:  # lookahead in use: mark where this forward starts
+            self._fwd_start = torch.cuda.Event()
+            self._fwd_start.record(torch.cuda.current_stream())
+        geo = self._consume_lookahead(pos, plan, train) if decimation_idx is None else None
         if geo is None:
             if decimation_idx is None:
                 self._seed_decimation()
@@ -620,19 +661,15 @@ class _Geometry:
         return g
 
 
-class _Lookahead:
-    """State of ``HipRandLANet.prefetch_geometry``: persistent Y (side stream writes) and X (network reads) buffers."""
+class _GeoSlot:
+    """One persistent buffer set of ``HipRandLANet.prefetch_geometry`` plus a ``_Geometry`` that points at it."""
 
-    def __init__(self, key):
+    def __init__(self, key, bufs: List[Tensor], template: _Geometry, main):
         self.key = key
-        self.y: Optional[List[Tensor]] = None
-        self.x: Optional[List[Tensor]] = None
-        self.template: Optional[_Geometry] = None
-        self.geo_x: Optional[_Geometry] = None
-        self.ready = None     # event: Y holds the prefetched geometry
-        self.ready_captured = False
-        self.x_free = None    # event: the last Y -> X copy has been enqueued (Y may be overwritten after it)
-        self.pending = False
+        self.bufs = bufs
+        self.geo = template.rebound(bufs, main)
+        self.ready = None   # event (side stream): the slot holds the prefetched geometry
+        self.ready_capture = 0  # id of the hipGraph capture the event was recorded in (0: eager)
         self.pos_ptr = 0
 
 

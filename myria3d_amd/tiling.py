@@ -61,6 +61,8 @@ def tile_select(pos: Tensor, tile_width: Number, subtile_width: Number,
     args = (pos.data_ptr(), pos.stride(0), n, cdev.data_ptr(), nc, radius, float(xy_range[0]), step, ws.data_ptr())
     call("m3d_tile_select", *args, 1, sample_ptr.data_ptr(), None, st)
     total = int(sample_ptr[-1].item())  # one host read per cloud: sizes the index list
+    if total < 0:
+        raise NotImplementedError("subtile_overlap too large: a point belongs to more than 64 samples")
     idx = torch.empty(total, dtype=torch.int32, device=dev)
     if total:
         call("m3d_tile_select", *args, 0, sample_ptr.data_ptr(), idx.data_ptr(), st)

@@ -434,6 +434,55 @@ def test_lfa_backward_persistent_loop_without_pipelining(ch, k, n):
     assert res.returncode == 0 and "1 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
 
 
+@pytest.mark.parametrize("ch,k,n", [(64, 16, 3000), (128, 16, 2500), (256, 16, 1500), (64, 32, 1500), (256, 32, 900),
+                                    (64, 16, 17000)])
+def test_lfa_bf16_matrix_core_variant(device, ch, k, n):
+    """BASELINE config 2's "bf16": the attention GEMMs of the LFA kernels on bf16 matrix cores (fp32 accumulate, fp32
+    everything else) vs the fp64 oracle.  Tolerances follow from bf16's 8-bit mantissa (relative 2^-9 per operand):
+    forward 2e-2 absolute on O(1) outputs, gradients 3e-2 relative L2."""
+    from myria3d_amd import ops
+    from oracle.randla_oracle import LocalFeatureAggregation, dense_to_edge_index, knn_kdtree
+
+    third = n // 3
+    sizes = [third, third + 5, n - 2 * third - 5]
+    x, pos, _, ptr = rand_batch(sizes, num_features=ch // 2, seed=ch + k)
+    x = x * 2 - 1
+    lfa = LocalFeatureAggregation(ch)
+    fill_params_deterministic(lfa, ch)
+    idx, _ = knn_kdtree(pos, ptr.tolist(), pos, ptr.tolist(), k)
+    ei = dense_to_edge_index(idx)
+    ref_m = lfa.double().train()
+    xr = x.double().requires_grad_(True)
+    ref = ref_m.aggregate(ei, xr, pos.double())
+    gy = torch.from_numpy(np.random.RandomState(ch).uniform(-1, 1, tuple(ref.shape)))
+    ref.backward(gy)
+    g = LocalFeatureAggregation(ch)
+    fill_params_deterministic(g, ch)
+    g = g.to(device).train()
+    enc_lin, enc_bn = g.mlp_encoder.lins[0], g.mlp_encoder.norms[0].module
+    w_att = g.mlp_attention.lins[0].weight
+    pos4 = ops.pad_pos(pos.to(device))
+    idx32 = idx.to(torch.int32).to(device)
+    num_edges = sum(m * min(k, m) for m in sizes)
+    mom = ops.lfa_moments(pos4, idx32)
+    xg = x.to(device).requires_grad_(True)
+    out = ops.LFATrainFn.apply(xg, pos4, idx32, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias,
+                               enc_lin, enc_bn, w_att, None, True)
+    out.backward(gy.float().to(device))
+    _close(f"lfa_bf16.out(ch={ch})", out, ref, 0.0, 2e-2)
+    _relclose("lfa_bf16.out", out, ref, 1e-2)
+    _relclose("lfa_bf16.dx", xg.grad, xr.grad, 3e-2)
+    _relclose("lfa_bf16.dW_att", w_att.grad, ref_m.mlp_attention.lins[0].weight.grad, 3e-2)
+    _relclose("lfa_bf16.dW_enc", enc_lin.weight.grad, ref_m.mlp_encoder.lins[0].weight.grad, 3e-2)
+    _relclose("lfa_bf16.dgamma_enc", enc_bn.weight.grad, ref_m.mlp_encoder.norms[0].module.weight.grad, 3e-2)
+    # and it IS a different arithmetic from the fp32 kernels (the bf16 path really ran)
+    xg2 = x.to(device).requires_grad_(True)
+    out32 = ops.LFATrainFn.apply(xg2, pos4, idx32, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
+                                 enc_bn.bias, enc_lin, enc_bn, w_att, None, False)
+    assert not torch.equal(out32, out)
+    assert (out32 - out).abs().max().item() < 5e-2
+
+
 # ----------------------------------------------------------------------------------------------- interpolation
 @pytest.mark.parametrize("k", [10, 3, 1])
 def test_knn_interpolate_dropin(device, k):

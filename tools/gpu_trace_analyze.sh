@@ -4,8 +4,10 @@ set -u
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 TAG=${1:-t}
+EXTRA=${2:-}
+export OUT TAG
 rm -rf /tmp/prof && mkdir -p /tmp/prof
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --skip-roofline --skip-extras ) > $OUT/trace_$TAG.log 2>&1
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --skip-cpu-baseline --skip-roofline --skip-extras $EXTRA ) > $OUT/trace_$TAG.log 2>&1
 f=$(find /tmp/prof -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
@@ -18,6 +20,11 @@ if len(adam) >= 4:
     a, b = adam[-3], adam[-2]   # one full train step between two Adam launches (timed region)
     seg = ev[a + 1:b + 1]
     t0, t1 = seg[0][0], seg[-1][1]
+    import os
+    with open(os.path.join(os.environ.get("OUT", "."), "step_timeline_" + os.environ.get("TAG", "t") + ".csv"), "w") as fh:
+        fh.write("start_us,dur_us,queue,kernel\n")
+        for s_, e_, n_, q_ in seg:
+            fh.write(f"{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f},{q_},{n_.split('(')[0][:70]}\n")
     wall = (t1 - t0) / 1e3
     # union of intervals
     busy = 0; cur_s, cur_e = seg[0][0], seg[0][1]
