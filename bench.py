@@ -47,9 +47,11 @@ def parse():
     ap.add_argument("--points", type=int, default=12800, help="points per tile")
     ap.add_argument("--neighbors", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--lookahead", action="store_true",
-                    help="EXPERIMENTAL: build the position-only tables of step i+1 beside step i "
-                         "(HipRandLANet.prefetch_geometry); off by default")
+    ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
+                    help="build the position-only tables (kNN, decimation) of a step inside that step instead of one "
+                         "step ahead (HipRandLANet.prefetch_geometry; bit-identical results either way)")
+    ap.add_argument("--lookahead", dest="lookahead", action="store_true", help="(default)")
+    ap.set_defaults(lookahead=True)
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
@@ -105,9 +107,11 @@ def _time_launch(launch, reps=20):
 def _pmc_traffic(*kernel_prefixes):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*pmc_fetch_size.csv and
     *pmc_write_size.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_target.py, per-kernel means in
-    KB).  FETCH_SIZE is reported raw: MI355X_MICROARCH.md calibrates a x2 correction for wide streaming reads only;
-    these kernels mostly gather.  ``kernel_prefixes``: the kernel's name in the newest pass first, older names after
-    (kernels were renamed when variants were added).  Returns None when no pass in the tree lists the kernel."""
+    KB; since round 2 one row per kernel name AND launch grid, so a level-1 launch is not averaged with the other
+    levels').  FETCH_SIZE is doubled: MI355X_MICROARCH.md calibrates it at exactly half the bytes of 16-byte-per-lane
+    reads on gfx950, which is what these kernels issue (row gathers and float4 streams); WRITE_SIZE is taken as is.
+    ``kernel_prefixes``: the kernel's name in the newest pass first, older names after (kernels were renamed when
+    variants were added).  Returns None when no pass in the tree lists the kernel."""
     import csv
     import glob
 
@@ -116,14 +120,15 @@ def _pmc_traffic(*kernel_prefixes):
 
     def lookup(files, col):
         for f in files:                      # newest pass first
+            rows = list(csv.DictReader(open(f)))
             for prefix in kernel_prefixes:
-                for row in csv.DictReader(open(f)):
-                    if row["kernel"].startswith(prefix):
-                        return float(row[col]) * 1024.0
+                vals = [float(row[col]) for row in rows if row["kernel"].startswith(prefix)]
+                if vals:
+                    return max(vals) * 1024.0  # several launch geometries of one kernel: the roofline entry is the largest
         return None
 
     r, w = lookup(fetch, "FETCH_SIZE"), lookup(write, "WRITE_SIZE")
-    return None if r is None or w is None else int(r + w)
+    return None if r is None or w is None else int(2 * r + w)
 
 
 def stage_rooflines(net, pos, plan):
@@ -193,10 +198,11 @@ def stage_rooflines(net, pos, plan):
         b_knn = n1 * (12 + 4 * K)
         b_lfa = n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1)
         out["knn_lse"] = [
-            {"kernel": f"knn_query_kernel<16> (level 1, n={n1}, K={K})", "bound": "hbm",
+            {"kernel": f"knn_query_queue_kernel<16> (level 1, n={n1}, K={K})", "bound": "hbm",
              "achieved": round(b_knn / (ms_knn * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(b_knn / (ms_knn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_knn,
-             "traffic": _pmc_traffic("void knn_query_kernel<16, KeyF64>", "void knn_query_kernel<16>"),
+             "traffic": _pmc_traffic("void knn_query_queue_kernel<16, KeyF64", "void knn_query_kernel<16, KeyF64>",
+                                     "void knn_query_kernel<16>"),
              "avg_launch_ms": round(ms_knn, 4)},
             {"kernel": f"lfa_fwd_kernel<16,16> (block1.lfa2, ch={ch1}, n={n1}, K={K})", "bound": "hbm",
              "achieved": round(b_lfa / (ms_lfa * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -464,10 +470,10 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
 
     def fwd_bwd():
         net.train()
+        if look:  # the NEXT step's kNN tables / decimation, enqueued stage by stage BETWEEN the blocks of this forward:
+            # the two chains share the head of the step (and of the captured graph's submission order)
+            net.prefetch_geometry(pos, ptr, plan, train=True, interleave=True)
         out = net(x, pos, None, ptr, plan=plan)  # (lookahead: consumes the tables the previous step prefetched)
-        if look:  # the NEXT step's kNN tables / decimation: enqueued (and, in the graph, submitted) behind the forward's
-            # kernels, dependent on the forward's START only, so they run beside the forward tail and the backward pass
-            net.prefetch_geometry(pos, ptr, plan, train=True, after="forward_start")
         loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
         loss.backward()
         if net.grad_side is not None:
@@ -482,9 +488,10 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     def fwd_step():
         net.eval()
         with torch.no_grad():
+            if look:
+                net.prefetch_geometry(pos, ptr, plan, train=False, interleave=True)
             net(x, pos, None, ptr, plan=plan)
             if look:
-                net.prefetch_geometry(pos, ptr, plan, train=False, after="forward_start")
                 net.join_geometry()
 
     launch = "eager"

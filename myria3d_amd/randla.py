@@ -142,6 +142,8 @@ class HipRandLANet(nn.Module):
         self._look_slots: List[Optional["_GeoSlot"]] = [None, None]
         self._look_queue: List[int] = []  # slots holding prefetched geometry nobody has consumed yet, oldest first
         self._look_turn = 1
+        self.interleave_paced = bool(int(__import__("os").environ.get("M3D_INTERLEAVE_PACED", "0")))
+        self._look_job = None  # an interleaved prefetch in progress: (stage generator, geometry, slot, key, pos, stream)
         self._fwd_start = None  # event: start of the most recent forward (prefetch_geometry(after="forward_start"))
         self._bf16 = False
         # a parent module's load_state_dict() reaches this module through _load_from_state_dict only
@@ -400,17 +402,31 @@ class HipRandLANet(nn.Module):
         g = _Geometry(main, side)
         if side is not main and wait_main:
             side.wait_stream(main)
+        for _ in self._geometry_stages(g, pos, plan, decimation_idx, train):
+            pass
+        return g
+
+    def _geometry_stages(self, g: "_Geometry", pos: Tensor, plan: LevelPlan, decimation_idx, train: bool):
+        """The position-only work as a generator: each ``next()`` enqueues one stage on ``g.side`` (10 stages: grid of
+        level 1; then per level its kNN table + encoder moments, and its decimation + the next level's grid; last the
+        decoder's four 1-NN tables).  ``_geometry`` runs them back to back; an interleaved prefetch lets the forward pass
+        enqueue one stage between its own blocks (see ``prefetch_geometry(interleave=True)``)."""
         K = self.num_neighbors
+        side = g.side
         with torch.cuda.stream(side):
             g.index.append(ops.KnnIndex(ops.pad_pos(pos), plan.ptrs[0]))
             g.pos4.append(g.index[0].sorted_pos4)
             g.mark()                                                            # stage 0
-            for lvl in range(4):
+        yield
+        for lvl in range(4):
+            with torch.cuda.stream(side):
                 ix = g.index[lvl]
                 idx, _ = ix.query(K, qry=ix, sorted_io=True)
                 g.knn.append(idx)
                 g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
                 g.mark()                                                        # stage 1 + 2*lvl
+            yield
+            with torch.cuda.stream(side):
                 # decimate(): pyg_randla_net.py:234-238.  d_int: sorted slots of this level that survive, listed in
                 # the reference order of the next level; d_ref: the same as reference rows of this level
                 if decimation_idx is not None:
@@ -429,10 +445,12 @@ class HipRandLANet(nn.Module):
                 g.index.append(nxt)
                 g.pos4.append(nxt.sorted_pos4)
                 g.mark()                                                        # stage 2 + 2*lvl
+            yield
+        with torch.cuda.stream(side):
             for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
                 g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True)[0])
             g.mark()                                                            # stage 9
-        return g
+        yield
 
     # ------------------------------------------------------------------------------------------
     # geometry lookahead.  The position-only work of a forward pass (kNN grids and tables, encoder moments, random
@@ -447,17 +465,22 @@ class HipRandLANet(nn.Module):
     # replay them in turn; every captured step ends with join_geometry().
     # ------------------------------------------------------------------------------------------
     def prefetch_geometry(self, pos: Tensor, ptr: Tensor, plan: Optional[LevelPlan] = None,
-                          train: Optional[bool] = None, after: str = "now") -> None:
+                          train: Optional[bool] = None, after: str = "now", interleave: bool = False) -> None:
         """Enqueue the position-only work for a batch the network will see later (at most two may be outstanding:
         the one the next ``forward`` consumes and the one after it).
 
         ``after="now"``: ordered behind everything enqueued on the current stream so far (always safe).
         ``after="forward_start"``: ordered behind the START of the most recent forward only — for callers whose ``pos``
-        was resident before that forward began (a dataloader prefetch queue, the benchmark's static batch).  Call it
-        right after ``net(...)``: the feature kernels of the step are then enqueued (and, in a captured hipGraph,
-        submitted) first, and the position-only kernels run beside them and beside the backward pass."""
+        was resident before that forward began (a dataloader prefetch queue, the benchmark's static batch).
+        ``interleave=True``: only the first stage is enqueued now; the NEXT ``forward`` call (which consumes an older
+        prefetch, or works in place) enqueues the remaining stages one by one between its own blocks.  A captured
+        hipGraph submits its nodes in capture order at several microseconds apiece: a hundred position-only nodes in
+        front of the feature kernels keep the chip nearly idle for the first millisecond of every replay, behind
+        them they start when the forward pass is over and fight the backward pass for the machine; interleaved, both
+        chains progress from the first microsecond."""
         if not pos.is_cuda:
             raise RuntimeError("HipRandLANet runs on an MI355X (cuda/HIP device) only; there is no CPU fallback")
+        self._finish_interleaved()  # (a request nobody advanced: complete it before its slot partner is rewritten)
         pos = pos.to(torch.float32).contiguous()
         ptr = ptr.to(torch.int64).contiguous()
         if plan is None:
@@ -465,7 +488,6 @@ class HipRandLANet(nn.Module):
         train = self.training if train is None else train
         key = (tuple(pos.shape), id(plan), bool(train))
         turn = self._look_turn = self._look_turn ^ 1
-        slot = self._look_slots[turn]
         side = self._side_stream(pos.device)
         main = torch.cuda.current_stream()
         # what comes first: the producer of ``pos`` and the step that last read the slot rewritten here (two prefetches
@@ -477,17 +499,46 @@ class HipRandLANet(nn.Module):
         with torch.cuda.stream(side):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
-        geo = self._geometry(pos, plan, None, train, wait_main=False)
-        with torch.cuda.stream(side):
+        geo = _Geometry(main, side)
+        stages = self._geometry_stages(geo, pos, plan, None, train)
+        self._look_job = (stages, geo, turn, key, pos.data_ptr(), main)
+        if interleave:
+            next(stages)
+        else:
+            self._finish_interleaved()
+
+    def _advance_interleaved(self) -> None:
+        """One more stage of the interleaved prefetch (called by the forward pass between its blocks)."""
+        if self._look_job is not None:
+            if self.interleave_paced:
+                # pace the side stream by the forward pass: stage k starts no earlier than the feature block in front of
+                # it.  A dependency the data does not need — it makes a hipGraph executor, which submits a branch until
+                # it meets a node whose predecessor is not submitted yet, alternate between the two chains
+                self._look_job[1].side.wait_stream(torch.cuda.current_stream())
+            try:
+                next(self._look_job[0])
+            except StopIteration:
+                self._finish_interleaved()
+
+    def _finish_interleaved(self) -> None:
+        job = self._look_job
+        if job is None:
+            return
+        self._look_job = None
+        stages, geo, turn, key, pos_ptr, main = job
+        for _ in stages:
+            pass
+        slot = self._look_slots[turn]
+        with torch.cuda.stream(geo.side):
             fresh = geo.tensors()
             if slot is None or slot.key != key:
                 slot = self._look_slots[turn] = _GeoSlot(key, [t.clone() for t in fresh], geo, main)
             else:
                 ops.copy_many(slot.bufs, fresh)  # one launch (a replayed graph pays ~9 us per memcpy node)
             slot.ready = torch.cuda.Event()
-            slot.ready.record(side)
-            slot.ready_capture = ops.capture_id(side)
-        slot.pos_ptr = pos.data_ptr()
+            slot.ready.record(geo.side)
+            slot.ready_capture = ops.capture_id(geo.side)
+        slot.pos_ptr = pos_ptr
         if turn in self._look_queue:
             self._look_queue.remove(turn)  # a prefetch nobody consumed: its slot has just been rewritten
         self._look_queue.append(turn)
@@ -495,6 +546,7 @@ class HipRandLANet(nn.Module):
     def join_geometry(self) -> None:
         """Make the current stream wait for every outstanding ``prefetch_geometry`` (end of a captured step: all
         streams of a hipGraph capture must be joined before the capture ends)."""
+        self._finish_interleaved()
         main = torch.cuda.current_stream()
         cap = ops.capture_id(main)
         for turn in self._look_queue:
@@ -574,10 +626,14 @@ class HipRandLANet(nn.Module):
                             record, f"block{lvl + 1}",
                             wait_graph=lambda s=1 + 2 * lvl: geo.wait(s))  # kNN table (+ encoder moments) of this level
             feats.append(h)
+            self._advance_interleaved()
+            self._advance_interleaved()  # (two position-only stages per level: table + moments, decimation + next grid)
             geo.wait(2 + 2 * lvl)  # decimation map into the next level
             h = ops.GatherRowsFn.apply(h, geo.src[lvl]) if train else ops.gather_rows(h, geo.src[lvl])
             hin.append(h)
         self.last_decimation_idx = dec_ref
+        self._advance_interleaved()  # (the last stage; the slot copy follows it)
+        self._advance_interleaved()
         geo.wait(9)  # decoder 1-NN tables
         h = self._shared_layer(self.mlp_summit, 0, h, train=train)
         if record is not None:

@@ -156,6 +156,14 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus():
     assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stdout + res.stderr)
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 _FLAT_DDP_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -196,7 +204,7 @@ def test_flat_bucket_broadcast_and_allreduce_world_size_2_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     res = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29533", str(script), ROOT],
+         "--master-port", str(_free_port()), str(script), ROOT],
         capture_output=True, text=True, env=env, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2

@@ -13,7 +13,8 @@ python - "$f" "$OUT/pmc_$TAG.csv" <<'PY'
 import csv, sys, collections
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = (r["Kernel_Name"][:60], r["Counter_Name"])
+    # one row per kernel NAME and launch geometry: the same template runs at four level sizes inside a step
+    k = (r["Kernel_Name"][:60] + " grid=" + r.get("Grid_Size", r.get("Grid_Size_X", "?")), r["Counter_Name"])
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
 kern = collections.OrderedDict()
 for (kn, cn), (n, v) in agg.items():
