@@ -64,7 +64,11 @@ int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t
  * gather on A0 (FPModule's x[nn], pyg_randla_net.py:250-251).  stat_part: optional fp64
  * [stat_parts][2][N] buffer receiving per-workgroup partial column sums / sums of squares of the raw (pre
  * scale/shift) output for train-mode BatchNorm (fully overwritten, no zero-fill needed; summed by
- * m3d_bn_finalize); stat_parts must equal m3d_gemm_stat_parts(M, N, k0 + k1).
+ * m3d_bn_finalize); stat_parts must equal m3d_gemm_stat_parts(M, N, k0 + k1).  stat_parts = -S (S > 0): SLOT MODE —
+ * stat_part is a PRE-ZEROED [S][2][N] table, workgroup w adds its partials to slot w % S (consumer: m3d_bn_stats_apply).
+ * act: bit 0 = LeakyReLU(slope) on the output; bit 8 = bf16 matrix-core operands (both operands rounded to bf16 as
+ * the fragments are built, v_mfma_f32_16x16x32_bf16, fp32 accumulate / epilogue / storage) — honoured by the K > 64
+ * kernels when K % 32 == 0, ignored elsewhere (the K <= 64 layers are HBM-bound).
  * accumulate != 0: atomically add into C (required when splitk > 1, which splits the K dimension). */
 int m3d_gemm_stat_parts(int64_t M, int32_t N, int32_t K);
 int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_t* a0_rows, int32_t k0,
@@ -95,10 +99,26 @@ int m3d_bn_fold_eval(const float* gamma, const float* beta, const float* running
  * (pyg_randla_net.py:186-187).  N % 4 == 0, contiguous rows. */
 int m3d_bn_apply(const float* z, const float* scale, const float* shift, const float* z2, const float* scale2,
                  const float* shift2, int32_t act, float slope, float* y, int64_t M, int32_t N, void* stream);
+
+/* m3d_bn_finalize + m3d_bn_apply in ONE launch, fed by SLOT-MODE statistics: m3d_gemm_f32 called with
+ * stat_parts = -nslots adds every workgroup's column partials into slot (workgroup % nslots) of a PRE-ZEROED fp64 table
+ * stat_part [nslots][2][N] (fp64 atomics), and each thread here sums the slots of its own four columns.  Writes scale /
+ * shift / mean / invstd (inputs of m3d_bn_bwd) and updates the running statistics exactly like m3d_bn_finalize.  The
+ * second argument block (slots2 ... z2, all optional) is the residual branch of m3d_bn_apply.  N: a power of two >= 4.
+ * (Summation order over workgroups is not fixed in this mode: the fp64 sums may differ in their last bits from run
+ * to run; the classic partial-row mode of m3d_gemm_f32 / m3d_bn_finalize is bitwise reproducible.) */
+int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                       float* mean_out, float* invstd_out, const float* z, const double* slots2, const float* gamma2,
+                       const float* beta2, float* running_mean2, float* running_var2, float* scale2, float* shift2,
+                       float* mean_out2, float* invstd_out2, const float* z2, int32_t act, float slope, float* y,
+                       int64_t M, int32_t N, void* stream);
 /* backward of m3d_bn_apply in train mode: dz (and dz2), dgamma/dbeta (and dgamma2/dbeta2).
  * sums_ws: m3d_bn_bwd_workspace_bytes(M, N) bytes of scratch (per-block partial column sums, no atomics).
- * accumulate_param_grads != 0: dgamma/dbeta are gradient sinks
- * (e.g. slices of the flat gradient buffer) and are added to instead of overwritten. */
+ * accumulate_param_grads: bit 0 = dgamma/dbeta are gradient sinks (e.g. slices of the flat gradient buffer) and are added
+ * to instead of overwritten; bits 8..15 = nslots > 0 selects SLOT MODE: sums_ws is then a PRE-ZEROED fp64 table
+ * [nslots][3][N] the reduce pass adds to (fp64 atomics) and the apply pass sums per column — two launches instead of
+ * three (no finalize kernel); N must be a power of two. */
 size_t m3d_bn_bwd_workspace_bytes(int64_t M, int32_t N);
 int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* z2, const float* scale2, const float* shift2, const float* mean2,

@@ -33,6 +33,8 @@ SIGNATURES = {
     "m3d_bn_finalize": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
     "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
+    "m3d_bn_stats_apply": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                  _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
     "m3d_bn_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,
                           _p, _p, _i32, _p]),

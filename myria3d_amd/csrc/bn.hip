@@ -131,6 +131,109 @@ extern "C" int m3d_bn_apply(const float* z, const float* scale, const float* shi
 }
 
 // ------------------------------------------------------------------------------------------
+// m3d_bn_stats_apply: m3d_bn_finalize + m3d_bn_apply in ONE launch (slot-mode statistics of m3d_gemm_f32).
+// The training step is a ~400-node chain in which a tiny kernel costs >= 5 us: instead of a finalize kernel per
+// BatchNorm, every thread of the apply kernel sums the few slots of ITS four columns (fp64) and derives scale / shift
+// itself; block 0 also stores mean / invstd / scale / shift for the backward pass and updates the running statistics.
+// N a power of two (all of this network's widths) so that a thread keeps its columns over the grid-stride loop.
+// ------------------------------------------------------------------------------------------
+struct BnStatsArgs {
+  const double* slots; const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* scale; float* shift; float* mean; float* invstd;
+};
+struct BnStatsApplyArgs {
+  BnStatsArgs b1, b2;  // b2.slots == nullptr: no residual branch
+  int nslots; double count; float eps, momentum;
+  const float4* z; const float4* z2; int act; float slope; float4* y; int64_t total4; int N;
+};
+
+#define BN_MAXN 1024  // widest BatchNorm the fused kernels keep in LDS (this network: 512)
+
+// scale / shift of column n from the slot sums (fp64); `writer`: also store the backward inputs and update the
+// running statistics (one block does it)
+__device__ __forceinline__ void bn_stats_col(const BnStatsApplyArgs& a, const BnStatsArgs& b, int n, bool writer,
+                                             float& sc, float& sh) {
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < a.nslots; ++p) {
+    s += b.slots[((size_t)p * 2 + 0) * a.N + n];
+    q += b.slots[((size_t)p * 2 + 1) * a.N + n];
+  }
+  const double mean = s / a.count;
+  double var = q / a.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)a.eps);
+  const double scd = (double)(b.gamma ? b.gamma[n] : 1.f) * invstd;
+  sc = (float)scd;
+  sh = (float)((double)(b.beta ? b.beta[n] : 0.f) - mean * scd);
+  if (writer) {
+    b.scale[n] = sc; b.shift[n] = sh;
+    if (b.mean) b.mean[n] = (float)mean;
+    if (b.invstd) b.invstd[n] = (float)invstd;
+    if (b.running_mean) b.running_mean[n] = (float)((1.0 - a.momentum) * (double)b.running_mean[n] + a.momentum * mean);
+    if (b.running_var) {
+      const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+      b.running_var[n] = (float)((1.0 - a.momentum) * (double)b.running_var[n] + a.momentum * unbiased);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a) {
+  // every block derives the N column constants ONCE (one thread per column, a few slot rows each, fp64) into LDS
+  __shared__ float s_sc[BN_MAXN], s_sh[BN_MAXN], s_sc2[BN_MAXN], s_sh2[BN_MAXN];
+  const bool writer = blockIdx.x == 0;
+  for (int n = threadIdx.x; n < a.N; n += 256) {
+    bn_stats_col(a, a.b1, n, writer, s_sc[n], s_sh[n]);
+    if (a.b2.slots) bn_stats_col(a, a.b2, n, writer, s_sc2[n], s_sh2[n]);
+  }
+  __syncthreads();
+  const int N4 = a.N / 4;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.total4) return;
+  const int c = (int)(i % N4) * 4;  // fixed for this thread: the grid stride is a multiple of N4 (checked by the host)
+  const float4 sc = *(const float4*)&s_sc[c], sh = *(const float4*)&s_sh[c];
+  float4 s2 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
+  if (a.b2.slots) { s2 = *(const float4*)&s_sc2[c]; h2 = *(const float4*)&s_sh2[c]; }
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < a.total4; i += stride) {
+    const float4 v = a.z[i];
+    float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (a.b2.slots) {
+      const float4 w = a.z2[i];
+      u.x += w.x * s2.x + h2.x; u.y += w.y * s2.y + h2.y; u.z += w.z * s2.z + h2.z; u.w += w.w * s2.w + h2.w;
+    }
+    if (a.act) { u.x = lrelu(u.x, a.slope); u.y = lrelu(u.y, a.slope); u.z = lrelu(u.z, a.slope); u.w = lrelu(u.w, a.slope); }
+    a.y[i] = u;
+  }
+}
+
+extern "C" int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t count, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                  float* scale, float* shift, float* mean_out, float* invstd_out, const float* z,
+                                  const double* slots2, const float* gamma2, const float* beta2, float* running_mean2,
+                                  float* running_var2, float* scale2, float* shift2, float* mean_out2,
+                                  float* invstd_out2, const float* z2, int32_t act, float slope, float* y, int64_t M,
+                                  int32_t N, void* stream) {
+  if (M < 0 || N < 0 || nslots < 1 || count < 1) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  if (!slots || !scale || !shift || !z || !y) return M3D_ERR_INVALID;
+  if (slots2 && (!scale2 || !shift2 || !z2)) return M3D_ERR_INVALID;
+  if ((N % 4) || (N & (N - 1)) || N > BN_MAXN) return M3D_ERR_UNSUPPORTED;  // power-of-two widths (a thread keeps its columns)
+  BnStatsApplyArgs a;
+  a.b1 = {slots, gamma, beta, running_mean, running_var, scale, shift, mean_out, invstd_out};
+  a.b2 = {slots2, gamma2, beta2, running_mean2, running_var2, scale2, shift2, mean_out2, invstd_out2};
+  a.nslots = nslots; a.count = (double)count; a.eps = eps; a.momentum = momentum;
+  a.z = (const float4*)z; a.z2 = (const float4*)z2; a.act = act; a.slope = slope; a.y = (float4*)y;
+  a.total4 = M * (N / 4); a.N = N;
+  int64_t gx = m3d_cdiv(a.total4, 256 * 8);  // ~8 float4 per thread: the per-block column pass is amortised
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  // stride = gx * 256 must be a multiple of N4 (a power of two <= 256 divides 256)
+  hipLaunchKernelGGL(bn_stats_apply_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, pass 1: sums[0][n] = sum_m dact, sums[1][n] = sum_m dact*zhat, sums[2][n] = sum_m dact*zhat2
 //   u = z*scale+shift (+ z2*scale2+shift2); dact = dy * (act ? (u>0 ? 1 : slope) : 1)
 //   zhat = (z - mean)*invstd
@@ -142,6 +245,7 @@ struct BnBwdArgs {
   double* sums;  // [3][N]
   float* dz; float* dz2; float* dgamma; float* dbeta; float* dgamma2; float* dbeta2;
   int acc_pg;  // != 0: add into dgamma/dbeta (gradient sinks) instead of overwriting
+  int nslots;  // > 0: sums is a pre-zeroed [nslots][3][N] table (reduce adds, apply sums; no finalize kernel)
 };
 
 __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, float4 zv, float4& z2v) {
@@ -200,13 +304,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int row
   for (int j = 0; j < 12; ++j) red[j * 256 + tid] = (double)s[j];
   __syncthreads();
   if (rl == 0 && c4 < N4) {
-    double* dst = part + (size_t)blockIdx.x * 3 * a.N;
+    double* dst = a.nslots > 0 ? a.sums + (size_t)(blockIdx.x % a.nslots) * 3 * a.N : part + (size_t)blockIdx.x * 3 * a.N;
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       double v = 0.0;
       if (j < 8 || a.z2)
         for (int q = 0; q < rpp; ++q) v += red[j * 256 + q * CG + cg];
-      dst[(size_t)(j / 4) * a.N + c4 * 4 + (j & 3)] = v;
+      double* d = &dst[(size_t)(j / 4) * a.N + c4 * 4 + (j & 3)];
+      if (a.nslots > 0) {
+        if (j < 8 || a.z2) atomicAdd(d, v);
+      } else {
+        *d = v;
+      }
     }
   }
 }
@@ -258,20 +367,49 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   // the same 4 columns and their constants (incl. the fp64 column sums) are loaded once, not per element
   const bool fixed = (stride % N4) == 0;
   BnCol k1, k2;
+  // slot mode: every block sums the slot rows of all N columns ONCE into LDS (one thread per column); block 0 also
+  // writes the parameter gradients the finalize kernel used to write (dbeta = s1, dgamma = s2, dgamma2 = s3)
+  __shared__ float s_m1[BN_MAXN], s_m2[BN_MAXN], s_m3[BN_MAXN];
+  if (a.nslots > 0) {
+    for (int n = threadIdx.x; n < a.N; n += 256) {
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      for (int p = 0; p < a.nslots; ++p) {
+        s1 += a.sums[((size_t)p * 3 + 0) * a.N + n];
+        s2 += a.sums[((size_t)p * 3 + 1) * a.N + n];
+        if (a.z2) s3 += a.sums[((size_t)p * 3 + 2) * a.N + n];
+      }
+      s_m1[n] = (float)(s1 * invM); s_m2[n] = (float)(s2 * invM); s_m3[n] = (float)(s3 * invM);
+      if (blockIdx.x == 0) {
+        if (a.dbeta) a.dbeta[n] = (a.acc_pg ? a.dbeta[n] : 0.f) + (float)s1;
+        if (a.z2 && a.dbeta2) a.dbeta2[n] = (a.acc_pg ? a.dbeta2[n] : 0.f) + (float)s1;
+        if (a.dgamma) a.dgamma[n] = (a.acc_pg ? a.dgamma[n] : 0.f) + (float)s2;
+        if (a.z2 && a.dgamma2) a.dgamma2[n] = (a.acc_pg ? a.dgamma2[n] : 0.f) + (float)s3;
+      }
+    }
+    __syncthreads();
+  }
   auto load_cols = [&](int c) {
     k1.sc = *(const float4*)(a.scale + c); k1.sh = *(const float4*)(a.shift + c);
     k1.mu = *(const float4*)(a.mean + c); k1.is = *(const float4*)(a.invstd + c);
-    k1.m1 = make_float4((float)(a.sums[c] * invM), (float)(a.sums[c + 1] * invM), (float)(a.sums[c + 2] * invM),
-                        (float)(a.sums[c + 3] * invM));
-    k1.m2 = make_float4((float)(a.sums[a.N + c] * invM), (float)(a.sums[a.N + c + 1] * invM),
-                        (float)(a.sums[a.N + c + 2] * invM), (float)(a.sums[a.N + c + 3] * invM));
+    if (a.nslots > 0) {
+      k1.m1 = *(const float4*)&s_m1[c];
+      k1.m2 = *(const float4*)&s_m2[c];
+    } else {
+      k1.m1 = make_float4((float)(a.sums[c] * invM), (float)(a.sums[c + 1] * invM), (float)(a.sums[c + 2] * invM),
+                          (float)(a.sums[c + 3] * invM));
+      k1.m2 = make_float4((float)(a.sums[a.N + c] * invM), (float)(a.sums[a.N + c + 1] * invM),
+                          (float)(a.sums[a.N + c + 2] * invM), (float)(a.sums[a.N + c + 3] * invM));
+    }
     if (a.z2) {
       const size_t o = 2 * (size_t)a.N + c;
       k2.sc = *(const float4*)(a.scale2 + c); k2.sh = *(const float4*)(a.shift2 + c);
       k2.mu = *(const float4*)(a.mean2 + c); k2.is = *(const float4*)(a.invstd2 + c);
       k2.m1 = k1.m1;
-      k2.m2 = make_float4((float)(a.sums[o] * invM), (float)(a.sums[o + 1] * invM), (float)(a.sums[o + 2] * invM),
-                          (float)(a.sums[o + 3] * invM));
+      if (a.nslots > 0)
+        k2.m2 = *(const float4*)&s_m3[c];
+      else
+        k2.m2 = make_float4((float)(a.sums[o] * invM), (float)(a.sums[o + 1] * invM), (float)(a.sums[o + 2] * invM),
+                            (float)(a.sums[o + 3] * invM));
     }
   };
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -332,19 +470,29 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   a.z2 = z2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.invstd2 = invstd2;
   a.act = act; a.slope = slope; a.M = M; a.N = N; a.sums = sums_ws;
   a.dz = dz; a.dz2 = dz2; a.dgamma = dgamma; a.dbeta = dbeta; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2;
-  a.acc_pg = accumulate_param_grads;
+  // accumulate_param_grads: bit 0 = add into dgamma / dbeta; bits 8.. = slot count of a PRE-ZEROED [slots][3][N] sums_ws
+  // (slot mode: two launches instead of three; N must be a power of two)
+  a.acc_pg = accumulate_param_grads & 1;
+  a.nslots = (accumulate_param_grads >> 8) & 0xff;
+  if (a.nslots > 0 && ((N & (N - 1)) || N > BN_MAXN)) return M3D_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const BnBwdPlan pl = bn_bwd_plan(M, N);
   double* part = sums_ws + 3 * (size_t)N;  // sums_ws = [3][N] totals, then [blocks][3][N] partial rows
   const int N4 = N / 4;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)pl.blocks, (unsigned)pl.passes), dim3(256), 0, st, a,
                      (int)pl.rows_per_block, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)N, z2 ? 3 : 2), dim3(64), 0, st, a, (const double*)part,
-                     (int)pl.blocks);
+  if (a.nslots <= 0)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)N, z2 ? 3 : 2), dim3(64), 0, st, a, (const double*)part,
+                       (int)pl.blocks);
   int64_t total4 = M * N4;
   int64_t gy = m3d_cdiv(total4, 256 * 4);
   if (gy > 4096) gy = 4096;
   if (gy < 1) gy = 1;
+  if (a.nslots > 0) {  // every block pays one pass over the slot table: fewer, fatter blocks
+    gy = m3d_cdiv(total4, 256 * 8);
+    if (gy > 1024) gy = 1024;
+    if (gy < 1) gy = 1;
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)gy), dim3(256), 0, st, a);
   M3D_CHECK_LAUNCH();
   return M3D_OK;

@@ -205,7 +205,9 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   if (M == 0 || N == 0) return M3D_OK;
   if (!c || !b || (k0 > 0 && !a0) || (k1 > 0 && !a1)) return M3D_ERR_INVALID;
   if (a_colmajor && (k1 > 0 || a0_rows)) return M3D_ERR_UNSUPPORTED;
-  if (stat_part && stat_parts != m3d_gemm_stat_parts(M, N, k0 + k1)) return M3D_ERR_INVALID;
+  // stat_parts < 0: slot mode — stat_part is a PRE-ZEROED [-stat_parts][2][N] table the workgroups add to
+  const int stat_slots = (stat_part && stat_parts < 0) ? -stat_parts : 0;
+  if (stat_part && !stat_slots && stat_parts != m3d_gemm_stat_parts(M, N, k0 + k1)) return M3D_ERR_INVALID;
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && (!accumulate || stat_part || scale || shift || act)) return M3D_ERR_INVALID;
   if (k0 + k1 == 0) return M3D_ERR_INVALID;
@@ -214,6 +216,9 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   g.a_cm = a_colmajor; g.b = b; g.ldb = ldb; g.b_cm = b_colmajor; g.M = M; g.N = N;
   g.bias = bias; g.scale = scale; g.shift = shift; g.act = act; g.slope = slope;
   g.stat_part = stat_part; g.stat_sum = stat_part; g.stat_sumsq = stat_part ? stat_part + N : nullptr; g.c = c; g.ldc = ldc; g.accumulate = accumulate;
+  g.stat_slots = stat_slots;
+  g.bf16 = (act >> 8) & 1;  // act: bit 0 = LeakyReLU, bit 8 = bf16 matrix-core operands (deep layers, K % 32 == 0)
+  g.act = act & 1;
   const int64_t K = (int64_t)k0 + k1;
   int64_t kchunk = m3d_align(m3d_cdiv(K, splitk), BK);
   splitk = (int)m3d_cdiv(K, kchunk);
@@ -228,8 +233,9 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
     }
   }
   // fallback: atomically accumulated statistics in partial row 0, the other rows stay zero
-  if (stat_part && hipMemsetAsync(stat_part, 0, sizeof(double) * 2 * (size_t)N * stat_parts, (hipStream_t)stream) != hipSuccess)
-    return M3D_ERR_LAUNCH;
+  if (stat_part && !stat_slots &&
+      hipMemsetAsync(stat_part, 0, sizeof(double) * 2 * (size_t)N * stat_parts, (hipStream_t)stream) != hipSuccess)
+    return M3D_ERR_LAUNCH;  // (slot mode: the table is already zero; everything lands in slot 0)
   const int NT = N <= 16 ? 1 : (N <= 32 ? 2 : 4);
   const int64_t mtiles = m3d_cdiv(M, BM);
   const int64_t ntiles = m3d_cdiv(N, 16 * NT);

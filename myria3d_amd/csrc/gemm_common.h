@@ -12,8 +12,12 @@ struct GemmArgs {
   const float* bias; const float* scale; const float* shift; int act; float slope;
   double* stat_sum; double* stat_sumsq;  // LDS-tiled fallback: atomically accumulated [N] vectors (row 0 of stat_part)
   double* stat_part;                     // direct kernels: [gridDim.x][2][N] per-workgroup partials, plainly stored
+  int stat_slots;                        // > 0: stat_part is a pre-zeroed [stat_slots][2][N] table; workgroup w ADDS its
+                                         // partial to slot w % stat_slots (fp64 atomics) -> the consumer sums a handful
+                                         // of slots itself and no finalize kernel is needed
   float* c; int64_t ldc; int accumulate;
   int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
+  int bf16;                    // != 0: operands rounded to bf16 on load, v_mfma_f32_16x16x32_bf16 (K % 32 == 0, K > 64)
 };
 
 // gemm_direct.hip: returns M3D_OK when it handled the problem, 1 when the shape is not covered (caller falls back)

@@ -215,9 +215,14 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
       double v = 0.0;
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) v += sred[w][which][col];
-      // plain store of this workgroup's partial (summed by m3d_bn_finalize): no same-address atomics, no zero-fill,
-      // bitwise reproducible
-      g.stat_part[((size_t)blockIdx.x * 2 + which) * g.N + n] = v;
+      if (g.stat_slots > 0) {
+        // slot mode: a few fp64 atomics per address (workgroups / slots); the table was zeroed by the caller
+        atomicAdd(&g.stat_part[((size_t)(blockIdx.x % g.stat_slots) * 2 + which) * g.N + n], v);
+      } else {
+        // plain store of this workgroup's partial (summed by m3d_bn_finalize): no same-address atomics, no
+        // zero-fill, bitwise reproducible
+        g.stat_part[((size_t)blockIdx.x * 2 + which) * g.N + n] = v;
+      }
     }
   }
 }
@@ -272,7 +277,10 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 // ------------------------------------------------------------------------------------------
 // any K: weights streamed from L1/L2 chunk by chunk.  grid: (row workgroups, column slices of 16*NTW)
 // ------------------------------------------------------------------------------------------
-template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM>
+// BF: both operands are rounded to bf16 as their fragments are assembled (8 consecutive k per lane = two 16-byte loads)
+// and the product runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (K a multiple of 32): the deep SharedMLP
+// layers in the net's "bf16" matmul precision.  Epilogue, statistics and storage stay fp32.
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false>
 __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
   // a wave owns MTW x NTW tiles of 16x16: every A / W fragment it loads feeds NTW / MTW MFMAs (these shapes are
   // L2-bandwidth bound on operand re-reads when MTW = NTW = 1)
@@ -301,6 +309,29 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+#pragma unroll 2
+      for (int q = 0; q < (K >> 5); ++q) {
+        const int k = 32 * q + 8 * lg;
+        Bf16Frag a[MTW], w[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const float4 lo = a_frag<VEC, CAT>(g, ra0, ra1, row[mt], k, K), hi = a_frag<VEC, CAT>(g, ra0, ra1, row[mt], k + 4, K);
+          a[mt].u[0] = pack_bf16(lo.x, lo.y); a[mt].u[1] = pack_bf16(lo.z, lo.w);
+          a[mt].u[2] = pack_bf16(hi.x, hi.y); a[mt].u[3] = pack_bf16(hi.z, hi.w);
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const float4 lo = w_frag<VEC, BCM>(g, rb, nb + 16 * t + lr, k, K), hi = w_frag<VEC, BCM>(g, rb, nb + 16 * t + lr, k + 4, K);
+          w[t].u[0] = pack_bf16(lo.x, lo.y); w[t].u[1] = pack_bf16(lo.z, lo.w);
+          w[t].u[2] = pack_bf16(hi.x, hi.y); w[t].u[3] = pack_bf16(hi.z, hi.w);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma_bf16(w[t].v, a[mt].v, acc[mt][t]);
+      }
+    } else
 #pragma unroll 4
     for (int q = 0; q < KQ; ++q) {
       const int k = 16 * q + 4 * lg;
@@ -357,6 +388,14 @@ static void launch_rowstream(const GemmArgs& g, int mode, int KQ, int variant, d
 
 template <int MTW, int NTW, int MODE>
 static void launch_kl(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (g.bf16 && variant <= 2 && ((g.k0 + g.k1) & 31) == 0) {  // bf16 matrix cores (vector-load variants only)
+    switch (variant) {
+      case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+      case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+      default: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec); break;
+    }
+    return;
+  }
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
     case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;

@@ -162,7 +162,7 @@ def gemm(a0: Tensor, b: Tensor, M: int, N: int, k0: int, *, lda0: Optional[int] 
          b_cm: bool = False, ldb: Optional[int] = None, bias: Optional[Tensor] = None,
          scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, act: bool = False,
          stats: Optional[Tensor] = None, out: Optional[Tensor] = None, ldc: Optional[int] = None,
-         accumulate: bool = False, splitk: int = 1) -> Tensor:
+         accumulate: bool = False, splitk: int = 1, stat_slots: bool = False, bf16: bool = False) -> Tensor:
     """C[M,N] (+)= [A0[rows] | A1] B^T, see ``m3d_gemm_f32`` in include/m3d_hip.h."""
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a0.device)
@@ -171,7 +171,8 @@ def gemm(a0: Tensor, b: Tensor, M: int, N: int, k0: int, *, lda0: Optional[int] 
     ldb = ldb if ldb is not None else b.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
     call("m3d_gemm_f32", _p(a0), lda0, int(a_cm), _p(rows), k0, _p(a1), lda1, k1, _p(b), ldb, int(b_cm), M, N,
-         _p(bias), _p(scale), _p(shift), int(act), LRELU_SLOPE, _p(stats), 0 if stats is None else stats.shape[0],
+         _p(bias), _p(scale), _p(shift), int(act) | (256 if bf16 else 0), LRELU_SLOPE, _p(stats),
+         0 if stats is None else (-stats.shape[0] if stat_slots else stats.shape[0]),
          _p(out), ldc, int(accumulate), splitk, _st())
     return out
 
@@ -188,11 +189,11 @@ def _splitk_for(red: int, m: int, n: int) -> int:
     return max(1, min(1024 // max(tiles, 1), red // 256))
 
 
-def linear_dgrad(dz: Tensor, w: Tensor) -> Tensor:
+def linear_dgrad(dz: Tensor, w: Tensor, bf16: bool = False) -> Tensor:
     """dX[M,K] = dZ[M,N] W[N,K]   (W stored [out,in] like torch.nn.Linear)."""
     M, N = dz.shape
     K = w.shape[1]
-    return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0))
+    return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0), bf16=bf16)
 
 
 class GradSideStream:
@@ -324,6 +325,42 @@ def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
     return scale, shift, mean, invstd
 
 
+BN_SLOTS = 16  # slot-mode statistics: workgroups add their column partials into this many fp64 rows
+
+
+def _pow2(n: int) -> bool:
+    return n >= 4 and (n & (n - 1)) == 0
+
+
+def stat_slots(N: int, device) -> Tensor:
+    """Pre-zeroed fp64 ``[BN_SLOTS, 2, N]`` table for the slot-mode statistics of a GEMM (``gemm(..., stats=table,
+    stat_slots=True)``), cut from the step's zero arena."""
+    return arena.zeros((BN_SLOTS, 2, N), torch.float64, device)
+
+
+def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tensor, act: bool, stats2=None, bn2=None,
+                   z2=None):
+    """``bn_finalize`` + ``bn_apply`` in one launch (``m3d_bn_stats_apply``) from slot-mode statistics.  Returns
+    ``(y, (scale, shift, mean, invstd)[, (scale2, shift2, mean2, invstd2)])``."""
+    if count < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [{count}, {bn.num_features}]")
+    n = bn.num_features
+    dev = z.device
+    p1 = tuple(torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
+    p2 = tuple(torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4)) if bn2 is not None else (None,) * 4
+    y = torch.empty_like(z)
+    call("m3d_bn_stats_apply", _p(stats), stats.shape[0], count, _p(bn.weight), _p(bn.bias), float(bn.eps),
+         float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p1[3]),
+         _p(_chk(z)), _p(stats2), _p(bn2.weight if bn2 is not None else None),
+         _p(bn2.bias if bn2 is not None else None), _p(bn2.running_mean if bn2 is not None else None),
+         _p(bn2.running_var if bn2 is not None else None), _p(p2[0]), _p(p2[1]), _p(p2[2]), _p(p2[3]), _p(z2), int(act),
+         LRELU_SLOPE, _p(y), z.shape[0], z.shape[1], _st())
+    for b in (bn, bn2):
+        if b is not None and not getattr(b, "_m3d_flat_counter", False):  # flattened nets bump all counters at once
+            b.num_batches_tracked += 1
+    return (y, p1, p2) if bn2 is not None else (y, p1)
+
+
 def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Tensor] = None,
              scale2: Optional[Tensor] = None, shift2: Optional[Tensor] = None) -> Tensor:
     y = torch.empty_like(z)
@@ -334,10 +371,15 @@ def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Te
 
 def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=None, mean2=None, invstd2=None,
            sinks=None):
-    """``sinks = (dgamma, dbeta[, dgamma2, dbeta2])``: gradient sinks that are added to (None is returned for them)."""
+    """``sinks = (dgamma, dbeta[, dgamma2, dbeta2])``: gradient sinks that are added to (None is returned for them).
+    Power-of-two widths take the slot mode of ``m3d_bn_bwd`` (two launches, pre-zeroed sums from the zero arena)."""
     M, N = z.shape
     dev = z.device
-    sums = torch.empty(lib().m3d_bn_bwd_workspace_bytes(M, N) // 8, dtype=torch.float64, device=dev)
+    slots = BN_SLOTS if _pow2(N) else 0
+    if slots:
+        sums = arena.zeros((slots, 3, N), torch.float64, dev)
+    else:
+        sums = torch.empty(lib().m3d_bn_bwd_workspace_bytes(M, N) // 8, dtype=torch.float64, device=dev)
     dz = torch.empty_like(z)
     dz2 = dgamma2 = dbeta2 = None
     if sinks is not None:
@@ -352,7 +394,7 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
         dz2 = torch.empty_like(z2)
     call("m3d_bn_bwd", _p(_chk(dy)), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), _p(z2), _p(scale2),
          _p(shift2), _p(mean2), _p(invstd2), int(act), LRELU_SLOPE, M, N, _p(sums), _p(dz), _p(dz2), _p(dgamma),
-         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None), _st())
+         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None) | (slots << 8), _st())
     if sinks is not None:
         return dz, None, None, dz2, None, None
     return dz, dgamma, dbeta, dz2, dgamma2, dbeta2
@@ -389,18 +431,24 @@ class LinearFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None):
-        # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None
+    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False):
+        # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None;  bf16: matrix-core precision of the K > 64 GEMMs
         ctx.sinks = sinks
+        ctx.bf16 = bool(bf16)
         ctx.side = _grad_side if sinks is not None else None
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         N = w.shape[0]
         k0 = x0.shape[1]
         k1 = x1.shape[1] if x1 is not None else 0
-        stats = stat_buffer(M, N, k0 + k1, w.device)
-        z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats)
-        scale, shift, mean, invstd = bn_finalize(stats, M, bn)
-        y = bn_apply(z, scale, shift, act)
+        if _pow2(N):  # slot-mode statistics: GEMM + ONE fused finalize/apply launch
+            stats = stat_slots(N, w.device)
+            z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, stat_slots=True, bf16=bf16)
+            y, (scale, shift, mean, invstd) = bn_stats_apply(stats, M, bn, z, act)
+        else:
+            stats = stat_buffer(M, N, k0 + k1, w.device)
+            z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, bf16=bf16)
+            scale, shift, mean, invstd = bn_finalize(stats, M, bn)
+            y = bn_apply(z, scale, shift, act)
         ctx.save_for_backward(x0, x1, w, z, scale, shift, mean, invstd, rows)
         ctx.act = act
         return y
@@ -415,7 +463,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
         k1 = x1.shape[1] if x1 is not None else 0
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dxc = linear_dgrad(dz, w)
+            dxc = linear_dgrad(dz, w, ctx.bf16)
             if ctx.needs_input_grad[0]:
                 dx0 = dxc[:, :k0]
                 if rows is not None:
@@ -426,23 +474,30 @@ class SharedLayerTrainFn(torch.autograd.Function):
                 dx1 = dxc[:, k0:].contiguous()
         dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
 class ResidualTailTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None):
+    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None, bf16=False):
         ctx.sinks = (sinks2, sinkss) if sinks2 is not None else None
+        ctx.bf16 = bool(bf16)
         ctx.side = _grad_side if sinks2 is not None else None
         M, N = x2.shape[0], w2.shape[0]
-        st2 = stat_buffer(M, N, x2.shape[1], w2.device)
-        sts = stat_buffer(M, N, xs.shape[1], w2.device)
-        z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2)
-        zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts)
-        sc2, sh2, mu2, is2 = bn_finalize(st2, M, bn2)
-        scs, shs, mus, iss = bn_finalize(sts, M, bns)
-        y = bn_apply(z2, sc2, sh2, True, zs, scs, shs)
+        if _pow2(N):
+            st2, sts = stat_slots(N, w2.device), stat_slots(N, w2.device)
+            z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, stat_slots=True, bf16=bf16)
+            zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts, stat_slots=True, bf16=bf16)
+            y, (sc2, sh2, mu2, is2), (scs, shs, mus, iss) = bn_stats_apply(st2, M, bn2, z2, True, sts, bns, zs)
+        else:
+            st2 = stat_buffer(M, N, x2.shape[1], w2.device)
+            sts = stat_buffer(M, N, xs.shape[1], w2.device)
+            z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, bf16=bf16)
+            zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts, bf16=bf16)
+            sc2, sh2, mu2, is2 = bn_finalize(st2, M, bn2)
+            scs, shs, mus, iss = bn_finalize(sts, M, bns)
+            y = bn_apply(z2, sc2, sh2, True, zs, scs, shs)
         ctx.save_for_backward(x2, w2, z2, sc2, sh2, mu2, is2, xs, ws, zs, scs, shs, mus, iss)
         return y
 
@@ -452,13 +507,13 @@ class ResidualTailTrainFn(torch.autograd.Function):
         sk = ctx.sinks
         dz2, dg2, db2, dzs, dgs, dbs = bn_bwd(dy.contiguous(), z2, sc2, sh2, mu2, is2, True, zs, scs, shs, mus, iss,
                                               sinks=(sk[0][2], sk[0][3], sk[1][2], sk[1][3]) if sk else None)
-        dx2 = linear_dgrad(dz2, w2)
-        dxs = linear_dgrad(dzs, ws)
+        dx2 = linear_dgrad(dz2, w2, ctx.bf16)
+        dxs = linear_dgrad(dzs, ws, ctx.bf16)
         dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None, side=ctx.side)
         dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None, side=ctx.side)
         z0_2 = None if sk else torch.zeros_like(db2)
         z0_s = None if sk else torch.zeros_like(dbs)
-        return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None)
+        return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None, None)
 
 
 class GatherRowsFn(torch.autograd.Function):

@@ -130,7 +130,8 @@ class HipRandLANet(nn.Module):
         # eval-mode derived tensors (folded BatchNorm scale/shift, folded encoder, packed attention weights) depend on
         # parameters / running statistics only: cached across forwards, dropped whenever those may have changed
         self._eval_cache: Dict = {}
-        # "fp32": the reference's arithmetic.  "bf16": the matrix-bound layers (LFA attention GEMMs at ch >= 64) take bf16
+        # "fp32": the reference's arithmetic.  "bf16": the matrix-bound layers (LFA attention GEMMs at ch >= 64, SharedMLP
+        # GEMMs with more than 64 input channels, forward and input gradient) take bf16
         # operands on the matrix cores with fp32 accumulation (BASELINE config 2); storage, positions, kNN, softmax and
         # the statistics stay fp32.  Also switched on by torch.autocast(dtype=bfloat16) around the call (Lightning's
         # ``trainer.precision: bf16-mixed``), like any autocast-aware module.
@@ -303,11 +304,12 @@ class HipRandLANet(nn.Module):
         if train:
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
-                                                sk)
+                                                sk, self._bf16)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
-                        k1=0 if x1 is None else x1.shape[1], bias=lin.bias, scale=scale, shift=shift, act=mlp.act)
+                        k1=0 if x1 is None else x1.shape[1], bias=lin.bias, scale=scale, shift=shift, act=mlp.act,
+                        bf16=self._bf16)
 
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
              train: bool) -> Tensor:
@@ -351,12 +353,12 @@ class HipRandLANet(nn.Module):
             sk2 = self._sinks(l2.weight, l2.bias, n2.weight, n2.bias) if self._use_sinks else None
             sks = self._sinks(ls.weight, ls.bias, ns.weight, ns.bias) if self._use_sinks else None
             out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
-                                                ns.weight, ns.bias, ns, sk2, sks)
+                                                ns.weight, ns.bias, ns, sk2, sks, self._bf16)
         else:
             sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2), self._bn_deps(n2))
             scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns), self._bn_deps(ns))
-            z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias)
-            zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias)
+            z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias, bf16=self._bf16)
+            zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias, bf16=self._bf16)
             out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
         if rec is not None:
             rec[name + ".out"] = out[index.inv.long()]

@@ -276,6 +276,47 @@ def test_gather_scatter_decimation(device):
     assert abs(seg.mean().item() / 12800 - 0.5) < 0.03
 
 
+def test_decimation_draws_look_uniform(device):
+    """The keyed Feistel permutation behind m3d_decimation_indices (rows.hip) stands in for torch.randperm
+    (pyg_randla_net.py:221): every point must survive with probability m / n and pairs of points with probability
+    m (m - 1) / (n (n - 1)), independently from cloud to cloud.  20 000 clouds of 40 points, 10 survivors each:
+    chi-square of the per-point survival counts (39 degrees of freedom) and z-scores of all 780 pair counts; 2 000
+    clouds of 1 000 points for a longer permutation."""
+    from myria3d_amd import ops
+
+    def draw(B, n, seed_val):
+        m = n // 4
+        ptr = torch.arange(0, (B + 1) * n, n, dtype=torch.int64, device=device)
+        ptr_out = torch.arange(0, (B + 1) * m, m, dtype=torch.int64, device=device)
+        seed = torch.tensor([seed_val], dtype=torch.int64, device=device)
+        idx = ops.decimation_indices(ptr, ptr_out, B * m, seed, 0).cpu().long().view(B, m)
+        local = idx - (torch.arange(B) * n)[:, None]
+        assert bool((local >= 0).all()) and bool((local < n).all())
+        sel = torch.zeros(B, n, dtype=torch.bool)
+        sel[torch.arange(B)[:, None], local] = True
+        assert bool((sel.sum(1) == m).all())  # distinct survivors in every cloud
+        return sel.double(), m
+
+    B, n = 20000, 40
+    sel, m = draw(B, n, 0x123456789ABCDEF)
+    p1 = m / n
+    cnt = sel.sum(0)
+    chi2 = (((cnt - B * p1) ** 2) / (B * p1 * (1 - p1))).sum().item()
+    p2 = p1 * (m - 1) / (n - 1)
+    co = sel.t() @ sel
+    iu = torch.triu_indices(n, n, 1)
+    z = (co[iu[0], iu[1]] - B * p2) / (B * p2 * (1 - p2)) ** 0.5
+    print(f"[stats] decimation: chi2(39 dof) = {chi2:.1f}, pair z: max |z| = {z.abs().max().item():.2f}, "
+          f"mean z^2 = {(z ** 2).mean().item():.2f}")
+    assert chi2 < 90.0            # P(chi2_39 > 90) ~ 1e-5
+    assert z.abs().max().item() < 5.5 and (z ** 2).mean().item() < 1.5
+    sel, m = draw(2000, 1000, 77)
+    cnt = sel.sum(0)
+    chi2 = (((cnt - 2000 * 0.25) ** 2) / (2000 * 0.25 * 0.75)).sum().item()
+    print(f"[stats] decimation, n = 1000: chi2(999 dof) = {chi2:.1f}")
+    assert 800.0 < chi2 < 1250.0  # mean 999, sd 44.7
+
+
 # ----------------------------------------------------------------------------------------------- LFA
 def _lfa_setup(ch, sizes, k, seed):
     from oracle.randla_oracle import LocalFeatureAggregation, dense_to_edge_index, knn_exact
