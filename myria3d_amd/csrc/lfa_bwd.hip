@@ -32,6 +32,7 @@ struct LfaBwdArgs {
   float* g_part;      // [parts][GP*16],  GP = max(16, D)
   int64_t n;
   int K, CH, D;
+  int stagger;  // experiment (M3D_LFA_BWD_STAGGER): start-up delay, in s_sleep(127) units (~3.4 us), per dispatch round
   int dbg;  // timing experiments only (M3D_LFA_BWD_DBG): 1 = skip the dx atomics, 2 = skip phases 4-7
   float slope;
 };
@@ -222,6 +223,12 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
     }
   };
+  if (a.stagger > 0) {
+    // de-phase the workgroups that share a CU (dispatch rounds of 256): all of them start together and, with equal work
+    // per group, stay in lock-step — every resident workgroup in its MFMA phase at once, then every one in a VALU phase
+    const int rounds = (int)(blockIdx.x >> 8) & 3;
+    for (int i = 0; i < rounds * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   int cur = 0;
   if (PIPE && (int64_t)blockIdx.x < ngroups) {
     const int j0 = load_idx(blockIdx.x);
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           }
         num = xgroup_sum(num);
         den = xgroup_sum(den);
-        const float inv = 1.f / (den + 1e-16f);
+        const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);  // (1 ulp; IEEE division costs ~10 instructions)
         const float o = num * inv;
         float g = 0.f;
         if (i < a.n && col < CH) {
@@ -808,6 +815,8 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
   static const int dbg = getenv("M3D_LFA_BWD_DBG") ? atoi(getenv("M3D_LFA_BWD_DBG")) : 0;
   a.dbg = dbg;
+  static const int stagger = getenv("M3D_LFA_BWD_STAGGER") ? atoi(getenv("M3D_LFA_BWD_STAGGER")) : 0;
+  a.stagger = stagger;
   int rc;
   switch (CH) {
     case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16); break;

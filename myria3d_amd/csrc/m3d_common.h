@@ -28,15 +28,31 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-// reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48): all lanes get the result
+// reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48): all lanes get the result.
+// gfx950 row swaps instead of __shfl_xor (which lowers to ds_bpermute_b32: an LDS-pipe round trip per step — the
+// softmax of the LFA kernels does six of them per centre): v_permlane16_swap exchanges the odd 16-lane rows of its first
+// operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the
+// second; fed the same value twice, the two results hold both members of every pair (row r, row r ^ 1) resp.
+// (half h, half h ^ 1) in every lane.
+typedef unsigned m3d_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void xgroup_pair16(float v, float& a, float& b) {
+  const m3d_u2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(t[0]); b = __uint_as_float(t[1]);
+}
+__device__ __forceinline__ void xgroup_pair32(float v, float& a, float& b) {
+  const m3d_u2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(t[0]); b = __uint_as_float(t[1]);
+}
 __device__ __forceinline__ float xgroup_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  float a, b;
+  xgroup_pair16(v, a, b); v = a + b;
+  xgroup_pair32(v, a, b); v = a + b;
   return v;
 }
 __device__ __forceinline__ float xgroup_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  float a, b;
+  xgroup_pair16(v, a, b); v = fmaxf(a, b);
+  xgroup_pair32(v, a, b); v = fmaxf(a, b);
   return v;
 }
 __device__ __forceinline__ double xgroup_sum_d(double v) {
