@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 3
+#define M3D_ABI_VERSION 4
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -118,13 +118,25 @@ int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t count, const
  * accumulate_param_grads: bit 0 = dgamma/dbeta are gradient sinks (e.g. slices of the flat gradient buffer) and are added
  * to instead of overwritten; bits 8..15 = nslots > 0 selects SLOT MODE: sums_ws is then a PRE-ZEROED fp64 table
  * [nslots][3][N] the reduce pass adds to (fp64 atomics) and the apply pass sums per column — two launches instead of
- * three (no finalize kernel); N must be a power of two. */
+ * three (no finalize kernel); N must be a power of two.  Bit 1 (slot mode, single BatchNorm only) = pass 1 ONLY: the
+ * slot table is filled and nothing else is written (dz may be NULL); pass 2 is then the prologue of m3d_bn_dgrad_f32. */
 size_t m3d_bn_bwd_workspace_bytes(int64_t M, int32_t N);
 int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
                const float* invstd, const float* z2, const float* scale2, const float* shift2, const float* mean2,
                const float* invstd2, int32_t act, float slope, int64_t M, int32_t N, double* sums_ws, float* dz,
                float* dz2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
                int32_t accumulate_param_grads, void* stream);
+/* Pass 2 of the BatchNorm backward fused into the input-gradient GEMM of the Linear in front of it (SharedMLP layer,
+ * pyg_randla_net.py:97-109: torch autograd runs BatchNorm1d.backward, then Linear.backward):
+ *   dz = scale * (dy * act'(z*scale+shift) - s1/M - (z-mean)*invstd * s2/M)   computed as the GEMM's A fragments are loaded
+ *   dx[M, Kin] = dz[M, N] w[N, Kin]     dz is also stored (the weight-gradient GEMM reads it), dbeta = s1, dgamma = s2
+ * sums = the [nslots][3][N] table left by m3d_bn_bwd(..., accumulate_param_grads = 2 | nslots << 8).
+ * flags: bit 0 = dgamma / dbeta are gradient sinks (added to); bit 8 = bf16 matrix-core operands (N % 32 == 0, N > 64).
+ * N % 4 == 0, N <= 1024, contiguous dy / z / dz; M3D_ERR_UNSUPPORTED otherwise (callers then use m3d_bn_bwd + m3d_gemm_f32). */
+int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, int32_t act, float slope, const double* sums, int32_t nslots, int64_t M,
+                     int32_t N, const float* w, int64_t ldw, int32_t Kin, float* dx, int64_t lddx, float* dz,
+                     float* dgamma, float* dbeta, int32_t flags, void* stream);
 
 /* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
 int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,

@@ -462,7 +462,10 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
                           float* dbeta2, int32_t accumulate_param_grads, void* stream) {
   if (M < 0 || N < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
-  if (!dy || !z || !scale || !shift || !mean || !invstd || !sums_ws || !dz) return M3D_ERR_INVALID;
+  // bit 1 of accumulate_param_grads: pass 1 only (slot mode; pass 2 is the A-prologue of m3d_bn_dgrad_f32)
+  const bool reduce_only = (accumulate_param_grads & 2) != 0;
+  if (reduce_only && (z2 || !((accumulate_param_grads >> 8) & 0xff))) return M3D_ERR_INVALID;
+  if (!dy || !z || !scale || !shift || !mean || !invstd || !sums_ws || (!dz && !reduce_only)) return M3D_ERR_INVALID;
   if (z2 && (!scale2 || !shift2 || !mean2 || !invstd2 || !dz2)) return M3D_ERR_INVALID;
   if (N % 4) return M3D_ERR_UNSUPPORTED;
   BnBwdArgs a;
@@ -470,7 +473,7 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   a.z2 = z2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.invstd2 = invstd2;
   a.act = act; a.slope = slope; a.M = M; a.N = N; a.sums = sums_ws;
   a.dz = dz; a.dz2 = dz2; a.dgamma = dgamma; a.dbeta = dbeta; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2;
-  // accumulate_param_grads: bit 0 = add into dgamma / dbeta; bits 8.. = slot count of a PRE-ZEROED [slots][3][N] sums_ws
+  // accumulate_param_grads: bit 0 = add into dgamma / dbeta; bit 1 = pass 1 only; bits 8.. = slot count of a PRE-ZEROED [slots][3][N] sums_ws
   // (slot mode: two launches instead of three; N must be a power of two)
   a.acc_pg = accumulate_param_grads & 1;
   a.nslots = (accumulate_param_grads >> 8) & 0xff;
@@ -484,6 +487,10 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   if (a.nslots <= 0)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)N, z2 ? 3 : 2), dim3(64), 0, st, a, (const double*)part,
                        (int)pl.blocks);
+  if (reduce_only) {
+    M3D_CHECK_LAUNCH();
+    return M3D_OK;
+  }
   int64_t total4 = M * N4;
   int64_t gy = m3d_cdiv(total4, 256 * 4);
   if (gy > 4096) gy = 4096;

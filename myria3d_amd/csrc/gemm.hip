@@ -211,7 +211,7 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && (!accumulate || stat_part || scale || shift || act)) return M3D_ERR_INVALID;
   if (k0 + k1 == 0) return M3D_ERR_INVALID;
-  GemmArgs g;
+  GemmArgs g{};
   g.a0 = a0; g.lda0 = lda0; g.a0_rows = a0_rows; g.k0 = k0; g.a1 = a1; g.lda1 = lda1; g.k1 = k1;
   g.a_cm = a_colmajor; g.b = b; g.ldb = ldb; g.b_cm = b_colmajor; g.M = M; g.N = N;
   g.bias = bias; g.scale = scale; g.shift = shift; g.act = act; g.slope = slope;
@@ -251,6 +251,31 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   else hipLaunchKernelGGL(gemm_kernel<4>, grid, block, 0, st, g);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
+}
+
+// BatchNorm backward (pass 2) fused into the dgrad GEMM of the Linear in front of it:
+//   dz = scale * (dy * act' - s1/M - zhat * s2/M)      (never read back by this launch; stored for the wgrad GEMM)
+//   dx[M, Kin] = dz[M, N] W[N, Kin]
+// `sums` is the slot table m3d_bn_bwd leaves behind in reduce-only mode.  Replaces bn_bwd_apply_kernel + the plain dgrad
+// launch for torch's BatchNorm1d / Linear backward (/root/reference/myria3d/models/modules/pyg_randla_net.py:97-109).
+extern "C" int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, int32_t act, float slope, const double* sums,
+                                int32_t nslots, int64_t M, int32_t N, const float* w, int64_t ldw, int32_t Kin,
+                                float* dx, int64_t lddx, float* dz, float* dgamma, float* dbeta, int32_t flags,
+                                void* stream) {
+  if (M < 0 || N < 0 || Kin < 0 || nslots < 1) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0 || Kin == 0) return M3D_OK;
+  if (!dy || !z || !scale || !shift || !mean || !invstd || !sums || !w || !dx || !dz) return M3D_ERR_INVALID;
+  if ((N % 4) || ((((uintptr_t)dy) | ((uintptr_t)z) | ((uintptr_t)dz)) & 15)) return M3D_ERR_UNSUPPORTED;
+  GemmArgs g{};
+  g.a0 = dy; g.lda0 = N; g.k0 = N; g.b = w; g.ldb = ldw; g.b_cm = 1; g.M = M; g.N = Kin;
+  g.c = dx; g.ldc = lddx; g.splitk = 1; g.kchunk = m3d_align((int64_t)N, BK);
+  g.bf16 = (flags >> 8) & 1;  // flags: bit 0 = add into dgamma / dbeta, bit 8 = bf16 matrix-core operands
+  g.pro_z = z; g.pro_scale = scale; g.pro_shift = shift; g.pro_mean = mean; g.pro_invstd = invstd;
+  g.pro_sums = sums; g.pro_slots = nslots; g.pro_act = act & 1; g.pro_slope = slope;
+  g.pro_dz = dz; g.pro_dgamma = dgamma; g.pro_dbeta = dbeta; g.pro_acc = flags & 1;
+  const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
+  return rc == 1 ? M3D_ERR_UNSUPPORTED : rc;
 }
 
 // per-column sum of a row-major [M, N] matrix, accumulated (atomically) into out[N]:

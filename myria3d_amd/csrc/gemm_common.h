@@ -18,6 +18,14 @@ struct GemmArgs {
   float* c; int64_t ldc; int accumulate;
   int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
   int bf16;                    // != 0: operands rounded to bf16 on load, v_mfma_f32_16x16x32_bf16 (K % 32 == 0, K > 64)
+  // BatchNorm-backward A-prologue (m3d_bn_dgrad_f32; direct kernels, dgrad pattern only).  a0 = dy and pro_z = z share
+  // the [M, k0] layout; the A operand the MFMAs see is
+  //   dz = scale * (dy * act'(z*scale + shift) - s1/M - (z - mean) * invstd * s2/M)
+  // with s1, s2 summed from the pre-reduced slot table pro_sums[pro_slots][3][k0] (m3d_bn_bwd, reduce-only mode).
+  // Column slice 0 also stores dz (the weight-gradient GEMM reads it) and workgroup (0, 0) the parameter gradients.
+  const float* pro_z; const float* pro_scale; const float* pro_shift; const float* pro_mean; const float* pro_invstd;
+  const double* pro_sums; int pro_slots; int pro_act; float pro_slope;
+  float* pro_dz; float* pro_dgamma; float* pro_dbeta; int pro_acc;
 };
 
 // gemm_direct.hip: returns M3D_OK when it handled the problem, 1 when the shape is not covered (caller falls back)

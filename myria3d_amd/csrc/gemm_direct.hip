@@ -126,6 +126,59 @@ __device__ __forceinline__ float4 w_frag(const GemmArgs& g, rsrc_t rb, int n, in
   return make_float4(t[0], t[1], t[2], t[3]);
 }
 
+// ------------------------------------------------------------------------------------------
+// BatchNorm-backward A-prologue (GemmArgs::pro_*): per-column constants in LDS, [6][KP] =
+// scale, shift, mean, invstd, s1/M, s2/M (zeros past K: padded k contribute dz = 0).
+// ------------------------------------------------------------------------------------------
+template <int KP>
+__device__ __forceinline__ void pro_setup(const GemmArgs& g, float (&cf)[6][KP]) {
+  const int K = g.k0;
+  const double invM = 1.0 / (double)g.M;
+  const int kmax = ((K + 31) & ~31) < KP ? ((K + 31) & ~31) : KP;
+  const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+  for (int k = threadIdx.x; k < kmax; k += 256) {
+    float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, m1 = 0.f, m2 = 0.f;
+    if (k < K) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int p = 0; p < g.pro_slots; ++p) {
+        s1 += g.pro_sums[((size_t)p * 3 + 0) * K + k];
+        s2 += g.pro_sums[((size_t)p * 3 + 1) * K + k];
+      }
+      sc = g.pro_scale[k]; sh = g.pro_shift[k]; mu = g.pro_mean[k]; is = g.pro_invstd[k];
+      m1 = (float)(s1 * invM); m2 = (float)(s2 * invM);
+      if (writer) {  // dbeta = s1, dgamma = s2 (what bn_bwd_apply_kernel's block 0 writes in the unfused path)
+        if (g.pro_dbeta) g.pro_dbeta[k] = (g.pro_acc ? g.pro_dbeta[k] : 0.f) + (float)s1;
+        if (g.pro_dgamma) g.pro_dgamma[k] = (g.pro_acc ? g.pro_dgamma[k] : 0.f) + (float)s2;
+      }
+    }
+    cf[0][k] = sc; cf[1][k] = sh; cf[2][k] = mu; cf[3][k] = is; cf[4][k] = m1; cf[5][k] = m2;
+  }
+  __syncthreads();
+}
+
+// dz[m][k .. k+3] from dy and z (same arithmetic as bn_bwd_apply_kernel); `store`: also write it to pro_dz
+template <int KP>
+__device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k,
+                                             const float (&cf)[6][KP], bool store) {
+  const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
+  float4 gy = ld4(ra0, f0);
+  const float4 zv = ld4(rz, f0);
+  const float4 sc = *(const float4*)&cf[0][k], mu = *(const float4*)&cf[2][k], is = *(const float4*)&cf[3][k];
+  const float4 m1 = *(const float4*)&cf[4][k], m2 = *(const float4*)&cf[5][k];
+  if (g.pro_act) {
+    const float4 sh = *(const float4*)&cf[1][k];
+    gy.x *= (zv.x * sc.x + sh.x) > 0.f ? 1.f : g.pro_slope; gy.y *= (zv.y * sc.y + sh.y) > 0.f ? 1.f : g.pro_slope;
+    gy.z *= (zv.z * sc.z + sh.z) > 0.f ? 1.f : g.pro_slope; gy.w *= (zv.w * sc.w + sh.w) > 0.f ? 1.f : g.pro_slope;
+  }
+  float4 o;
+  o.x = sc.x * (gy.x - m1.x - (zv.x - mu.x) * is.x * m2.x);
+  o.y = sc.y * (gy.y - m1.y - (zv.y - mu.y) * is.y * m2.y);
+  o.z = sc.z * (gy.z - m1.z - (zv.z - mu.z) * is.z * m2.z);
+  o.w = sc.w * (gy.w - m1.w - (zv.w - mu.w) * is.w * m2.w);
+  if (store && f0 != OOB) *(float4*)((char*)g.pro_dz + f0) = o;
+  return o;
+}
+
 // Epilogue modes (template parameter MODE): the network never needs statistics and an affine map in one launch
 //   0 PLAIN   + bias                      (dgrad, plain Linear)
 //   1 STATS   + bias, column sum/sumsq    (train-mode SharedMLP: BatchNorm statistics of the raw output)
@@ -231,12 +284,15 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
 // K <= 16*KQ <= 64, column slice 16*NT <= 64: weights in registers, rows streamed.
 // grid: (row workgroups, column slices); 4 waves per workgroup take interleaved 16-row tiles.
 // ------------------------------------------------------------------------------------------
-template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM>
+template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM, bool PRO = false>
 __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * NT;
   const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b);
+  __shared__ float cf[PRO ? 6 : 1][PRO ? 64 : 4];
+  const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
+  if constexpr (PRO) pro_setup<64>(g, (float (&)[6][64])cf);
   float4 w[NT][KQ];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -258,7 +314,10 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
     const ARow row = a_row(g, m);
     float4 a[KQ];
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
+    for (int q = 0; q < KQ; ++q) {
+      if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
+      else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
+    }
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -280,7 +339,8 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 // BF: both operands are rounded to bf16 as their fragments are assembled (8 consecutive k per lane = two 16-byte loads)
 // and the product runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (K a multiple of 32): the deep SharedMLP
 // layers in the net's "bf16" matmul precision.  Epilogue, statistics and storage stay fp32.
-template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false>
+#define PRO_KMAX 1024  // widest BatchNorm the prologue keeps in LDS (this network: 512)
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false, bool PRO = false>
 __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
   // a wave owns MTW x NTW tiles of 16x16: every A / W fragment it loads feeds NTW / MTW MFMAs (these shapes are
   // L2-bandwidth bound on operand re-reads when MTW = NTW = 1)
@@ -289,6 +349,14 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
   const int KQ = (K + 15) >> 4;
   const int nb = blockIdx.y * 16 * NTW;
   const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b);
+  __shared__ float cf[PRO ? 6 : 1][PRO ? PRO_KMAX : 4];
+  const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
+  const bool pst = blockIdx.y == 0;  // column slice 0 stores dz
+  auto afr = [&](const ARow& r, int k) -> float4 {
+    if constexpr (PRO) return a_frag_pro<PRO_KMAX>(g, ra0, rz, r, k, (const float (&)[6][PRO_KMAX])cf, pst);
+    else return a_frag<VEC, CAT>(g, ra0, ra1, r, k, K);
+  };
+  if constexpr (PRO) pro_setup<PRO_KMAX>(g, (float (&)[6][PRO_KMAX])cf);
   Epi<MODE> e[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) e[t] = epi_load<MODE>(g, nb + 16 * t + 4 * lg);
@@ -316,7 +384,7 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
         Bf16Frag a[MTW], w[NTW];
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-          const float4 lo = a_frag<VEC, CAT>(g, ra0, ra1, row[mt], k, K), hi = a_frag<VEC, CAT>(g, ra0, ra1, row[mt], k + 4, K);
+          const float4 lo = afr(row[mt], k), hi = afr(row[mt], k + 4);
           a[mt].u[0] = pack_bf16(lo.x, lo.y); a[mt].u[1] = pack_bf16(lo.z, lo.w);
           a[mt].u[2] = pack_bf16(hi.x, hi.y); a[mt].u[3] = pack_bf16(hi.z, hi.w);
         }
@@ -337,7 +405,7 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
       const int k = 16 * q + 4 * lg;
       float4 a[MTW], w[NTW];
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) a[mt] = a_frag<VEC, CAT>(g, ra0, ra1, row[mt], k, K);
+      for (int mt = 0; mt < MTW; ++mt) a[mt] = afr(row[mt], k);
 #pragma unroll
       for (int t = 0; t < NTW; ++t) w[t] = w_frag<VEC, BCM>(g, rb, nb + 16 * t + lr, k, K);
 #pragma unroll
@@ -366,7 +434,10 @@ static void launch_rs(const GemmArgs& g, int variant, dim3 grid, hipStream_t st,
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
     case 1: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 2: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    case 2:
+      if (g.pro_z) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec);
+      else hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec);
+      break;
     case 3: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
     default: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
   }
@@ -392,14 +463,20 @@ static void launch_kl(const GemmArgs& g, int variant, dim3 grid, hipStream_t st,
     switch (variant) {
       case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
       case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
-      default: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec); break;
+      default:
+        if (g.pro_z) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true, true>), grid, dim3(256), 0, st, g, cvec);
+        else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec);
+        break;
     }
     return;
   }
   switch (variant) {
     case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
     case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 2: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    case 2:
+      if (g.pro_z) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, false, true>), grid, dim3(256), 0, st, g, cvec);
+      else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec);
+      break;
     case 3: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
     default: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
   }
@@ -467,7 +544,7 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   const int K = g.k0 + g.k1;
   // debugging aid: M3D_GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
   static const int disable = getenv("M3D_GEMM_DISABLE") ? atoi(getenv("M3D_GEMM_DISABLE")) : 0;
-  if (g.a_cm || g.accumulate || g.splitk > 1) return 1;  // column-major A / split-K: the LDS-tiled kernel
+  if (g.a_cm || g.accumulate || g.splitk > 1) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // column-major A / split-K: the LDS-tiled kernel
   if ((disable & 2) && K <= 64) return 1;
   if ((disable & 4) && K > 64) return 1;
   if ((disable & 8) && g.stat_part) return 1;
@@ -486,6 +563,8 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   if (g.M * g.lda0 * 4 > lim || (g.k1 > 0 && g.M * g.lda1 * 4 > lim) || (int64_t)(g.b_cm ? K : g.N) * g.ldb * 4 > lim)
     return 1;
   const int variant = vec ? (g.b_cm ? 2 : (g.k1 > 0 ? 1 : 0)) : (g.b_cm ? 4 : 3);
+  // the BatchNorm-backward prologue exists for the vector-load dgrad kernels only (m3d_bn_dgrad_f32 checks the rest)
+  if (g.pro_z && (variant != 2 || K > PRO_KMAX || g.a0_rows || g.lda0 != K)) return M3D_ERR_UNSUPPORTED;
   const RowPlan rp = plan_rows(g.M, g.N, K, mode);
   if (rp.slices > 65535) return 1;
   dim3 grid((unsigned)rp.wgs, (unsigned)rp.slices);

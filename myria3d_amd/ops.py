@@ -6,6 +6,7 @@ device memory, to provide the stream and for autograd bookkeeping.  Reference ca
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -325,6 +326,7 @@ def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
     return scale, shift, mean, invstd
 
 
+FUSE_BN_DGRAD = os.environ.get("M3D_FUSE_BN_DGRAD", "1") != "0"  # A/B switch for bn_dgrad (see its docstring)
 BN_SLOTS = 16  # slot-mode statistics: workgroups add their column partials into this many fp64 rows
 
 
@@ -400,6 +402,36 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
     return dz, dgamma, dbeta, dz2, dgamma2, dbeta2
 
 
+def bn_dgrad_ok(N: int) -> bool:
+    """Shapes ``m3d_bn_dgrad_f32`` takes: power-of-two BatchNorm widths (slot-mode sums) up to 1024."""
+    return _pow2(N) and N <= 1024
+
+
+def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False):
+    """BatchNorm backward + input gradient of the Linear in front of it in TWO launches: the column sums
+    (``m3d_bn_bwd`` pass 1, slot mode), then ``m3d_bn_dgrad_f32``, whose A fragments are dz computed on the fly.
+    Returns ``(dx, dz, dgamma, dbeta)`` (the last two None with sinks)."""
+    M, N = z.shape
+    dev = z.device
+    dy = _chk(dy)
+    sums = arena.zeros((BN_SLOTS, 3, N), torch.float64, dev)
+    call("m3d_bn_bwd", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), None, None, None, None, None,
+         int(act), LRELU_SLOPE, M, N, _p(sums), None, None, None, None, None, None, 2 | (BN_SLOTS << 8), _st())
+    if sinks is not None:
+        dgamma, dbeta = sinks
+    else:
+        dgamma, dbeta = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    Kin = w.shape[1]
+    dz = torch.empty_like(z)
+    dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
+    call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
+         _p(sums), BN_SLOTS, M, N, _p(w), w.stride(0), Kin, _p(dx), Kin, _p(dz), _p(dgamma), _p(dbeta),
+         int(sinks is not None) | (256 if bf16 else 0), _st())
+    if sinks is not None:
+        return dx, dz, None, None
+    return dx, dz, dgamma, dbeta
+
+
 # --------------------------------------------------------------------------------------------------
 # autograd: Linear (fc0, fc_classif: pyg_randla_net.py:42,53)
 # --------------------------------------------------------------------------------------------------
@@ -457,13 +489,20 @@ class SharedLayerTrainFn(torch.autograd.Function):
     def backward(ctx, dy):
         x0, x1, w, z, scale, shift, mean, invstd, rows = ctx.saved_tensors
         sk = ctx.sinks
-        dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act,
-                                            sinks=(sk[2], sk[3]) if sk else None)
         k0 = x0.shape[1]
         k1 = x1.shape[1] if x1 is not None else 0
         dx0 = dx1 = None
-        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dxc = linear_dgrad(dz, w, ctx.bf16)
+        want_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
+        dxc = None
+        if want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1]):
+            dxc, dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
+                                              sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16)
+        else:
+            dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act,
+                                                sinks=(sk[2], sk[3]) if sk else None)
+        if want_dx:
+            if dxc is None:
+                dxc = linear_dgrad(dz, w, ctx.bf16)
             if ctx.needs_input_grad[0]:
                 dx0 = dxc[:, :k0]
                 if rows is not None:

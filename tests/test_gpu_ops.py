@@ -164,7 +164,9 @@ def _cpu_layer(x, w, b, gamma, beta, act):
     return (torch.nn.functional.leaky_relu(y, 0.2) if act else y), lin, bn
 
 
-@pytest.mark.parametrize("M,K,N,act", [(1000, 32, 32, True), (517, 64, 128, False), (3, 512, 512, True)])
+@pytest.mark.parametrize("M,K,N,act", [(1000, 32, 32, True), (517, 64, 128, False), (3, 512, 512, True),
+                                        (20011, 64, 64, True), (3333, 128, 16, True), (801, 16, 256, False),
+                                        (1000, 24, 40, True)])
 def test_shared_layer_train_fwd_bwd(device, M, K, N, act):
     from myria3d_amd import ops
 
@@ -195,6 +197,38 @@ def test_shared_layer_train_fwd_bwd(device, M, K, N, act):
     _close("layer.dgamma", bn.weight.grad, bn_ref.weight.grad, 1e-3 * s, 1e-4 * s)
     _close("layer.dbeta", bn.bias.grad, bn_ref.bias.grad, 1e-3 * s, 1e-4 * s)
     _close("layer.dbias", bg.grad, lin.bias.grad, 0, 1e-3)  # analytically zero
+
+
+@pytest.mark.parametrize("M,K,N,act,bf16", [(20011, 8, 8, True, False), (5000, 32, 16, False, False),
+                                             (4099, 64, 32, True, False), (12800, 32, 64, True, False),
+                                             (3200, 256, 128, True, False), (801, 96, 512, True, False),
+                                             (3200, 256, 128, True, True), (37, 512, 256, False, True)])
+def test_bn_dgrad_fused_matches_the_two_pass_backward(device, M, K, N, act, bf16):
+    """m3d_bn_dgrad_f32 (BatchNorm backward as the A-prologue of the dgrad GEMM) against m3d_bn_bwd + m3d_gemm_f32: same
+    arithmetic per element, so dz / dgamma / dbeta agree to rounding of the fp64 slot sums and dx to fp32 GEMM order."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M + N)
+    x = torch.from_numpy(rs.uniform(-1, 1, (M, K)).astype(np.float32)).to(device)
+    w = torch.from_numpy((rs.uniform(-1, 1, (N, K)) / np.sqrt(K)).astype(np.float32)).to(device)
+    b = torch.zeros(N, device=device)
+    gy = torch.from_numpy(rs.uniform(-1, 1, (M, N)).astype(np.float32)).to(device)
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_BN_DGRAD = fused
+        try:
+            bn = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, N)), bn.bias.copy_(torch.linspace(-0.3, 0.3, N))
+            xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            y = ops.SharedLayerTrainFn.apply(xg, None, wg, b, bn.weight, bn.bias, bn, act, None, None, bf16)
+            y.backward(gy)
+            res[fused] = (xg.grad.clone(), wg.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        finally:
+            ops.FUSE_BN_DGRAD = True
+    tol = 3e-2 if bf16 else 2e-5
+    for name, a, r in zip(("dx", "dW", "dgamma", "dbeta"), res[True], res[False]):
+        _relclose(f"bn_dgrad.{name}", a, r, tol)
 
 
 def test_residual_tail_train(device):
