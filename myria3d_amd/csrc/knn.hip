@@ -274,6 +274,17 @@ __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float
   return ab + c;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 dist2_exact_pk(f32x2 qx, f32x2 qy, f32x2 qz, f32x2 x, f32x2 y, f32x2 z) {
+#pragma clang fp contract(off)
+  f32x2 dx = x - qx, dy = y - qy, dz = z - qz;
+  f32x2 a = dx * dx;
+  f32x2 b = dy * dy;
+  f32x2 c = dz * dz;
+  f32x2 ab = a + b;
+  return ab + c;
+}
+
 template <int KMAX, class KP>
 __device__ __forceinline__ void scan_range(typename KP::T (&best)[KMAX], const float4* __restrict__ sorted, int p0,
                                            int p1, float qx, float qy, float qz) {
@@ -575,6 +586,302 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// self-query, wavefront-cooperative (queries = the sources, in their own cell-sorted order)
+//
+// Same keys, same total order, same termination rule => bit-identical tables; different data path.  The per-lane ring
+// walks above are memory-latency bound (profiles/r02c_*: a wavefront waits on memory for half of its ~100 us life: 64
+// lanes each gather their own 16-byte records through ~10-15 dependent round trips).  But the 64 queries of a wavefront
+// are CONSECUTIVE in cell-sorted order, i.e. they sit in a handful of adjacent cells of one grid row, and their 3 x 3
+// neighbourhoods are nearly the same cells.  So the wavefront walks ONE block: the union rectangle of its lanes' rings.
+// The cells a ring adds are a few contiguous runs of the sorted array; a run is fetched with coalesced 1-KB loads
+// (lane i takes record i) into LDS, and every lane scans the staged records with broadcast LDS reads: no divergence,
+// no per-lane gathers, a global round trip per 64 candidates of the whole wavefront (prefetched one chunk ahead).
+// A lane stops when its k-th distance is inside the explored rectangle (which contains its own ring block, so the
+// bound is at least the per-lane one); the wavefront stops when all of its lanes have.  Lanes of a wavefront that lie
+// in different grid rows (row wrap, cloud boundary) are handled as successive segments.
+// ------------------------------------------------------------------------------------------
+#ifndef KNNC_MINW
+#define KNNC_MINW 4
+#endif
+#ifdef KNNC_STATS  // instrumented build (tools/build_variant.sh ... -DKNNC_STATS): per-launch totals, read by m3d_knn_debug_stats
+__device__ unsigned long long knnc_stats[8];  // waves, segments, rings, chunks, candidates (per wave), chain trips, appends (per lane), max ring
+#define KSTAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&knnc_stats[i], (unsigned long long)(v)); } while (0)
+extern "C" int m3d_knn_debug_stats(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(knnc_stats), sizeof(knnc_stats)) != hipSuccess) return M3D_ERR_LAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(knnc_stats), z, sizeof(z)) != hipSuccess) return M3D_ERR_LAUNCH; }
+  return M3D_OK;
+}
+#else
+#define KSTAT(i, v) do { } while (0)
+#endif
+template <int KMAX, class KP, int QD>
+__global__ __launch_bounds__(64, (KMAX <= 16 ? KNNC_MINW : (KMAX <= 32 ? 2 : 1))) void knn_query_coop_kernel(KnnWs w, const int64_t* __restrict__ ptr, int B,
+                                                                      int64_t n_qry, int k, int* __restrict__ idx_out,
+                                                                      float* __restrict__ d2_out, int flags) {
+  const int sorted_io = flags & 1;
+  typedef typename KP::T KT;
+  __shared__ KT queue[QD][64];
+  __shared__ float chunk[2][4][64 + 4];  // staged records, one array per component: pairs of candidates feed packed fp32 ops
+  const int lane = threadIdx.x;
+  int64_t wg = blockIdx.x;
+  {  // XCD-aware order (see knn_query_queue_kernel)
+    const int64_t nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+    const int64_t xcd = wg & 7, i8 = wg >> 3;
+    wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
+  }
+  const int64_t t = wg * 64 + lane;
+  const bool valid = t < n_qry;
+  int b = 0;
+  {
+    int lo = 0, hi = B;
+    const int64_t tc = valid ? t : n_qry - 1;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (ptr[mid] <= tc) lo = mid; else hi = mid;
+    }
+    b = lo;
+  }
+  const float4 q = w.sorted[valid ? t : n_qry - 1];
+  const float qx = q.x, qy = q.y, qz = q.z;
+  const int64_t orow = sorted_io ? t : (int64_t)__float_as_int(q.w);
+  int cx, cy;
+  {
+    const float* gp = w.gridp + (size_t)b * GP_STRIDE;
+    const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6];
+    cx = min(Gx - 1, max(0, (int)((qx - gp[0]) * gp[2])));
+    cy = min(Gy - 1, max(0, (int)((qy - gp[1]) * gp[2])));
+  }
+  KT best[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
+  int cnt = 0;
+  float kth = __builtin_inff();
+  // Admission threshold before the list is full.  All lanes scan the staged records in the SAME order, so a lane at
+  // the far end of a row would otherwise meet its candidates in order of decreasing distance and insert every one of
+  // them.  Any k distinct points bound the k-th distance from above: take the k records around the query in the
+  // cell-sorted array (own cell and its row neighbours), thr0 = their largest d2.  Records with d2 > thr0 cannot be
+  // among the k nearest (ties pass), so the result is unchanged; termination still uses the exact list (kth).
+  float thr0 = __builtin_inff();
+  {
+    const int64_t c0 = ptr[b], c1 = ptr[b + 1];
+    if (valid && c1 - c0 >= k) {
+      int64_t s0 = t - (k >> 1);
+      s0 = s0 < c0 ? c0 : s0;
+      s0 = s0 > c1 - k ? c1 - k : s0;
+      float4 r[KMAX];
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) r[j] = w.sorted[s0 + (j < k ? j : 0)];
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) m = fmaxf(m, dist2_exact(qx, qy, qz, r[j]));
+      thr0 = m;
+    }
+  }
+
+  auto chain = [&](KT key) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if constexpr (KP::IS_F64) {
+        KT hi2;
+        asm("v_max_f64 %0, %1, %2" : "=&v"(hi2) : "v"(best[j]), "v"(key));
+        asm("v_min_f64 %0, %0, %1" : "+v"(best[j]) : "v"(key));
+        key = hi2;
+      } else {
+        const KT cur = best[j];
+        const bool lt = key < cur;
+        best[j] = lt ? key : cur;
+        key = lt ? cur : key;
+      }
+    }
+  };
+  float thr = thr0;  // = min(thr0, kth)
+  auto drain = [&]() {
+#ifdef KNNC_STATS
+    { int mx = cnt;
+      for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+      KSTAT(5, mx);
+      int sm = cnt;
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      KSTAT(6, sm); }
+#endif
+    for (int i = 0; i < cnt; i += KNNQ_DRAIN) {
+      KT key[KNNQ_DRAIN];
+#pragma unroll
+      for (int u = 0; u < KNNQ_DRAIN; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
+#pragma unroll
+      for (int u = 0; u < KNNQ_DRAIN; ++u) chain(u == 0 || i + u < cnt ? key[u] : KP::empty());
+    }
+    cnt = 0;
+    unsigned hw = KP::hi32(best[KMAX - 1]);
+    if (k < KMAX) {
+      hw = 0u;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const unsigned v = j < k ? KP::hi32(best[j]) : 0u;
+        hw = v > hw ? v : hw;
+      }
+    }
+    kth = hw == KP::hi32(KP::empty()) ? __builtin_inff() : __uint_as_float(KP::d2bits_of_hi(hw));
+    thr = fminf(thr0, kth);
+  };
+
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+  KSTAT(0, 1);
+  while (todo != 0ull) {
+    KSTAT(1, 1);
+    // ---- next segment: the pending lanes that share the leader's cloud and grid row
+    const int lead = __builtin_ctzll(todo);
+    const int b0 = __builtin_amdgcn_readlane(b, lead), cy0 = __builtin_amdgcn_readlane(cy, lead);
+    const bool mine = valid && b == b0 && cy == cy0 && ((todo >> lane) & 1ull);
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    const float* gp = w.gridp + (size_t)b0 * GP_STRIDE;
+    const float gx0 = gp[0], gy0 = gp[1], h = gp[3], eps = gp[4];
+    const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6];
+    const int* cs = w.cell_start + (size_t)b0 * (CELLS_MAX + 1);
+    const float4* sorted = w.sorted + ptr[b0];
+    int cxmin = mine ? cx : 0x7fffffff, cxmax = mine ? cx : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cxmin = min(cxmin, __shfl_xor(cxmin, o, 64));
+      cxmax = max(cxmax, __shfl_xor(cxmax, o, 64));
+    }
+    cxmin = __builtin_amdgcn_readfirstlane(cxmin);
+    cxmax = __builtin_amdgcn_readfirstlane(cxmax);
+    bool act = mine;  // lanes of this segment whose search is still open
+    for (int R = 0;; ++R) {
+      KSTAT(2, 1);
+      const int xa = max(cxmin - R, 0), xb = min(cxmax + R, Gx - 1);
+      const int ya = cy0 - R, yb = cy0 + R;
+      // ---- the runs of the sorted array this ring adds, one per lane: R = 0: the row segment itself; R >= 1: the
+      // full-width rows ya and yb, then the two single cells left and right of every row in between
+      const int nruns = R == 0 ? 1 : 4 * R;
+      for (int i0 = 0; i0 < nruns; i0 += 64) {
+        const int i = i0 + lane;
+        int yy = cy0, x0 = xa, x1 = xb;
+        bool rok = i < nruns;
+        if (R > 0) {
+          if (i < 2) {
+            yy = i == 0 ? ya : yb;
+          } else {
+            const int j = (i - 2) >> 1;
+            yy = ya + 1 + j;
+            x0 = x1 = ((i & 1) == 0) ? cxmin - R : cxmax + R;
+          }
+        }
+        rok = rok && yy >= 0 && yy < Gy && x0 >= 0 && x1 < Gx && x0 <= x1;
+        int p0 = 0, p1 = 0;
+        if (rok) { p0 = cs[yy * Gx + x0]; p1 = cs[yy * Gx + x1 + 1]; }
+        // chunk list: run r owns chunks [pre_r, pre_r + nch_r)
+        const int nch = (p1 - p0 + 63) >> 6;
+        int incl = nch;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += v;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - nch;
+        auto chunk_of = [&](int c, int& base, int& count) {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(incl > c);
+          const int r = __builtin_ctzll(m);
+          const int rp0 = __builtin_amdgcn_readlane(p0, r), rp1 = __builtin_amdgcn_readlane(p1, r);
+          base = rp0 + ((c - __builtin_amdgcn_readlane(excl, r)) << 6);
+          count = min(64, rp1 - base);
+        };
+        int nbase = 0, ncount = 0;
+        float4 nrec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (total > 0) {
+          chunk_of(0, nbase, ncount);
+          nrec = sorted[nbase + min(lane, ncount - 1)];
+        }
+        for (int c = 0; c < total; ++c) {
+          const int count = ncount;
+          KSTAT(3, 1); KSTAT(4, count);
+          chunk[c & 1][0][lane] = nrec.x; chunk[c & 1][1][lane] = nrec.y;
+          chunk[c & 1][2][lane] = nrec.z; chunk[c & 1][3][lane] = nrec.w;
+          if (c + 1 < total) {  // next chunk's records: in flight while this one is scanned
+            chunk_of(c + 1, nbase, ncount);
+            nrec = sorted[nbase + min(lane, ncount - 1)];
+          }
+          __syncthreads();
+          const float(*ch)[64 + 4] = chunk[c & 1];
+          const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+          for (int j = 0; j < count; j += 4) {
+            // 4 candidates per trip as 2 pairs (broadcast 8-byte LDS reads); the distance arithmetic is the packed
+            // (v_pk_*_f32) form of dist2_exact: same IEEE operations per element, same bits
+            f32x2 X[2], Y[2], Z[2], W[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              X[u] = *(const f32x2*)&ch[0][j + 2 * u]; Y[u] = *(const f32x2*)&ch[1][j + 2 * u];
+              Z[u] = *(const f32x2*)&ch[2][j + 2 * u]; W[u] = *(const f32x2*)&ch[3][j + 2 * u];
+            }
+            if (__builtin_amdgcn_ballot_w64(cnt > QD - 4) != 0) drain();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const f32x2 d = dist2_exact_pk(q2x, q2y, q2z, X[u], Y[u], Z[u]);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                // branch-free append: the slot is always written, the count only moves for admitted candidates
+                queue[cnt][lane] = KP::make(d[e], __float_as_int(W[u][e]));
+                cnt += (act && j + 2 * u + e < count && !(d[e] > thr)) ? 1 : 0;
+              }
+            }
+          }
+        }
+      }
+      drain();
+      const bool covers = xa == 0 && xb == Gx - 1 && ya <= 0 && yb >= Gy - 1;
+      if (covers) break;
+      // distance from the query to the nearest side of the explored rectangle that is not a border of the grid
+      float bound = 3.4e38f;
+      if (xa > 0) bound = fminf(bound, qx - (gx0 + (float)xa * h));
+      if (xb < Gx - 1) bound = fminf(bound, (gx0 + (float)(xb + 1) * h) - qx);
+      if (ya > 0) bound = fminf(bound, qy - (gy0 + (float)ya * h));
+      if (yb < Gy - 1) bound = fminf(bound, (gy0 + (float)(yb + 1) * h) - qy);
+      bound = fmaxf(bound - eps, 0.f);
+      if (kth <= bound * bound) act = false;
+      if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+    }
+  }
+  if (!valid) return;
+  int ids[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) ids[j] = KP::is_empty(best[j]) ? -1 : KP::row(best[j]);
+  if (sorted_io) {
+    int tr[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) tr[j] = w.inv[ids[j] < 0 ? 0 : ids[j]];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? -1 : tr[j];
+  }
+  int* io = idx_out + orow * k;
+  if (k == KMAX && KMAX % 4 == 0 && (flags & 2)) {
+#pragma unroll
+    for (int j = 0; j < KMAX; j += 4) *(int4*)(io + j) = make_int4(ids[j], ids[j + 1], ids[j + 2], ids[j + 3]);
+    if (d2_out) {
+      float* dq = d2_out + orow * k;
+#pragma unroll
+      for (int j = 0; j < KMAX; j += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = KP::is_empty(best[j + u]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j + u]));
+        *(float4*)(dq + j) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < k) {
+        io[j] = ids[j];
+        if (d2_out)
+          d2_out[orow * k + j] = KP::is_empty(best[j]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j]));
+      }
+    }
+  }
+}
+
 extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int64_t* ptr_src, int32_t num_clouds,
                              int64_t n_src, void* ws, void* stream) {
   if (!ptr_src || !ws || num_clouds < 0 || n_src < 0 || pos_stride < 3) return M3D_ERR_INVALID;
@@ -628,6 +935,16 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
 #define LAUNCH_Q(KM, KP)                                                                                          \
   hipLaunchKernelGGL((knn_query_queue_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
                      w, ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags)
+  // M3D_KNN_COOP=1 (read at every call; default off): the wavefront-cooperative kernel for self-queries (queries = the
+  // sources in their own cell-sorted order: knn_graph(loop=True) of every level) with k > 4.  Bit-identical tables;
+  // measured 180-196 us against 188-193 us at level 1 and 20-50 % slower at the deeper levels (profiles/r02s_*), so it
+  // is an opt-in cross-check, not the default
+  const char* coop_s = getenv("M3D_KNN_COOP");
+  const bool self = qry_ws == ws && ptr_qry == ptr_src && n_qry == n_src && !pos_qry;
+  const bool use_coop = self && coop_s && atoi(coop_s) != 0;
+#define LAUNCH_C(KM, KP)                                                                                              \
+  hipLaunchKernelGGL((knn_query_coop_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
+                     w, ptr_src, num_clouds, n_qry, k, idx_out, d2_out, qflags)
 #define LAUNCH(KM)                       \
   do {                                   \
     if (f64_keys) LAUNCH_KP(KM, KeyF64); \
@@ -635,7 +952,10 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   } while (0)
 #define LAUNCHQ(KM)                      \
   do {                                   \
-    if (!use_queue) LAUNCH(KM);          \
+    if (use_coop) {                      \
+      if (f64_keys) LAUNCH_C(KM, KeyF64); \
+      else LAUNCH_C(KM, KeyU64);         \
+    } else if (!use_queue) LAUNCH(KM);   \
     else if (f64_keys) LAUNCH_Q(KM, KeyF64); \
     else LAUNCH_Q(KM, KeyU64);           \
   } while (0)
@@ -648,6 +968,7 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
 #undef LAUNCH
 #undef LAUNCHQ
 #undef LAUNCH_Q
+#undef LAUNCH_C
 #undef LAUNCH_KP
   M3D_CHECK_LAUNCH();
   return M3D_OK;

@@ -60,6 +60,24 @@ def test_knn_lidar_tile_and_duplicates(device):
     _knn_case(device, line, torch.tensor([0, 300]), 16)
 
 
+def test_knn_cooperative_self_query_kernel_is_bit_identical(device, monkeypatch):
+    """M3D_KNN_COOP=1: the wavefront-cooperative self-query kernel (union-rectangle ring walk, LDS-staged records) must
+    give the oracle's table bit for bit, like the per-lane kernels: ragged clouds, row wraps, duplicates, K = 8/16/32."""
+    from oracle.randla_oracle import synthetic_batch
+
+    monkeypatch.setenv("M3D_KNN_COOP", "1")
+    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32)):
+        _, pos, _, ptr = rand_batch(sizes, seed=len(sizes) + k)
+        _knn_case(device, pos, ptr, k)
+    _, pos, _, ptr, _ = synthetic_batch([2500, 1800, 4000])
+    _knn_case(device, pos, ptr, 16)
+    pos_dup = torch.cat([pos[:40].repeat(8, 1), pos[:200]])
+    _knn_case(device, pos_dup, torch.tensor([0, pos_dup.shape[0]]), 16)
+    line = torch.zeros(300, 3)
+    line[:, 2] = torch.linspace(0, 1, 300)
+    _knn_case(device, line, torch.tensor([0, 300]), 16)
+
+
 def test_knn_k32_and_cross_set(device):
     from myria3d_amd import ops
     from oracle.randla_oracle import knn_exact
