@@ -52,6 +52,11 @@ def parse():
                          "step ahead (HipRandLANet.prefetch_geometry; bit-identical results either way)")
     ap.add_argument("--lookahead", dest="lookahead", action="store_true", help="(default)")
     ap.set_defaults(lookahead=True)
+    ap.add_argument("--lookahead-mode", choices=("dual", "single"), default="single",
+                    help="hipGraph launch of the lookahead: 'single' = one graph holding the step and the next step's "
+                         "position-only branch (default: 5.75 ms); 'dual' = two graphs replayed on two streams, which really "
+                         "overlap — and compete: 6.1-6.5 ms per training step, 1.17 vs 1.22 ms per eval forward "
+                         "(profiles/r02v_*, r02x_*)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
@@ -468,10 +473,9 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
 
     look = args.lookahead
 
-    def fwd_bwd():
+    def fwd_bwd(prefetch=look):
         net.train()
-        if look:  # the NEXT step's kNN tables / decimation, enqueued stage by stage BETWEEN the blocks of this forward:
-            # the two chains share the head of the step (and of the captured graph's submission order)
+        if prefetch:  # the NEXT step's kNN tables / decimation, enqueued stage by stage BETWEEN the blocks of this forward
             net.prefetch_geometry(pos, ptr, plan, train=True, interleave=True)
         out = net(x, pos, None, ptr, plan=plan)  # (lookahead: consumes the tables the previous step prefetched)
         loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
@@ -481,18 +485,59 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
         if look:
             net.join_geometry()
 
-    def train_step():
-        fwd_bwd()
+    def train_step(prefetch=look):
+        fwd_bwd(prefetch)
         opt.step()  # (N>1: ONE flat-gradient all-reduce over RCCL) + Adam + gradient clear
 
-    def fwd_step():
+    def fwd_step(prefetch=look):
         net.eval()
         with torch.no_grad():
-            if look:
+            if prefetch:
                 net.prefetch_geometry(pos, ptr, plan, train=False, interleave=True)
             net(x, pos, None, ptr, plan=plan)
             if look:
                 net.join_geometry()
+
+    def geo_step(train):
+        """The position-only work of the NEXT step as a stand-alone unit (its own hipGraph in the dual-graph launch)."""
+        net.prefetch_geometry(pos, ptr, plan, train=train)
+        net.join_geometry()
+
+    def capture_dual(body, train):
+        """Two hipGraphs per buffer set instead of one: B = the step (consumes the tables prefetched one step earlier), A =
+        the position-only work for the step after it.  Replayed on two streams they run CONCURRENTLY — inside one graph
+        the executor submits the position-only branch first and the feature chain starts ~0.8 ms into every replay
+        (profiles/r02u_step_timeline.csv).  Ordering between the streams: B_i waits for A_{i-1} (its tables), A_i waits
+        for B_{i-1} (the last reader of the buffer set A_i rewrites)."""
+        gB, gA = [], []
+        for _ in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                body()
+            gB.append(g)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                geo_step(train)
+            gA.append(g)
+        sA = torch.cuda.Stream()
+        evA, evB = torch.cuda.Event(), torch.cuda.Event()
+        evA.record()
+        evB.record()
+        turn = [0]
+
+        def step():
+            k = turn[0] & 1
+            cur = torch.cuda.current_stream()
+            cur.wait_event(evA)
+            gB[k].replay()
+            sA.wait_event(evB)
+            with torch.cuda.stream(sA):
+                gA[k].replay()
+                evA.record(sA)
+            evB.record(cur)
+            turn[0] += 1
+
+        return step
 
     launch = "eager"
     step_fn, fwd_fn = train_step, fwd_step
@@ -518,22 +563,30 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                 train_step()
                 torch.cuda.synchronize()
             # with the lookahead the prefetched tables live in two buffer sets used in turn: one captured step per set
-            g_train = []
-            for _ in range(2 if look else 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
-                    if world == 1:
-                        train_step()  # no collective: the optimizer launches are part of the graph
-                    else:
-                        fwd_bwd()
-                g_train.append(g)
-            turn = [0]
+            if look and args.lookahead_mode == "dual":
+                dual = capture_dual((lambda: train_step(False)) if world == 1 else (lambda: fwd_bwd(False)), True)
 
-            def graph_step():
-                g_train[turn[0] % len(g_train)].replay()
-                turn[0] += 1
-                if world > 1:
-                    opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
+                def graph_step():
+                    dual()
+                    if world > 1:
+                        opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
+            else:
+                g_train = []
+                for _ in range(2 if look else 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
+                        if world == 1:
+                            train_step()  # no collective: the optimizer launches are part of the graph
+                        else:
+                            fwd_bwd()
+                    g_train.append(g)
+                turn = [0]
+
+                def graph_step():
+                    g_train[turn[0] % len(g_train)].replay()
+                    turn[0] += 1
+                    if world > 1:
+                        opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
 
             step_fn, launch = graph_step, "hipgraph"
         except Exception as e:  # capture is an optimisation, never a requirement
@@ -552,17 +605,20 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     if launch == "hipgraph":
         try:
             torch.cuda.synchronize()
-            g_fwd = []
-            for _ in range(2 if look else 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    fwd_step()
-                g_fwd.append(g)
-            fturn = [0]
+            if look and args.lookahead_mode == "dual":
+                fwd_graph = capture_dual(lambda: fwd_step(False), False)
+            else:
+                g_fwd = []
+                for _ in range(2 if look else 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        fwd_step()
+                    g_fwd.append(g)
+                fturn = [0]
 
-            def fwd_graph():
-                g_fwd[fturn[0] % len(g_fwd)].replay()
-                fturn[0] += 1
+                def fwd_graph():
+                    g_fwd[fturn[0] % len(g_fwd)].replay()
+                    fturn[0] += 1
 
             fwd_fn = fwd_graph
         except Exception as e:
@@ -591,7 +647,7 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                                f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, fp32)",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
                    "collective": "one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" if world > 1 else "none (1 rank)",
-                   "launch": launch, **({"geometry_lookahead": True} if look else {})},
+                   "launch": launch, **({"geometry_lookahead": args.lookahead_mode} if look else {})},
         "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
                      "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad"},
     }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 4
+#define M3D_ABI_VERSION 5
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -56,6 +56,14 @@ int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t
                   int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
                   int32_t sorted_io, int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */,
                   void* stream);
+/* Up to 8 independent queries in ONE launch: job j searches the grid ws[j] (n_src[j] sources) for the cell-sorted queries
+ * of qry_ws[j] (n_qry[j]; may be ws[j] itself) and writes idx_out[j][n_qry[j], k].  Same k, num_clouds and sorted_io
+ * for every job, no distances, bit-identical to njobs calls of m3d_knn_query.  The pointer arrays are HOST arrays (read
+ * during the call).  Used for the four K-NN tables / the four decoder 1-NN tables of a forward pass
+ * (pyg_randla_net.py:180, :250), whose deep-level launches are otherwise latency-bound one after the other. */
+int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const int64_t* const* ptr_src, const int64_t* n_src,
+                        const void* const* qry_ws, const int64_t* const* ptr_qry, const int64_t* n_qry,
+                        int32_t num_clouds, int32_t k, int32_t sorted_io, int32_t* const* idx_out, void* stream);
 
 /* ---- SharedMLP GEMM -------------------------------------------------------------------------------------
  * Linear of PyG MLP / torch.nn.Linear (pyg_randla_net.py:42,53,97-109), forward, dgrad and wgrad:
@@ -155,6 +163,10 @@ int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out, int32_t n
 /* first/second moments of the 10-vector r over all valid edges: mom65 = [sum r (10) | upper triangle of
  * sum r r^T (55)], fp64, zeroed inside */
 int m3d_lfa_moments(const float* pos4, const int32_t* idx, int64_t n, int32_t K, double* mom65, void* stream);
+/* m3d_lfa_moments for up to 8 levels in one launch: job j writes mom[j * mom_stride .. + 65) (mom_stride >= 65 doubles;
+ * the whole [njobs][mom_stride] block is zeroed by the call); host pointer arrays. */
+int m3d_lfa_moments_batch(int32_t njobs, const float* const* pos4, const int32_t* const* idx, const int64_t* n, int32_t K,
+                          double* mom, int64_t mom_stride, void* stream);
 /* folds mlp_encoder's BatchNorm into its Linear.  mom65 != NULL: train mode (batch statistics over
  * num_edges edges, running stats updated); mom65 == NULL: eval mode (running stats). */
 int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, const float* w /* [D,10] */, const float* b,

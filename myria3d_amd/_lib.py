@@ -45,6 +45,8 @@ SIGNATURES = {
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
     "m3d_decimation_indices": (_i32, [_p, _p, _i32, _p, _u32, _p, _i64, _p]),
     "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    "m3d_lfa_moments_batch": (_i32, [_i32, _p, _p, _p, _i32, _p, _i64, _p]),
+    "m3d_knn_query_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_lfa_pack_att": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_prepare": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _i32,
@@ -73,7 +75,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 4  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 5  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

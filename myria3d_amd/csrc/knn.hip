@@ -308,13 +308,12 @@ __device__ __forceinline__ void scan_range(typename KP::T (&best)[KMAX], const f
 // qmode 0: queries are pos_qry rows (row index = output row)
 // qmode 1: queries are the float4 records of qsorted (output row = record.w) — cell-sorted, wave-coherent
 template <int KMAX, class KP>
-__global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w, const int64_t* __restrict__ ptr_src, int B,
-                                                        const float* __restrict__ pos_qry, int qstride,
-                                                        const float4* __restrict__ qsorted,
-                                                        const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
-                                                        int* __restrict__ idx_out, float* __restrict__ d2_out,
-                                                        int sorted_io) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void knn_query_direct_body(const KnnWs& w, const int64_t* __restrict__ ptr_src, int B,
+                                                      const float* __restrict__ pos_qry, int qstride,
+                                                      const float4* __restrict__ qsorted,
+                                                      const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
+                                                      int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                      int sorted_io, int64_t t) {
   if (t >= n_qry) return;
   // cloud of this query: largest b with ptr_qry[b] <= t
   int lo = 0, hi = B;
@@ -387,6 +386,47 @@ __global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w,
   }
 }
 
+template <int KMAX, class KP>
+__global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w, const int64_t* __restrict__ ptr_src, int B,
+                                                        const float* __restrict__ pos_qry, int qstride,
+                                                        const float4* __restrict__ qsorted,
+                                                        const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
+                                                        int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                        int sorted_io) {
+  knn_query_direct_body<KMAX, KP>(w, ptr_src, B, pos_qry, qstride, qsorted, ptr_qry, n_qry, k, idx_out, d2_out, sorted_io,
+                                  (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Several independent query problems in ONE launch (m3d_knn_query_batch): the K-NN tables of the four resolution levels
+// (or the decoder's four 1-NN tables) are separate launches otherwise, and the deep ones are a few wavefronts per CU
+// of pure latency (105 / 77 / 45 us for 51 200 / 12 800 / 3 200 queries) that run one after the other while the
+// level-1 launch ends on its slowest wavefronts with most SIMDs idle.  Workgroup b belongs to job j with
+// wg_start[j] <= b < wg_start[j + 1]; cell-sorted queries only (qry_ws), no distances.
+#define KNN_BATCH_MAX 8
+struct KnnBatch {
+  KnnWs w[KNN_BATCH_MAX];
+  const int64_t* ptr_src[KNN_BATCH_MAX];
+  const float4* qsorted[KNN_BATCH_MAX];
+  const int64_t* ptr_qry[KNN_BATCH_MAX];
+  int64_t n_qry[KNN_BATCH_MAX];
+  int* idx_out[KNN_BATCH_MAX];
+  unsigned wg_start[KNN_BATCH_MAX + 1];
+  int njobs;
+};
+__device__ __forceinline__ int knn_batch_job(const KnnBatch& a) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < KNN_BATCH_MAX; ++i) j += (i < a.njobs && blockIdx.x >= a.wg_start[i]) ? 1 : 0;
+  return j;
+}
+template <int KMAX, class KP>
+__global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_batch_kernel(KnnBatch a, int B, int k, int sorted_io) {
+  const int j = knn_batch_job(a);
+  knn_query_direct_body<KMAX, KP>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
+                                  a.idx_out[j], nullptr, sorted_io,
+                                  (int64_t)(blockIdx.x - a.wg_start[j]) * 256 + threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------
 // query, deferred insertion (the default for k > 4)
 //
@@ -402,10 +442,10 @@ __global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w,
 // barriers, the hardware balances 3 200 independent wavefronts over the CUs.
 // ------------------------------------------------------------------------------------------
 template <int KMAX, class KP, int QD>
-__global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
-    KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float* __restrict__ pos_qry, int qstride,
+__device__ __forceinline__ void knn_query_queue_body(
+    const KnnWs& w, const int64_t* __restrict__ ptr_src, int B, const float* __restrict__ pos_qry, int qstride,
     const float4* __restrict__ qsorted, const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
-    int* __restrict__ idx_out, float* __restrict__ d2_out, int flags) {
+    int* __restrict__ idx_out, float* __restrict__ d2_out, int flags, int64_t wg_in, int64_t nblk_in) {
   const int sorted_io = flags & 1;  // bit 1: idx_out / d2_out are 16-byte aligned (vector stores allowed)
   typedef typename KP::T KT;
   __shared__ KT queue[QD][64];
@@ -414,9 +454,9 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
   // only), so workgroup b takes the queries of chunk (b % 8): every XCD then walks one contiguous eighth of the
   // (cell-sorted) queries — two whole tiles at BASELINE config 2 — and its private L2 holds just those tiles' records
   // instead of all of them (memory waits were ~50 % of the wave cycles with the plain order, profiles/r02c_*)
-  int64_t wg = blockIdx.x;
+  int64_t wg = wg_in;
   {
-    const int64_t nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+    const int64_t nblk = nblk_in, q8 = nblk >> 3, r8 = nblk & 7;
     const int64_t xcd = wg & 7, i8 = wg >> 3;
     wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
   }
@@ -584,6 +624,23 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
       }
     }
   }
+}
+
+template <int KMAX, class KP, int QD>
+__global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
+    KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float* __restrict__ pos_qry, int qstride,
+    const float4* __restrict__ qsorted, const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
+    int* __restrict__ idx_out, float* __restrict__ d2_out, int flags) {
+  knn_query_queue_body<KMAX, KP, QD>(w, ptr_src, B, pos_qry, qstride, qsorted, ptr_qry, n_qry, k, idx_out, d2_out, flags,
+                                     blockIdx.x, gridDim.x);
+}
+
+template <int KMAX, class KP, int QD>
+__global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_batch_kernel(KnnBatch a, int B, int k, int flags) {
+  const int j = knn_batch_job(a);
+  knn_query_queue_body<KMAX, KP, QD>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
+                                     a.idx_out[j], nullptr, flags, (int64_t)(blockIdx.x - a.wg_start[j]),
+                                     (int64_t)(a.wg_start[j + 1] - a.wg_start[j]));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -970,6 +1027,73 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
 #undef LAUNCH_Q
 #undef LAUNCH_C
 #undef LAUNCH_KP
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// the four K-NN tables of a forward pass (or its four 1-NN tables) in one launch: see KnnBatch
+extern "C" int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const int64_t* const* ptr_src,
+                                   const int64_t* n_src, const void* const* qry_ws, const int64_t* const* ptr_qry,
+                                   const int64_t* n_qry, int32_t num_clouds, int32_t k, int32_t sorted_io,
+                                   int32_t* const* idx_out, void* stream) {
+  if (njobs < 0 || njobs > KNN_BATCH_MAX) return M3D_ERR_UNSUPPORTED;
+  if (njobs == 0 || num_clouds == 0) return M3D_OK;
+  if (!ws || !ptr_src || !n_src || !qry_ws || !ptr_qry || !n_qry || !idx_out || num_clouds < 0) return M3D_ERR_INVALID;
+  if (k < 1 || k > 64) return M3D_ERR_UNSUPPORTED;
+  static const bool f64_keys = knn_f64_keys();
+  // same kernel choice for every job: deferred insertion when the largest job is big enough (see m3d_knn_query)
+  int64_t nmax = 0;
+  bool al = true;
+  for (int j = 0; j < njobs; ++j) {
+    if (n_qry[j] < 0 || n_src[j] < 0) return M3D_ERR_INVALID;
+    if (n_qry[j] > 0 && (!ws[j] || !qry_ws[j] || !ptr_src[j] || !ptr_qry[j] || !idx_out[j])) return M3D_ERR_INVALID;
+    nmax = n_qry[j] > nmax ? n_qry[j] : nmax;
+    al = al && ((((uintptr_t)idx_out[j]) & 15) == 0);
+  }
+  static const int queue_env = getenv("M3D_KNN_QUEUE") ? atoi(getenv("M3D_KNN_QUEUE")) : -1;
+  const bool use_queue = k > 4 && (queue_env < 0 ? nmax * (int64_t)k >= (1 << 20) : queue_env != 0);
+  const int per_wg = use_queue ? 64 : 256;
+  KnnBatch a;
+  a.njobs = njobs;
+  unsigned total = 0;
+  for (int j = 0; j < KNN_BATCH_MAX; ++j) {
+    a.wg_start[j] = total;
+    if (j < njobs) {
+      a.w[j] = ws_carve((void*)ws[j], num_clouds, n_src[j]);
+      a.ptr_src[j] = ptr_src[j];
+      a.qsorted[j] = ws_carve((void*)qry_ws[j], num_clouds, n_qry[j]).sorted;
+      a.ptr_qry[j] = ptr_qry[j];
+      a.n_qry[j] = n_qry[j];
+      a.idx_out[j] = idx_out[j];
+      total += (unsigned)m3d_cdiv(n_qry[j], per_wg);
+    } else {
+      a.w[j] = a.w[0]; a.ptr_src[j] = nullptr; a.qsorted[j] = nullptr; a.ptr_qry[j] = nullptr; a.n_qry[j] = 0;
+      a.idx_out[j] = nullptr;
+    }
+  }
+  a.wg_start[KNN_BATCH_MAX] = total;
+  for (int j = njobs; j < KNN_BATCH_MAX; ++j) a.wg_start[j] = total;
+  if (total == 0) return M3D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int qflags = (sorted_io ? 1 : 0) | (al ? 2 : 0);
+#define LAUNCH_BD(KM, KP) \
+  hipLaunchKernelGGL((knn_query_batch_kernel<KM, KP>), dim3(total), dim3(256), 0, st, a, num_clouds, k, sorted_io)
+#define LAUNCH_BQ(KM, KP) \
+  hipLaunchKernelGGL((knn_query_queue_batch_kernel<KM, KP, KNNQ_DEPTH>), dim3(total), dim3(64), 0, st, a, num_clouds, k, qflags)
+#define LAUNCH_B(KM)                                            \
+  do {                                                          \
+    if (use_queue) { if (f64_keys) LAUNCH_BQ(KM, KeyF64); else LAUNCH_BQ(KM, KeyU64); } \
+    else { if (f64_keys) LAUNCH_BD(KM, KeyF64); else LAUNCH_BD(KM, KeyU64); }           \
+  } while (0)
+  if (k == 1) LAUNCH_B(1);
+  else if (k <= 4) LAUNCH_B(4);
+  else if (k <= 8) LAUNCH_B(8);
+  else if (k <= 16) LAUNCH_B(16);
+  else if (k <= 32) LAUNCH_B(32);
+  else LAUNCH_B(64);
+#undef LAUNCH_B
+#undef LAUNCH_BQ
+#undef LAUNCH_BD
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

@@ -317,15 +317,14 @@ extern "C" int m3d_lfa_pack_att(const float* w, int32_t CH, float* packed, float
 // ------------------------------------------------------------------------------------------
 // moments of r over all valid edges: mom[0:10] = sum r, mom[10:65] = sum r_p r_q (p<=q, row-major upper)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lfa_moments_kernel(const float4* __restrict__ pos4,
-                                                          const int32_t* __restrict__ idx, int64_t n, int K,
-                                                          double* __restrict__ mom) {
+__device__ __forceinline__ void lfa_moments_body(const float4* __restrict__ pos4, const int32_t* __restrict__ idx,
+                                                 int64_t n, int K, double* __restrict__ mom, int64_t blk, int64_t nblk) {
   __shared__ double red[4][65];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   double acc[65];
 #pragma unroll
   for (int q = 0; q < 65; ++q) acc[q] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = blk * 256 + tid; i < n; i += nblk * 256) {
     const float4 pi = pos4[i];
     // 8 neighbours per trip: ids first, then all 8 positions in flight (unconditional loads from a clamped id; a
     // branch around the load serialises one memory round trip per neighbour)
@@ -360,6 +359,58 @@ __global__ __launch_bounds__(256) void lfa_moments_kernel(const float4* __restri
   }
   __syncthreads();
   if (tid < 65) atomicAdd(&mom[tid], red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void lfa_moments_kernel(const float4* __restrict__ pos4,
+                                                          const int32_t* __restrict__ idx, int64_t n, int K,
+                                                          double* __restrict__ mom) {
+  lfa_moments_body(pos4, idx, n, K, mom, blockIdx.x, gridDim.x);
+}
+
+// the encoder moments of every resolution level in one launch (m3d_lfa_moments_batch): the deep levels are a few
+// thousand points each — four latency-bound launches of 20-40 us one after the other otherwise
+#define MOM_BATCH_MAX 8
+struct MomBatch {
+  const float4* pos4[MOM_BATCH_MAX];
+  const int32_t* idx[MOM_BATCH_MAX];
+  int64_t n[MOM_BATCH_MAX];
+  unsigned wg_start[MOM_BATCH_MAX + 1];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void lfa_moments_batch_kernel(MomBatch a, int K, double* __restrict__ mom, int64_t ldm) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < MOM_BATCH_MAX; ++i) j += (i < a.njobs && blockIdx.x >= a.wg_start[i]) ? 1 : 0;
+  lfa_moments_body(a.pos4[j], a.idx[j], a.n[j], K, mom + (size_t)j * ldm, (int64_t)(blockIdx.x - a.wg_start[j]),
+                   (int64_t)(a.wg_start[j + 1] - a.wg_start[j]));
+}
+
+extern "C" int m3d_lfa_moments_batch(int32_t njobs, const float* const* pos4, const int32_t* const* idx,
+                                     const int64_t* n, int32_t K, double* mom, int64_t mom_stride, void* stream) {
+  if (njobs < 0 || njobs > MOM_BATCH_MAX) return M3D_ERR_UNSUPPORTED;
+  if (njobs == 0) return M3D_OK;
+  if (!pos4 || !idx || !n || !mom || K < 1 || mom_stride < 65) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(mom, 0, (size_t)njobs * mom_stride * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  MomBatch a;
+  a.njobs = njobs;
+  unsigned total = 0;
+  for (int j = 0; j < MOM_BATCH_MAX; ++j) {
+    a.wg_start[j] = total;
+    if (j < njobs) {
+      if (n[j] < 0 || (n[j] > 0 && (!pos4[j] || !idx[j]))) return M3D_ERR_INVALID;
+      a.pos4[j] = (const float4*)pos4[j]; a.idx[j] = idx[j]; a.n[j] = n[j];
+      int64_t gx = m3d_cdiv(n[j], 256);
+      total += (unsigned)(gx > 512 ? 512 : gx);
+    } else {
+      a.pos4[j] = nullptr; a.idx[j] = nullptr; a.n[j] = 0;
+    }
+  }
+  a.wg_start[MOM_BATCH_MAX] = total;
+  if (total == 0) return M3D_OK;
+  hipLaunchKernelGGL(lfa_moments_batch_kernel, dim3(total), dim3(256), 0, st, a, K, mom, mom_stride);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
 }
 
 extern "C" int m3d_lfa_moments(const float* pos4, const int32_t* idx, int64_t n, int32_t K, double* mom65,

@@ -7,7 +7,7 @@ device memory, to provide the stream and for autograd bookkeeping.  Reference ca
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -50,14 +50,19 @@ class ZeroArena:
         self.active = False
 
     def begin(self, device) -> None:
-        self.need = max(self.need, self.off + self.grew) if self.active else self.need
-        self.off = self.grew = 0
+        self._learn()
         self.active = True
         self.buf = torch.zeros(self.need, dtype=torch.uint8, device=device) if self.need else None
 
     def stop(self) -> None:
+        self._learn()  # (an eval pass between two training steps must not forget what the last step needed)
         self.active = False
         self.buf = None
+
+    def _learn(self) -> None:
+        if self.active:
+            self.need = max(self.need, self.off + self.grew)
+        self.off = self.grew = 0
 
     def zeros(self, shape, dtype, device) -> Tensor:
         numel = 1
@@ -591,6 +596,36 @@ def pack_attention_weights(w: Tensor, with_transpose: bool) -> Tuple[Tensor, Opt
     wpt = torch.empty_like(wp) if with_transpose else None
     call("m3d_lfa_pack_att", _p(_chk(w)), w.shape[0], _p(wp), _p(wpt), _st())
     return wp, wpt
+
+
+def lfa_moments_batch(pos4s, idxs) -> List[Tensor]:
+    """``lfa_moments`` of several levels in one launch (``m3d_lfa_moments_batch``); returns ``[65]`` views of one buffer."""
+    import ctypes
+
+    m = len(pos4s)
+    mom = torch.empty((m, 72), dtype=torch.float64, device=pos4s[0].device)  # 576-byte rows: 16-byte aligned views
+    pp = (ctypes.c_void_p * m)(*[t.data_ptr() for t in pos4s])
+    ip = (ctypes.c_void_p * m)(*[_chk(t, torch.int32).data_ptr() for t in idxs])
+    nn_ = (ctypes.c_int64 * m)(*[t.shape[0] for t in idxs])
+    call("m3d_lfa_moments_batch", m, pp, ip, nn_, idxs[0].shape[1], _p(mom), mom.stride(0), _st())
+    return [mom[i, :65] for i in range(m)]
+
+
+def knn_query_batch(pairs, k: int, sorted_io: bool = True) -> List[Tensor]:
+    """``src.query(k, qry=qry, sorted_io=...)`` for up to 8 ``(src, qry)`` pairs of built ``KnnIndex`` objects in ONE
+    launch (``m3d_knn_query_batch``); bit-identical tables."""
+    import ctypes
+
+    m = len(pairs)
+    dev = pairs[0][0].ws.device
+    outs = [torch.empty((q.n, k), dtype=torch.int32, device=dev) for _, q in pairs]
+    for s_, q in pairs:
+        assert s_.num_clouds == q.num_clouds == pairs[0][0].num_clouds
+    vp = lambda ts: (ctypes.c_void_p * m)(*[t.data_ptr() for t in ts])
+    call("m3d_knn_query_batch", m, vp([s_.ws for s_, _ in pairs]), vp([s_.ptr for s_, _ in pairs]),
+         (ctypes.c_int64 * m)(*[s_.n for s_, _ in pairs]), vp([q.ws for _, q in pairs]), vp([q.ptr for _, q in pairs]),
+         (ctypes.c_int64 * m)(*[q.n for _, q in pairs]), pairs[0][0].num_clouds, k, int(sorted_io), vp(outs), _st())
+    return outs
 
 
 def lfa_moments(pos4: Tensor, idx: Tensor) -> Tensor:

@@ -137,6 +137,9 @@ class HipRandLANet(nn.Module):
         # ``trainer.precision: bf16-mixed``), like any autocast-aware module.
         self.matmul_precision = "fp32"
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
+        # the K-NN tables / encoder moments / decoder 1-NN tables of the four levels as one launch each (see
+        # _geometry_stages); M3D_GEO_BATCH=0: level by level (A/B and cross-check)
+        self.batch_geometry = __import__("os").environ.get("M3D_GEO_BATCH", "1") != "0"
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
         # geometry of the NEXT forward (see prefetch_geometry()): two persistent slots used in turn
@@ -415,20 +418,26 @@ class HipRandLANet(nn.Module):
         enqueue one stage between its own blocks (see ``prefetch_geometry(interleave=True)``)."""
         K = self.num_neighbors
         side = g.side
+        # batched launches pay off where launches are the cost: eagerly (7.5 -> 6.8 ms per training step).  Inside a
+        # captured graph the per-level launches are free for the host and run one after the other without competing with
+        # the feature kernels, which measured 0.04 ms better (profiles/r02x_geo_batch.log) — same tables either way
+        batched = self.batch_geometry and not torch.cuda.is_current_stream_capturing()
         with torch.cuda.stream(side):
             g.index.append(ops.KnnIndex(ops.pad_pos(pos), plan.ptrs[0]))
             g.pos4.append(g.index[0].sorted_pos4)
-            g.mark()                                                            # stage 0
+            g.mark(0)
         yield
         for lvl in range(4):
+            if not batched:
+                with torch.cuda.stream(side):
+                    ix = g.index[lvl]
+                    idx, _ = ix.query(K, qry=ix, sorted_io=True)
+                    g.knn.append(idx)
+                    g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
+                    g.mark(1 + 2 * lvl)
+                yield
             with torch.cuda.stream(side):
                 ix = g.index[lvl]
-                idx, _ = ix.query(K, qry=ix, sorted_io=True)
-                g.knn.append(idx)
-                g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
-                g.mark()                                                        # stage 1 + 2*lvl
-            yield
-            with torch.cuda.stream(side):
                 # decimate(): pyg_randla_net.py:234-238.  d_int: sorted slots of this level that survive, listed in
                 # the reference order of the next level; d_ref: the same as reference rows of this level
                 if decimation_idx is not None:
@@ -446,12 +455,26 @@ class HipRandLANet(nn.Module):
                 g.src.append(ops.gather_i32(d_int, nxt.perm))  # sorted slot of level lvl+1 -> sorted slot of level lvl
                 g.index.append(nxt)
                 g.pos4.append(nxt.sorted_pos4)
-                g.mark()                                                        # stage 2 + 2*lvl
+                g.mark(2 + 2 * lvl)
+            yield
+        if batched:
+            # the grids of all five levels exist (a chain of short kernels: nothing above waits for a table): the four
+            # K-NN tables are ONE launch, the four moment sets one, the four decoder 1-NN tables one.  Launched level by
+            # level the deep ones are latency-bound (105 / 77 / 45 us for 51 200 / 12 800 / 3 200 queries) and the
+            # level-1 launch ends on its slowest wavefronts with most SIMDs idle (profiles/r02u_step_timeline.csv)
+            with torch.cuda.stream(side):
+                g.knn.extend(ops.knn_query_batch([(g.index[l], g.index[l]) for l in range(4)], K))
+                g.mom.extend(ops.lfa_moments_batch(g.pos4[:4], g.knn) if train else [None] * 4)
+                for lvl in range(4):
+                    g.mark(1 + 2 * lvl, new=(lvl == 0))
             yield
         with torch.cuda.stream(side):
-            for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
-                g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True)[0])
-            g.mark()                                                            # stage 9
+            if batched:
+                g.nn.extend(ops.knn_query_batch([(g.index[l + 1], g.index[l]) for l in range(4)], 1))
+            else:
+                for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
+                    g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True)[0])
+            g.mark(9)
         yield
 
     # ------------------------------------------------------------------------------------------
@@ -683,13 +706,17 @@ class _Geometry:
         self.src: List[Tensor] = []
         self.dec_ref: List[Tensor] = []
         self.nn: List[Tensor] = []
-        self.events: List = []
+        self.events: Dict[int, object] = {}
+        self._last_event = None
 
-    def mark(self) -> None:
+    def mark(self, stage: int, new: bool = True) -> None:
+        """Stage ``stage`` is complete at this point of the side stream (``new=False``: at the same point as the stage
+        marked just before)."""
         if self.side is not self.main:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            self.events.append(ev)
+            if new or self._last_event is None:
+                self._last_event = torch.cuda.Event()
+                self._last_event.record(self.side)
+            self.events[stage] = self._last_event
 
     def wait(self, stage: int) -> None:
         if self.side is not self.main:

@@ -309,3 +309,28 @@ def test_eval_cache_notices_parameter_updates_through_a_parent_module():
         bn.weight.add_(1.0)
     assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 4)
     assert net._cached(("bn", id(bn)), fold, deps) == ("folded", 4)
+
+
+def test_zero_arena_learns_its_size_across_an_eval_pass():
+    """ops.ZeroArena: the training step's accumulation targets come from ONE zero fill once the size is known — also when
+    an eval pass (arena.stop()) runs between two training steps, as in bench.py and in any train/validate loop."""
+    from myria3d_amd.ops import ZeroArena
+
+    dev = torch.device("cpu")
+    ar = ZeroArena()
+    ar.begin(dev)
+    a = ar.zeros((3, 5), torch.float32, dev)
+    b = ar.zeros((7,), torch.float64, dev)
+    assert ar.buf is None and a.abs().sum() == 0 and b.abs().sum() == 0   # first step: individual fills
+    ar.stop()                                                              # eval pass
+    assert ar.need >= 3 * 5 * 4 + 7 * 8
+    ar.begin(dev)
+    a = ar.zeros((3, 5), torch.float32, dev)
+    b = ar.zeros((7,), torch.float64, dev)
+    base = ar.buf.data_ptr()
+    assert a.data_ptr() == base and b.data_ptr() == base + 256            # views of the one buffer, 256-byte spans
+    assert a.dtype == torch.float32 and b.dtype == torch.float64 and b.shape == (7,)
+    c = ar.zeros((1000,), torch.float32, dev)                              # more than last time: falls back, and is learned
+    assert c.data_ptr() < base or c.data_ptr() >= base + ar.buf.numel()
+    ar.begin(dev)
+    assert ar.buf.numel() >= 512 + 4096

@@ -12,7 +12,7 @@ f=$(find /tmp/prof -name '*kernel_trace.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in rows))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", ""), r.get("Grid_Size_X", r.get("Grid_Size", ""))) for r in rows))
 # find adam kernels = step boundaries
 adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[2]]
 print("adam launches", len(adam))
@@ -22,23 +22,23 @@ if len(adam) >= 4:
     t0, t1 = seg[0][0], seg[-1][1]
     import os
     with open(os.path.join(os.environ.get("OUT", "."), "step_timeline_" + os.environ.get("TAG", "t") + ".csv"), "w") as fh:
-        fh.write("start_us,dur_us,queue,kernel\n")
-        for s_, e_, n_, q_ in seg:
-            fh.write(f"{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f},{q_},{n_.split('(')[0][:70]}\n")
+        fh.write("start_us,dur_us,queue,grid_x,kernel\n")
+        for s_, e_, n_, q_, g_ in seg:
+            fh.write(f"{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f},{q_},{g_},{n_.split('(')[0][:70]}\n")
     wall = (t1 - t0) / 1e3
     # union of intervals
     busy = 0; cur_s, cur_e = seg[0][0], seg[0][1]
-    for s, e, _, _ in seg[1:]:
+    for s, e, *_ in seg[1:]:
         if s > cur_e: busy += cur_e - cur_s; cur_s, cur_e = s, e
         else: cur_e = max(cur_e, e)
     busy += cur_e - cur_s
-    tot = sum(e - s for s, e, _, _ in seg)
+    tot = sum(e - s for s, e, *_ in seg)
     print(f"step: {len(seg)} kernels, wall {wall:.1f} us, union-busy {busy/1e3:.1f} us, sum of durations {tot/1e3:.1f} us, idle {wall - busy/1e3:.1f} us")
     perq = collections.Counter()
-    for s, e, n, q in seg: perq[q] += e - s
+    for s, e, n, q, _g in seg: perq[q] += e - s
     print("per queue busy us:", {q: round(v / 1e3, 1) for q, v in perq.items()})
     agg = collections.Counter(); cnt = collections.Counter()
-    for s, e, n, q in seg:
+    for s, e, n, q, _g in seg:
         k = n.split("(")[0][:48]; agg[k] += e - s; cnt[k] += 1
     for k, v in agg.most_common(12): print(f"  {k:50s} n={cnt[k]:4d} {v/1e3:8.1f} us")
     # gaps on the busiest queue (main stream): where does it wait?
@@ -46,7 +46,7 @@ if len(adam) >= 4:
     mq = [e for e in seg if e[3] == mainq]
     print("main queue", mainq, "kernels", len(mq), "span us", (mq[-1][1] - mq[0][0]) / 1e3, "first start rel", (mq[0][0] - t0) / 1e3)
     gaps = []
-    for (s0, e0, n0, _), (s1, e1, n1, _) in zip(mq, mq[1:]):
+    for (s0, e0, n0, *_a), (s1, e1, n1, *_b) in zip(mq, mq[1:]):
         if s1 - e0 > 15000: gaps.append((s1 - e0, (e0 - t0) / 1e3, n0.split("(")[0][:40], n1.split("(")[0][:40]))
     print("main-queue gaps > 15 us: total", sum(g[0] for g in gaps) / 1e3, "us in", len(gaps))
     for g in sorted(gaps, reverse=True)[:25]: print(f"   gap {g[0]/1e3:7.1f} us at t={g[1]:7.1f}: after {g[2]} -> before {g[3]}")
