@@ -115,8 +115,14 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_FN: dict = {}  # name -> bound ctypes function (skips the library / attribute look-up on the hot path)
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise :class:`M3DError` on a non-zero status."""
-    rc = getattr(lib(), name)(*args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
+    rc = fn(*args)
     if rc != 0:
         raise M3DError(f"{name} failed: {_ERRORS.get(rc, rc)}")

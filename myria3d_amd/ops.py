@@ -23,7 +23,15 @@ def _p(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# raw handle of the current HIP stream: torch.cuda.current_stream().cuda_stream builds two Python objects per call, and
+# every kernel launch asks (~280 per training step, host-bound when launched eagerly)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _st():
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -353,8 +361,10 @@ def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tenso
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [{count}, {bn.num_features}]")
     n = bn.num_features
     dev = z.device
-    p1 = tuple(torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
-    p2 = tuple(torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4)) if bn2 is not None else (None,) * 4
+    # (one allocation for the 4 (+4) per-column vectors: widths are multiples of 4, so every row stays 16-byte aligned)
+    pv = torch.empty((8 if bn2 is not None else 4, n), dtype=torch.float32, device=dev).unbind(0)
+    p1 = pv[:4]
+    p2 = pv[4:] if bn2 is not None else (None,) * 4
     y = torch.empty_like(z)
     call("m3d_bn_stats_apply", _p(stats), stats.shape[0], count, _p(bn.weight), _p(bn.bias), float(bn.eps),
          float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p1[3]),

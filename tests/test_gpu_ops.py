@@ -78,6 +78,36 @@ def test_knn_cooperative_self_query_kernel_is_bit_identical(device, monkeypatch)
     _knn_case(device, line, torch.tensor([0, 300]), 16)
 
 
+def test_batched_queries_match_the_per_level_launches(device):
+    """m3d_knn_query_batch / m3d_lfa_moments_batch: the four levels in one launch give the tables of four launches bit for
+    bit (moments: same fp64 sums up to the order of the atomics)."""
+    from myria3d_amd import ops
+    from oracle.randla_oracle import synthetic_batch
+
+    _, pos, _, ptr, _ = synthetic_batch([2500, 1800, 3100])
+    pos, ptr = pos.to(device), ptr.to(device)
+    idxs = [ops.KnnIndex(ops.pad_pos(pos), ptr)]
+    ptrs = [ptr]
+    for l in range(3):  # three decimated levels (every 4th point of each cloud)
+        sizes = (ptrs[-1][1:] - ptrs[-1][:-1]) // 4
+        keep = torch.cat([torch.arange(int(n), device=device) * 4 + int(ptrs[-1][b]) for b, n in enumerate(sizes)]).to(torch.int32)
+        p_next = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(sizes, 0)])
+        idxs.append(ops.KnnIndex(ops.gather_rows(idxs[-1].sorted_pos4, ops.gather_i32(idxs[-1].inv, keep)), p_next))
+        ptrs.append(p_next)
+    for k, pairs in ((16, [(ix, ix) for ix in idxs]), (1, [(idxs[l + 1], idxs[l]) for l in range(3)]),
+                     (8, [(idxs[0], idxs[0])])):
+        got = ops.knn_query_batch(pairs, k)
+        for (src, qry), g in zip(pairs, got):
+            ref, _ = src.query(k, qry=qry, sorted_io=True)
+            assert torch.equal(g, ref), f"batched k={k} table differs from the single launch"
+    tabs = ops.knn_query_batch([(ix, ix) for ix in idxs], 16)
+    moms = ops.lfa_moments_batch([ix.sorted_pos4 for ix in idxs], tabs)
+    for ix, t, m in zip(idxs, tabs, moms):
+        ref = ops.lfa_moments(ix.sorted_pos4, t)
+        assert m.shape == (65,) and m.data_ptr() % 16 == 0
+        _close("moments(batch)", m, ref, 1e-12, 1e-12)
+
+
 def test_knn_k32_and_cross_set(device):
     from myria3d_amd import ops
     from oracle.randla_oracle import knn_exact
