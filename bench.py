@@ -46,7 +46,11 @@ def parse():
     ap.add_argument("--tiles", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--points", type=int, default=12800, help="points per tile")
     ap.add_argument("--neighbors", type=int, default=16)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph (= --launch eager)")
+    ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
+                    help="how the timed steps are launched: replayed hipGraph, kernel by kernel, or (default) whichever a "
+                         "10-step probe of each measures faster on this host — both run the same kernels; since the host "
+                         "path was trimmed the eager step is no longer launch-bound (DESIGN.md section 4)")
     ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
                     help="build the position-only tables (kNN, decimation) of a step inside that step instead of one "
                          "step ahead (HipRandLANet.prefetch_geometry; bit-identical results either way)")
@@ -545,14 +549,16 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     launch = "eager"
     step_fn, fwd_fn = train_step, fwd_step
     eager_ms = None
-    if with_eager:  # what a Lightning loop (no capture, model.py:79) sees: host-bound launching of the same kernels
-        for _ in range(8):  # (caching allocator, zero arena and lookahead slots reach their steady state in a few steps)
+    mode = "eager" if args.no_graph else args.launch
+    probe = {}
+    if with_eager or mode == "auto":  # what a Lightning loop (no capture, model.py:79) sees: the same kernels, launched one by one
+        for _ in range(40):  # (the eager path needs ~30 steps to settle: 6.2 -> 5.55 ms, tools/scratch/eager_ramp.py)
             train_step()
-        eager_ms = timed(train_step, 10, world) / 10 * 1e3
+        eager_ms = probe["eager"] = timed(train_step, 15, world) / 15 * 1e3
     # hipGraph: the forward+loss+backward launch sequence (parallel branches for the position-only work and the weight
     # gradients) is captured once and replayed.  With N > 1 the optimizer (all-reduce + 2 launches) stays outside the
     # graph so that no collective is captured
-    if not args.no_graph:
+    if mode != "eager":
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -598,6 +604,12 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
             torch.cuda.synchronize()
             step_fn, launch = train_step, "eager"
 
+    if mode == "auto" and launch == "hipgraph":
+        for _ in range(5):
+            step_fn()
+        probe["hipgraph"] = timed(step_fn, 10, world) / 10 * 1e3
+        if probe["eager"] < probe["hipgraph"]:
+            step_fn, launch = train_step, "eager"
     for _ in range(warmup):
         step_fn()
     dt = timed(step_fn, steps, world)
@@ -605,7 +617,12 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     # (cached by the module until the next training phase); the captured graph then holds the per-batch work only
     fwd_step()
     fwd_step()  # (lookahead: the second call consumes what the first one prefetched and leaves an eval-mode slot pending)
-    if launch == "hipgraph":
+    fprobe = {}
+    if mode == "auto":
+        for _ in range(20):
+            fwd_step()
+        fprobe["eager"] = timed(fwd_step, 15, world) / 15 * 1e3
+    if mode != "eager":
         try:
             torch.cuda.synchronize()
             if look and args.lookahead_mode == "dual":
@@ -628,6 +645,12 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
             if rank == 0:
                 print(f"[bench] eval hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
+    if mode == "auto" and fwd_fn is not fwd_step:
+        for _ in range(3):
+            fwd_fn()
+        fprobe["hipgraph"] = timed(fwd_fn, 10, world) / 10 * 1e3
+        if fprobe["eager"] < fprobe["hipgraph"]:
+            fwd_fn = fwd_step
     for _ in range(max(1, warmup // 2)):
         fwd_fn()
     dt_f = timed(fwd_fn, steps, world)
@@ -652,8 +675,11 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                    "collective": "one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" if world > 1 else "none (1 rank)",
                    "launch": launch, **({"geometry_lookahead": args.lookahead_mode} if look else {})},
         "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
-                     "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad"},
+                     "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad",
+                     "launch": "eager" if fwd_fn is fwd_step else "hipgraph"},
     }
+    if probe:
+        res["launch_probe_ms"] = {k: round(v, 4) for k, v in probe.items()}
     if eager_ms is not None:
         res["eager_ms_per_step"] = round(eager_ms, 4)
     return res, net, pos, plan

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 5
+#define M3D_ABI_VERSION 6
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -48,6 +48,10 @@ size_t m3d_knn_workspace_offset(int64_t n_src, int32_t num_clouds, int32_t which
 /* builds the per-cloud search grid over the SOURCE points into ws */
 int m3d_knn_build(const float* pos_src, int32_t pos_stride /* floats per row, >= 3 */, const int64_t* ptr_src,
                   int32_t num_clouds, int64_t n_src, void* ws, void* stream);
+/* m3d_knn_build that also carries one int32 per source row into cell-sorted order: map_out[slot] = map_in[row]
+ * (both NULL: plain build).  Composes a level's decimation map with the next level's order in the same launch. */
+int m3d_knn_build_map(const float* pos_src, int32_t pos_stride, const int64_t* ptr_src, int32_t num_clouds,
+                      int64_t n_src, void* ws, const int32_t* map_in, int32_t* map_out, void* stream);
 /* queries: either pos_qry rows (row q -> idx_out[q]) or, if qry_ws != NULL, the points of another built
  * workspace in its cell-sorted order (wave-coherent; each record carries its original row).  Self-kNN =
  * qry_ws == ws.  d2_out may be NULL.  sorted_io != 0 (needs qry_ws): output row = the query's cell-sorted slot and
@@ -158,6 +162,12 @@ int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64
  * myria3d/pctl/transforms/transforms.py:66-84): slots n_b.. continue with further independent permutations. */
 int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds, const uint64_t* seed,
                            uint32_t level, int32_t* idx_out, int64_t m, void* stream);
+/* decimate() of one level (pyg_randla_net.py:234-238) in one launch: slot t of the next level draws d_ref_out[t] exactly
+ * as m3d_decimation_indices does (or takes d_ref_in[t] when given: then ptr / ptr_out / seed / d_ref_out may be NULL),
+ * d_int_out[t] = inv[d_ref] (this level's cell-sorted slot) and pos4_out[t] = pos4[d_int] (16-byte records). */
+int m3d_decimate_level(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds, const uint64_t* seed,
+                       uint32_t level, const int32_t* d_ref_in, const int32_t* inv, const float* pos4,
+                       int32_t* d_ref_out, int32_t* d_int_out, float* pos4_out, int64_t m, void* stream);
 
 /* ---- Local spatial encoding + attentive pooling (pyg_randla_net.py:112-152) ----------------------------- */
 /* first/second moments of the 10-vector r over all valid edges: mom65 = [sum r (10) | upper triangle of

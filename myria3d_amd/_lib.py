@@ -22,6 +22,7 @@ SIGNATURES = {
     "m3d_copy_many": (_i32, [_p, _p, _p, _i32, _p]),
     "m3d_knn_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_knn_build": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p]),
+    "m3d_knn_build_map": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p, _p, _p]),
     "m3d_knn_workspace_offset": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_knn_query": (_i32, [_p, _p, _i64, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "m3d_gemm_stat_parts": (_i32, [_i64, _i32, _i32]),
@@ -44,6 +45,7 @@ SIGNATURES = {
     "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
     "m3d_decimation_indices": (_i32, [_p, _p, _i32, _p, _u32, _p, _i64, _p]),
+    "m3d_decimate_level": (_i32, [_p, _p, _i32, _p, _u32, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "m3d_lfa_moments_batch": (_i32, [_i32, _p, _p, _p, _i32, _p, _i64, _p]),
     "m3d_knn_query_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
@@ -75,7 +77,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 5  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 6  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

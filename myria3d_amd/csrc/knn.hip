@@ -92,7 +92,8 @@ extern "C" size_t m3d_knn_workspace_offset(int64_t n_src, int32_t num_clouds, in
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void knn_build_kernel(const float* __restrict__ pos, int pstride,
                                                          const int64_t* __restrict__ ptr, KnnWs w,
-                                                         float cell_target) {
+                                                         float cell_target, const int32_t* __restrict__ map_in,
+                                                         int32_t* __restrict__ map_out) {
   __shared__ float red[4][16];
   __shared__ int cnt[CELLS_MAX];
   __shared__ int wsum[16];
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(1024) void knn_build_kernel(const float* __restrict
     w.sorted[s0 + slot] = make_float4(x, y, z, __int_as_float((int)(s0 + i)));
     w.perm[s0 + slot] = (int)(s0 + i);
     w.inv[s0 + i] = (int)(s0 + slot);
+    if (map_out) map_out[s0 + slot] = map_in[s0 + i];  // a per-row payload carried into cell-sorted order (m3d_knn_build_map)
   }
 }
 
@@ -939,8 +941,11 @@ __global__ __launch_bounds__(64, (KMAX <= 16 ? KNNC_MINW : (KMAX <= 32 ? 2 : 1))
   }
 }
 
-extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int64_t* ptr_src, int32_t num_clouds,
-                             int64_t n_src, void* ws, void* stream) {
+// m3d_knn_build that also carries one int32 per source row into cell-sorted order: map_out[slot] = map_in[row] (the
+// decimation map of a level composed with the next level's order: one launch less per level)
+extern "C" int m3d_knn_build_map(const float* pos_src, int32_t pos_stride, const int64_t* ptr_src, int32_t num_clouds,
+                                 int64_t n_src, void* ws, const int32_t* map_in, int32_t* map_out, void* stream) {
+  if ((map_in == nullptr) != (map_out == nullptr)) return M3D_ERR_INVALID;
   if (!ptr_src || !ws || num_clouds < 0 || n_src < 0 || pos_stride < 3) return M3D_ERR_INVALID;
   if (num_clouds == 0) return M3D_OK;
   if (!pos_src && n_src > 0) return M3D_ERR_INVALID;
@@ -952,9 +957,14 @@ extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int
     return v > 0.f ? v : M3D_KNN_CELL_TARGET;
   }();
   hipLaunchKernelGGL(knn_build_kernel, dim3(num_clouds), dim3(1024), 0, (hipStream_t)stream, pos_src, pos_stride,
-                     ptr_src, w, cell_target);
+                     ptr_src, w, cell_target, map_in, map_out);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
+}
+
+extern "C" int m3d_knn_build(const float* pos_src, int32_t pos_stride, const int64_t* ptr_src, int32_t num_clouds,
+                             int64_t n_src, void* ws, void* stream) {
+  return m3d_knn_build_map(pos_src, pos_stride, ptr_src, num_clouds, n_src, ws, nullptr, nullptr, stream);
 }
 
 // key policy of the top-k registers: M3D_KNN_KEYS=u64 (integer compare/select chain) | f64 (v_min/v_max_f64 chain)

@@ -150,6 +150,61 @@ __global__ __launch_bounds__(256) void decimation_kernel(const int64_t* __restri
   idx_out[t] = (int32_t)(ptr[b] + (int64_t)feistel_perm(r, n, key));
 }
 
+// decimate() of one level in ONE launch (pyg_randla_net.py:234-238 with the indices of :192-231): slot t of the next level
+// draws its reference row d_ref (or takes it from d_ref_in), maps it to this level's cell-sorted slot d_int = inv[d_ref]
+// and fetches that slot's position record.  Same draws as m3d_decimation_indices; replaces that launch + two gathers.
+__global__ __launch_bounds__(256) void decimate_level_kernel(const int64_t* __restrict__ ptr,
+                                                             const int64_t* __restrict__ ptr_out, int B,
+                                                             const uint64_t* __restrict__ seed, uint32_t level,
+                                                             const int32_t* __restrict__ d_ref_in,
+                                                             const int32_t* __restrict__ inv,
+                                                             const float4* __restrict__ pos4,
+                                                             int32_t* __restrict__ d_ref_out, int32_t* __restrict__ d_int_out,
+                                                             float4* __restrict__ pos_out, int64_t m) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m) return;
+  int32_t d_ref;
+  if (d_ref_in) {
+    d_ref = d_ref_in[t];
+  } else {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (ptr_out[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    uint32_t r = (uint32_t)(t - ptr_out[b]);
+    const uint32_t n = (uint32_t)(ptr[b + 1] - ptr[b]);
+    const uint64_t s = seed[0];
+    uint32_t key = mix32((uint32_t)s ^ mix32((uint32_t)(s >> 32) + 0x85ebca6bu * (level + 1u)) ^ mix32((uint32_t)b * 0xc2b2ae35u + 1u));
+    if (r >= n && n > 0) {
+      const uint32_t rep = r / n;
+      r -= rep * n;
+      key = mix32(key ^ (rep * 0x27d4eb2fu));
+    }
+    d_ref = (int32_t)(ptr[b] + (int64_t)feistel_perm(r, n, key));
+    d_ref_out[t] = d_ref;
+  }
+  const int32_t d_int = inv[d_ref];
+  d_int_out[t] = d_int;
+  pos_out[t] = pos4[d_int];
+}
+
+extern "C" int m3d_decimate_level(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds, const uint64_t* seed,
+                                  uint32_t level, const int32_t* d_ref_in, const int32_t* inv, const float* pos4,
+                                  int32_t* d_ref_out, int32_t* d_int_out, float* pos4_out, int64_t m, void* stream) {
+  if (num_clouds < 0 || m < 0) return M3D_ERR_INVALID;
+  if (m == 0 || num_clouds == 0) return M3D_OK;
+  if (!inv || !pos4 || !d_int_out || !pos4_out) return M3D_ERR_INVALID;
+  if (!d_ref_in && (!ptr || !ptr_out || !seed || !d_ref_out)) return M3D_ERR_INVALID;
+  if ((((uintptr_t)pos4) | ((uintptr_t)pos4_out)) & 15) return M3D_ERR_INVALID;
+  hipLaunchKernelGGL(decimate_level_kernel, dim3((unsigned)m3d_cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, ptr,
+                     ptr_out, num_clouds, seed, level, d_ref_in, inv, (const float4*)pos4, d_ref_out, d_int_out,
+                     (float4*)pos4_out, m);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
 extern "C" int m3d_decimation_indices(const int64_t* ptr, const int64_t* ptr_out, int32_t num_clouds,
                                       const uint64_t* seed, uint32_t level, int32_t* idx_out, int64_t m,
                                       void* stream) {

@@ -118,7 +118,9 @@ def _chk(t: Tensor, dtype=torch.float32):
 class KnnIndex:
     """Per-cloud search grid over a set of source points (device workspace owned by a torch tensor)."""
 
-    def __init__(self, pos: Tensor, ptr: Tensor):
+    def __init__(self, pos: Tensor, ptr: Tensor, carry: Optional[Tensor] = None):
+        """``carry``: an int32 value per source row; ``self.carried[slot]`` is then the value of the row that landed in
+        cell-sorted slot ``slot`` (same launch)."""
         assert pos.is_cuda and pos.dtype == torch.float32 and pos.dim() == 2 and pos.stride(1) == 1
         assert ptr.is_cuda and ptr.dtype == torch.int64 and ptr.is_contiguous()
         self.n = pos.shape[0]
@@ -126,7 +128,12 @@ class KnnIndex:
         self.ptr = ptr
         nbytes = lib().m3d_knn_workspace_bytes(self.n, self.num_clouds)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
-        call("m3d_knn_build", _p(pos), pos.stride(0), _p(ptr), self.num_clouds, self.n, _p(self.ws), _st())
+        self.carried = None
+        if carry is not None:
+            assert carry.dtype == torch.int32 and carry.is_contiguous() and carry.numel() == self.n
+            self.carried = torch.empty_like(carry)
+        call("m3d_knn_build_map", _p(pos), pos.stride(0), _p(ptr), self.num_clouds, self.n, _p(self.ws), _p(carry),
+             _p(self.carried), _st())
 
     def _view(self, which: int, dtype, cols: int) -> Tensor:
         off = lib().m3d_knn_workspace_offset(self.n, self.num_clouds, which)
@@ -312,6 +319,22 @@ def decimation_indices(ptr: Tensor, ptr_out: Tensor, m: int, seed: Tensor, level
     idx = torch.empty(m, dtype=torch.int32, device=ptr.device)
     call("m3d_decimation_indices", _p(ptr), _p(ptr_out), ptr.numel() - 1, _p(seed), level, _p(idx), m, _st())
     return idx
+
+
+def decimate_level(ptr: Tensor, ptr_out: Tensor, m: int, seed: Tensor, level: int, index: "KnnIndex",
+                   d_ref: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """``decimate()`` of one level in one launch (``m3d_decimate_level``): returns ``(d_ref, d_int, pos4_next)`` = the
+    surviving reference rows (drawn like ``decimation_indices`` unless given), their cell-sorted slots in ``index`` and
+    their position records."""
+    dev = ptr.device
+    given = d_ref is not None
+    if not given:
+        d_ref = torch.empty(m, dtype=torch.int32, device=dev)
+    d_int = torch.empty(m, dtype=torch.int32, device=dev)
+    pos_next = torch.empty((m, 4), dtype=torch.float32, device=dev)
+    call("m3d_decimate_level", _p(ptr), _p(ptr_out), ptr.numel() - 1, _p(seed), level, _p(d_ref) if given else None,
+         _p(index.inv), _p(index.sorted_pos4), None if given else _p(d_ref), _p(d_int), _p(pos_next), m, _st())
+    return d_ref, d_int, pos_next
 
 
 def bn_fold_eval(bn: torch.nn.BatchNorm1d) -> Tuple[Tensor, Tensor]:

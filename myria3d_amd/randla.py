@@ -447,19 +447,19 @@ class HipRandLANet(nn.Module):
                 ix = g.index[lvl]
                 # decimate(): pyg_randla_net.py:234-238.  d_int: sorted slots of this level that survive, listed in
                 # the reference order of the next level; d_ref: the same as reference rows of this level
+                d_ref = None
                 if decimation_idx is not None:
                     d_ref = decimation_idx[lvl].to(device=pos.device, dtype=torch.int32).contiguous()
                     assert d_ref.numel() == plan.totals[lvl + 1]
-                    d_int = ops.gather_i32(ix.inv, d_ref)
-                else:
-                    # drawn in REFERENCE rows (like the reference's randperm, pyg_randla_net.py:221): which points
-                    # survive depends on the seed only, not on the (arbitrary) order of points inside a grid cell
-                    d_ref = ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
-                                                   self._decim_seed, lvl)
-                    d_int = ops.gather_i32(ix.inv, d_ref)
+                # drawn in REFERENCE rows (like the reference's randperm, pyg_randla_net.py:221): which points survive
+                # depends on the seed only, not on the (arbitrary) order of points inside a grid cell.  One launch draws,
+                # maps to sorted slots and fetches the survivors' positions; the next level's grid build carries the slot
+                # map into its own order (src: sorted slot of level lvl+1 -> sorted slot of level lvl)
+                d_ref, d_int, pos_next = ops.decimate_level(plan.ptrs[lvl], plan.ptrs[lvl + 1], plan.totals[lvl + 1],
+                                                            self._decim_seed, lvl, ix, d_ref)
                 g.dec_ref.append(d_ref)
-                nxt = ops.KnnIndex(ops.gather_rows(g.pos4[lvl], d_int), plan.ptrs[lvl + 1])
-                g.src.append(ops.gather_i32(d_int, nxt.perm))  # sorted slot of level lvl+1 -> sorted slot of level lvl
+                nxt = ops.KnnIndex(pos_next, plan.ptrs[lvl + 1], carry=d_int)
+                g.src.append(nxt.carried)
                 g.index.append(nxt)
                 g.pos4.append(nxt.sorted_pos4)
                 g.mark(2 + 2 * lvl)
