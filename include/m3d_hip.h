@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 6
+#define M3D_ABI_VERSION 7
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -96,6 +96,14 @@ size_t m3d_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t K);
 int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* x0, int64_t ldx0, const int32_t* x0_rows,
                          int32_t k0, const float* x1, int64_t ldx1, int32_t k1, int64_t M, int32_t N, float* dw,
                          int64_t lddw, int32_t accumulate, void* ws, void* stream);
+/* The weight gradients of several layers in a handful of launches (one per tile class + one for the partial sums): job j
+ * is m3d_linear_wgrad_f32(dz[j], ..., dw[j], lddw[j], accumulate, ws[j]).  accumulate must be non-zero (gradient sinks:
+ * the flat gradient buffer); host arrays of length njobs.  The backward pass of the network hands all 29 Linear layers
+ * over at its end (torch autograd would run each Linear.backward's weight product where it stands). */
+int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, const int64_t* lddz, const float* const* x0,
+                           const int64_t* ldx0, const int32_t* const* x0_rows, const int32_t* k0, const float* const* x1,
+                           const int64_t* ldx1, const int32_t* k1, const int64_t* M, const int32_t* N, float* const* dw,
+                           const int64_t* lddw, int32_t accumulate, void* const* ws, void* stream);
 /* out[N] += column sums of x[M,N] (bias gradient of a Linear without BatchNorm: fc0, fc_classif) */
 int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
                             _f32, _p, _i32, _p, _i64, _i32, _i32, _p]),
     "m3d_linear_wgrad_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_linear_wgrad_f32": (_i32, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _i64, _i32, _p, _i64, _i32, _p, _p]),
+    "m3d_linear_wgrad_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "m3d_colsum_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "m3d_bn_finalize": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
@@ -77,7 +78,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 6  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 7  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

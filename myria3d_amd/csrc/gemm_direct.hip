@@ -641,7 +641,7 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 #define WGRAD_DEPTH 4
 #endif
 template <int TN, int TK>
-__global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
+__device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
   // big tiles (16 accumulator quads: the deep, few-row layers) keep one partial per WAVE and two steps in flight: their
   // register budget has no room for four, and their LDS reduction would take 48 KB
   constexpr bool WGR = TN * TK < 16;
@@ -649,9 +649,9 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
   __shared__ float red[WGR ? 3 : 1][WGR ? TN * TK * 256 : 1];  // accumulators of waves 1..3 (wave 0 keeps its own)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
-  const int nb = blockIdx.y * 16 * TN, kb = blockIdx.z * 16 * TK;
+  const int nb = by * 16 * TN, kb = bz * 16 * TK;
   const int64_t steps_total = (g.M + 3) >> 2;
-  const int64_t split = (int64_t)blockIdx.x * 4 + wid;           // wave-level row split
+  const int64_t split = (int64_t)bx * 4 + wid;           // wave-level row split
   const int64_t s0 = split * g.steps_per_split;
   const int64_t s1 = s0 + g.steps_per_split < steps_total ? s0 + g.steps_per_split : steps_total;
   f32x4 acc[TN][TK];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
           const int o = ((a * TK + b) * 4 + r) * 64 + lane;
           acc[a][b][r] += (red[0][o] + red[1][o]) + red[2][o];
         }
-    part = blockIdx.x;
+    part = bx;
   } else {
     if (s0 >= steps_total) return;  // (no rows: this wave has no partial slot either)
   }
@@ -717,14 +717,43 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
       }
 }
 
+template <int TN, int TK>
+__global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
+  wgrad2_body<TN, TK>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several weight-gradient GEMMs of one tile class in ONE launch (m3d_linear_wgrad_batch).  The 29 Linear layers of the
+// network need their dW only when the optimizer runs, so the whole backward pass can hand them over at its end: launched
+// layer by layer they are 58 launches whose tails (a few waves per SIMD on the deep levels, partial-sum reduces of a few
+// microseconds) never overlap, and — knock-out timing, tools/scratch/knockout.sh — they cost the training step 1.0 ms of
+// wall time although they run on a side stream.  Workgroup w of the flattened grid belongs to job j with
+// wg_start[j] <= w < wg_start[j + 1]; inside the job it is (x, y, z) of that job's own grid.
+#define WGRAD_BATCH_MAX 16
+struct WgradBatch {
+  WgradArgs g[WGRAD_BATCH_MAX];
+  unsigned wg_start[WGRAD_BATCH_MAX + 1];
+  unsigned gx[WGRAD_BATCH_MAX], gy[WGRAD_BATCH_MAX];
+  int njobs;
+};
+template <int TN, int TK>
+__global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_batch_kernel(WgradBatch b) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < WGRAD_BATCH_MAX; ++i) j += (i < b.njobs && blockIdx.x >= b.wg_start[i]) ? 1 : 0;
+  const unsigned w = blockIdx.x - b.wg_start[j];
+  const unsigned gx = b.gx[j], gy = b.gy[j];
+  wgrad2_body<TN, TK>(b.g[j], w % gx, (w / gx) % gy, w / (gx * gy));
+}
+
 // dw[n][k] (+)= sum_s ws[s][n][k]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int N, int K,
-                                                           float* __restrict__ dw, int64_t lddw, int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, int S, int N, int K,
+                                                  float* __restrict__ dw, int64_t lddw, int accumulate, unsigned bx,
+                                                  unsigned by, unsigned ny) {
+  const int e = bx * 256 + threadIdx.x;
   const int E = N * K;
   if (e >= E) return;
-  const int per = (S + gridDim.y - 1) / gridDim.y;
-  const int p0 = blockIdx.y * per, p1 = min(S, p0 + per);
+  const int per = (S + ny - 1) / ny;
+  const int p0 = by * per, p1 = min(S, p0 + per);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int p = p0;
   for (; p + 3 < p1; p += 4) {
@@ -736,8 +765,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   for (; p < p1; ++p) s0 += ws[(size_t)p * E + e];
   const float v = (s0 + s1) + (s2 + s3);
   float* cp = dw + (int64_t)(e / K) * lddw + (e % K);
-  if (gridDim.y == 1) *cp = accumulate ? *cp + v : v;
+  if (ny == 1) *cp = accumulate ? *cp + v : v;
   else if (p1 > p0) atomicAdd(cp, v);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int N, int K,
+                                                           float* __restrict__ dw, int64_t lddw, int accumulate) {
+  wgrad_reduce_body(ws, S, N, K, dw, lddw, accumulate, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+#define WREDUCE_BATCH_MAX 32
+struct WreduceBatch {
+  const float* ws[WREDUCE_BATCH_MAX]; float* dw[WREDUCE_BATCH_MAX]; int64_t lddw[WREDUCE_BATCH_MAX];
+  int S[WREDUCE_BATCH_MAX], N[WREDUCE_BATCH_MAX], K[WREDUCE_BATCH_MAX];
+  unsigned gx[WREDUCE_BATCH_MAX], gy[WREDUCE_BATCH_MAX], wg_start[WREDUCE_BATCH_MAX + 1];
+  int njobs, accumulate;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WreduceBatch b) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < WREDUCE_BATCH_MAX; ++i) j += (i < b.njobs && blockIdx.x >= b.wg_start[i]) ? 1 : 0;
+  const unsigned w = blockIdx.x - b.wg_start[j];
+  wgrad_reduce_body(b.ws[j], b.S[j], b.N[j], b.K[j], b.dw[j], b.lddw[j], b.accumulate, w % b.gx[j], w / b.gx[j], b.gy[j]);
 }
 
 __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, int64_t ld, int N, int K) {
@@ -828,6 +877,112 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, (const float*)ws, (int)p.S, N, K, dw, lddw,
                        accumulate);
   }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+template <int TN, int TK>
+static void launch_wgrad2_batch(const WgradBatch& b, unsigned total, hipStream_t st) {
+  hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK>), dim3(total), dim3(256), 0, st, b);
+}
+
+// dW of several layers at once (see WgradBatch).  Host arrays of length njobs; `accumulate` != 0 (gradient sinks) is
+// required: the partial-sum reduce of a job may add into dw from several workgroups.  ws[j]: the job's own
+// m3d_linear_wgrad_workspace_bytes(M, N, K) scratch (NULL when that is 0).
+extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, const int64_t* lddz, const float* const* x0,
+                                      const int64_t* ldx0, const int32_t* const* x0_rows, const int32_t* k0,
+                                      const float* const* x1, const int64_t* ldx1, const int32_t* k1, const int64_t* M,
+                                      const int32_t* N, float* const* dw, const int64_t* lddw, int32_t accumulate,
+                                      void* const* ws, void* stream) {
+  if (njobs < 0) return M3D_ERR_INVALID;
+  if (njobs == 0) return M3D_OK;
+  if (!accumulate) return M3D_ERR_UNSUPPORTED;
+  if (!dz || !lddz || !x0 || !ldx0 || !x0_rows || !k0 || !x1 || !ldx1 || !k1 || !M || !N || !dw || !lddw || !ws)
+    return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  static const int variants[7][2] = {{4, 4}, {4, 2}, {2, 4}, {2, 2}, {1, 2}, {2, 1}, {1, 1}};
+  WreduceBatch rb;
+  rb.njobs = 0; rb.accumulate = 1;
+  unsigned rtotal = 0;
+  auto flush_reduce = [&]() {
+    if (rb.njobs == 0) return;
+    rb.wg_start[rb.njobs] = rtotal;
+    for (int i = rb.njobs + 1; i <= WREDUCE_BATCH_MAX; ++i) rb.wg_start[i] = rtotal;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rtotal), dim3(256), 0, st, rb);
+    rb.njobs = 0; rtotal = 0;
+  };
+  // pass 1: the GEMMs, one launch per tile class (and per 16 jobs); their reduces are queued and launched afterwards
+  struct Pending { int j; WgradPlan p; };
+  for (int v = 0; v < 7; ++v) {
+    WgradBatch b;
+    b.njobs = 0;
+    unsigned total = 0;
+    auto flush = [&]() {
+      if (b.njobs == 0) return;
+      b.wg_start[b.njobs] = total;
+      for (int i = b.njobs + 1; i <= WGRAD_BATCH_MAX; ++i) b.wg_start[i] = total;
+      for (int i = b.njobs; i < WGRAD_BATCH_MAX; ++i) { b.g[i] = b.g[0]; b.gx[i] = 1; b.gy[i] = 1; }
+      const int TN = variants[v][0], TK = variants[v][1];
+      if (TN == 4 && TK == 4) launch_wgrad2_batch<4, 4>(b, total, st);
+      else if (TN == 4 && TK == 2) launch_wgrad2_batch<4, 2>(b, total, st);
+      else if (TN == 2 && TK == 4) launch_wgrad2_batch<2, 4>(b, total, st);
+      else if (TN == 2 && TK == 2) launch_wgrad2_batch<2, 2>(b, total, st);
+      else if (TN == 1 && TK == 2) launch_wgrad2_batch<1, 2>(b, total, st);
+      else if (TN == 2 && TK == 1) launch_wgrad2_batch<2, 1>(b, total, st);
+      else launch_wgrad2_batch<1, 1>(b, total, st);
+      b.njobs = 0; total = 0;
+    };
+    for (int j = 0; j < njobs; ++j) {
+      const int K = k0[j] + k1[j];
+      if (M[j] <= 0 || N[j] <= 0 || K <= 0) continue;  // (accumulate: nothing to add)
+      const WgradPlan p = wgrad_plan(M[j], N[j], K);
+      // tile classes the single-job launcher can produce: (4,4) (4,2) (4,1)->TK 1 ... map (TN, TK) to a class index
+      int cls = -1;
+      for (int c = 0; c < 7; ++c) if (variants[c][0] == p.TN && variants[c][1] == p.TK) cls = c;
+      if (cls < 0) {  // (4,1) / (1,4): rare shapes, launched on their own
+        if (v == 0) {
+          const int rc = m3d_linear_wgrad_f32(dz[j], lddz[j], x0[j], ldx0[j], x0_rows[j], k0[j], x1[j], ldx1[j], k1[j], M[j],
+                                              N[j], dw[j], lddw[j], 1, ws[j], stream);
+          if (rc != M3D_OK) return rc;
+        }
+        continue;
+      }
+      if (cls != v) continue;
+      if (!dz[j] || k0[j] < 1 || !x0[j] || (k1[j] > 0 && !x1[j]) || !dw[j] || (p.S > 1 && !ws[j])) return M3D_ERR_INVALID;
+      const int64_t lim = (int64_t)M3D_BUF_BYTES - 64;
+      if (M[j] * lddz[j] * 4 > lim || M[j] * ldx0[j] * 4 > lim || (k1[j] > 0 && M[j] * ldx1[j] * 4 > lim))
+        return M3D_ERR_UNSUPPORTED;
+      WgradArgs& g = b.g[b.njobs];
+      g.dz = dz[j]; g.lddz = lddz[j]; g.x0 = x0[j]; g.ldx0 = ldx0[j]; g.rows = x0_rows[j]; g.k0 = k0[j]; g.x1 = x1[j];
+      g.ldx1 = ldx1[j]; g.k1 = k1[j]; g.M = M[j]; g.N = N[j]; g.dw = dw[j]; g.lddw = lddw[j]; g.accumulate = 1;
+      g.ws = (float*)ws[j]; g.S = (int)p.S; g.steps_per_split = p.spw;
+      b.wg_start[b.njobs] = total;
+      b.gx[b.njobs] = (unsigned)p.wgs; b.gy[b.njobs] = (unsigned)p.by;
+      total += (unsigned)(p.wgs * p.by * p.bz);
+      if (++b.njobs == WGRAD_BATCH_MAX) flush();
+    }
+    flush();
+  }
+  // pass 2: the partial-sum reduces (stream order puts them behind every GEMM launch)
+  for (int j = 0; j < njobs; ++j) {
+    const int K = k0[j] + k1[j];
+    if (M[j] <= 0 || N[j] <= 0 || K <= 0) continue;
+    const WgradPlan p = wgrad_plan(M[j], N[j], K);
+    bool cls_ok = false;
+    for (int c = 0; c < 7; ++c) if (variants[c][0] == p.TN && variants[c][1] == p.TK) cls_ok = true;
+    if (!cls_ok || p.S <= 1) continue;
+    const int E = N[j] * K;
+    const int gx = (E + 255) / 256;
+    int gy = (int)(p.S / 16);
+    if (gy > 2048 / gx) gy = 2048 / gx;
+    if (gy < 1) gy = 1;
+    const int i = rb.njobs;
+    rb.ws[i] = (const float*)ws[j]; rb.dw[i] = dw[j]; rb.lddw[i] = lddw[j]; rb.S[i] = (int)p.S; rb.N[i] = N[j]; rb.K[i] = K;
+    rb.gx[i] = (unsigned)gx; rb.gy[i] = (unsigned)gy; rb.wg_start[i] = rtotal;
+    rtotal += (unsigned)(gx * gy);
+    if (++rb.njobs == WREDUCE_BATCH_MAX) flush_reduce();
+  }
+  flush_reduce();
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

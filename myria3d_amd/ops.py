@@ -227,14 +227,10 @@ class GradSideStream:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device=device)
         self.keep: list = []
+        self.jobs: list = []  # deferred weight-gradient GEMMs (``defer``): launched together by ``join``
         self._join_queued = False
 
-    def run(self, fn, *tensors):
-        main = torch.cuda.current_stream()
-        self.stream.wait_stream(main)  # operands were produced on the main stream
-        with torch.cuda.stream(self.stream):
-            fn()
-        self.keep.append(tensors)      # their memory must not be recycled by the main stream before join()
+    def _queue_join(self):
         if not self._join_queued:
             try:  # inside a backward pass: join when the engine has run its last node
                 torch.autograd.Variable._execution_engine.queue_callback(self.join)
@@ -242,7 +238,50 @@ class GradSideStream:
             except RuntimeError:  # called outside a backward pass (direct use of the op): the caller joins
                 pass
 
+    def run(self, fn, *tensors):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)  # operands were produced on the main stream
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.append(tensors)      # their memory must not be recycled by the main stream before join()
+        self._queue_join()
+
+    def defer(self, job: tuple) -> None:
+        """Queue one weight-gradient GEMM ``(dz, x0, k0, rows, x1, k1, out)`` for the batched launch at the end of the
+        backward pass (``m3d_linear_wgrad_batch``); the tuple keeps the operands alive until then."""
+        self.jobs.append(job)
+        self._queue_join()
+
+    def flush(self) -> None:
+        """Launch the queued weight-gradient GEMMs (current stream): a handful of launches for all layers."""
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        import ctypes
+
+        m = len(jobs)
+        h = lib()
+        need = [h.m3d_linear_wgrad_workspace_bytes(dz.shape[0], dz.shape[1], k0 + k1) for dz, _, k0, _, _, k1, _ in jobs]
+        offs, tot = [], 0
+        for nb in need:
+            offs.append(tot)
+            tot += (nb + 255) // 256 * 256
+        ws = torch.empty(max(tot, 1), dtype=torch.uint8, device=jobs[0][0].device)
+        base = ws.data_ptr()
+        vp = lambda vals: (ctypes.c_void_p * m)(*vals)
+        i64 = lambda vals: (ctypes.c_int64 * m)(*vals)
+        i32 = lambda vals: (ctypes.c_int32 * m)(*vals)
+        call("m3d_linear_wgrad_batch", m,
+             vp([j[0].data_ptr() for j in jobs]), i64([j[0].stride(0) for j in jobs]),
+             vp([j[1].data_ptr() for j in jobs]), i64([j[1].stride(0) for j in jobs]),
+             vp([_p(j[3]) for j in jobs]), i32([j[2] for j in jobs]),
+             vp([_p(j[4]) for j in jobs]), i64([j[4].stride(0) if j[4] is not None else 0 for j in jobs]),
+             i32([j[5] for j in jobs]), i64([j[0].shape[0] for j in jobs]), i32([j[0].shape[1] for j in jobs]),
+             vp([j[6].data_ptr() for j in jobs]), i64([j[6].stride(0) for j in jobs]), 1,
+             vp([base + o if nb else None for o, nb in zip(offs, need)]), _st())
+
     def join(self):
+        self.flush()
         torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
         self._join_queued = False
@@ -263,6 +302,9 @@ def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None,
     K = k0 + k1
     sink = out is not None
     dw = out if sink else torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    if sink and side is not None and DEFER_WGRAD:
+        side.defer((dz, x0, k0, rows, x1, k1, dw))  # launched with all the others at the end of the backward pass
+        return None
     nbytes = lib().m3d_linear_wgrad_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dz.device) if nbytes else None
 
@@ -362,6 +404,9 @@ def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
     return scale, shift, mean, invstd
 
 
+# weight gradients of all layers in a handful of launches at the END of the backward pass (GradSideStream.defer / flush)
+# instead of one GEMM + one reduce per layer on the side stream; M3D_DEFER_WGRAD=0: the per-layer launches (A/B)
+DEFER_WGRAD = os.environ.get("M3D_DEFER_WGRAD", "1") != "0"
 FUSE_BN_DGRAD = os.environ.get("M3D_FUSE_BN_DGRAD", "1") != "0"  # A/B switch for bn_dgrad (see its docstring)
 BN_SLOTS = 16  # slot-mode statistics: workgroups add their column partials into this many fp64 rows
 
