@@ -29,6 +29,7 @@
 // Train-mode BatchNorm column statistics (sum, sum of squares of the raw output) are accumulated in fp64 per lane,
 // then across lanes / waves (LDS); every workgroup stores its partial row and m3d_bn_finalize sums the rows.
 #include <stdlib.h>
+#include <vector>
 #include "gemm_common.h"
 
 // wavefronts per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument in HIP).  hipcc sizes
@@ -596,7 +597,24 @@ struct WgradArgs {
   float* dw; int64_t lddw; int accumulate;
   float* ws;  // [S][N][K] partials (S > 1)
   int S; int64_t steps_per_split;
+  int vec;  // != 0: permuted tile columns (tile a of a TN-tile group holds n = nb + TN*i + a, likewise k): a lane's TN / TK
+            // operand values are consecutive floats -> ONE 4*TN / 4*TK-byte load instead of TN / TK dword loads, and one
+            // vector store per accumulator row (the level-1 layers stream at dword granularity otherwise: ~2 TB/s)
 };
+
+template <int V>
+__device__ __forceinline__ void ldv(rsrc_t r, unsigned off, float (&out)[V]) {
+  if constexpr (V == 1) {
+    out[0] = ld1(r, off);
+  } else if constexpr (V == 2) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    out[0] = v[0]; out[1] = v[1];
+  } else {
+    const float4 v = ld4(r, off);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+}
 
 template <int TN, int TK>
 struct WgradFrag {
@@ -616,6 +634,18 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
   const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
   const unsigned o0 = (ok && rr >= 0) ? (unsigned)(rr * g.ldx0 * 4) : OOB;
   const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
+  if (g.vec) {
+    const int n0 = nb + TN * lr;
+    ldv<TN>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, f.a);
+    const int kk = kb + TK * lr;
+    const bool in0 = kk < g.k0;
+    float t0[TK], t1[TK];
+    ldv<TK>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
+    ldv<TK>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
+#pragma unroll
+    for (int b = 0; b < TK; ++b) f.b[b] = t0[b] + t1[b];
+    return f;
+  }
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
     const int n = nb + 16 * a + lr;
@@ -697,6 +727,33 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
     part = bx;
   } else {
     if (s0 >= steps_total) return;  // (no rows: this wave has no partial slot either)
+  }
+  if (g.vec) {
+    // permuted columns: accumulator (a, b, r) of lane (lr, lg) is dW[nb + TN*(4lg + r) + a][kb + TK*lr + b]: the TK values
+    // of a row are consecutive -> one 4*TK-byte store (16 lanes = 64*TK contiguous bytes)
+    const int kk = kb + TK * lr;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + TN * (4 * lg + r) + a;
+        if (n < g.N && kk < K) {
+          float* cp = g.S > 1 ? g.ws + ((size_t)part * g.N + n) * K + kk : g.dw + (int64_t)n * g.lddw + kk;
+          const bool add = g.S <= 1 && g.accumulate;
+          if constexpr (TK == 4) {
+            float4 v = make_float4(acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]);
+            if (add) { const float4 o = *(float4*)cp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *(float4*)cp = v;
+          } else if constexpr (TK == 2) {
+            float2 v = make_float2(acc[a][0][r], acc[a][1][r]);
+            if (add) { const float2 o = *(float2*)cp; v.x += o.x; v.y += o.y; }
+            *(float2*)cp = v;
+          } else {
+            *cp = add ? *cp + acc[a][0][r] : acc[a][0][r];
+          }
+        }
+      }
+    return;
   }
   // D layout: row n = 16a + 4lg + r, col k = 16b + lr  (16 lanes = 64 contiguous bytes per store)
 #pragma unroll
@@ -795,7 +852,7 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, i
 }
 
 struct WgradPlan { int TN, TK; int64_t by, bz, S, spw, wgs; };  // S: partials in ws, spw: 4-row steps per WAVE, wgs: grid.x
-static WgradPlan wgrad_plan(int64_t M, int N, int K) {
+static WgradPlan wgrad_plan(int64_t M, int N, int K, int64_t target_waves = 0) {
   WgradPlan p;
   const int tn = (int)m3d_cdiv(N, 16), tk = (int)m3d_cdiv(K, 16);
   p.TN = tn >= 4 ? 4 : (tn >= 2 ? 2 : 1);
@@ -805,7 +862,8 @@ static WgradPlan wgrad_plan(int64_t M, int N, int K) {
   const bool wgr = p.TN * p.TK < 16;  // workgroup-level partials (see wgrad2_kernel)
   const int64_t steps_total = m3d_cdiv(M > 0 ? M : 1, 4);
   static const int target_env = getenv("M3D_WGRAD_WAVES") ? atoi(getenv("M3D_WGRAD_WAVES")) : 0;
-  const int target = target_env > 0 ? target_env : (wgr ? 8192 : 2048);
+  // target_waves > 0: this job's share of a batched launch (m3d_linear_wgrad_batch), instead of the whole chip
+  const int64_t target = target_waves > 0 ? target_waves : (target_env > 0 ? target_env : (wgr ? 8192 : 2048));
   int64_t waves = m3d_cdiv(target, p.by * p.bz);  // streaming tiles: ~8 waves per SIMD over the chip
   if (waves > steps_total / 8) waves = steps_total / 8;  // >= 8 steps (32 rows) per wave
   if (waves < 1) waves = 1;
@@ -826,6 +884,18 @@ extern "C" size_t m3d_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const WgradPlan p = wgrad_plan(M, N, K);
   return p.S > 1 ? (size_t)p.S * N * K * sizeof(float) : 0;
+}
+
+// permuted-column vector loads / stores (WgradArgs::vec): every row offset must stay a multiple of the vector width
+static int wgrad_vec_ok(const WgradArgs& g, int TN, int TK) {
+  static const bool off = getenv("M3D_WGRAD_VEC") && atoi(getenv("M3D_WGRAD_VEC")) == 0;
+  if (off) return 0;
+  const int K = g.k0 + g.k1;
+  auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  if (g.N % TN || K % TK || (g.k1 > 0 && g.k0 % TK)) return 0;
+  if (g.lddz % TN || g.ldx0 % TK || (g.k1 > 0 && g.ldx1 % TK) || g.lddw % TK) return 0;
+  if (!al(g.dz) || !al(g.x0) || (g.k1 > 0 && !al(g.x1)) || !al(g.dw) || (g.ws && !al(g.ws))) return 0;
+  return 1;
 }
 
 template <int TN>
@@ -863,6 +933,7 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
   g.dz = dz; g.lddz = lddz; g.x0 = x0; g.ldx0 = ldx0; g.rows = x0_rows; g.k0 = k0; g.x1 = x1; g.ldx1 = ldx1; g.k1 = k1;
   g.M = M; g.N = N; g.dw = dw; g.lddw = lddw; g.accumulate = accumulate; g.ws = (float*)ws; g.S = (int)p.S;
   g.steps_per_split = p.spw;
+  g.vec = wgrad_vec_ok(g, p.TN, p.TK);
   dim3 grid((unsigned)p.wgs, (unsigned)p.by, (unsigned)p.bz);
   if (p.TN == 4) launch_wgrad2<4>(g, p.TK, grid, st);
   else if (p.TN == 2) launch_wgrad2<2>(g, p.TK, grid, st);
@@ -911,8 +982,31 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
     hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(rtotal), dim3(256), 0, st, rb);
     rb.njobs = 0; rtotal = 0;
   };
+  // every job gets a share of its tile class's wave budget in proportion to its flops: planned one by one (as if each
+  // had the chip to itself) the 14 deep-layer jobs of a batch would split their rows 14 x finer than needed and pay
+  // for it in partial-sum traffic
+  static const int budget_big = getenv("M3D_WGRAD_BATCH_WAVES_BIG") ? atoi(getenv("M3D_WGRAD_BATCH_WAVES_BIG")) : 4096;
+  static const int budget_small = getenv("M3D_WGRAD_BATCH_WAVES_SMALL") ? atoi(getenv("M3D_WGRAD_BATCH_WAVES_SMALL")) : 8192;
+  double class_flops[7] = {0, 0, 0, 0, 0, 0, 0};
+  std::vector<int> cls_of(njobs, -1);
+  for (int j = 0; j < njobs; ++j) {
+    const int K = k0[j] + k1[j];
+    if (M[j] <= 0 || N[j] <= 0 || K <= 0) continue;
+    const WgradPlan p = wgrad_plan(M[j], N[j], K);
+    for (int c = 0; c < 7; ++c) if (variants[c][0] == p.TN && variants[c][1] == p.TK) cls_of[j] = c;
+    if (cls_of[j] >= 0) class_flops[cls_of[j]] += (double)M[j] * N[j] * K;
+  }
+  auto plan_of = [&](int j) {
+    const int K = k0[j] + k1[j];
+    const int c = cls_of[j];
+    const bool big = variants[c][0] * variants[c][1] >= 16;
+    int64_t share = (int64_t)((big ? budget_big : budget_small) * ((double)M[j] * N[j] * K / class_flops[c]));
+    if (share < 64) share = 64;
+    const int64_t cap = big ? 2048 : 8192;  // never finer than the single-job plan: ws[j] is sized for that one
+    if (share > cap) share = cap;
+    return wgrad_plan(M[j], N[j], K, share);
+  };
   // pass 1: the GEMMs, one launch per tile class (and per 16 jobs); their reduces are queued and launched afterwards
-  struct Pending { int j; WgradPlan p; };
   for (int v = 0; v < 7; ++v) {
     WgradBatch b;
     b.njobs = 0;
@@ -935,10 +1029,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
     for (int j = 0; j < njobs; ++j) {
       const int K = k0[j] + k1[j];
       if (M[j] <= 0 || N[j] <= 0 || K <= 0) continue;  // (accumulate: nothing to add)
-      const WgradPlan p = wgrad_plan(M[j], N[j], K);
-      // tile classes the single-job launcher can produce: (4,4) (4,2) (4,1)->TK 1 ... map (TN, TK) to a class index
-      int cls = -1;
-      for (int c = 0; c < 7; ++c) if (variants[c][0] == p.TN && variants[c][1] == p.TK) cls = c;
+      const int cls = cls_of[j];
       if (cls < 0) {  // (4,1) / (1,4): rare shapes, launched on their own
         if (v == 0) {
           const int rc = m3d_linear_wgrad_f32(dz[j], lddz[j], x0[j], ldx0[j], x0_rows[j], k0[j], x1[j], ldx1[j], k1[j], M[j],
@@ -948,6 +1039,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
         continue;
       }
       if (cls != v) continue;
+      const WgradPlan p = plan_of(j);
       if (!dz[j] || k0[j] < 1 || !x0[j] || (k1[j] > 0 && !x1[j]) || !dw[j] || (p.S > 1 && !ws[j])) return M3D_ERR_INVALID;
       const int64_t lim = (int64_t)M3D_BUF_BYTES - 64;
       if (M[j] * lddz[j] * 4 > lim || M[j] * ldx0[j] * 4 > lim || (k1[j] > 0 && M[j] * ldx1[j] * 4 > lim))
@@ -956,6 +1048,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
       g.dz = dz[j]; g.lddz = lddz[j]; g.x0 = x0[j]; g.ldx0 = ldx0[j]; g.rows = x0_rows[j]; g.k0 = k0[j]; g.x1 = x1[j];
       g.ldx1 = ldx1[j]; g.k1 = k1[j]; g.M = M[j]; g.N = N[j]; g.dw = dw[j]; g.lddw = lddw[j]; g.accumulate = 1;
       g.ws = (float*)ws[j]; g.S = (int)p.S; g.steps_per_split = p.spw;
+      g.vec = wgrad_vec_ok(g, p.TN, p.TK);
       b.wg_start[b.njobs] = total;
       b.gx[b.njobs] = (unsigned)p.wgs; b.gy[b.njobs] = (unsigned)p.by;
       total += (unsigned)(p.wgs * p.by * p.bz);
@@ -967,10 +1060,9 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
   for (int j = 0; j < njobs; ++j) {
     const int K = k0[j] + k1[j];
     if (M[j] <= 0 || N[j] <= 0 || K <= 0) continue;
-    const WgradPlan p = wgrad_plan(M[j], N[j], K);
-    bool cls_ok = false;
-    for (int c = 0; c < 7; ++c) if (variants[c][0] == p.TN && variants[c][1] == p.TK) cls_ok = true;
-    if (!cls_ok || p.S <= 1) continue;
+    if (cls_of[j] < 0) continue;
+    const WgradPlan p = plan_of(j);
+    if (p.S <= 1) continue;
     const int E = N[j] * K;
     const int gx = (E + 255) / 256;
     int gy = (int)(p.S / 16);
