@@ -56,11 +56,12 @@ def parse():
                          "step ahead (HipRandLANet.prefetch_geometry; bit-identical results either way)")
     ap.add_argument("--lookahead", dest="lookahead", action="store_true", help="(default)")
     ap.set_defaults(lookahead=True)
-    ap.add_argument("--lookahead-mode", choices=("dual", "single"), default="single",
-                    help="hipGraph launch of the lookahead: 'single' = one graph holding the step and the next step's "
-                         "position-only branch (default: 5.75 ms); 'dual' = two graphs replayed on two streams, which really "
-                         "overlap — and compete: 6.1-6.5 ms per training step, 1.17 vs 1.22 ms per eval forward "
-                         "(profiles/r02v_*, r02x_*)")
+    ap.add_argument("--lookahead-mode", choices=("dual", "single"), default="dual",
+                    help="hipGraph launch of the lookahead: 'dual' (default) = the step and the next step's position-only "
+                         "work as two graphs replayed on two streams, so that they overlap; 'single' = one graph holding both "
+                         "branches (the executor then runs the position-only branch first, ~0.8 ms ahead of the features). "
+                         "dual was the slower one while the weight gradients still ran on a side stream (profiles/r02vwx_*), "
+                         "and is 0.08 ms faster since they are batched at the end of the backward pass")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
