@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 7
+#define M3D_ABI_VERSION 8
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -152,11 +152,14 @@ int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float*
  *   dx[M, Kin] = dz[M, N] w[N, Kin]     dz is also stored (the weight-gradient GEMM reads it), dbeta = s1, dgamma = s2
  * sums = the [nslots][3][N] table left by m3d_bn_bwd(..., accumulate_param_grads = 2 | nslots << 8).
  * flags: bit 0 = dgamma / dbeta are gradient sinks (added to); bit 8 = bf16 matrix-core operands (N % 32 == 0, N > 64).
- * N % 4 == 0, N <= 1024, contiguous dy / z / dz; M3D_ERR_UNSUPPORTED otherwise (callers then use m3d_bn_bwd + m3d_gemm_f32). */
+ * N % 4 == 0, N <= 1024, contiguous dy / z / dz; M3D_ERR_UNSUPPORTED otherwise (callers then use m3d_bn_bwd + m3d_gemm_f32).
+ * dx_split > 0 (the layer's input was a concatenation, FPModule: pyg_randla_net.py:249-252): columns [0, dx_split) of the
+ * input gradient are stored to dx[m][.] (lddx), columns [dx_split, Kin) to dx1[m][. - dx_split] (lddx1); multiples of 4. */
 int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* scale, const float* shift, const float* mean,
                      const float* invstd, int32_t act, float slope, const double* sums, int32_t nslots, int64_t M,
                      int32_t N, const float* w, int64_t ldw, int32_t Kin, float* dx, int64_t lddx, float* dz,
-                     float* dgamma, float* dbeta, int32_t flags, void* stream);
+                     float* dgamma, float* dbeta, int32_t flags, int32_t dx_split, float* dx1, int64_t lddx1,
+                     void* stream);
 
 /* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
 int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,

@@ -41,7 +41,7 @@ SIGNATURES = {
     "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,
                           _p, _p, _i32, _p]),
     "m3d_bn_dgrad_f32": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i32, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p,
-                                _p, _i32, _p]),
+                                _p, _i32, _i32, _p, _i64, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
     "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
@@ -78,7 +78,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 7  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 8  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

@@ -236,6 +236,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
     y[r] = v;
   }
   if (!rowok) return;
+  if (MODE == 0 && g.c_split > 0) {  // (c_split, N multiples of 4: a lane's four columns fall on one side)
+    if (n0 < g.c_split) *(float4*)(g.c + m * g.ldc + n0) = make_float4(y[0], y[1], y[2], y[3]);
+    else if (n0 < g.N) *(float4*)(g.c1 + m * g.ldc1 + (n0 - g.c_split)) = make_float4(y[0], y[1], y[2], y[3]);
+    return;
+  }
   float* cp = g.c + m * g.ldc + n0;
   if (cvec) {  // N % 4 == 0, ldc % 4 == 0, 16-byte aligned C
     if (n0 < g.N) *(float4*)cp = make_float4(y[0], y[1], y[2], y[3]);
@@ -566,6 +571,9 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   const int variant = vec ? (g.b_cm ? 2 : (g.k1 > 0 ? 1 : 0)) : (g.b_cm ? 4 : 3);
   // the BatchNorm-backward prologue exists for the vector-load dgrad kernels only (m3d_bn_dgrad_f32 checks the rest)
   if (g.pro_z && (variant != 2 || K > PRO_KMAX || g.a0_rows || g.lda0 != K)) return M3D_ERR_UNSUPPORTED;
+  if (g.c_split > 0 && (mode != 0 || (g.c_split & 3) || (g.N & 3) || g.c_split >= g.N || !g.c1 || (g.ldc1 & 3) ||
+                        (g.ldc & 3) || !al16(g.c1) || !al16(g.c)))
+    return M3D_ERR_UNSUPPORTED;
   const RowPlan rp = plan_rows(g.M, g.N, K, mode);
   if (rp.slices > 65535) return 1;
   dim3 grid((unsigned)rp.wgs, (unsigned)rp.slices);

@@ -490,10 +490,11 @@ def bn_dgrad_ok(N: int) -> bool:
     return _pow2(N) and N <= 1024
 
 
-def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False):
+def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, split: int = 0):
     """BatchNorm backward + input gradient of the Linear in front of it in TWO launches: the column sums
     (``m3d_bn_bwd`` pass 1, slot mode), then ``m3d_bn_dgrad_f32``, whose A fragments are dz computed on the fly.
-    Returns ``(dx, dz, dgamma, dbeta)`` (the last two None with sinks)."""
+    Returns ``(dx, dz, dgamma, dbeta)`` (the last two None with sinks).  ``split = k0 > 0``: ``dx`` is the pair
+    ``(dx[:, :k0], dx[:, k0:])`` as two contiguous matrices (the layer's input was a concatenation)."""
     M, N = z.shape
     dev = z.device
     dy = _chk(dy)
@@ -506,10 +507,17 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False):
         dgamma, dbeta = torch.empty(N, device=dev), torch.empty(N, device=dev)
     Kin = w.shape[1]
     dz = torch.empty_like(z)
-    dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
-    call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
-         _p(sums), BN_SLOTS, M, N, _p(w), w.stride(0), Kin, _p(dx), Kin, _p(dz), _p(dgamma), _p(dbeta),
-         int(sinks is not None) | (256 if bf16 else 0), _st())
+    if split:
+        dx = (torch.empty((M, split), dtype=torch.float32, device=dev),
+              torch.empty((M, Kin - split), dtype=torch.float32, device=dev))
+        call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
+             _p(sums), BN_SLOTS, M, N, _p(w), w.stride(0), Kin, _p(dx[0]), split, _p(dz), _p(dgamma), _p(dbeta),
+             int(sinks is not None) | (256 if bf16 else 0), split, _p(dx[1]), Kin - split, _st())
+    else:
+        dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
+        call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
+             _p(sums), BN_SLOTS, M, N, _p(w), w.stride(0), Kin, _p(dx), Kin, _p(dz), _p(dgamma), _p(dbeta),
+             int(sinks is not None) | (256 if bf16 else 0), 0, None, 0, _st())
     if sinks is not None:
         return dx, dz, None, None
     return dx, dz, dgamma, dbeta
@@ -577,7 +585,17 @@ class SharedLayerTrainFn(torch.autograd.Function):
         dx0 = dx1 = None
         want_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
         dxc = None
-        if want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1]):
+        fused = want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1])
+        if fused and k1 and k0 % 4 == 0 and k1 % 4 == 0:
+            # concatenated input: the two column blocks of the input gradient leave the GEMM as two contiguous matrices
+            (s0, s1), dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
+                                                   sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16, split=k0)
+            if ctx.needs_input_grad[0]:
+                dx0 = scatter_add_rows(s0, rows, x0.shape[0]) if rows is not None else s0
+            if ctx.needs_input_grad[1]:
+                dx1 = s1
+            want_dx = False
+        elif fused:
             dxc, dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
                                               sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16)
         else:
