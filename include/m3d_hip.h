@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 8
+#define M3D_ABI_VERSION 9
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -251,6 +251,17 @@ int m3d_lfa_edge_features_bwd(const float* dF, const float* pos4, const int32_t*
 int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_edges, const float* w, const float* b,
                              const float* gamma, const float* mean, const float* invstd, float* dw, float* db,
                              float* dgamma, float* dbeta, int32_t D, int32_t accumulate, void* stream);
+/* m3d_lfa_enc_bwd_finalize for up to any number of layers in one launch per 16 (host arrays of length njobs). */
+int m3d_lfa_enc_bwd_finalize_batch(int32_t njobs, const double* const* G, const double* const* mom65,
+                                   const int64_t* num_edges, const float* const* w, const float* const* b,
+                                   const float* const* gamma, const float* const* mean, const float* const* invstd,
+                                   float* const* dw, float* const* db, float* const* dgamma, float* const* dbeta,
+                                   const int32_t* D, int32_t accumulate, void* stream);
+/* The partial-sum reduces of m3d_lfa_bwd / m3d_lfa_bwd_bf16 calls made with flags bit 2 set, in one launch per 16 layers:
+ * job j is the layer launched with (n[j], K[j], CH[j], ws[j]); its sums are ADDED into dw_att[j] (gradient sink) and G[j]
+ * (pre-zeroed).  dW_att and G feed parameter gradients only, so the whole backward pass can hand them over at its end. */
+int m3d_lfa_bwd_reduce_batch(int32_t njobs, const int64_t* n, const int32_t* K, const int32_t* CH, void* const* ws,
+                             float* const* dw_att, double* const* G, void* stream);
 
 /* ---- knn_interpolate arithmetic (model.py:90-98; pyg_randla_net.py:250) ---------------------------------- */
 int m3d_idw_interpolate_fwd(const float* x, int64_t ldx, const int32_t* idx, const float* d2, int64_t n_qry,

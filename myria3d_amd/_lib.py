@@ -65,6 +65,8 @@ SIGNATURES = {
     "m3d_lfa_edge_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "m3d_lfa_edge_features_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p, _p]),
     "m3d_lfa_enc_bwd_finalize": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
+    "m3d_lfa_enc_bwd_finalize_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "m3d_lfa_bwd_reduce_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p]),
     "m3d_idw_interpolate_fwd": (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _p, _p]),
     "m3d_predict_reduce": (_i32, [_p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "m3d_grid_sampling_workspace_bytes": (C.c_size_t, [_i64, _i32]),
@@ -78,7 +80,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 8  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 9  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

@@ -808,15 +808,14 @@ extern "C" int m3d_lfa_edge_features_bwd(const float* dF, const float* pos4, con
 //   dbeta = g0, dgamma = invstd*(w.G + (b-mean) g0)
 //   dW[c,q] = scale*( G[c,q] - (g0/E) S1[q] - (dgamma/E) * invstd*( sum_p w_p M2[p,q] + (b-mean) S1[q] ) )
 //   db = 0 (BatchNorm removes the mean)
-__global__ __launch_bounds__(64) void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G,
-                                                                  const double* __restrict__ mom, double E,
-                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                  const float* __restrict__ gamma,
-                                                                  const float* __restrict__ mean,
-                                                                  const float* __restrict__ invstd, float* dw, float* db,
-                                                                  float* dgamma, float* dbeta, int D, int acc) {
+__device__ __forceinline__ void lfa_enc_bwd_finalize_body(const double* __restrict__ G, const double* __restrict__ mom,
+                                                          double E, const float* __restrict__ w,
+                                                          const float* __restrict__ b, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, float* dw, float* db,
+                                                          float* dgamma, float* dbeta, int D, int acc, int c) {
   // one wave per channel; lane q < 10 owns dW[c, q]
-  const int c = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
   if (c >= D) return;
   const double* g = G + c * 11;
   const double g0 = g[10];
@@ -837,6 +836,68 @@ __global__ __launch_bounds__(64) void lfa_enc_bwd_finalize_kernel(const double* 
   if (!acc) db[c] = 0.f;  // BatchNorm removes the mean: d/d(bias) is exactly 0
   dgamma[c] = acc ? dgamma[c] + (float)dgam : (float)dgam;
   dbeta[c] = acc ? dbeta[c] + (float)g0 : (float)g0;
+}
+
+__global__ __launch_bounds__(64) void lfa_enc_bwd_finalize_kernel(const double* __restrict__ G,
+                                                                  const double* __restrict__ mom, double E,
+                                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, float* dw, float* db,
+                                                                  float* dgamma, float* dbeta, int D, int acc) {
+  lfa_enc_bwd_finalize_body(G, mom, E, w, b, gamma, mean, invstd, dw, db, dgamma, dbeta, D, acc, blockIdx.x);
+}
+
+// the encoder parameter gradients of several LFA layers in one launch (leaves of the backward pass, see
+// lfa_bwd_reduce_batch_kernel): wave w of the flattened grid is channel w - start[j] of job j
+#define LFA_FIN_BATCH_MAX 16
+struct LfaFinBatch {
+  const double* G[LFA_FIN_BATCH_MAX]; const double* mom[LFA_FIN_BATCH_MAX]; double E[LFA_FIN_BATCH_MAX];
+  const float* w[LFA_FIN_BATCH_MAX]; const float* b[LFA_FIN_BATCH_MAX]; const float* gamma[LFA_FIN_BATCH_MAX];
+  const float* mean[LFA_FIN_BATCH_MAX]; const float* invstd[LFA_FIN_BATCH_MAX];
+  float* dw[LFA_FIN_BATCH_MAX]; float* db[LFA_FIN_BATCH_MAX]; float* dgamma[LFA_FIN_BATCH_MAX]; float* dbeta[LFA_FIN_BATCH_MAX];
+  int D[LFA_FIN_BATCH_MAX]; unsigned start[LFA_FIN_BATCH_MAX + 1];
+  int njobs, acc;
+};
+__global__ __launch_bounds__(64) void lfa_enc_bwd_finalize_batch_kernel(LfaFinBatch a) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < LFA_FIN_BATCH_MAX; ++i) j += (i < a.njobs && blockIdx.x >= a.start[i]) ? 1 : 0;
+  lfa_enc_bwd_finalize_body(a.G[j], a.mom[j], a.E[j], a.w[j], a.b[j], a.gamma[j], a.mean[j], a.invstd[j], a.dw[j], a.db[j],
+                            a.dgamma[j], a.dbeta[j], a.D[j], a.acc, (int)(blockIdx.x - a.start[j]));
+}
+
+extern "C" int m3d_lfa_enc_bwd_finalize_batch(int32_t njobs, const double* const* G, const double* const* mom65,
+                                              const int64_t* num_edges, const float* const* w, const float* const* b,
+                                              const float* const* gamma, const float* const* mean,
+                                              const float* const* invstd, float* const* dw, float* const* db,
+                                              float* const* dgamma, float* const* dbeta, const int32_t* D,
+                                              int32_t accumulate, void* stream) {
+  if (njobs < 0) return M3D_ERR_INVALID;
+  if (njobs == 0) return M3D_OK;
+  if (!G || !mom65 || !num_edges || !w || !b || !gamma || !mean || !invstd || !dw || !db || !dgamma || !dbeta || !D)
+    return M3D_ERR_INVALID;
+  for (int j0 = 0; j0 < njobs; j0 += LFA_FIN_BATCH_MAX) {
+    LfaFinBatch a;
+    const int m = njobs - j0 < LFA_FIN_BATCH_MAX ? njobs - j0 : LFA_FIN_BATCH_MAX;
+    a.njobs = m; a.acc = accumulate;
+    unsigned total = 0;
+    for (int i = 0; i < LFA_FIN_BATCH_MAX; ++i) {
+      a.start[i] = total;
+      const int j = j0 + (i < m ? i : 0);
+      if (i < m && (D[j] < 0 || num_edges[j] < 1 || !G[j] || !mom65[j] || !w[j] || !b[j] || !gamma[j] || !mean[j] ||
+                    !invstd[j] || !dw[j] || !db[j] || !dgamma[j] || !dbeta[j]))
+        return M3D_ERR_INVALID;
+      a.G[i] = G[j]; a.mom[i] = mom65[j]; a.E[i] = (double)num_edges[j]; a.w[i] = w[j]; a.b[i] = b[j]; a.gamma[i] = gamma[j];
+      a.mean[i] = mean[j]; a.invstd[i] = invstd[j]; a.dw[i] = dw[j]; a.db[i] = db[j]; a.dgamma[i] = dgamma[j];
+      a.dbeta[i] = dbeta[j]; a.D[i] = i < m ? D[j] : 0;
+      if (i < m) total += (unsigned)D[j];
+    }
+    a.start[LFA_FIN_BATCH_MAX] = total;
+    if (total) hipLaunchKernelGGL(lfa_enc_bwd_finalize_batch_kernel, dim3(total), dim3(64), 0, (hipStream_t)stream, a);
+  }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
 }
 
 extern "C" int m3d_lfa_enc_bwd_finalize(const double* G, const double* mom65, int64_t num_edges, const float* w,

@@ -703,13 +703,13 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 // sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64).  blockIdx.x owns 256 consecutive
 // elements, blockIdx.y a contiguous chunk of the partials; chunks are combined with one atomic per element per
 // chunk into the (pre-zeroed) outputs, so the pass runs at HBM speed instead of one block walking every partial.
-__global__ __launch_bounds__(256) void lfa_bwd_reduce_kernel(const float* __restrict__ dw_part, int parts3, int CHP,
-                                                             int CH, float* __restrict__ dw_att,
-                                                             const float* __restrict__ g_part, int parts4, int DP,
-                                                             int D, double* __restrict__ G) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void lfa_bwd_reduce_body(const float* __restrict__ dw_part, int parts3, int CHP, int CH,
+                                                    float* __restrict__ dw_att, const float* __restrict__ g_part,
+                                                    int parts4, int DP, int D, double* __restrict__ G, unsigned bx,
+                                                    unsigned by, unsigned nyy) {
+  const int t = bx * 256 + threadIdx.x;
   const int nw = CHP * CHP;
-  const int ny = gridDim.y, y = blockIdx.y;
+  const int ny = (int)nyy, y = (int)by;
   if (t < nw) {
     const int per = (parts3 + ny - 1) / ny;
     const int p0 = y * per, p1 = min(parts3, p0 + per);
@@ -735,6 +735,33 @@ __global__ __launch_bounds__(256) void lfa_bwd_reduce_kernel(const float* __rest
       if (c < D && q < 11 && p1 > p0) atomicAdd(&G[c * 11 + q], s);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void lfa_bwd_reduce_kernel(const float* __restrict__ dw_part, int parts3, int CHP,
+                                                             int CH, float* __restrict__ dw_att,
+                                                             const float* __restrict__ g_part, int parts4, int DP,
+                                                             int D, double* __restrict__ G) {
+  lfa_bwd_reduce_body(dw_part, parts3, CHP, CH, dw_att, g_part, parts4, DP, D, G, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// the partial sums of several LFA layers in one launch (m3d_lfa_bwd_reduce_batch): dW_att and the encoder sums G are
+// PARAMETER-gradient material — nothing in the backward chain reads them — so every layer's reduce can wait for the
+// end of the backward pass (8 launches of 10-20 us in the dependent chain otherwise)
+#define LFA_RED_BATCH_MAX 16
+struct LfaRedBatch {
+  const float* dw_part[LFA_RED_BATCH_MAX]; const float* g_part[LFA_RED_BATCH_MAX];
+  float* dw_att[LFA_RED_BATCH_MAX]; double* G[LFA_RED_BATCH_MAX];
+  int parts3[LFA_RED_BATCH_MAX], parts4[LFA_RED_BATCH_MAX], chp[LFA_RED_BATCH_MAX], ch[LFA_RED_BATCH_MAX], dp[LFA_RED_BATCH_MAX];
+  unsigned gx[LFA_RED_BATCH_MAX], gy[LFA_RED_BATCH_MAX], wg_start[LFA_RED_BATCH_MAX + 1];
+  int njobs;
+};
+__global__ __launch_bounds__(256) void lfa_bwd_reduce_batch_kernel(LfaRedBatch b) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < LFA_RED_BATCH_MAX; ++i) j += (i < b.njobs && blockIdx.x >= b.wg_start[i]) ? 1 : 0;
+  const unsigned w = blockIdx.x - b.wg_start[j];
+  lfa_bwd_reduce_body(b.dw_part[j], b.parts3[j], b.chp[j], b.ch[j], b.dw_att[j], b.g_part[j], b.parts4[j], b.dp[j],
+                      b.ch[j] / 2, b.G[j], w % b.gx[j], w / b.gx[j], b.gy[j]);
 }
 
 struct BwdPlan { int chp, rows, grid, kspl3, kspl4, dp; };
@@ -827,6 +854,7 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
     default: rc = launch_lfa_bwd<256>(a, p, st, bf16); break;
   }
   if (rc != M3D_OK) return rc;
+  if (flags & 4) return M3D_OK;  // the caller sums the partials later (m3d_lfa_bwd_reduce_batch): ws must live until then
   const int total = p.chp * p.chp + p.dp * 16;
   const int gx = (total + 255) / 256;
   const int parts = p.grid * p.kspl3;
@@ -842,7 +870,51 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   return M3D_OK;
 }
 
-// flags: bit 0 = add into dw_att (gradient sink) instead of overwriting it, bit 1 = G is already zero (skips a memset)
+// the deferred reduces of m3d_lfa_bwd(..., flags | 4) calls: job j = the layer launched with (n[j], K[j], CH[j], ws[j]);
+// its partial sums are ADDED into dw_att[j] (a gradient sink) and G[j] (pre-zeroed [11 * CH / 2] doubles)
+extern "C" int m3d_lfa_bwd_reduce_batch(int32_t njobs, const int64_t* n, const int32_t* K, const int32_t* CH,
+                                        void* const* ws, float* const* dw_att, double* const* G, void* stream) {
+  if (njobs < 0) return M3D_ERR_INVALID;
+  if (njobs == 0) return M3D_OK;
+  if (!n || !K || !CH || !ws || !dw_att || !G) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += LFA_RED_BATCH_MAX) {
+    LfaRedBatch b;
+    const int m = njobs - j0 < LFA_RED_BATCH_MAX ? njobs - j0 : LFA_RED_BATCH_MAX;
+    b.njobs = m;
+    unsigned total_wg = 0;
+    for (int i = 0; i < LFA_RED_BATCH_MAX; ++i) {
+      b.wg_start[i] = total_wg;
+      if (i >= m) {
+        b.dw_part[i] = nullptr; b.g_part[i] = nullptr; b.dw_att[i] = nullptr; b.G[i] = nullptr;
+        b.parts3[i] = b.parts4[i] = 0; b.chp[i] = b.dp[i] = 16; b.ch[i] = 8; b.gx[i] = b.gy[i] = 1;
+        continue;
+      }
+      const int j = j0 + i;
+      if (n[j] < 0 || K[j] < 1 || K[j] > 32 || !ws[j] || !dw_att[j] || !G[j]) return M3D_ERR_INVALID;
+      if (CH[j] != 8 && CH[j] != 16 && CH[j] != 32 && CH[j] != 64 && CH[j] != 128 && CH[j] != 256) return M3D_ERR_UNSUPPORTED;
+      const BwdPlan p = bwd_plan(n[j], K[j], CH[j]);
+      b.dw_part[i] = (const float*)ws[j];
+      b.g_part[i] = b.dw_part[i] + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
+      b.dw_att[i] = dw_att[j]; b.G[i] = G[j];
+      b.parts3[i] = p.grid * p.kspl3; b.parts4[i] = p.grid * p.kspl4; b.chp[i] = p.chp; b.ch[i] = CH[j]; b.dp[i] = p.dp;
+      const int total = p.chp * p.chp + p.dp * 16;
+      const int gx = (total + 255) / 256;
+      int gy = 2048 / gx;
+      if (gy > b.parts3[i] / 8) gy = b.parts3[i] / 8;
+      if (gy < 1) gy = 1;
+      b.gx[i] = (unsigned)gx; b.gy[i] = (unsigned)gy;
+      total_wg += (unsigned)(gx * gy);
+    }
+    b.wg_start[LFA_RED_BATCH_MAX] = total_wg;
+    if (total_wg) hipLaunchKernelGGL(lfa_bwd_reduce_batch_kernel, dim3(total_wg), dim3(256), 0, st, b);
+  }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// flags: bit 0 = add into dw_att (gradient sink) instead of overwriting it, bit 1 = G is already zero (skips a memset),
+// bit 2 = do not sum the partials (m3d_lfa_bwd_reduce_batch does, later; dw_att / G are not touched)
 extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                            const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
                            const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,

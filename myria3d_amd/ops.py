@@ -228,6 +228,7 @@ class GradSideStream:
         self.stream = torch.cuda.Stream(device=device)
         self.keep: list = []
         self.jobs: list = []  # deferred weight-gradient GEMMs (``defer``): launched together by ``join``
+        self.lfa_jobs: list = []  # deferred LFA partial-sum reduces + encoder parameter gradients (``defer_lfa``)
         self._join_queued = False
 
     def _queue_join(self):
@@ -252,8 +253,30 @@ class GradSideStream:
         self.jobs.append(job)
         self._queue_join()
 
+    def defer_lfa(self, job: tuple) -> None:
+        """Queue the partial-sum reduce and the encoder parameter gradients of one LFA backward:
+        ``(n, K, ch, ws, dw_att, G, mom, num_edges, enc_w, enc_b, enc_gamma, mean, invstd, dw, db, dgamma, dbeta)``."""
+        self.lfa_jobs.append(job)
+        self._queue_join()
+
+    def _flush_lfa(self) -> None:
+        jobs, self.lfa_jobs = self.lfa_jobs, []
+        if not jobs:
+            return
+        import ctypes
+
+        m = len(jobs)
+        vp = lambda k: (ctypes.c_void_p * m)(*[j[k].data_ptr() for j in jobs])
+        call("m3d_lfa_bwd_reduce_batch", m, (ctypes.c_int64 * m)(*[j[0] for j in jobs]),
+             (ctypes.c_int32 * m)(*[j[1] for j in jobs]), (ctypes.c_int32 * m)(*[j[2] for j in jobs]), vp(3), vp(4), vp(5),
+             _st())
+        call("m3d_lfa_enc_bwd_finalize_batch", m, vp(5), vp(6), (ctypes.c_int64 * m)(*[j[7] for j in jobs]), vp(8), vp(9),
+             vp(10), vp(11), vp(12), vp(13), vp(14), vp(15), vp(16), (ctypes.c_int32 * m)(*[j[2] // 2 for j in jobs]), 1,
+             _st())
+
     def flush(self) -> None:
         """Launch the queued weight-gradient GEMMs (current stream): a handful of launches for all layers."""
+        self._flush_lfa()
         jobs, self.jobs = self.jobs, []
         if not jobs:
             return
@@ -815,6 +838,7 @@ class LFATrainFn(torch.autograd.Function):
                 sinks=None, bf16=False):
         # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
         ctx.sinks = sinks
+        ctx.side = _grad_side if sinks is not None else None
         x = x.contiguous()
         K = idx.shape[1]
         bf16 = bool(bf16) and lfa_bf16_ok(w_att.shape[0], K)
@@ -845,9 +869,16 @@ class LFATrainFn(torch.autograd.Function):
             dw_att = sk[4] if sk else torch.empty((ch, ch), dtype=torch.float32, device=dev)
             ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
             wp, wpt = ctx.packed  # packed in the forward pass (one launch for both orientations)
+            defer = sk is not None and ctx.side is not None and DEFER_WGRAD
             call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
-                 _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2, _p(G),
-                 _p(ws), _st())
+                 _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2 |
+                 (4 if defer else 0), _p(G), _p(ws), _st())
+            if defer:
+                # dW_att, G and the encoder parameter gradients are leaves: summed / finished with every other LFA
+                # layer's at the end of the backward pass (GradSideStream.flush) instead of two launches in the chain
+                ctx.side.defer_lfa((n, K, ch, ws, dw_att, G, mom, ctx.num_edges, enc_w, enc_b, enc_gamma, mean, invstd,
+                                    sk[0], sk[1], sk[2], sk[3]))
+                return (dx,) + (None,) * 13
         else:
             G = torch.empty(11 * D, dtype=torch.float64, device=dev)
             dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
