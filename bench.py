@@ -569,7 +569,10 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                     fwd_step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            if look:  # the captured steps must CONSUME tables prefetched one step earlier: leave one pending
+            if look:  # the captured steps must CONSUME tables prefetched one step earlier: leave one pending.  Two steps:
+                # the warm-up above alternated train and eval prefetches, so one of the two buffer sets still has the
+                # eval layout — a captured prefetch into it would re-create it (25 clone copies per replay)
+                train_step()
                 train_step()
                 torch.cuda.synchronize()
             # with the lookahead the prefetched tables live in two buffer sets used in turn: one captured step per set
