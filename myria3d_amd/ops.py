@@ -437,6 +437,18 @@ _SLOT_TABLE = tuple((int(a), int(b)) for a, b in
                     (t.split(":") for t in os.environ.get("M3D_BN_SLOTS", "100000:8,0:4").split(",")))
 
 
+_BWD_SLOT_TABLE = tuple((int(a), int(b)) for a, b in
+                        (t.split(":") for t in os.environ.get("M3D_BN_BWD_SLOTS", "100000:8,0:4").split(",")))
+
+
+def bn_bwd_slots(M: int) -> int:
+    """Slot rows of the backward column sums (filled by up to 2 048 reduce workgroups, read by the dgrad prologue)."""
+    for rows, slots in _BWD_SLOT_TABLE:
+        if M >= rows:
+            return min(slots, BN_SLOTS)
+    return 1
+
+
 def bn_slots(M: int) -> int:
     """Slot rows for a layer with ``M`` rows.  Every consumer workgroup sums all slot rows of its columns (the apply
     kernels, the dgrad prologue), so fewer rows are cheaper to read; the deep levels (a few thousand rows, a few dozen
@@ -496,7 +508,7 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
     Power-of-two widths take the slot mode of ``m3d_bn_bwd`` (two launches, pre-zeroed sums from the zero arena)."""
     M, N = z.shape
     dev = z.device
-    slots = bn_slots(M) if _pow2(N) else 0
+    slots = bn_bwd_slots(M) if _pow2(N) else 0
     if slots:
         sums = arena.zeros((slots, 3, N), torch.float64, dev)
     else:
@@ -534,7 +546,7 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, 
     M, N = z.shape
     dev = z.device
     dy = _chk(dy)
-    ns = bn_slots(M)
+    ns = bn_bwd_slots(M)
     sums = arena.zeros((ns, 3, N), torch.float64, dev)
     call("m3d_bn_bwd", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), None, None, None, None, None,
          int(act), LRELU_SLOPE, M, N, _p(sums), None, None, None, None, None, None, 2 | (ns << 8), _st())
