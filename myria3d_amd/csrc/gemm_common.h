@@ -18,6 +18,9 @@ struct GemmArgs {
   float* c; int64_t ldc; int accumulate;
   int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
   int bf16;                    // != 0: operands rounded to bf16 on load, v_mfma_f32_16x16x32_bf16 (K % 32 == 0, K > 64)
+  int ksplit;                  // k-loop kernels: != 0: the four waves of a workgroup share ONE row group and a quarter of K each
+                               // (accumulators meet in LDS): the deep layers have < 1 wave per SIMD and a K loop of 16-48
+                               // dependent chunks otherwise
   // BatchNorm-backward A-prologue (m3d_bn_dgrad_f32; direct kernels, dgrad pattern only).  a0 = dy and pro_z = z share
   // the [M, k0] layout; the A operand the MFMAs see is
   //   dz = scale * (dy * act'(z*scale + shift) - s1/M - (z - mean) * invstd * s2/M)

@@ -373,8 +373,10 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
     for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.0; ssq[t][r] = 0.0; }
 
   const int64_t ngroups = (g.M + 16 * MTW - 1) / (16 * MTW);
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wid; grp < ngroups; grp += stride) {
+  const bool ks = g.ksplit != 0;  // (uniform) split K over the four waves: same group, a quarter of the chunks each
+  __shared__ float kred[3][MTW * NTW * 4 * 64];
+  const int64_t stride = ks ? (int64_t)gridDim.x : (int64_t)gridDim.x * 4;
+  for (int64_t grp = ks ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wid; grp < ngroups; grp += stride) {
     ARow row[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) row[mt] = a_row(g, (grp * MTW + mt) * 16 + lr);
@@ -384,8 +386,10 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (BF) {
+      const int nq = K >> 5, per = (nq + 3) >> 2;
+      const int q0 = ks ? wid * per : 0, q1 = ks ? (q0 + per < nq ? q0 + per : nq) : nq;
 #pragma unroll 2
-      for (int q = 0; q < (K >> 5); ++q) {
+      for (int q = q0; q < q1; ++q) {
         const int k = 32 * q + 8 * lg;
         Bf16Frag a[MTW], w[NTW];
 #pragma unroll
@@ -405,9 +409,11 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
 #pragma unroll
           for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma_bf16(w[t].v, a[mt].v, acc[mt][t]);
       }
-    } else
+    } else {
+    const int per = (KQ + 3) >> 2;
+    const int q0 = ks ? wid * per : 0, q1 = ks ? (q0 + per < KQ ? q0 + per : KQ) : KQ;
 #pragma unroll 4
-    for (int q = 0; q < KQ; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const int k = 16 * q + 4 * lg;
       float4 a[MTW], w[NTW];
 #pragma unroll
@@ -421,11 +427,37 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
 #pragma unroll
           for (int t = 0; t < NTW; ++t) acc[mt][t] = mfma16(f4(w[t], i), f4(a[mt], i), acc[mt][t]);
     }
+    }
+    if (ks) {  // the partial products of waves 1..3 meet wave 0's in LDS (same lane layout)
+      if (wid > 0) {
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-      for (int t = 0; t < NTW; ++t)
-        epi_store<MODE>(g, e[t], acc[mt][t], (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+          for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kred[wid - 1][((mt * NTW + t) * 4 + r) * 64 + lane] = acc[mt][t][r];
+      }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int o = ((mt * NTW + t) * 4 + r) * 64 + lane;
+              acc[mt][t][r] += (kred[0][o] + kred[1][o]) + kred[2][o];
+            }
+      }
+    }
+    if (!ks || wid == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          epi_store<MODE>(g, e[t], acc[mt][t], (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+    }
+    if (ks) __syncthreads();  // kred is reused by the next group
   }
   if (MODE == 1) stats_flush<NTW, 4>(g, nb, ssum, ssq);
 }
@@ -498,12 +530,13 @@ static void launch_kloop(const GemmArgs& g, int mode, int variant, dim3 grid, hi
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // launch geometry of the forward / dgrad kernels (shared with m3d_gemm_direct_stat_parts)
-struct RowPlan { int rowstream, NT, MT, KQ; int64_t wgs, slices; };
+struct RowPlan { int rowstream, NT, MT, KQ, ksplit; int64_t wgs, slices; };
 static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
   RowPlan p;
   const int64_t ntiles = m3d_cdiv(M, 16);
   const int ncol16 = (int)m3d_cdiv(N, 16);
   p.rowstream = K <= 64;
+  p.ksplit = 0;
   p.KQ = K <= 16 ? 1 : (K <= 32 ? 2 : 4);
   if (p.rowstream) {
     int NT = ncol16 >= 4 ? 4 : (ncol16 >= 2 ? 2 : 1);
@@ -516,14 +549,20 @@ static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
     // 4.85 -> 4.80 ms per step)
     static const int cand[4][2] = {{2, 4}, {2, 2}, {1, 2}, {1, 1}};
     static const int64_t kl_min_waves = getenv("M3D_GEMM_KL_MINWAVES") ? atoi(getenv("M3D_GEMM_KL_MINWAVES")) : 1536;
-    p.MT = 1; p.NT = 1;
+    // split K over the four waves of a workgroup (GemmArgs::ksplit) when K is long: a (row group, column slice) pair
+    // then counts as four waves, so the big wave tiles stay affordable on the deep levels.  M3D_GEMM_KSPLIT=0: never
+    static const int ksplit_env = getenv("M3D_GEMM_KSPLIT") ? atoi(getenv("M3D_GEMM_KSPLIT")) : 1;
+    static const int ksplit_mink = getenv("M3D_GEMM_KSPLIT_MINK") ? atoi(getenv("M3D_GEMM_KSPLIT_MINK")) : 128;
+    const bool can_split = ksplit_env != 0 && K >= ksplit_mink;
+    p.MT = 1; p.NT = 1; p.ksplit = 0;
     for (int c = 0; c < 4; ++c) {
       const int64_t waves = m3d_cdiv(ntiles, cand[c][0]) * m3d_cdiv(ncol16, cand[c][1]);
       if (waves >= kl_min_waves || c == 3) { p.MT = cand[c][0]; p.NT = cand[c][1]; break; }
+      if (can_split && waves * 4 >= kl_min_waves) { p.MT = cand[c][0]; p.NT = cand[c][1]; p.ksplit = 1; break; }
     }
     p.slices = m3d_cdiv(ncol16, p.NT);
     const int64_t ngroups = m3d_cdiv(ntiles, p.MT);
-    int64_t wgs = m3d_cdiv(ngroups, 4);
+    int64_t wgs = p.ksplit ? ngroups : m3d_cdiv(ngroups, 4);
     int64_t cap = 2048 / p.slices;  // statistics partial rows = wgs: keep them bounded
     if (cap < 1) cap = 1;
     if (wgs > cap) wgs = cap;
@@ -581,15 +620,17 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   const RowPlan rp = plan_rows(g.M, g.N, K, mode);
   if (rp.slices > 65535) return 1;
   dim3 grid((unsigned)rp.wgs, (unsigned)rp.slices);
+  GemmArgs gk = g;
+  gk.ksplit = rp.ksplit;
   if (rp.rowstream) {
     if (rp.NT == 4) launch_rowstream<4>(g, mode, rp.KQ, variant, grid, st, cvec);
     else if (rp.NT == 2) launch_rowstream<2>(g, mode, rp.KQ, variant, grid, st, cvec);
     else launch_rowstream<1>(g, mode, rp.KQ, variant, grid, st, cvec);
   } else {
-    if (rp.MT == 2 && rp.NT == 4) launch_kloop<2, 4>(g, mode, variant, grid, st, cvec);
-    else if (rp.MT == 2) launch_kloop<2, 2>(g, mode, variant, grid, st, cvec);
-    else if (rp.NT == 2) launch_kloop<1, 2>(g, mode, variant, grid, st, cvec);
-    else launch_kloop<1, 1>(g, mode, variant, grid, st, cvec);
+    if (rp.MT == 2 && rp.NT == 4) launch_kloop<2, 4>(gk, mode, variant, grid, st, cvec);
+    else if (rp.MT == 2) launch_kloop<2, 2>(gk, mode, variant, grid, st, cvec);
+    else if (rp.NT == 2) launch_kloop<1, 2>(gk, mode, variant, grid, st, cvec);
+    else launch_kloop<1, 1>(gk, mode, variant, grid, st, cvec);
   }
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
