@@ -62,6 +62,8 @@ def parse():
                          "branches (the executor then runs the position-only branch first, ~0.8 ms ahead of the features). "
                          "dual was the slower one while the weight gradients still ran on a side stream (profiles/r02vwx_*), "
                          "and is 0.08 ms faster since they are batched at the end of the backward pass")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="matmul precision of the timed net (the contract line is fp32; 'bf16' is what the \"bf16\" leg runs)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
@@ -77,6 +79,22 @@ def parse():
                     help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative).  "
                          "prepare: the data-preparation chain in front of the net (informative)")
     return ap.parse_args()
+
+
+def _leg_in_fresh_process(extra_args, timeout=600):
+    """One training-step leg (bf16 mode, dense tiles) in a process of its own: a second net in THIS process shares the
+    first one's hardware queues (torch streams are dealt round-robin onto 4 of them) and measured 10 % slower than the
+    same leg alone.  Returns the leg's JSON line as a dict."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--skip-cpu-baseline", "--skip-roofline", "--skip-extras"] + extra_args
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    if out.returncode != 0:
+        raise RuntimeError(f"leg {extra_args} failed: {out.stderr[-400:]}")
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 def timed(fn, steps, world):
@@ -671,10 +689,10 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if precision == "fp32" else "f32 storage / accumulate, bf16 matrix-core operands",
         "data": "synthetic",
         "config": {"workload": f"RandLA-Net train step (fwd + CE + bwd + grad all-reduce + Adam), {B} tiles x {N} pts per GPU, "
-                               f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, fp32)",
+                               f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, {precision})",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
                    "collective": "one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" if world > 1 else "none (1 rank)",
                    "launch": launch, **({"geometry_lookahead": args.lookahead_mode} if look else {})},
@@ -732,7 +750,8 @@ def main():
     else:
         B, N, K = args.tiles, args.points, args.neighbors
         extras = world == 1 and not args.skip_extras
-        res, net, pos, plan = train_bench(args, dev, world, rank, B, N, K, args.steps, args.warmup, with_eager=extras)
+        res, net, pos, plan = train_bench(args, dev, world, rank, B, N, K, args.steps, args.warmup, with_eager=extras,
+                                          precision=args.precision)
         if world > 1:
             res["rccl_ranks"] = dist.get_world_size()
         if rank == 0:
@@ -755,7 +774,8 @@ def main():
             try:  # BASELINE config 2 names bf16: the same step with the matrix-bound layers on bf16 matrix cores (fp32
                 # accumulate; parity bar of SURVEY 8c: logits within 3e-2 of the fp32 oracle, tests/test_gpu_net.py)
                 torch.cuda.empty_cache()
-                b16, *_ = train_bench(args, dev, 1, 0, B, N, K, args.steps, args.warmup, precision="bf16")
+                b16 = _leg_in_fresh_process(["--precision", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                             "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
                 res["bf16"] = {"value": b16["value"], "unit": "points/s", "ms_per_step": b16["ms_per_step"],
                                "fwd_only": b16["fwd_only"],
                                "what": "LFA attention GEMMs (ch >= 64, fwd + bwd) and SharedMLP GEMMs with K > 64 (fwd + "
@@ -766,7 +786,8 @@ def main():
             if (N, K) == (12800, 16):
                 try:
                     torch.cuda.empty_cache()
-                    d5, *_ = train_bench(args, dev, 1, 0, 16, 40000, 32, 5, 2)
+                    d5 = _leg_in_fresh_process(["--steps", "5", "--warmup", "2", "--tiles", "16", "--points", "40000",
+                                                "--neighbors", "32"])
                     res["dense_tiles_config5"] = {"value": d5["value"], "unit": "points/s", "ms_per_step": d5["ms_per_step"],
                                                   "fwd_only": d5["fwd_only"], "workload": d5["config"]["workload"]}
                 except Exception as e:
