@@ -779,8 +779,8 @@ def main():
                 res["bf16"] = {"value": b16["value"], "unit": "points/s", "ms_per_step": b16["ms_per_step"],
                                "fwd_only": b16["fwd_only"],
                                "what": "LFA attention GEMMs (ch >= 64, fwd + bwd) and SharedMLP GEMMs with K > 64 (fwd + "
-                                       "dgrad) on v_mfma_f32_16x16x32_bf16, fp32 accumulate; storage / kNN / softmax / "
-                                       "BatchNorm / weight gradients / level-1 GEMMs fp32"}
+                                       "dgrad; deep-layer wgrad) on v_mfma_f32_16x16x32_bf16, fp32 accumulate; storage / kNN / "
+                                       "softmax / BatchNorm / level-1 GEMMs fp32"}
             except Exception as e:
                 res["bf16"] = {"error": f"{type(e).__name__}: {e}"}
             if (N, K) == (12800, 16):

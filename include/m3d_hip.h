@@ -97,8 +97,9 @@ int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* x0, int64_t
                          int32_t k0, const float* x1, int64_t ldx1, int32_t k1, int64_t M, int32_t N, float* dw,
                          int64_t lddw, int32_t accumulate, void* ws, void* stream);
 /* The weight gradients of several layers in a handful of launches (one per tile class + one for the partial sums): job j
- * is m3d_linear_wgrad_f32(dz[j], ..., dw[j], lddw[j], accumulate, ws[j]).  accumulate must be non-zero (gradient sinks:
- * the flat gradient buffer); host arrays of length njobs.  The backward pass of the network hands all 29 Linear layers
+ * is m3d_linear_wgrad_f32(dz[j], ..., dw[j], lddw[j], 1, ws[j]).  accumulate: bit 0 must be set (gradient sinks: the flat
+ * gradient buffer); bit 8 = the matrix-bound jobs (16 x 16-tile groups of 8 or more per wave) take bf16 operands on
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation; host arrays of length njobs.  The backward pass of the network hands all 29 Linear layers
  * over at its end (torch autograd would run each Linear.backward's weight product where it stands). */
 int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, const int64_t* lddz, const float* const* x0,
                            const int64_t* ldx0, const int32_t* const* x0_rows, const int32_t* k0, const float* const* x1,

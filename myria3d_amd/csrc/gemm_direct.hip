@@ -650,6 +650,7 @@ struct WgradArgs {
   float* dw; int64_t lddw; int accumulate;
   float* ws;  // [S][N][K] partials (S > 1)
   int S; int64_t steps_per_split;
+  int bf16;  // != 0 (with vec): operands rounded to bf16, v_mfma_f32_16x16x32_bf16, 32 rows per step (the net's "bf16" mode)
   int vec;  // != 0: permuted tile columns (tile a of a TN-tile group holds n = nb + TN*i + a, likewise k): a lane's TN / TK
             // operand values are consecutive floats -> ONE 4*TN / 4*TK-byte load instead of TN / TK dword loads, and one
             // vector store per accumulator row (the level-1 layers stream at dword granularity otherwise: ~2 TB/s)
@@ -723,7 +724,7 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 #ifndef WGRAD_DEPTH
 #define WGRAD_DEPTH 4
 #endif
-template <int TN, int TK>
+template <int TN, int TK, bool BF = false>
 __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
   // big tiles (16 accumulator quads: the deep, few-row layers) keep one partial per WAVE and two steps in flight: their
   // register budget has no room for four, and their LDS reduction would take 48 KB
@@ -744,6 +745,47 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
     for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const rsrc_t rz = mk_rsrc(g.dz), rx0 = mk_rsrc(g.x0), rx1 = mk_rsrc(g.x1);
 
+  if constexpr (BF && TN * TK >= 8) {
+    if (g.bf16 && g.vec) {
+      // bf16 matrix cores: a 32-row step; lane (lr, lg) supplies rows 8 lg .. 8 lg + 7 of the step for its TN / TK
+      // (permuted) columns: 8 vector loads per operand, all 16 in flight, then TN x TK MFMAs of 32 rows each
+      for (int64_t s = s0; s < s1; s += 8) {
+        float av[8][TN], bv[8][TK];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t m = 4 * s + 8 * lg + j;
+          const bool ok = m < 4 * s1 && m < g.M;
+          const int64_t mc = ok ? m : 0;
+          const int64_t rr = g.rows ? (int64_t)g.rows[mc] : mc;
+          const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
+          const unsigned o0 = (ok && rr >= 0) ? (unsigned)(rr * g.ldx0 * 4) : OOB;
+          const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
+          const int n0 = nb + TN * lr, kk = kb + TK * lr;
+          ldv<TN>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, av[j]);
+          const bool in0 = kk < g.k0;
+          float t0[TK], t1[TK];
+          ldv<TK>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
+          ldv<TK>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
+#pragma unroll
+          for (int b = 0; b < TK; ++b) bv[j][b] = t0[b] + t1[b];
+        }
+        Bf16Frag fa[TN], fb[TK];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa[a].u[i] = pack_bf16(av[2 * i][a], av[2 * i + 1][a]);
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fb[b].u[i] = pack_bf16(bv[2 * i][b], bv[2 * i + 1][b]);
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TK; ++b) acc[a][b] = mfma_bf16(fa[a].v, fb[b].v, acc[a][b]);
+      }
+      goto reduce_and_store;
+    }
+  }
   for (int64_t s = s0; s < s1; s += DEPTH) {
     WgradFrag<TN, TK> f[DEPTH];
 #pragma unroll
@@ -755,6 +797,7 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
 #pragma unroll
         for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f[d].a[a], f[d].b[b], acc[a][b]);
   }
+reduce_and_store:
   int64_t part = split;
   if constexpr (WGR) {
     // ---- the workgroup's four accumulators meet in LDS (same lane layout: element (a, b, r) of lane l <-> l)
@@ -845,14 +888,14 @@ struct WgradBatch {
   unsigned gx[WGRAD_BATCH_MAX], gy[WGRAD_BATCH_MAX];
   int njobs;
 };
-template <int TN, int TK>
+template <int TN, int TK, bool BF = false>
 __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_batch_kernel(WgradBatch b) {
   int j = 0;
 #pragma unroll
   for (int i = 1; i < WGRAD_BATCH_MAX; ++i) j += (i < b.njobs && blockIdx.x >= b.wg_start[i]) ? 1 : 0;
   const unsigned w = blockIdx.x - b.wg_start[j];
   const unsigned gx = b.gx[j], gy = b.gy[j];
-  wgrad2_body<TN, TK>(b.g[j], w % gx, (w / gx) % gy, w / (gx * gy));
+  wgrad2_body<TN, TK, BF>(b.g[j], w % gx, (w / gx) % gy, w / (gx * gy));
 }
 
 // dw[n][k] (+)= sum_s ws[s][n][k]
@@ -987,6 +1030,7 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
   g.M = M; g.N = N; g.dw = dw; g.lddw = lddw; g.accumulate = accumulate; g.ws = (float*)ws; g.S = (int)p.S;
   g.steps_per_split = p.spw;
   g.vec = wgrad_vec_ok(g, p.TN, p.TK);
+  g.bf16 = 0;
   dim3 grid((unsigned)p.wgs, (unsigned)p.by, (unsigned)p.bz);
   if (p.TN == 4) launch_wgrad2<4>(g, p.TK, grid, st);
   else if (p.TN == 2) launch_wgrad2<2>(g, p.TK, grid, st);
@@ -1007,6 +1051,12 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
 
 template <int TN, int TK>
 static void launch_wgrad2_batch(const WgradBatch& b, unsigned total, hipStream_t st) {
+  if constexpr (TN * TK >= 8) {  // bf16 matrix-core variant (its register budget would cost the fp32 kernel a wave per SIMD)
+    if (b.g[0].bf16) {
+      hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK, true>), dim3(total), dim3(256), 0, st, b);
+      return;
+    }
+  }
   hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK>), dim3(total), dim3(256), 0, st, b);
 }
 
@@ -1020,7 +1070,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
                                       void* const* ws, void* stream) {
   if (njobs < 0) return M3D_ERR_INVALID;
   if (njobs == 0) return M3D_OK;
-  if (!accumulate) return M3D_ERR_UNSUPPORTED;
+  if (!(accumulate & 1)) return M3D_ERR_UNSUPPORTED;  // bit 0: add into dw (required); bit 8: bf16 matrix cores
   if (!dz || !lddz || !x0 || !ldx0 || !x0_rows || !k0 || !x1 || !ldx1 || !k1 || !M || !N || !dw || !lddw || !ws)
     return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -1102,6 +1152,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
       g.ldx1 = ldx1[j]; g.k1 = k1[j]; g.M = M[j]; g.N = N[j]; g.dw = dw[j]; g.lddw = lddw[j]; g.accumulate = 1;
       g.ws = (float*)ws[j]; g.S = (int)p.S; g.steps_per_split = p.spw;
       g.vec = wgrad_vec_ok(g, p.TN, p.TK);
+      g.bf16 = ((accumulate >> 8) & 1) && g.vec && p.TN * p.TK >= 8;  // the matrix-bound (deep) layers only
       b.wg_start[b.njobs] = total;
       b.gx[b.njobs] = (unsigned)p.wgs; b.gy[b.njobs] = (unsigned)p.by;
       total += (unsigned)(p.wgs * p.by * p.bz);

@@ -284,7 +284,7 @@ class GradSideStream:
 
         m = len(jobs)
         h = lib()
-        need = [h.m3d_linear_wgrad_workspace_bytes(dz.shape[0], dz.shape[1], k0 + k1) for dz, _, k0, _, _, k1, _ in jobs]
+        need = [h.m3d_linear_wgrad_workspace_bytes(j[0].shape[0], j[0].shape[1], j[2] + j[5]) for j in jobs]
         offs, tot = [], 0
         for nb in need:
             offs.append(tot)
@@ -300,7 +300,8 @@ class GradSideStream:
              vp([_p(j[3]) for j in jobs]), i32([j[2] for j in jobs]),
              vp([_p(j[4]) for j in jobs]), i64([j[4].stride(0) if j[4] is not None else 0 for j in jobs]),
              i32([j[5] for j in jobs]), i64([j[0].shape[0] for j in jobs]), i32([j[0].shape[1] for j in jobs]),
-             vp([j[6].data_ptr() for j in jobs]), i64([j[6].stride(0) for j in jobs]), 1,
+             vp([j[6].data_ptr() for j in jobs]), i64([j[6].stride(0) for j in jobs]),
+             1 | (256 if any(len(j) > 7 and j[7] for j in jobs) else 0),
              vp([base + o if nb else None for o, nb in zip(offs, need)]), _st())
 
     def join(self):
@@ -316,7 +317,8 @@ _grad_side: Optional[GradSideStream] = None
 
 
 def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None, x1: Optional[Tensor] = None,
-                 k1: int = 0, out: Optional[Tensor] = None, side: Optional[GradSideStream] = None) -> Optional[Tensor]:
+                 k1: int = 0, out: Optional[Tensor] = None, side: Optional[GradSideStream] = None,
+                 bf16: bool = False) -> Optional[Tensor]:
     """dW[N, k0+k1] = dZ^T [X0[rows] | X1] (``m3d_linear_wgrad_f32``): the reduction over the M rows is split across
     waves whose partials meet in a workspace.  ``out``: a gradient sink (contiguous ``[N, k0+k1]``, e.g. a slice of the
     flat gradient buffer) that is added to; nothing is returned then (and the kernels may run on the gradient side
@@ -326,7 +328,7 @@ def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None,
     sink = out is not None
     dw = out if sink else torch.empty((N, K), dtype=torch.float32, device=dz.device)
     if sink and side is not None and DEFER_WGRAD:
-        side.defer((dz, x0, k0, rows, x1, k1, dw))  # launched with all the others at the end of the backward pass
+        side.defer((dz, x0, k0, rows, x1, k1, dw, bool(bf16)))  # launched with all the others at the end of the backward pass
         return None
     nbytes = lib().m3d_linear_wgrad_workspace_bytes(M, N, K)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dz.device) if nbytes else None
@@ -661,7 +663,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
                     dx0 = dx0.contiguous()
             if x1 is not None and ctx.needs_input_grad[1]:
                 dx1 = dxc[:, k0:].contiguous()
-        dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side)
+        dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
         return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None
 
@@ -698,8 +700,8 @@ class ResidualTailTrainFn(torch.autograd.Function):
                                               sinks=(sk[0][2], sk[0][3], sk[1][2], sk[1][3]) if sk else None)
         dx2 = linear_dgrad(dz2, w2, ctx.bf16)
         dxs = linear_dgrad(dzs, ws, ctx.bf16)
-        dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None, side=ctx.side)
-        dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None, side=ctx.side)
+        dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None, side=ctx.side, bf16=ctx.bf16)
+        dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         z0_2 = None if sk else torch.zeros_like(db2)
         z0_s = None if sk else torch.zeros_like(dbs)
         return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None, None)
