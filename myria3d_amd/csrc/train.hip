@@ -83,7 +83,7 @@ extern "C" int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* t
   if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
   if (n > 0) {
     int64_t gx = m3d_cdiv(n, 256);
-    if (gx > 1024) gx = 1024;
+    if (gx > 256) gx = 256;  // every block ends in two same-address fp64 atomics: one block per CU, not 800 of them
     hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)gx), dim3(256), 0, st, logits, ld, target, n, C, ignore_index, lse,
                        acc2);
   }

@@ -708,16 +708,21 @@ class ResidualTailTrainFn(torch.autograd.Function):
 
 
 class GatherRowsFn(torch.autograd.Function):
+    """``x[idx]``.  ``inverse``: ``idx`` is a permutation and ``inverse`` its inverse map — the backward pass is then the
+    gather ``dy[inverse]`` (no atomics, no zero fill) instead of a scatter-add."""
+
     @staticmethod
-    def forward(ctx, x, idx):
-        ctx.save_for_backward(idx)
+    def forward(ctx, x, idx, inverse=None):
+        ctx.save_for_backward(idx, inverse)
         ctx.n = x.shape[0]
         return gather_rows(x.contiguous(), idx)
 
     @staticmethod
     def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
-        return scatter_add_rows(dy.contiguous(), idx, ctx.n), None
+        idx, inverse = ctx.saved_tensors
+        if inverse is not None:
+            return gather_rows(dy.contiguous(), inverse), None, None
+        return scatter_add_rows(dy.contiguous(), idx, ctx.n), None, None
 
 
 # --------------------------------------------------------------------------------------------------

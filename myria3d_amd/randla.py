@@ -649,7 +649,7 @@ class HipRandLANet(nn.Module):
         feats: List[Tensor] = []
         hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
         geo.wait(0)
-        x = ops.GatherRowsFn.apply(x, index[0].perm) if x.requires_grad else ops.gather_rows(x, index[0].perm)
+        x = ops.GatherRowsFn.apply(x, index[0].perm, index[0].inv) if x.requires_grad else ops.gather_rows(x, index[0].perm)
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
                                self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
@@ -691,7 +691,7 @@ class HipRandLANet(nn.Module):
             logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias,
                                         self._sinks(self.fc_classif.weight, self.fc_classif.bias)
                                         if self._use_sinks else None)
-            logits = ops.GatherRowsFn.apply(logits, index[0].inv)  # back to the caller's row order
+            logits = ops.GatherRowsFn.apply(logits, index[0].inv, index[0].perm)  # back to the caller's row order
         else:
             logits = ops.gemm(h, self.fc_classif.weight, h.shape[0], self.fc_classif.weight.shape[0], h.shape[1],
                               bias=self.fc_classif.bias)
