@@ -39,14 +39,37 @@ GRAD_KEYS = ["fc0.weight", "block1.lfa1.mlp_attention.lins.0.weight", "block1.lf
              "fc_classif.weight"]
 
 
-def load_reference_module(ref_root: str):
-    """The reference's net module, imported by file path.  Raises ImportError when its dependencies are missing."""
+STUB_DIR = os.path.join(ROOT, "tests", "_pyg_stub")
+
+
+def load_reference_module(ref_root: str, allow_stub: bool = True):
+    """The reference's net module, imported by file path.  With the real PyG stack importable it runs on that
+    (``mod.M3D_STACK == "real PyG wheels"``); otherwise — and with ``allow_stub`` — on ``tests/_pyg_stub`` (a
+    restatement of the six third-party symbols the file needs; ``mod.M3D_STACK == "reference file + stub PyG"``).
+    Raises ImportError when there is no checkout (the GPU box) or no usable stack."""
     path = os.path.join(ref_root, "myria3d", "models", "modules", "pyg_randla_net.py")
     if not os.path.exists(path):
         raise ImportError(f"no reference checkout at {ref_root}")
-    spec = importlib.util.spec_from_file_location("_m3d_reference_pyg_randla_net", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)  # ImportError here = torch_geometric / torch_cluster / torch_scatter missing
+
+    def load():
+        spec = importlib.util.spec_from_file_location("_m3d_reference_pyg_randla_net", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)  # ImportError here = torch_geometric / torch_cluster / torch_scatter missing
+        return mod
+
+    try:
+        mod = load()
+        import torch_geometric
+
+        mod.M3D_STACK = "reference file + stub PyG" if getattr(torch_geometric, "IS_M3D_STUB", False) else "real PyG wheels"
+    except ImportError:
+        if not allow_stub:
+            raise
+        for name in [m for m in sys.modules if m.split(".")[0] in ("torch_geometric", "torch_scatter", "torchmetrics")]:
+            del sys.modules[name]  # (a half-imported real stack must not shadow the stub)
+        sys.path.insert(0, STUB_DIR)
+        mod = load()
+        mod.M3D_STACK = "reference file + stub PyG"
     return mod
 
 
@@ -112,7 +135,7 @@ def main():
     out = dict(x=x.numpy(), pos=pos.numpy(), ptr=ptr.numpy(), y=y.numpy(), param_seed=np.int64(PARAM_SEED),
                logits_eval=r["logits_eval"].numpy(), logits_train=r["logits_train"].numpy(),
                loss_train=np.float64(r["loss"].item()), knn_src=r["knn_src"].numpy(), knn_dst=r["knn_dst"].numpy(),
-               knn_d2=r["knn_d2"].numpy())
+               knn_d2=r["knn_d2"].numpy(), stack=np.array(mod.M3D_STACK))
     for i, d in enumerate(dec):
         out[f"dec{i}"] = d.numpy().astype(np.int64)
     for k in GRAD_KEYS:
@@ -121,7 +144,7 @@ def main():
         if k.startswith(("block1.lfa1.mlp_encoder", "block3.mlp2", "mlp_summit")):
             out["buf:" + k] = b.numpy()
     np.savez_compressed(OUT, **out)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes — generated from the reference at", ref_root)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes — generated from the reference at", ref_root, "on:", mod.M3D_STACK)
 
 
 if __name__ == "__main__":
