@@ -75,9 +75,14 @@ def parse():
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launch check without GPUs: bring the N ranks up over gloo, exchange one all-reduce, print the "
                          "rank census (used by the CPU tests)")
-    ap.add_argument("--mode", choices=["train", "predict", "prepare"], default="train",
+    ap.add_argument("--mode", choices=["train", "predict", "prepare", "dropin"], default="train",
                     help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative).  "
-                         "prepare: the data-preparation chain in front of the net (informative)")
+                         "prepare: the data-preparation chain in front of the net (informative).  dropin: the plain "
+                         "Lightning-style step (no plan / prefetch / graph / flat buffers, torch loss and Adam)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: bring up a 1-rank RCCL process group and take the N > 1 code path (captured fwd + bwd, "
+                         "out-of-graph all-reduce of the flat gradient bucket, eager Adam) — exercises the collective and "
+                         "its interplay with hipGraph capture on a one-GPU box")
     return ap.parse_args()
 
 
@@ -132,66 +137,103 @@ def _time_launch(launch, reps=20):
     return sum(a.elapsed_time(b) for a, b in evs) / reps
 
 
-def _pmc_traffic(*kernel_prefixes):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*pmc_fetch_size.csv and
-    *pmc_write_size.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_target.py, per-kernel means in
-    KB; since round 2 one row per kernel name AND launch grid, so a level-1 launch is not averaged with the other
-    levels').  FETCH_SIZE is doubled: MI355X_MICROARCH.md calibrates it at exactly half the bytes of 16-byte-per-lane
-    reads on gfx950, which is what these kernels issue (row gathers and float4 streams); WRITE_SIZE is taken as is.
-    ``kernel_prefixes``: the kernel's name in the newest pass first, older names after (kernels were renamed when
-    variants were added).  Returns None when no pass in the tree lists the kernel."""
+class PmcMissing(RuntimeError):
+    pass
+
+
+def _pmc_traffic(prefix, grid=None):
+    """HBM-side bytes per launch of a kernel from the NEWEST committed rocprofv3 PMC pass (profiles/*pmc_fetch_size.csv
+    and *pmc_write_size.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of tools/pmc_target.py, per-kernel means
+    in KB, one row per kernel name AND launch grid).  FETCH_SIZE is doubled: MI355X_MICROARCH.md calibrates it at
+    exactly half the bytes of 16-byte-per-lane reads on gfx950, which is what these kernels issue (row gathers and
+    float4 streams); WRITE_SIZE is taken as is.  ``prefix``: start of the kernel's name in that pass (template
+    arguments that were appended since are covered by the prefix match); ``grid``: pick the row of that launch grid
+    (several levels run the same template).  Raises PmcMissing when the newest pass does not list the kernel — an older
+    round's row for a kernel that has changed since is not evidence."""
     import csv
     import glob
 
-    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_size.csv")), reverse=True)
-    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_write_size.csv")), reverse=True)
+    def newest(pattern):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        if not files:
+            raise PmcMissing(f"no profiles/{pattern}")
+        return files[-1]
 
-    def lookup(files, col):
-        for f in files:                      # newest pass first
-            rows = list(csv.DictReader(open(f)))
-            for prefix in kernel_prefixes:
-                vals = [float(row[col]) for row in rows if row["kernel"].startswith(prefix)]
-                if vals:
-                    return max(vals) * 1024.0  # several launch geometries of one kernel: the roofline entry is the largest
-        return None
+    def lookup(path, col):
+        rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(prefix)]
+        if grid is not None:
+            rows = [r for r in rows if r["kernel"].rstrip().endswith(f"grid={grid}")] or rows
+        if not rows:
+            raise PmcMissing(f"{os.path.basename(path)} has no row for {prefix!r}")
+        return max(float(r[col]) for r in rows) * 1024.0
 
-    r, w = lookup(fetch, "FETCH_SIZE"), lookup(write, "WRITE_SIZE")
-    return None if r is None or w is None else int(2 * r + w)
+    r = lookup(newest("*pmc_fetch_size.csv"), "FETCH_SIZE")
+    w = lookup(newest("*pmc_write_size.csv"), "WRITE_SIZE")
+    return int(2 * r + w)
+
+
+def _traffic_fields(prefix, grid=None):
+    try:
+        return {"traffic": _pmc_traffic(prefix, grid)}
+    except PmcMissing as e:
+        return {"traffic": None, "traffic_error": str(e)}
 
 
 def stage_rooflines(net, pos, plan):
-    """Roofline entries, timed live.  ``dominant``: the kernel with the largest share of the training step —
-    lfa_bwd_kernel<64,16,PIPE=true> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an fp32-MFMA kernel:
-    3 x 2 x n x K x (ch^2 + 10 ch/2) flop per launch (recomputed attention GEMM + its two backward GEMMs).
-    ``knn_lse``: the HBM-class kernels of the kNN + LSE-gather stage at level 1 (204 800 points), algorithmic bytes
-    per launch from SURVEY 8d: kNN read 12 n + write 4 n K; LFA(ch) read n (12 + 4 ch/2 + 4 K), write 4 n ch."""
+    """Roofline entries, timed live with HIP events on the launch stream.  ``dominant``: the kernel with the largest
+    share of the training step — lfa_bwd_kernel<64,16> (block 2 / lfa2: 51 200 centres x 16 neighbours, ch = 64), an
+    fp32-MFMA kernel: 3 x 2 x n x K x (ch^2 + 10 ch/2) flop per launch (recomputed attention GEMM + its two backward
+    GEMMs).  ``knn_lse``: the HBM-class kernels of the kNN + LSE-gather stage with the algorithmic bytes of SURVEY 8d:
+    kNN read 12 n + write 4 n K (all four levels); LFA(ch) forward read n (12 + 4 ch/2 + 4 K), write 4 n ch; LFA(ch)
+    backward read n (12 + 4 ch/2 + 4 ch + 4 K), write 4 n ch/2 — both layers of level 1 (ch 8 and 16)."""
     from myria3d_amd import ops
 
     K = net.num_neighbors
     st = torch.cuda.current_stream().cuda_stream
+    dev = pos.device
     out = {}
+
+    def lfa_operands(lfa, lvl, geo):
+        ch = lfa.mlp_attention.lins[0].weight.shape[0]
+        n, D = geo.pos4[lvl].shape[0], ch // 2
+        enc_lin, enc_bn = lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module
+        wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
+        wp, wpt = ops.pack_attention_weights(lfa.mlp_attention.lins[0].weight, True)
+        return ch, n, D, wf, bf, wp, wpt
+
+    def time_lfa_fwd(lfa, lvl, geo):
+        ch, n, D, wf, bf, wp, _ = lfa_operands(lfa, lvl, geo)
+        x, o = torch.randn(n, D, device=dev), torch.empty((n, ch), device=dev)
+        ms = _time_launch(lambda: ops.call(
+            "m3d_lfa_fwd", x.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
+            bf.data_ptr(), wp.data_ptr(), ops.LRELU_SLOPE, o.data_ptr(), st))
+        return ch, n, ms
+
+    def time_lfa_bwd(lfa, lvl, geo):
+        ch, n, D, wf, bf, wp, wpt = lfa_operands(lfa, lvl, geo)
+        xin, dout = torch.randn(n, D, device=dev), torch.randn(n, ch, device=dev)
+        dx, dw = torch.zeros((n, D), device=dev), torch.empty((ch, ch), device=dev)
+        G = torch.empty(11 * D, dtype=torch.float64, device=dev)
+        ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
+        ms = _time_launch(lambda: ops.call(
+            "m3d_lfa_bwd", xin.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
+            bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+            0, G.data_ptr(), ws.data_ptr(), st))
+        return ch, n, D, ms
+
+    def hbm_entry(kernel, nbytes, ms, prefix, grid=None):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                **_traffic_fields(prefix, grid), "avg_launch_ms": round(ms, 4)}
+
     with torch.no_grad():
         net.overlap_geometry, keep = False, net.overlap_geometry
         net.batch_geometry, keep_b = False, net.batch_geometry  # per-level launches: the kernels the captured step runs
         geo = net._geometry(pos, plan, None, True)
         net.overlap_geometry, net.batch_geometry = keep, keep_b
         # ---- dominant kernel: LFA backward at level 2, ch = 64
-        lfa = net.block2.lfa2
-        ch = lfa.mlp_attention.lins[0].weight.shape[0]
-        n2, D = geo.pos4[1].shape[0], ch // 2
-        xin = torch.randn(n2, D, device=pos.device)
-        dout = torch.randn(n2, ch, device=pos.device)
-        enc_lin, enc_bn = lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module
-        wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
-        wp, wpt = ops.pack_attention_weights(lfa.mlp_attention.lins[0].weight, True)
-        dx = torch.zeros((n2, D), device=pos.device)
-        dw = torch.empty((ch, ch), device=pos.device)
-        G = torch.empty(11 * D, dtype=torch.float64, device=pos.device)
-        ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n2, K, ch), dtype=torch.uint8, device=pos.device)
-        ms = _time_launch(lambda: ops.call(
-            "m3d_lfa_bwd", xin.data_ptr(), geo.pos4[1].data_ptr(), geo.knn[1].data_ptr(), n2, K, ch, wf.data_ptr(),
-            bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-            0, G.data_ptr(), ws.data_ptr(), st))
+        ch, n2, D, ms = time_lfa_bwd(net.block2.lfa2, 1, geo)
         # ALGORITHMIC flops of this backward (SURVEY 8d: backward = 2 x forward: dF = dA W and dW = dA^T F, plus the
         # encoder's two transposes) vs the flops the kernel EXECUTES (it recomputes the forward attention GEMM
         # A = F W^T instead of saving [E, ch] logits: a third GEMM)
@@ -204,41 +246,36 @@ def stage_rooflines(net, pos, plan):
                            "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
                            "frac_algorithmic": round(tf / FP32_MFMA_PEAK_TF, 4),
                            "frac_executed": round(tf_exe / FP32_MFMA_PEAK_TF, 4),
-                           "traffic": _pmc_traffic("void lfa_bwd_kernel<64, 16, true>", "void lfa_bwd_pipe_kernel<64, 16>",
-                                                    "void lfa_bwd_kernel<64, 16>"),
+                           **_traffic_fields("void lfa_bwd_kernel<64, 16, true"),
                            "algorithmic_flop_per_launch": flop_alg, "executed_flop_per_launch": flop_exe,
                            "avg_launch_ms": round(ms, 4)}
-        # ---- kNN + LSE gather stage at level 1
-        n1 = geo.pos4[0].shape[0]
-        ix = geo.index[0]
-        idx = torch.empty((n1, K), dtype=torch.int32, device=pos.device)
-        ms_knn = _time_launch(lambda: ops.call(
-            "m3d_knn_query", ix.ws.data_ptr(), ix.ptr.data_ptr(), n1, ix.num_clouds, None, 0, ix.ws.data_ptr(),
-            ix.ptr.data_ptr(), n1, K, 1, idx.data_ptr(), None, st))
-        lfa1 = net.block1.lfa2
-        ch1 = lfa1.mlp_attention.lins[0].weight.shape[0]
-        x1 = torch.randn(n1, ch1 // 2, device=pos.device)
-        wf1, bf1, _, _ = ops.lfa_enc_fold(lfa1.mlp_encoder.lins[0], lfa1.mlp_encoder.norms[0].module, None, 0)
-        wp1, _ = ops.pack_attention_weights(lfa1.mlp_attention.lins[0].weight, False)
-        o1 = torch.empty((n1, ch1), device=pos.device)
-        ms_lfa = _time_launch(lambda: ops.call(
-            "m3d_lfa_fwd", x1.data_ptr(), geo.pos4[0].data_ptr(), geo.knn[0].data_ptr(), n1, K, ch1, wf1.data_ptr(),
-            bf1.data_ptr(), wp1.data_ptr(), ops.LRELU_SLOPE, o1.data_ptr(), st))
-        b_knn = n1 * (12 + 4 * K)
-        b_lfa = n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1)
-        out["knn_lse"] = [
-            {"kernel": f"knn_query_queue_kernel<16> (level 1, n={n1}, K={K})", "bound": "hbm",
-             "achieved": round(b_knn / (ms_knn * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(b_knn / (ms_knn * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_knn,
-             "traffic": _pmc_traffic("void knn_query_queue_kernel<16, KeyF64", "void knn_query_kernel<16, KeyF64>",
-                                     "void knn_query_kernel<16>"),
-             "avg_launch_ms": round(ms_knn, 4)},
-            {"kernel": f"lfa_fwd_kernel<16,16> (block1.lfa2, ch={ch1}, n={n1}, K={K})", "bound": "hbm",
-             "achieved": round(b_lfa / (ms_lfa * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(b_lfa / (ms_lfa * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": b_lfa,
-             "traffic": _pmc_traffic("void lfa_fwd_kernel<16, 16>"),
-             "avg_launch_ms": round(ms_lfa, 4)}]
+        # ---- kNN + LSE gather stage: the K-NN tables of all four levels, both LFA layers of level 1 fwd + bwd
+        stage = []
+        for lvl in range(4):
+            ix = geo.index[lvl]
+            n = ix.n
+            idx = torch.empty((n, K), dtype=torch.int32, device=dev)
+            ms_knn = _time_launch(lambda: ops.call(
+                "m3d_knn_query", ix.ws.data_ptr(), ix.ptr.data_ptr(), n, ix.num_clouds, None, 0, ix.ws.data_ptr(),
+                ix.ptr.data_ptr(), n, K, 1, idx.data_ptr(), None, st))
+            stage.append(hbm_entry(f"knn_query (self-kNN, level {lvl + 1}, n={n}, K={K})", n * (12 + 4 * K), ms_knn,
+                                   KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], (n + 63) // 64 * 64))
+        for lfa in (net.block1.lfa1, net.block1.lfa2):
+            ch1, n1, ms_f = time_lfa_fwd(lfa, 0, geo)
+            stage.append(hbm_entry(f"lfa_fwd_kernel<{max(ch1, 16) if ch1 > 8 else 8},16> (level 1, ch={ch1}, n={n1}, K={K})",
+                                   n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1), ms_f, f"void lfa_fwd_kernel<{ch1}, 16"))
+        for lfa in (net.block1.lfa1, net.block1.lfa2):
+            ch1, n1, D1, ms_b = time_lfa_bwd(lfa, 0, geo)
+            stage.append(hbm_entry(f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K}) + partial reduce",
+                                   n1 * (12 + 4 * D1 + 4 * ch1 + 4 * K) + 4 * n1 * D1, ms_b,
+                                   f"void lfa_bwd_kernel<{ch1}, 16"))
+        out["knn_lse"] = stage
     return out
+
+
+# kernel-name prefixes of the self-kNN query in the PMC passes (level 1 takes the deferred-insertion kernel, the
+# deeper levels the direct one); the CSV has one row per launch grid (= queries rounded up to 64)
+KNN_KERNEL_PREFIX = ("void knn_query_queue_kernel<16", "void knn_query_kernel<16")
 
 
 def _pick_threads():
@@ -261,11 +298,11 @@ def _pick_threads():
 
 def cpu_baseline(tiles, points, K, full=False):
     """The CPU oracle (op-for-op restatement of the reference path; kNN through cKDTree like torch_cluster's CPU
-    path) on the SAME workload as the GPU line (B = 16 tiles x 12 800 points; fewer tiles only when
-    the host has too little free memory), fwd+bwd in train mode (CE loss) and fwd-only in eval mode, median of the
-    timed iterations.  Default (bounded to ~30 s of CPU work so the driver's default run stays short): 1 warm-up + 3
-    timed iterations at the thread count a micro-probe picks.  ``full`` = BASELINE.md 3 to the letter: 3 warm-up + 10
-    timed, at the probe-picked count AND on every host core."""
+    path), BASELINE.md section 3 protocol: fwd+bwd in train mode (CE loss) and fwd-only in eval mode, 3 warm-up + 10
+    timed iterations, median, at the thread count a micro-probe picks; then on every host core (bounded: 1 warm-up + 3
+    timed — some hosts are several times slower oversubscribed).  Default sample: 4 of the GPU line's 16 tiles (every
+    op is per point or per tile, the time per point does not depend on the tile count; ~40-60 s of CPU work so the
+    driver's default run stays short); ``full``: all ``tiles`` tiles, 3 + 10 at both thread counts."""
     import statistics
 
     from oracle.randla_oracle import RandLANetOracle
@@ -277,14 +314,14 @@ def cpu_baseline(tiles, points, K, full=False):
         free_gb = psutil.virtual_memory().available / 2**30
     except Exception:
         free_gb = 16.0
+    tiles = tiles if full else min(tiles, 4)
     tiles = max(1, min(tiles, int(free_gb // 1.5)))  # ~0.7 GB of autograd intermediates per 12 800-point tile
     picked = _pick_threads()
     torch.manual_seed(0)
     net = RandLANetOracle(9, 6, num_neighbors=K, return_logits=True, knn="kdtree")
     x, pos, batch, ptr, y = synthetic_batch([points] * tiles)
-    warm, reps = (3, 10) if full else (1, 3)
 
-    def leg(threads):
+    def leg(threads, warm, reps):
         torch.set_num_threads(threads)
 
         def train_step():
@@ -309,17 +346,102 @@ def cpu_baseline(tiles, points, K, full=False):
             res[name] = tiles * points / statistics.median(ts)
         return res
 
-    main = leg(picked)
+    main = leg(picked, 3, 10)
     out = {"value": round(main["fwd_bwd"], 1), "unit": "points/s", "cores": picked, "kind": "port",
            "fwd_only": round(main["fwd_only"], 1), "host_cores": ncpu,
-           "sample": f"{tiles} tiles x {points} pts (the GPU line's batch), median of {reps} timed iteration(s) after "
-                     f"{warm} warm-up; fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
+           "sample": f"{tiles} tiles x {points} pts (of the GPU line's batch), median of 10 timed iterations after 3 "
+                     f"warm-up (BASELINE.md 3); fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
                      f"oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN); threads = {picked} (fastest of "
                      f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
-    if full and picked != ncpu:
-        allc = leg(ncpu)
-        out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1), "fwd_only": round(allc["fwd_only"], 1)}
+    if picked != ncpu:
+        allc = leg(ncpu, *((3, 10) if full else (1, 3)))
+        out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1), "fwd_only": round(allc["fwd_only"], 1),
+                            "sample": "same tiles, 3 + 10" if full else "same tiles, 1 warm-up + 3 timed (bounded)"}
     return out
+
+
+def torch_rocm_baseline(dev, tiles, points, K):
+    """BASELINE.md section 3's second, informative baseline: the restated reference path (the oracle's unfused module
+    tree, op for op) through STOCK PyTorch-ROCm ops on the same MI355X — gathers, cat, Linear, BatchNorm1d,
+    scatter-add, segment softmax, kNN by torch.cdist + topk per cloud, Python-loop decimation with host syncs like
+    pyg_randla_net.py:219-229 — eval forward and train step (CE + backward, no optimizer).  What the hand-written
+    kernels buy over "just run the PyG model on the GPU" (torch_cluster's CUDA kNN is a brute force as well)."""
+    import statistics
+
+    from oracle.randla_oracle import RandLANetOracle
+    from myria3d_amd.synthetic import synthetic_batch
+
+    torch.manual_seed(0)
+    net = RandLANetOracle(9, 6, num_neighbors=K, return_logits=True, knn="cdist").to(dev)
+    x, pos, batch, ptr, y = synthetic_batch([points] * tiles)
+    x, pos, y = x.to(dev), pos.to(dev), y.to(dev)  # (ptr stays on the host: the oracle reads it with int())
+
+    def train_step():
+        net.train()
+        net.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(net(x, pos, None, ptr), y).backward()
+
+    def fwd_step():
+        net.eval()
+        with torch.no_grad():
+            net(x, pos, None, ptr)
+
+    res = {}
+    for name, fn in (("fwd_bwd", train_step), ("fwd_only", fwd_step)):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        res[name] = statistics.median(ts)
+    n = tiles * points
+    return {"value": round(n / res["fwd_bwd"], 1), "unit": "points/s", "ms_per_step": round(res["fwd_bwd"] * 1e3, 2),
+            "fwd_only": round(n / res["fwd_only"], 1), "fwd_only_ms": round(res["fwd_only"] * 1e3, 2),
+            "what": f"oracle module tree on cuda through stock torch-ROCm ops (cdist + topk kNN), {tiles} x {points} pts, "
+                    "fp32, eager, median of 5 after 3 warm-up; fwd+bwd = train mode + CE + backward (no optimizer)"}
+
+
+def dropin_bench(args, dev):
+    """``--mode dropin``: the step a Lightning loop gets by changing ONE yaml key (model.py:61-62,79,105-120): the
+    class behind the boundary, nothing else — ``HipRandLANet(x, pos, batch, ptr)`` with no plan, no
+    ``prefetch_geometry``, no hipGraph, parameters NOT flattened, ``torch.nn.CrossEntropyLoss(ignore_index=65)`` and
+    ``torch.optim.Adam`` (a process of its own: hardware queues are shared inside one)."""
+    from myria3d_amd import HipRandLANet
+    from myria3d_amd.synthetic import synthetic_batch
+
+    B, N, K = args.tiles, args.points, args.neighbors
+    x, pos, batch, ptr, y = synthetic_batch([N] * B)
+    x, pos, batch, ptr, y = (t.to(dev) for t in (x, pos, batch, ptr, y))
+    torch.manual_seed(0)
+    net = HipRandLANet(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=0.003933709606504788)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=65)
+
+    def step():
+        opt.zero_grad()
+        crit(net(x, pos, batch, ptr), y).backward()
+        opt.step()
+
+    for _ in range(30):
+        step()
+    dt = timed(step, 15, 1) / 15
+    net.eval()
+
+    def fwd():
+        with torch.no_grad():
+            net(x, pos, batch, ptr)
+
+    for _ in range(10):
+        fwd()
+    dtf = timed(fwd, 15, 1) / 15
+    print(json.dumps({"dropin_eager_ms_per_step": round(dt * 1e3, 4), "value": round(B * N / dt, 1),
+                      "fwd_only_ms": round(dtf * 1e3, 4), "unit": "points/s",
+                      "what": "HipRandLANet.forward(x, pos, batch, ptr) + torch CrossEntropyLoss + backward + torch.optim.Adam, "
+                              "eager, no plan / prefetch_geometry / hipGraph / flat buffers"}), flush=True)
 
 
 def predict_bench(args, dev, world=1, rank=0, reps=None):
@@ -477,8 +599,9 @@ def _dry_run_gloo(args, world, rank):
 
 def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False, precision="fp32"):
     """The contract measurement: ``steps`` training steps (fwd + CE + bwd + [all-reduce] + Adam) and ``steps`` eval
-    forwards over B tiles x N points per rank.  Returns (record, net, pos, plan)."""
-    from myria3d_amd import FusedAdam, HipRandLANet, cross_entropy, make_plan
+    forwards over B tiles x N points per rank, launched through ``myria3d_amd.GraphedStep`` (the launch form is product
+    code with its own parity tests).  Returns (record, net, pos, plan)."""
+    from myria3d_amd import FusedAdam, GraphedStep, HipRandLANet
     from myria3d_amd.ddp import broadcast_module_state, shard_tiles
     from myria3d_amd.synthetic import synthetic_batch
 
@@ -492,192 +615,56 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     # all-reduces it as ONE 4.45 MB bucket, m3d_adam_step updates (and clears) it in one launch
     net.flatten_parameters()
     broadcast_module_state(net)
-    plan = make_plan(ptr.tolist(), 4, K, dev)
-    opt = FusedAdam(net, lr=0.003933709606504788, all_reduce=True)  # lr: configs/model/pyg_randla_net_model.yaml:4
-
+    opt = FusedAdam(net, lr=0.003933709606504788, all_reduce=True,  # lr: configs/model/pyg_randla_net_model.yaml:4
+                    force_collective=args.force_collective)
     look = args.lookahead
-
-    def fwd_bwd(prefetch=look):
-        if not net.training:
-            net.train()  # (walks 266 modules: ~0.3 ms of host time when every step pays it)
-        if prefetch:  # the NEXT step's kNN tables / decimation, enqueued stage by stage BETWEEN the blocks of this forward
-            net.prefetch_geometry(pos, ptr, plan, train=True, interleave=True)
-        out = net(x, pos, None, ptr, plan=plan)  # (lookahead: consumes the tables the previous step prefetched)
-        loss = cross_entropy(out, y, ignore_index=65)  # configs/model/criterion/CrossEntropyLoss.yaml
-        loss.backward()
-        if net.grad_side is not None:
-            net.grad_side.join()  # weight-gradient side stream rejoins (must happen inside a captured region)
-        if look:
-            net.join_geometry()
-
-    def train_step(prefetch=look):
-        fwd_bwd(prefetch)
-        opt.step()  # (N>1: ONE flat-gradient all-reduce over RCCL) + Adam + gradient clear
-
-    def fwd_step(prefetch=look):
-        if net.training:
-            net.eval()
-        with torch.no_grad():
-            if prefetch:
-                net.prefetch_geometry(pos, ptr, plan, train=False, interleave=True)
-            net(x, pos, None, ptr, plan=plan)
-            if look:
-                net.join_geometry()
-
-    def geo_step(train):
-        """The position-only work of the NEXT step as a stand-alone unit (its own hipGraph in the dual-graph launch)."""
-        net.prefetch_geometry(pos, ptr, plan, train=train)
-        net.join_geometry()
-
-    def capture_dual(body, train):
-        """Two hipGraphs per buffer set instead of one: B = the step (consumes the tables prefetched one step earlier), A =
-        the position-only work for the step after it.  Replayed on two streams they run CONCURRENTLY — inside one graph
-        the executor submits the position-only branch first and the feature chain starts ~0.8 ms into every replay
-        (profiles/r02u_step_timeline.csv).  Ordering between the streams: B_i waits for A_{i-1} (its tables), A_i waits
-        for B_{i-1} (the last reader of the buffer set A_i rewrites)."""
-        gB, gA = [], []
-        for _ in range(2):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                body()
-            gB.append(g)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                geo_step(train)
-            gA.append(g)
-        sA = torch.cuda.Stream()
-        evA, evB = torch.cuda.Event(), torch.cuda.Event()
-        evA.record()
-        evB.record()
-        turn = [0]
-
-        def step():
-            k = turn[0] & 1
-            cur = torch.cuda.current_stream()
-            cur.wait_event(evA)
-            gB[k].replay()
-            sA.wait_event(evB)
-            with torch.cuda.stream(sA):
-                gA[k].replay()
-                evA.record(sA)
-            evB.record(cur)
-            turn[0] += 1
-
-        return step
-
-    launch = "eager"
-    step_fn, fwd_fn = train_step, fwd_step
-    eager_ms = None
     mode = "eager" if args.no_graph else args.launch
-    probe = {}
-    if with_eager or mode == "auto":  # what a Lightning loop (no capture, model.py:79) sees: the same kernels, launched one by one
-        for _ in range(40):  # (the eager path needs ~30 steps to settle: 6.2 -> 5.55 ms, tools/scratch/eager_ramp.py)
-            train_step()
-        eager_ms = probe["eager"] = timed(train_step, 15, world) / 15 * 1e3
-    # hipGraph: the forward+loss+backward launch sequence (parallel branches for the position-only work and the weight
-    # gradients) is captured once and replayed.  With N > 1 the optimizer (all-reduce + 2 launches) stays outside the
-    # graph so that no collective is captured
-    if mode != "eager":
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    train_step()
-                    fwd_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            if look:  # the captured steps must CONSUME tables prefetched one step earlier: leave one pending.  Two steps:
-                # the warm-up above alternated train and eval prefetches, so one of the two buffer sets still has the
-                # eval layout — a captured prefetch into it would re-create it (25 clone copies per replay)
-                train_step()
-                train_step()
+
+    def make(kind, launch):
+        gs = GraphedStep(net, ptr, x.shape[1], mode=kind, optimizer=opt if kind == "train" else None, ignore_index=65,
+                         lookahead=look, launch=launch, lookahead_mode=args.lookahead_mode)
+        gs.load_all(x, pos, y)
+        return gs
+
+    def pick(kind, eager_warm, graph_warm):
+        """(step function, launch name, probe timings): the replayed hipGraphs, the eager launcher, or (``auto``)
+        whichever a short probe of each measures faster on this host — both run the same kernels."""
+        probe, fn, launch = {}, None, "eager"
+        if with_eager or mode in ("auto", "eager"):
+            ge = make(kind, "eager")
+            for _ in range(eager_warm):  # (the eager path needs ~30 steps to settle: allocator, arena, geometry slots)
+                ge.step()
+            probe["eager"] = timed(ge.step, 15, world) / 15 * 1e3
+            fn = ge.step
+        if mode != "eager":
+            try:
+                gg = make(kind, "graph").prepare(preserve_state=False)
+                for _ in range(graph_warm):
+                    gg.step()
+                probe["hipgraph"] = timed(gg.step, 10, world) / 10 * 1e3
+                if mode == "graph" or fn is None or probe["hipgraph"] <= probe["eager"]:
+                    fn, launch = gg.step, "hipgraph"
+            except Exception as e:  # capture is an optimisation, never a requirement
+                if rank == 0:
+                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
-            # with the lookahead the prefetched tables live in two buffer sets used in turn: one captured step per set
-            if look and args.lookahead_mode == "dual":
-                dual = capture_dual((lambda: train_step(False)) if world == 1 else (lambda: fwd_bwd(False)), True)
+                if fn is None:
+                    fn = make(kind, "eager").step
+        return fn, launch, probe
 
-                def graph_step():
-                    dual()
-                    if world > 1:
-                        opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
-            else:
-                g_train = []
-                for _ in range(2 if look else 1):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void the capture)
-                        if world == 1:
-                            train_step()  # no collective: the optimizer launches are part of the graph
-                        else:
-                            fwd_bwd()
-                    g_train.append(g)
-                turn = [0]
-
-                def graph_step():
-                    g_train[turn[0] % len(g_train)].replay()
-                    turn[0] += 1
-                    if world > 1:
-                        opt.step()  # RCCL all-reduce + Adam stay outside the captured graph
-
-            step_fn, launch = graph_step, "hipgraph"
-        except Exception as e:  # capture is an optimisation, never a requirement
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-            step_fn, launch = train_step, "eager"
-
-    if mode == "auto" and launch == "hipgraph":
-        for _ in range(5):
-            step_fn()
-        probe["hipgraph"] = timed(step_fn, 10, world) / 10 * 1e3
-        if probe["eager"] < probe["hipgraph"]:
-            step_fn, launch = train_step, "eager"
+    step_fn, launch, probe = pick("train", 40, 5)
     for _ in range(warmup):
         step_fn()
     dt = timed(step_fn, steps, world)
-    # eval forward of the trained weights.  The first (eager) pass folds the BatchNorms / packs the attention weights
-    # (cached by the module until the next training phase); the captured graph then holds the per-batch work only
-    fwd_step()
-    fwd_step()  # (lookahead: the second call consumes what the first one prefetched and leaves an eval-mode slot pending)
-    fprobe = {}
-    if mode == "auto":
-        for _ in range(20):
-            fwd_step()
-        fprobe["eager"] = timed(fwd_step, 15, world) / 15 * 1e3
-    if mode != "eager":
-        try:
-            torch.cuda.synchronize()
-            if look and args.lookahead_mode == "dual":
-                fwd_graph = capture_dual(lambda: fwd_step(False), False)
-            else:
-                g_fwd = []
-                for _ in range(2 if look else 1):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        fwd_step()
-                    g_fwd.append(g)
-                fturn = [0]
-
-                def fwd_graph():
-                    g_fwd[fturn[0] % len(g_fwd)].replay()
-                    fturn[0] += 1
-
-            fwd_fn = fwd_graph
-        except Exception as e:
-            if rank == 0:
-                print(f"[bench] eval hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            torch.cuda.synchronize()
-    if mode == "auto" and fwd_fn is not fwd_step:
-        for _ in range(3):
-            fwd_fn()
-        fprobe["hipgraph"] = timed(fwd_fn, 10, world) / 10 * 1e3
-        if fprobe["eager"] < fprobe["hipgraph"]:
-            fwd_fn = fwd_step
+    # eval forward of the trained weights (the first eval pass folds the BatchNorms / packs the attention weights; the
+    # module caches them until the next training phase)
+    fwd_fn, flaunch, fprobe = pick("eval", 20, 3)
     for _ in range(max(1, warmup // 2)):
         fwd_fn()
     dt_f = timed(fwd_fn, steps, world)
 
     total_points = B * N * world
+    collective = opt.uses_collective()
     res = {
         "metric": f"points/sec fwd+bwd, RandLA-Net, {N // 1000} {N % 1000:03d}-pt tiles",
         "value": round(total_points * steps / dt, 1),
@@ -694,17 +681,33 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
         "config": {"workload": f"RandLA-Net train step (fwd + CE + bwd + grad all-reduce + Adam), {B} tiles x {N} pts per GPU, "
                                f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, {precision})",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
-                   "collective": "one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" if world > 1 else "none (1 rank)",
-                   "launch": launch, **({"geometry_lookahead": args.lookahead_mode} if look else {})},
+                   "collective": ("one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" +
+                                  (" — forced on a 1-rank group" if world == 1 else "")) if collective else "none (1 rank)",
+                   "launch": launch + (" (myria3d_amd.GraphedStep)"), **({"geometry_lookahead": args.lookahead_mode} if look else {})},
         "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
-                     "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad",
-                     "launch": "eager" if fwd_fn is fwd_step else "hipgraph"},
+                     "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad", "launch": flaunch},
     }
     if probe:
         res["launch_probe_ms"] = {k: round(v, 4) for k, v in probe.items()}
-    if eager_ms is not None:
-        res["eager_ms_per_step"] = round(eager_ms, 4)
-    return res, net, pos, plan
+    if "eager" in probe:
+        res["eager_ms_per_step"] = round(probe["eager"], 4)  # same kernels launched one by one, lookahead interleaved
+    if collective:
+        # the gradient exchange alone: ONE all-reduce of the flat bucket, HIP events on the current stream
+        g = net.flat_grads
+        for _ in range(3):
+            dist.all_reduce(g)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a_, b_ in evs:
+            a_.record()
+            dist.all_reduce(g)
+            b_.record()
+        torch.cuda.synchronize()
+        g.zero_()
+        res["allreduce_ms"] = round(sum(a_.elapsed_time(b_) for a_, b_ in evs) / len(evs), 4)
+        res["allreduce_bytes"] = g.numel() * 4
+    from myria3d_amd import make_plan
+
+    return res, net, pos, make_plan(ptr.tolist(), 4, K, dev)
 
 
 def main():
@@ -726,11 +729,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if world > torch.cuda.device_count():
         raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) are visible")
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world,  # "nccl" IS RCCL on ROCm
+                                device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL came up with {dist.get_world_size()} ranks, --gpus says {args.gpus}")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -747,12 +752,16 @@ def main():
         if world > 1:
             raise SystemExit("--mode prepare is a single-GPU run")
         prepare_bench(args, dev)
+    elif args.mode == "dropin":
+        if world > 1:
+            raise SystemExit("--mode dropin is a single-GPU run")
+        dropin_bench(args, dev)
     else:
         B, N, K = args.tiles, args.points, args.neighbors
-        extras = world == 1 and not args.skip_extras
+        extras = world == 1 and not args.skip_extras and not args.force_collective
         res, net, pos, plan = train_bench(args, dev, world, rank, B, N, K, args.steps, args.warmup, with_eager=extras,
                                           precision=args.precision)
-        if world > 1:
+        if world > 1 or args.force_collective:
             res["rccl_ranks"] = dist.get_world_size()
         if rank == 0:
             if not args.skip_roofline:
@@ -783,6 +792,26 @@ def main():
                                        "softmax / BatchNorm / level-1 GEMMs fp32"}
             except Exception as e:
                 res["bf16"] = {"error": f"{type(e).__name__}: {e}"}
+            try:  # the plain drop-in step (what model.py:79 + Lightning's loop get) in a process of its own
+                di = _leg_in_fresh_process(["--mode", "dropin", "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+                res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
+                res["dropin"] = di
+            except Exception as e:
+                res["dropin"] = {"error": f"{type(e).__name__}: {e}"}
+            try:  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)
+                fc = _leg_in_fresh_process(["--force-collective", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                            "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+                res["forced_collective_1rank"] = {k: fc[k] for k in ("ms_per_step", "allreduce_ms", "allreduce_bytes",
+                                                                     "rccl_ranks") if k in fc} | {
+                    "launch": fc["config"]["launch"], "collective": fc["config"]["collective"]}
+            except Exception as e:
+                res["forced_collective_1rank"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                torch.cuda.empty_cache()
+                res["torch_rocm_baseline"] = torch_rocm_baseline(dev, B, N, K)
+            except Exception as e:
+                res["torch_rocm_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
             if (N, K) == (12800, 16):
                 try:
                     torch.cuda.empty_cache()
@@ -796,7 +825,7 @@ def main():
             if world == 1 and not args.skip_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_tiles, N, K, full=args.cpu_baseline_full)
             print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -10,7 +10,8 @@ from .interpolation import DeviceInterpolator, knn_interpolate, predict_reduce, 
 from .registration import register_in_model_zoo  # noqa: F401
 from .model_forward import SimpleBatch, collate_tiles, forward_like_model  # noqa: F401
 from .train import FusedAdam, cross_entropy  # noqa: F401
+from .graphed import GraphedStep  # noqa: F401
 from . import tiling, transforms  # noqa: F401
 
 __all__ = ["HipRandLANet", "make_plan", "knn_interpolate", "scatter_sum", "predict_reduce", "DeviceInterpolator",
-           "register_in_model_zoo", "forward_like_model", "collate_tiles", "SimpleBatch", "FusedAdam", "cross_entropy", "transforms", "tiling"]
+           "register_in_model_zoo", "forward_like_model", "collate_tiles", "SimpleBatch", "FusedAdam", "cross_entropy", "GraphedStep", "transforms", "tiling"]

@@ -1,0 +1,286 @@
+"""The launch form of the hot path that ``bench.py`` times, as a product class: ``GraphedStep``.
+
+One step of ``Model.training_step`` (``/root/reference/myria3d/models/model.py:105-120``: forward, criterion,
+``backward``) plus the optimizer step — or one eval forward (``model.py:79``) — over batches of a FIXED tile layout
+(``ptr``; the reference's ``fixed_num_points`` preparation gives every tile the same size,
+``configs/datamodule/transforms/preparations/fixed_num_points.yaml:19-24``), launched as hipGraphs:
+
+* ``B[k]`` = the step on input buffer set ``k`` (it consumes the position-only tables — kNN grids and tables, encoder
+  moments, random decimation, decoder 1-NN tables — that were computed one step earlier into geometry slot ``k``);
+* ``A[k]`` = the position-only work for the NEXT step (buffer set ``k ^ 1`` -> geometry slot ``k ^ 1``).
+
+``B[k]`` and ``A[k]`` are replayed on two streams and overlap; across steps they alternate ``k``.  Ordering:
+``B_i`` waits for ``A_{i-1}`` (its tables); ``A_i`` waits for ``B_{i-1}`` (the last reader of the slot it rewrites) and
+for ``load_next`` (the positions it reads).  Inside ONE graph the executor submits the position-only branch first
+and the feature chain starts ~0.8 ms late, hence two graphs.
+
+Data pipeline: two input buffer sets; ``load_next(x, pos, y)`` fills the set of the step AFTER the coming one while the
+coming one still reads its own (``load(x, pos, y)`` fills the coming one and rebuilds its tables eagerly — first batch,
+or after a gap).  With N > 1 ranks the gradient all-reduce (RCCL) and the Adam launch stay outside the graphs; they
+run on the step's stream beside ``A_i``.
+
+``launch="eager"`` runs the same step kernel by kernel (lookahead interleaved between the blocks of the forward);
+``lookahead=False`` builds the tables inside the step (one graph, one buffer set).  Results are the same in every
+form (``tests/test_gpu_train.py::test_graphed_step_*``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .randla import HipRandLANet, make_plan
+from .train import FusedAdam, cross_entropy
+
+
+class _BufferSet:
+    def __init__(self, n: int, num_features: int, device, with_labels: bool):
+        self.x = torch.zeros((n, num_features), dtype=torch.float32, device=device)
+        self.pos = torch.zeros((n, 3), dtype=torch.float32, device=device)
+        self.y = torch.zeros(n, dtype=torch.int64, device=device) if with_labels else None
+        self.out: Optional[Tensor] = None  # loss (train) / logits (eval) of the last step on this set
+
+
+class GraphedStep:
+    """``mode="train"``: ``step()`` = forward + cross-entropy (``ignore_index``) + backward + ``optimizer.step()``;
+    returns the loss (a device scalar).  ``mode="eval"``: ``step()`` = eval forward under ``no_grad``; returns the
+    logits.  ``ptr``: the tile layout every batch shares (host list or tensor)."""
+
+    def __init__(self, net: HipRandLANet, ptr, num_features: int, *, mode: str = "train",
+                 optimizer: Optional[FusedAdam] = None, ignore_index: int = 65, lookahead: bool = True,
+                 launch: str = "graph", lookahead_mode: str = "dual", optimizer_in_graph: Optional[bool] = None,
+                 warmup: int = 2):
+        if mode not in ("train", "eval") or launch not in ("graph", "eager") or lookahead_mode not in ("dual", "single"):
+            raise ValueError("mode: train|eval, launch: graph|eager, lookahead_mode: dual|single")
+        if mode == "train" and optimizer is None:
+            raise ValueError("GraphedStep(mode='train') needs the FusedAdam that owns the net's flat buffers")
+        self.net, self.opt, self.mode = net, optimizer, mode
+        self.ignore_index = ignore_index
+        self.lookahead, self.launch, self.lookahead_mode = bool(lookahead), launch, lookahead_mode
+        dev = next(net.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedStep runs on an MI355X (cuda/HIP device) only")
+        host_ptr = [int(v) for v in (ptr.tolist() if torch.is_tensor(ptr) else ptr)]
+        self.ptr = torch.tensor(host_ptr, dtype=torch.int64, device=dev)
+        self.plan = make_plan(host_ptr, net.decimation, net.num_neighbors, dev)
+        n = host_ptr[-1]
+        self.sets: List[_BufferSet] = [_BufferSet(n, num_features, dev, mode == "train")
+                                       for _ in range(2 if self.lookahead else 1)]
+        multi = mode == "train" and optimizer.uses_collective()
+        # a collective is never captured: with a gradient exchange the optimizer runs after the graph
+        self.opt_in_graph = (not multi) if optimizer_in_graph is None else bool(optimizer_in_graph)
+        if multi and self.opt_in_graph:
+            raise ValueError("optimizer_in_graph=True would capture the RCCL all-reduce")
+        self.turn = 0
+        self._warmup = max(1, warmup)
+        self._graphs = None  # (gB, gA) once captured
+        self._sA: Optional[torch.cuda.Stream] = None
+        self._evA = self._evReady = None
+        self._primed = False
+
+    # ------------------------------------------------------------------------------------------
+    def _cur(self) -> _BufferSet:
+        return self.sets[self.turn % len(self.sets)]
+
+    def load(self, x: Tensor, pos: Tensor, y: Optional[Tensor] = None) -> None:
+        """Fill the buffer set of the COMING step and rebuild its position-only tables."""
+        self._sync_geometry_stream()
+        self._fill(self._cur(), x, pos, y)
+        self._primed = False
+
+    def load_next(self, x: Tensor, pos: Tensor, y: Optional[Tensor] = None) -> None:
+        """Fill the buffer set of the step AFTER the coming one (the coming step prefetches its tables)."""
+        if not self.lookahead:
+            raise RuntimeError("load_next() needs lookahead=True (two buffer sets)")
+        self._fill(self.sets[(self.turn + 1) & 1], x, pos, y)
+
+    def load_all(self, x: Tensor, pos: Tensor, y: Optional[Tensor] = None) -> None:
+        """The same batch into every buffer set (benchmarks: a static batch)."""
+        self._sync_geometry_stream()
+        for s in self.sets:
+            self._fill(s, x, pos, y)
+        self._primed = False
+
+    def _sync_geometry_stream(self) -> None:
+        """The previous step's graph ``A`` (other stream) reads the coming step's positions and writes its slot."""
+        if self._sA is not None:
+            torch.cuda.current_stream().wait_stream(self._sA)
+
+    def _fill(self, s: _BufferSet, x, pos, y) -> None:
+        s.x.copy_(x, non_blocking=True)
+        s.pos.copy_(pos, non_blocking=True)
+        if s.y is not None:
+            s.y.copy_(y, non_blocking=True)
+        if self._evReady is not None:
+            self._evReady.record(torch.cuda.current_stream())
+
+    # ------------------------------------------------------------------------------------------
+    def _set_mode(self) -> None:
+        want = self.mode == "train"
+        if self.net.training != want:
+            self.net.train(want)  # (walks 266 modules: only when it changes anything)
+
+    def _body(self, k: int, prefetch: Optional[int], with_opt: bool):
+        """The step on buffer set ``k``.  ``prefetch``: buffer set whose tables are enqueued, stage by stage, between the
+        blocks of this forward (eager lookahead); None: no prefetch here."""
+        net, s = self.net, self.sets[k]
+        if self.mode == "train":
+            if prefetch is not None:
+                net.prefetch_geometry(self.sets[prefetch].pos, self.ptr, self.plan, train=True, interleave=True,
+                                      slot=prefetch, owner=id(self))
+            out = net(s.x, s.pos, None, self.ptr, plan=self.plan)
+            loss = cross_entropy(out, s.y, ignore_index=self.ignore_index)  # model.py:118
+            loss.backward()
+            if net.grad_side is not None:
+                net.grad_side.join()  # (inside a capture the deferred leaf launches must be part of it)
+            if self.lookahead:
+                net.join_geometry()
+            s.out = loss.detach()
+            if with_opt:
+                self.opt.step()
+        else:
+            with torch.no_grad():
+                if prefetch is not None:
+                    net.prefetch_geometry(self.sets[prefetch].pos, self.ptr, self.plan, train=False, interleave=True,
+                                          slot=prefetch, owner=id(self))
+                s.out = net(s.x, s.pos, None, self.ptr, plan=self.plan)
+                if self.lookahead:
+                    net.join_geometry()
+
+    def _geo(self, k: int) -> None:
+        """The position-only work for buffer set ``k`` as a unit of its own (graph ``A``; also the eager priming)."""
+        with torch.no_grad():
+            self.net.prefetch_geometry(self.sets[k].pos, self.ptr, self.plan, train=self.mode == "train", slot=k,
+                                       owner=id(self))
+            self.net.join_geometry()
+
+    def _state(self):
+        net = self.net
+        keep = [t for t in (net.flat_parameters, net.flat_grads) if t is not None] if net.flat_parameters is not None \
+            else [p.data for p in net.parameters()]
+        keep += [b for b in net.buffers()]
+        if self.opt is not None:
+            keep += [self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.step_count]
+        return keep
+
+    def prepare(self, preserve_state: bool = True) -> "GraphedStep":
+        """Warm up (allocator, zero arena, geometry slots of both buffer sets) and capture.  The warm-up runs real
+        steps on whatever the buffer sets hold; ``preserve_state`` puts parameters, optimizer moments, BatchNorm
+        statistics and the decimation RNG state back afterwards."""
+        self._set_mode()
+        net = self.net
+        saved = [t.clone() for t in self._state()] if preserve_state else None
+        nsets = len(self.sets)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # (warm-up off the default stream, as torch's graph recipe asks)
+            for _ in range(self._warmup):
+                for k in range(nsets):
+                    if self.lookahead:
+                        self._geo(k)
+                    self._body(k, None, self.mode == "train")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if self.launch == "graph":
+            net._finish_interleaved()
+            net._look_queue.clear()
+            gB, gA = [], []
+            with_opt = self.mode == "train" and self.opt_in_graph
+            if self.lookahead:
+                self._geo(0)  # pending tables for the first captured step
+                torch.cuda.synchronize()
+            if self.lookahead and self.lookahead_mode == "dual":
+                for k in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void it)
+                        self._body(k, None, with_opt)
+                    gB.append(g)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._geo(k ^ 1)
+                    gA.append(g)
+                self._sA = torch.cuda.Stream()
+            elif self.lookahead:  # one graph per buffer set holding both branches
+                for k in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._body(k, k ^ 1, with_opt)
+                    gB.append(g)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._body(0, None, with_opt)
+                gB.append(g)
+            net._finish_interleaved()
+            net._look_queue.clear()  # (consumed inside the captures: nothing is pending for eager callers)
+            self._graphs = (gB, gA)
+            self._evA, self._evReady = torch.cuda.Event(), torch.cuda.Event()
+            self._evA.record()
+            self._evReady.record()
+        if saved is not None:
+            with torch.no_grad():
+                for t, v in zip(self._state(), saved):
+                    t.copy_(v)
+            net.invalidate_eval_cache()
+        self._primed = False
+        torch.cuda.synchronize()
+        return self
+
+    def prime(self) -> None:
+        """Eagerly build the position-only tables of the coming step (first step, after ``load()``, after a seed
+        change).  Without lookahead there is nothing to prime."""
+        if self.lookahead:
+            k = self.turn & 1
+            self._sync_geometry_stream()
+            self.net._finish_interleaved()
+            self.net._look_queue.clear()
+            self._geo(k)
+            if self._graphs is not None:
+                self.net._look_queue.clear()  # the captured step reads slot k directly
+                self._evA.record(torch.cuda.current_stream())
+        self._primed = True
+
+    # ------------------------------------------------------------------------------------------
+    def step(self) -> Tensor:
+        self._set_mode()
+        if self._graphs is None and self.launch == "graph":
+            self.prepare()
+        if not self._primed:
+            self.prime()
+        k = self.turn % len(self.sets)
+        cur = torch.cuda.current_stream()
+        if self._graphs is not None:
+            gB, gA = self._graphs
+            if gA:
+                cur.wait_event(self._evA)             # tables of this step (A of the previous step, or prime())
+                self._sA.wait_event(self._evReady)    # previous step done with the slot A rewrites; next positions loaded
+                gB[k].replay()
+                with torch.cuda.stream(self._sA):
+                    gA[k].replay()
+                    self._evA.record(self._sA)
+                self._evReady.record(cur)
+            else:
+                gB[k].replay()
+            if self.mode == "train" and not self.opt_in_graph:
+                self.opt.step()  # RCCL all-reduce + Adam: outside the graph, beside A on the other stream
+        else:
+            self._body(k, (k ^ 1) if self.lookahead else None, self.mode == "train")
+        self.turn += 1
+        return self.sets[k].out
+
+    __call__ = step
+
+    # ------------------------------------------------------------------------------------------
+    def consumed_geometry(self, k: Optional[int] = None):
+        """The position-only tables buffer set ``k`` (default: the last step's) was processed with — tests compare
+        them with an eager run: ``(decimation indices per level [reference rows], level-1 kNN table [reference order])``.
+        Only meaningful with lookahead (they live in the net's geometry slot ``k``) and before the next-but-one step."""
+        from .randla import _knn_to_reference_order
+
+        if not self.lookahead:
+            raise RuntimeError("consumed_geometry() reads the lookahead slots")
+        k = (self.turn - 1) & 1 if k is None else k
+        geo = self.net._look_slots[(id(self), self.mode == "train", k)].geo
+        return [d.clone() for d in geo.dec_ref], _knn_to_reference_order(geo.knn[0], geo.index[0])

@@ -231,6 +231,14 @@ class GradSideStream:
         self.lfa_jobs: list = []  # deferred LFA partial-sum reduces + encoder parameter gradients (``defer_lfa``)
         self._join_queued = False
 
+    def begin_step(self) -> None:
+        """Start of a training forward.  A backward pass that raised (out of memory, an anomaly check) never ran the
+        engine callback: its queued jobs — operands of a step that no longer exists — must not be flushed into the
+        next step's gradients."""
+        if self._join_queued:
+            self.jobs.clear(), self.lfa_jobs.clear(), self.keep.clear()
+            self._join_queued = False
+
     def _queue_join(self):
         if not self._join_queued:
             try:  # inside a backward pass: join when the engine has run its last node

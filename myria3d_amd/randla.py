@@ -143,12 +143,15 @@ class HipRandLANet(nn.Module):
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
         # geometry of the NEXT forward (see prefetch_geometry()): two persistent slots used in turn
-        self._look_slots: List[Optional["_GeoSlot"]] = [None, None]
-        self._look_queue: List[int] = []  # slots holding prefetched geometry nobody has consumed yet, oldest first
+        # persistent buffer sets, keyed (owner, train flag, 0 / 1): a GraphedStep owns its pair (captured graphs hold
+        # the addresses), the train- and eval-mode layouts differ (encoder moments), plain callers share owner None
+        self._look_slots: Dict[tuple, "_GeoSlot"] = {}
+        self._look_queue: List[tuple] = []  # slots holding prefetched geometry nobody has consumed yet, oldest first
         self._look_turn = 1
         self.interleave_paced = bool(int(__import__("os").environ.get("M3D_INTERLEAVE_PACED", "0")))
         self._look_job = None  # an interleaved prefetch in progress: (stage generator, geometry, slot, key, pos, stream)
         self._fwd_start = None  # event: start of the most recent forward (prefetch_geometry(after="forward_start"))
+        self._fwd_count = 0  # forwards started so far (which forward consumed a slot: _GeoSlot.consumer_fwd)
         self._bf16 = False
         # a parent module's load_state_dict() reaches this module through _load_from_state_dict only
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._eval_cache.clear())
@@ -284,6 +287,10 @@ class HipRandLANet(nn.Module):
     def train(self, mode: bool = True):
         if mode or self.training:  # entering or leaving a training phase: weights / running statistics change
             self._eval_cache.clear()
+        if bool(mode) != self.training:
+            # geometry prefetched for the other mode (train-mode sets carry the encoder moments) is never consumed
+            self._finish_interleaved()
+            self._look_queue.clear()
         return super().train(mode)
 
     def _apply(self, fn, recurse=True):
@@ -497,13 +504,21 @@ class HipRandLANet(nn.Module):
     # replay them in turn; every captured step ends with join_geometry().
     # ------------------------------------------------------------------------------------------
     def prefetch_geometry(self, pos: Tensor, ptr: Tensor, plan: Optional[LevelPlan] = None,
-                          train: Optional[bool] = None, after: str = "now", interleave: bool = False) -> None:
+                          train: Optional[bool] = None, after: str = "now", interleave: bool = False,
+                          slot: Optional[int] = None, owner=None) -> None:
         """Enqueue the position-only work for a batch the network will see later (at most two may be outstanding:
-        the one the next ``forward`` consumes and the one after it).
+        the one the next ``forward`` consumes and the one after it).  The tables are matched to the forward that
+        consumes them by the IDENTITY of ``pos`` (the same tensor object, unmodified since: its autograd version
+        counter is part of the match) — a different batch that happens to land at the same address, or a static
+        buffer refilled in place after the prefetch, gets fresh tables instead of stale ones.  ``slot`` (0 / 1): which
+        of the two persistent buffer sets to write (default: the one not written last).
 
         ``after="now"``: ordered behind everything enqueued on the current stream so far (always safe).
         ``after="forward_start"``: ordered behind the START of the most recent forward only — for callers whose ``pos``
-        was resident before that forward began (a dataloader prefetch queue, the benchmark's static batch).
+        was resident before that forward began (a dataloader prefetch queue).  Honoured only when a forward has
+        started SINCE the one that consumed the buffer set rewritten here (that forward's start is then behind the
+        consumer's backward pass in stream order — one training step in flight at a time); otherwise the call falls
+        back to ``"now"``: the consumer's forward and backward kernels still read the buffers.
         ``interleave=True``: only the first stage is enqueued now; the NEXT ``forward`` call (which consumes an older
         prefetch, or works in place) enqueues the remaining stages one by one between its own blocks.  A captured
         hipGraph submits its nodes in capture order at several microseconds apiece: a hundred position-only nodes in
@@ -519,12 +534,15 @@ class HipRandLANet(nn.Module):
             plan = self.plan_for(ptr)
         train = self.training if train is None else train
         key = (tuple(pos.shape), id(plan), bool(train))
-        turn = self._look_turn = self._look_turn ^ 1
+        self._look_turn = (self._look_turn ^ 1) if slot is None else int(slot) & 1
+        turn = (owner, bool(train), self._look_turn)
         side = self._side_stream(pos.device)
         main = torch.cuda.current_stream()
-        # what comes first: the producer of ``pos`` and the step that last read the slot rewritten here (two prefetches
-        # ago: complete before the most recent forward began)
-        if after == "forward_start" and self._fwd_start is not None:
+        # what comes first: the producer of ``pos`` and the step that last read the slot rewritten here
+        old = self._look_slots.get(turn)
+        if (after == "forward_start" and self._fwd_start is not None
+                and (old is None or old.consumer_fwd < self._fwd_count)
+                and ops.capture_id(main) == 0):
             side.wait_event(self._fwd_start)
         else:
             side.wait_stream(main)
@@ -533,7 +551,7 @@ class HipRandLANet(nn.Module):
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
         geo = _Geometry(main, side)
         stages = self._geometry_stages(geo, pos, plan, None, train)
-        self._look_job = (stages, geo, turn, key, pos.data_ptr(), main)
+        self._look_job = (stages, geo, turn, key, pos, main)
         if interleave:
             next(stages)
         else:
@@ -557,10 +575,10 @@ class HipRandLANet(nn.Module):
         if job is None:
             return
         self._look_job = None
-        stages, geo, turn, key, pos_ptr, main = job
+        stages, geo, turn, key, pos, main = job
         for _ in stages:
             pass
-        slot = self._look_slots[turn]
+        slot = self._look_slots.get(turn)
         with torch.cuda.stream(geo.side):
             fresh = geo.tensors()
             if slot is None or slot.key != key:
@@ -570,7 +588,7 @@ class HipRandLANet(nn.Module):
             slot.ready = torch.cuda.Event()
             slot.ready.record(geo.side)
             slot.ready_capture = ops.capture_id(geo.side)
-        slot.pos_ptr = pos_ptr
+        slot.pos, slot.version = pos, pos._version  # (the reference also keeps the address from being recycled)
         if turn in self._look_queue:
             self._look_queue.remove(turn)  # a prefetch nobody consumed: its slot has just been rewritten
         self._look_queue.append(turn)
@@ -593,8 +611,10 @@ class HipRandLANet(nn.Module):
         while self._look_queue:
             turn = self._look_queue.pop(0)  # oldest first
             slot = self._look_slots[turn]
-            if slot.key != want or slot.pos_ptr != pos.data_ptr():
-                continue  # prefetched for another batch / mode: dropped (falls back to the in-place path if none fits)
+            if slot.key != want or slot.pos is not pos or slot.version != pos._version:
+                continue  # prefetched for another batch / mode, or ``pos`` was written since: dropped (the in-place
+                # path computes fresh tables if nothing fits)
+            slot.consumer_fwd = self._fwd_count
             main = torch.cuda.current_stream()
             cap = ops.capture_id(main)
             if slot.ready_capture == cap:
@@ -636,9 +656,12 @@ class HipRandLANet(nn.Module):
         # weight gradients on a side stream: only with gradient sinks and an optimizer that joins the stream
         ops._grad_side = self.grad_side if self._use_sinks else None
         blocks = (self.block1, self.block2, self.block3, self.block4)
-        if self._look_slots[0] is not None or self._look_queue:  # lookahead in use: mark where this forward starts
+        self._fwd_count += 1
+        if self._look_slots or self._look_queue:  # lookahead in use: mark where this forward starts
             self._fwd_start = torch.cuda.Event()
             self._fwd_start.record(torch.cuda.current_stream())
+        if train and self._use_sinks and self.grad_side is not None:
+            self.grad_side.begin_step()
         geo = self._consume_lookahead(pos, plan, train) if decimation_idx is None else None
         if geo is None:
             if decimation_idx is None:
@@ -762,7 +785,9 @@ class _GeoSlot:
         self.geo = template.rebound(bufs, main)
         self.ready = None   # event (side stream): the slot holds the prefetched geometry
         self.ready_capture = 0  # id of the hipGraph capture the event was recorded in (0: eager)
-        self.pos_ptr = 0
+        self.pos: Optional[Tensor] = None  # the tensor the tables were computed from, and its version counter then
+        self.version = -1
+        self.consumer_fwd = 0  # index (HipRandLANet._fwd_count) of the forward that last consumed this buffer set
 
 
 def _knn_to_reference_order(idx: Tensor, index: "ops.KnnIndex") -> Tensor:

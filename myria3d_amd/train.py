@@ -31,7 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
     launch updates the whole flat buffer."""
 
     def __init__(self, net, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 all_reduce: bool = False, overlap_wgrad: bool = True):
+                 all_reduce: bool = False, overlap_wgrad: bool = True, force_collective: bool = False):
         if net.flat_parameters is None:
             net.flatten_parameters()
         self.net = net
@@ -46,6 +46,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.lr_dev: Optional[torch.Tensor] = None  # optional device-side learning rate (graph-replay safe)
         self.all_reduce = all_reduce
+        # run the gradient all-reduce even on a 1-rank process group (exercises RCCL and its interplay with hipGraph
+        # capture on a one-GPU box: tests, ``bench.py --force-collective``)
+        self.force_collective = force_collective
         if overlap_wgrad and flat.is_cuda:  # weight-gradient GEMMs run beside the rest of the backward pass
             net.grad_side = ops.GradSideStream(flat.device)
 
@@ -114,10 +117,16 @@ class FusedAdam(torch.optim.Optimizer):
             net.grad_side.join()  # the weight-gradient side stream has finished writing the flat gradient buffer
         if not net._flat_intact():
             net._check_flat()
-        if self.all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.uses_collective():
             dist.all_reduce(net.flat_grads, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0
+
+    def uses_collective(self) -> bool:
+        """True when ``step()`` exchanges gradients: ``all_reduce`` under an initialised process group with more than
+        one rank (or ``force_collective``)."""
+        return bool(self.all_reduce and dist.is_available() and dist.is_initialized()
+                    and (dist.get_world_size() > 1 or self.force_collective))
 
     @torch.no_grad()
     def step(self, closure=None):

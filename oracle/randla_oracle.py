@@ -117,21 +117,43 @@ def knn_kdtree(
     return idx, d2o
 
 
-_KNN = {"exact": knn_exact, "kdtree": knn_kdtree}
+def knn_cdist(
+    pos_src: Tensor, ptr_src: Sequence[int], pos_qry: Tensor, ptr_qry: Sequence[int], k: int
+) -> Tuple[Tensor, Tensor]:
+    """Same contract through stock torch ops on whatever device the positions live on (``torch.cdist`` + ``topk`` per
+    cloud): the kNN of the "restated path through stock PyTorch-ROCm ops" baseline (BASELINE.md section 3,
+    ``bench.py`` ``torch_rocm_baseline``).  Not bit-exact with :func:`knn_exact` (cdist's arithmetic)."""
+    nq, dev = pos_qry.shape[0], pos_qry.device
+    idx = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+    d2o = torch.full((nq, k), float("inf"), dtype=torch.float32, device=dev)
+    for b in range(len(ptr_src) - 1):
+        s0, s1 = int(ptr_src[b]), int(ptr_src[b + 1])
+        q0, q1 = int(ptr_qry[b]), int(ptr_qry[b + 1])
+        if s1 == s0 or q1 == q0:
+            continue
+        keff = min(k, s1 - s0)
+        d = torch.cdist(pos_qry[q0:q1].detach(), pos_src[s0:s1].detach())
+        dk, ik = torch.topk(d, keff, dim=1, largest=False, sorted=True)
+        idx[q0:q1, :keff] = ik + s0
+        d2o[q0:q1, :keff] = dk * dk
+    return idx, d2o
+
+
+_KNN = {"exact": knn_exact, "kdtree": knn_kdtree, "cdist": knn_cdist}
 
 
 def dense_to_edge_index(idx: Tensor) -> Tensor:
     """``knn_graph(..., loop=True, flow='source_to_target')`` layout:
     row 0 = neighbour j (source), row 1 = centre i (target); edges grouped by centre, ascending distance."""
     n, k = idx.shape
-    centre = torch.arange(n, dtype=torch.int64)[:, None].expand(n, k)
+    centre = torch.arange(n, dtype=torch.int64, device=idx.device)[:, None].expand(n, k)
     keep = idx >= 0
     return torch.stack([idx[keep], centre[keep]], dim=0)
 
 
 def scatter_sum(src: Tensor, index: Tensor, dim_size: int) -> Tensor:
     """torch_scatter.scatter_sum(src, index, dim=0, dim_size=...) (Appendix A.6)."""
-    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     return out.index_add(0, index, src)
 
 
@@ -139,7 +161,7 @@ def segment_softmax(src: Tensor, index: Tensor, num_nodes: int) -> Tensor:
     """torch_geometric.utils.softmax(src, index) (Appendix A.4): per-channel softmax over the rows that
     share ``index``; max subtracted on a detached copy; ``+1e-16`` in the denominator."""
     c = src.shape[1]
-    mx = torch.full((num_nodes, c), float("-inf"), dtype=src.dtype)
+    mx = torch.full((num_nodes, c), float("-inf"), dtype=src.dtype, device=src.device)
     mx = mx.scatter_reduce(0, index[:, None].expand(-1, c), src.detach(), reduce="amax", include_self=True)
     e = torch.exp(src - mx[index])
     s = scatter_sum(e, index, num_nodes) + 1e-16
@@ -163,7 +185,7 @@ def knn_interpolate(
             nn_idx, _ = _KNN[knn](pos_x, ptr_x, pos_y, ptr_y, k)
         ny = pos_y.shape[0]
         keep = nn_idx >= 0
-        y_idx = torch.arange(ny, dtype=torch.int64)[:, None].expand_as(nn_idx)[keep]
+        y_idx = torch.arange(ny, dtype=torch.int64, device=nn_idx.device)[:, None].expand_as(nn_idx)[keep]
         x_idx = nn_idx[keep]
         diff = pos_x[x_idx] - pos_y[y_idx]
         d2 = (diff * diff).sum(dim=-1, keepdim=True)
@@ -293,7 +315,7 @@ class DilatedResidualBlock(nn.Module):
         return x
 
 
-def decimation_indices(ptr: Sequence[int], factor: int, generator: Optional[torch.Generator] = None):
+def decimation_indices(ptr: Sequence[int], factor: int, generator: Optional[torch.Generator] = None, device=None):
     """pyg_randla_net.py:192-231: per cloud keep ``max(1, n // factor)`` points, the head of a random
     permutation; returns (global indices, new ptr)."""
     if factor < 1:
@@ -305,7 +327,7 @@ def decimation_indices(ptr: Sequence[int], factor: int, generator: Optional[torc
     for b in range(len(ptr) - 1):
         n = int(ptr[b + 1]) - int(ptr[b])
         m = max(1, n // factor)
-        idx.append(int(ptr[b]) + torch.randperm(n, generator=generator)[:m])
+        idx.append(int(ptr[b]) + torch.randperm(n, generator=generator, device=device)[:m])
         new_ptr.append(new_ptr[-1] + m)
     return torch.cat(idx), new_ptr
 
@@ -352,7 +374,7 @@ class RandLANetOracle(nn.Module):
                     new_ptr.append(new_ptr[-1] + max(1, (ptrs[lvl][b + 1] - ptrs[lvl][b]) // self.decimation))
                 assert idx.numel() == new_ptr[-1]
             else:
-                idx, new_ptr = decimation_indices(ptrs[lvl], self.decimation)
+                idx, new_ptr = decimation_indices(ptrs[lvl], self.decimation, device=pos.device)
             used_idx.append(idx)
             h = h[idx]
             poss.append(poss[lvl][idx])

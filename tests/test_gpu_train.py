@@ -277,3 +277,205 @@ def test_gradients_are_ready_when_backward_returns(device):
         total = torch.nn.utils.clip_grad_norm_(flat.parameters(), 1e9)     # reads every p.grad on the main stream
         ref = torch.nn.utils.clip_grad_norm_(plain.parameters(), 1e9)
         assert abs(total.item() - ref.item()) <= 2e-4 * ref.item(), (rep, total.item(), ref.item())
+
+
+# --------------------------------------------------------------------------------------------------
+# GraphedStep: the launch form bench.py times (dual hipGraphs + geometry lookahead), as product code
+# --------------------------------------------------------------------------------------------------
+def _graphed_fixture(device, sizes=(2600, 2200)):
+    xa, pa, _, ptr = rand_batch(list(sizes), seed=41)
+    xb, pb, _, _ = rand_batch(list(sizes), seed=42)
+    rs = np.random.RandomState(7)
+    ya = torch.from_numpy(rs.randint(0, 6, (sum(sizes),)))
+    yb = torch.from_numpy(rs.randint(0, 6, (sum(sizes),)))
+    to = lambda *ts: tuple(t.to(device) for t in ts)
+    return to(xa, pa, ya), to(xb, pb, yb), ptr
+
+
+def _fresh_flat_net(device, seed=31):
+    from myria3d_amd import FusedAdam, HipRandLANet
+
+    net = HipRandLANet(9, 6, return_logits=True)
+    fill_params_deterministic(net, seed)
+    net.mlp_classif.dropout = [0.0, 0.0]  # torch's dropout stream differs between a replayed graph and eager launches
+    net = net.to(device).flatten_parameters().train()
+    return net, FusedAdam(net, lr=1e-3)
+
+
+def _eager_reference_steps(device, a, b, ptr, nsteps, seed):
+    """``nsteps`` plain steps — no lookahead, no graph — alternating the two batches; returns per-step decimation
+    indices, level-1 kNN table and loss, and the final state."""
+    from myria3d_amd import cross_entropy
+
+    net, opt = _fresh_flat_net(device)
+    net.set_decimation_seed(seed)
+    ptrd = ptr.to(device)
+    trace = []
+    for i in range(nsteps):
+        x, pos, y = a if i % 2 == 0 else b
+        rec = {}
+        loss = cross_entropy(net(x, pos, None, ptrd, record=rec), y, ignore_index=65)
+        loss.backward()
+        opt.step()
+        trace.append(([d.clone() for d in net.last_decimation_idx], rec["block1.knn_idx"].clone(), loss.item()))
+    torch.cuda.synchronize()
+    return trace, net, opt
+
+
+def _assert_same_training_state(net, opt, net_ref, opt_ref, what):
+    worst = ("", 0.0)
+    for (k, p), (_, q) in zip(net.named_parameters(), net_ref.named_parameters()):
+        err = (p - q).abs().max().item()
+        if err > worst[1]:
+            worst = (k, err)
+        assert torch.allclose(p, q, rtol=5e-3, atol=2e-4), (what, k, err)
+    for name in ("exp_avg", "exp_avg_sq"):
+        a, b = getattr(opt, name), getattr(opt_ref, name)
+        assert torch.allclose(a, b, rtol=5e-3, atol=2e-4), (what, name, (a - b).abs().max().item())
+    assert float(opt.step_count) == float(opt_ref.step_count)
+    for (k, p), (_, q) in zip(net.named_buffers(), net_ref.named_buffers()):
+        if k.endswith(("running_mean", "running_var")):
+            assert torch.allclose(p, q, rtol=1e-3, atol=1e-5), (what, k)
+    print(f"[parity] {what}: worst parameter difference {worst[0]} {worst[1]:.3e}")
+
+
+@pytest.mark.parametrize("launch,lookahead,lookahead_mode", [("graph", True, "dual"), ("graph", True, "single"),
+                                                            ("eager", True, "dual"), ("graph", False, "dual")])
+def test_graphed_step_matches_plain_eager_steps(device, launch, lookahead, lookahead_mode):
+    """Six steps through ``GraphedStep`` (two input buffer sets holding two DIFFERENT batches, the position-only tables
+    of each step prefetched one step ahead into a persistent slot that the previous replay's graph wrote) against six
+    plain eager steps from the same seed: per step the decimation draw of every level and the level-1 kNN table are
+    BIT-IDENTICAL (a slot rewrite racing a reader would show here), the loss agrees; afterwards parameters, Adam
+    moments and running statistics agree (rtol 5e-3 / atol 2e-4: atomic accumulation order differs run to run)."""
+    from myria3d_amd import GraphedStep
+
+    a, b, ptr = _graphed_fixture(device)
+    nsteps, seed = 6, 1234
+    trace, net_ref, opt_ref = _eager_reference_steps(device, a, b, ptr, nsteps, seed)
+    net, opt = _fresh_flat_net(device)
+    gs = GraphedStep(net, ptr, 9, mode="train", optimizer=opt, lookahead=lookahead, launch=launch,
+                     lookahead_mode=lookahead_mode)
+    gs.load_all(*a)
+    if lookahead:
+        gs.load_next(*b)
+    if launch == "graph":
+        before = net.flat_parameters.clone()
+        gs.prepare()  # warm-up + capture; parameters / moments / statistics / RNG state are put back
+        assert torch.equal(before, net.flat_parameters) and float(opt.step_count) == 0.0
+    net.set_decimation_seed(seed)
+    for i in range(nsteps):
+        if not lookahead:  # one buffer set: load the batch of this step
+            gs.load(*(a if i % 2 == 0 else b))
+        loss = gs.step()
+        torch.cuda.synchronize()
+        dec_ref, knn_ref, loss_ref = trace[i]
+        if lookahead:
+            dec, knn = gs.consumed_geometry()
+            for lvl, (d0, d1) in enumerate(zip(dec, dec_ref)):
+                assert torch.equal(d0, d1), (i, lvl)
+            assert torch.equal(knn, knn_ref), i
+        else:
+            for lvl, (d0, d1) in enumerate(zip(net.last_decimation_idx, dec_ref)):
+                assert torch.equal(d0, d1), (i, lvl)
+        assert abs(loss.item() - loss_ref) <= 2e-4 * max(1.0, abs(loss_ref)), (i, loss.item(), loss_ref)
+    _assert_same_training_state(net, opt, net_ref, opt_ref, f"GraphedStep[{launch}, lookahead={lookahead}, {lookahead_mode}]")
+
+
+def test_graphed_eval_step_matches_plain_forward(device):
+    from myria3d_amd import GraphedStep, HipRandLANet
+
+    a, b, ptr = _graphed_fixture(device)
+    net = HipRandLANet(9, 6, return_logits=True)
+    fill_params_deterministic(net, 5)
+    net = net.to(device).eval()
+    gs = GraphedStep(net, ptr, 9, mode="eval")
+    gs.load_all(a[0], a[1])
+    gs.load_next(b[0], b[1])
+    gs.prepare()
+    net.set_decimation_seed(77)
+    outs = [gs.step().clone() for _ in range(4)]
+    torch.cuda.synchronize()
+    plain = HipRandLANet(9, 6, return_logits=True)
+    fill_params_deterministic(plain, 5)
+    plain = plain.to(device).eval()
+    plain.set_decimation_seed(77)
+    with torch.no_grad():
+        for i in range(4):
+            x, pos, _ = a if i % 2 == 0 else b
+            ref = plain(x, pos, None, ptr.to(device))
+            assert torch.allclose(outs[i], ref, rtol=1e-5, atol=1e-6), (i, (outs[i] - ref).abs().max().item())
+
+
+def test_stale_prefetch_is_not_consumed(device):
+    """tables prefetched for a ``pos`` that is rewritten in place afterwards (a static input buffer), or for
+    another tensor at a recycled address, must not be used: the match is the tensor's identity + version counter."""
+    from myria3d_amd import HipRandLANet
+
+    x, pos_a, _, ptr = rand_batch([900, 700], seed=3)
+    _, pos_b, _, _ = rand_batch([900, 700], seed=4)
+    net = HipRandLANet(9, 6, return_logits=True)
+    fill_params_deterministic(net, 2)
+    net = net.to(device).eval()
+    buf = pos_a.to(device)
+    ptrd, xd = ptr.to(device), x.to(device)
+    with torch.no_grad():
+        net.prefetch_geometry(buf, ptrd)
+        buf.copy_(pos_b.to(device))  # refilled in place AFTER the prefetch
+        rec = {}
+        net(xd, buf, None, ptrd, record=rec)
+        assert not net._look_queue
+        fresh = {}
+        net(xd, pos_b.to(device), None, ptrd, record=fresh)
+        assert torch.equal(rec["block1.knn_idx"], fresh["block1.knn_idx"])
+        # same address, different tensor object: dropped as well
+        net.prefetch_geometry(buf, ptrd)
+        alias = buf.view_as(buf)
+        rec2 = {}
+        net(xd, alias, None, ptrd, record=rec2)
+        assert torch.equal(rec2["block1.knn_idx"], fresh["block1.knn_idx"])
+        # and the plain case still hits
+        net.prefetch_geometry(buf, ptrd)
+        count = net._fwd_count
+        net(xd, buf, None, ptrd)
+        assert any(s.consumer_fwd == count + 1 for s in net._look_slots.values())
+
+
+def test_collective_path_on_a_one_rank_rccl_group(device):
+    """The N > 1 code path on the 1-GPU box: a 1-rank RCCL ("nccl") process group, ``FusedAdam(force_collective=True)``:
+    fwd + bwd captured (capture_error_mode thread_local beside RCCL's watchdog), the flat-bucket all-reduce and Adam
+    outside the graph — 3 steps must leave the same state as the N = 1 path (optimizer inside the graph)."""
+    import torch.distributed as dist
+
+    from myria3d_amd import FusedAdam, GraphedStep
+
+    a, b, ptr = _graphed_fixture(device)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                                device_id=torch.device(device))
+        created = True
+    try:
+        states = []
+        for force in (False, True):
+            net, _ = _fresh_flat_net(device)
+            net.grad_side = None
+            opt = FusedAdam(net, lr=1e-3, all_reduce=True, force_collective=force)
+            assert opt.uses_collective() == force
+            gs = GraphedStep(net, ptr, 9, mode="train", optimizer=opt)
+            assert gs.opt_in_graph == (not force)
+            gs.load_all(*a)
+            gs.load_next(*b)
+            gs.prepare()
+            net.set_decimation_seed(99)
+            for _ in range(3):
+                gs.step()
+            torch.cuda.synchronize()
+            states.append((net, opt))
+        _assert_same_training_state(states[1][0], states[1][1], states[0][0], states[0][1], "1-rank RCCL path vs N=1 path")
+        g = states[1][0].flat_grads
+        g.fill_(1.0)
+        dist.all_reduce(g)
+        assert float(g.min()) == 1.0 and float(g.max()) == 1.0
+    finally:
+        if created:
+            dist.destroy_process_group()
