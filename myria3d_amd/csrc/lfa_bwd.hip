@@ -32,11 +32,14 @@ struct LfaBwdArgs {
   float* g_part;      // [parts][GP*16],  GP = max(16, D)
   int64_t n;
   int K, CH, D;
-  int stagger;  // experiment (M3D_LFA_BWD_STAGGER): start-up delay, in s_sleep(127) units (~3.4 us), per dispatch round
-  int dbg;  // timing experiments only (M3D_LFA_BWD_DBG): 1 = skip the dx atomics, 2 = skip phases 4-7
   float slope;
 };
 
+// phase-ablation builds only (tools/build_variant.sh bwd_dbgN lfa_bwd.hip -DLFA_BWD_DBG=N; profiles/r02d_*): bit 0 skips
+// the dx atomics, bits 1..5 stop a group after phase 1 / 2 / 3 / 5 / 6.  0 in the product: the branches fold away.
+#ifndef LFA_BWD_DBG
+#define LFA_BWD_DBG 0
+#endif
 // tile geometry of the backward kernel per padded channel count: edge rows per workgroup iteration, waves per
 // workgroup, cap on resident (persistent) workgroups.  Overridable at compile time for tuning sweeps.
 // 1: double-buffer the weight fragments of GEMM-1 / GEMM-2 in the non-pipelined kernel (ch >= 128): untuned A/B knob
@@ -223,12 +226,6 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
     }
   };
-  if (a.stagger > 0) {
-    // de-phase the workgroups that share a CU (dispatch rounds of 256): all of them start together and, with equal work
-    // per group, stay in lock-step — every resident workgroup in its MFMA phase at once, then every one in a VALU phase
-    const int rounds = (int)(blockIdx.x >> 8) & 3;
-    for (int i = 0; i < rounds * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   int cur = 0;
   if (PIPE && (int64_t)blockIdx.x < ngroups) {
     const int j0 = load_idx(blockIdx.x);
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       __syncthreads();
     }
 
-    if (a.dbg & 2) continue;   // timing experiment: phase 1 only
+    if (LFA_BWD_DBG & 2) continue;   // timing experiment: phase 1 only
     // ---- phase 2: A = F * W_att^T
     f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -447,7 +444,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         for (int t = 0; t < NTW; ++t) b4[s4][t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
     }
 
-    if (a.dbg & 4) continue;   // timing experiment: phases 1-2
+    if (LFA_BWD_DBG & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
 #pragma unroll
     for (int cc = 0; cc < MTW / KT; ++cc) {
@@ -505,7 +502,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     }
     __syncthreads();
 
-    if (a.dbg & 8) continue;   // timing experiment: phases 1-3
+    if (LFA_BWD_DBG & 8) continue;   // timing experiment: phases 1-3
     // ---- phase 4: dF = dout*s + DA * W_att
     if constexpr (BF) {
       constexpr int KS = CHP / 32;
@@ -633,7 +630,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
     }
     __syncthreads();
-    if (a.dbg & 16) continue;  // timing experiment: phases 1-5
+    if (LFA_BWD_DBG & 16) continue;  // timing experiment: phases 1-5
     // ---- phase 6: scatter dx; dy -> DA[:, D:2D]
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
@@ -649,7 +646,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
               DA[row * STR + col] = v;  // D < 16: only D of 16 lanes hold dx columns -> repacked below
             } else {
               const int j = nbr[row];
-              if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
+              if (j >= 0 && !(LFA_BWD_DBG & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
             }
           } else if (col < CH) {
             const float lse = F[row * STR + col];
@@ -664,10 +661,10 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       for (int f = tid; f < ROWS * D; f += NTHR) {
         const int row = f / D, col = f % D;
         const int j = nbr[row];
-        if (j >= 0 && !(a.dbg & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
+        if (j >= 0 && !(LFA_BWD_DBG & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
       }
     }
-    if (a.dbg & 32) continue;  // timing experiment: phases 1-6
+    if (LFA_BWD_DBG & 32) continue;  // timing experiment: phases 1-6
     // ---- phase 7: G[c', q] += sum_e dy[e, c'] * [r|1][e, q]
     if (wid < GT * KSPL4) {
       const bool crow = gt * 16 + lr < D;
@@ -809,7 +806,7 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
   }
   if (bf16) return M3D_ERR_UNSUPPORTED;
   if constexpr (CH <= 64) {
-    if (pipe && !a.dbg) {
+    if (pipe && !LFA_BWD_DBG) {
       if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
       return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
@@ -840,10 +837,6 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   a.dw_part = (float*)ws;
   a.g_part = a.dw_part + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
   a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
-  static const int dbg = getenv("M3D_LFA_BWD_DBG") ? atoi(getenv("M3D_LFA_BWD_DBG")) : 0;
-  a.dbg = dbg;
-  static const int stagger = getenv("M3D_LFA_BWD_STAGGER") ? atoi(getenv("M3D_LFA_BWD_STAGGER")) : 0;
-  a.stagger = stagger;
   int rc;
   switch (CH) {
     case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16); break;
