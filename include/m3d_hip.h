@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 9
+#define M3D_ABI_VERSION 10
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -60,6 +60,18 @@ int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t
                   int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
                   int32_t sorted_io, int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */,
                   void* stream);
+/* Staged form of m3d_knn_query for CELL-SORTED queries (qry_ws) and 4 < k <= 32: the same search cut into launches by
+ * ring radius — the queries whose search is still open after a stage are compacted into a pool (scratch) and get a
+ * group of lanes each in the next stage — so that the launch no longer ends on its slowest wavefronts
+ * (csrc/knn.hip: knn_stage_kernel).  Bit-identical tables.  m3d_knn_staged_supported: 1 when the host side should
+ * route a query here (large query sets; M3D_KNN_STAGED=0/1 overrides).  scratch: m3d_knn_staged_workspace_bytes bytes
+ * of device memory, contents irrelevant, must stay alive until the launches have run. */
+size_t m3d_knn_staged_workspace_bytes(int64_t n_qry, int32_t k);
+int m3d_knn_staged_supported(int64_t n_qry, int32_t k);
+int m3d_knn_query_staged(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds, const void* qry_ws,
+                         const int64_t* ptr_qry, int64_t n_qry, int32_t k, int32_t sorted_io, int32_t* idx_out,
+                         float* d2_out, void* scratch, void* stream);
+
 /* Up to 8 independent queries in ONE launch: job j searches the grid ws[j] (n_src[j] sources) for the cell-sorted queries
  * of qry_ws[j] (n_qry[j]; may be ws[j] itself) and writes idx_out[j][n_qry[j], k].  Same k, num_clouds and sorted_io
  * for every job, no distances, bit-identical to njobs calls of m3d_knn_query.  The pointer arrays are HOST arrays (read

@@ -646,296 +646,272 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_batch_kernel(Kn
 }
 
 // ------------------------------------------------------------------------------------------
-// self-query, wavefront-cooperative (queries = the sources, in their own cell-sorted order)
+// query, STAGED (round 3; the default for large cell-sorted query sets): the deferred-insertion search above, cut
+// into launches by ring radius, with the unfinished queries compacted between the launches.
 //
-// Same keys, same total order, same termination rule => bit-identical tables; different data path.  The per-lane ring
-// walks above are memory-latency bound (profiles/r02c_*: a wavefront waits on memory for half of its ~100 us life: 64
-// lanes each gather their own 16-byte records through ~10-15 dependent round trips).  But the 64 queries of a wavefront
-// are CONSECUTIVE in cell-sorted order, i.e. they sit in a handful of adjacent cells of one grid row, and their 3 x 3
-// neighbourhoods are nearly the same cells.  So the wavefront walks ONE block: the union rectangle of its lanes' rings.
-// The cells a ring adds are a few contiguous runs of the sorted array; a run is fetched with coalesced 1-KB loads
-// (lane i takes record i) into LDS, and every lane scans the staged records with broadcast LDS reads: no divergence,
-// no per-lane gathers, a global round trip per 64 candidates of the whole wavefront (prefetched one chunk ahead).
-// A lane stops when its k-th distance is inside the explored rectangle (which contains its own ring block, so the
-// bound is at least the per-lane one); the wavefront stops when all of its lanes have.  Lanes of a wavefront that lie
-// in different grid rows (row wrap, cloud boundary) are handled as successive segments.
+// Why: a lane's ring walk ends when ITS k-th distance is inside the explored block, a wavefront ends with its slowest
+// lane.  On Lidar tiles most queries (ground, roofs) stop after ring 2 (25 grid columns, ~175 candidates) but a
+// vegetation point high above the ground needs ring 4-6 (~850 candidates): nearly every wavefront of 64 consecutive
+// queries holds one, so the mean lane sat idle for ~75 % of its wavefront's life and the launch ended on a tail of
+// slow wavefronts (profiles/r02c_*, r02rs_*: mean wavefront 94-100 us, launch 190 us, slowest lane 679 slots vs a mean
+// of 200).  Here
+//   stage 0   every query, one lane each, rings 0 .. r0 (uniform work); a query whose search is still open leaves its
+//             state — the sorted key list, its position, cloud and query index — in a pool in HBM, appended at a slot
+//             from ONE atomic per wavefront (ballot + prefix);
+//   stage s   reads the pool of stage s-1 DENSELY (no idle lanes) and gives every open query a GROUP of G lanes that
+//             split each ring's candidates (lane g takes records p0+g, p0+g+G, ...: adjacent lanes read adjacent
+//             records); candidates that pass the group's shared k-th distance go to the lane's LDS queue and the group
+//             OWNER merges the G queues into the key list at the end of the ring — no partial lists, no merge network;
+//             the late rings, which are long (8 R columns) and concern few queries, are scanned G-wide instead of serially;
+//   last      the same with the largest group, looping until every query is closed.
+// Same keys, same total order, same termination test per query => tables bit-identical to the kernels above.
 // ------------------------------------------------------------------------------------------
-#ifndef KNNC_MINW
-#define KNNC_MINW 4
-#endif
-#ifdef KNNC_STATS  // instrumented build (tools/build_variant.sh ... -DKNNC_STATS): per-launch totals, read by m3d_knn_debug_stats
-__device__ unsigned long long knnc_stats[8];  // waves, segments, rings, chunks, candidates (per wave), chain trips, appends (per lane), max ring
-#define KSTAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&knnc_stats[i], (unsigned long long)(v)); } while (0)
-extern "C" int m3d_knn_debug_stats(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(knnc_stats), sizeof(knnc_stats)) != hipSuccess) return M3D_ERR_LAUNCH;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(knnc_stats), z, sizeof(z)) != hipSuccess) return M3D_ERR_LAUNCH; }
-  return M3D_OK;
-}
-#else
-#define KSTAT(i, v) do { } while (0)
-#endif
-template <int KMAX, class KP, int QD>
-__global__ __launch_bounds__(64, (KMAX <= 16 ? KNNC_MINW : (KMAX <= 32 ? 2 : 1))) void knn_query_coop_kernel(KnnWs w, const int64_t* __restrict__ ptr, int B,
-                                                                      int64_t n_qry, int k, int* __restrict__ idx_out,
-                                                                      float* __restrict__ d2_out, int flags) {
-  const int sorted_io = flags & 1;
-  typedef typename KP::T KT;
-  __shared__ KT queue[QD][64];
-  __shared__ float chunk[2][4][64 + 4];  // staged records, one array per component: pairs of candidates feed packed fp32 ops
-  const int lane = threadIdx.x;
-  int64_t wg = blockIdx.x;
-  {  // XCD-aware order (see knn_query_queue_kernel)
-    const int64_t nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
-    const int64_t xcd = wg & 7, i8 = wg >> 3;
-    wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
-  }
-  const int64_t t = wg * 64 + lane;
-  const bool valid = t < n_qry;
-  int b = 0;
-  {
-    int lo = 0, hi = B;
-    const int64_t tc = valid ? t : n_qry - 1;
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (ptr[mid] <= tc) lo = mid; else hi = mid;
-    }
-    b = lo;
-  }
-  const float4 q = w.sorted[valid ? t : n_qry - 1];
-  const float qx = q.x, qy = q.y, qz = q.z;
-  const int64_t orow = sorted_io ? t : (int64_t)__float_as_int(q.w);
-  int cx, cy;
-  {
-    const float* gp = w.gridp + (size_t)b * GP_STRIDE;
-    const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6];
-    cx = min(Gx - 1, max(0, (int)((qx - gp[0]) * gp[2])));
-    cy = min(Gy - 1, max(0, (int)((qy - gp[1]) * gp[2])));
-  }
-  KT best[KMAX];
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
-  int cnt = 0;
-  float kth = __builtin_inff();
-  // Admission threshold before the list is full.  All lanes scan the staged records in the SAME order, so a lane at
-  // the far end of a row would otherwise meet its candidates in order of decreasing distance and insert every one of
-  // them.  Any k distinct points bound the k-th distance from above: take the k records around the query in the
-  // cell-sorted array (own cell and its row neighbours), thr0 = their largest d2.  Records with d2 > thr0 cannot be
-  // among the k nearest (ties pass), so the result is unchanged; termination still uses the exact list (kth).
-  float thr0 = __builtin_inff();
-  {
-    const int64_t c0 = ptr[b], c1 = ptr[b + 1];
-    if (valid && c1 - c0 >= k) {
-      int64_t s0 = t - (k >> 1);
-      s0 = s0 < c0 ? c0 : s0;
-      s0 = s0 > c1 - k ? c1 - k : s0;
-      float4 r[KMAX];
-#pragma unroll
-      for (int j = 0; j < KMAX; ++j) r[j] = w.sorted[s0 + (j < k ? j : 0)];
-      float m = 0.f;
-#pragma unroll
-      for (int j = 0; j < KMAX; ++j) m = fmaxf(m, dist2_exact(qx, qy, qz, r[j]));
-      thr0 = m;
-    }
-  }
+#define KNNS_MAX_STAGES 4
+struct KnnPoolBuf {
+  float4* q;    // [cap] (x, y, z, bits of the query's index t)
+  int* cloud;   // [cap]
+  void* best;   // KT [KMAX][cap]
+};
+struct KnnStageArgs {
+  KnnPoolBuf in, out;
+  const unsigned* cnt_in;  // open queries left by the previous stage
+  unsigned* cnt_out;
+  int64_t cap;
+  int r_first, r_last;  // rings of this stage (r_last < 0: until closed)
+};
 
-  auto chain = [&](KT key) {
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      if constexpr (KP::IS_F64) {
-        KT hi2;
-        asm("v_max_f64 %0, %1, %2" : "=&v"(hi2) : "v"(best[j]), "v"(key));
-        asm("v_min_f64 %0, %0, %1" : "+v"(best[j]) : "v"(key));
-        key = hi2;
-      } else {
-        const KT cur = best[j];
-        const bool lt = key < cur;
-        best[j] = lt ? key : cur;
-        key = lt ? cur : key;
+template <int KMAX, class KP, int QD, int G, bool FIRST, bool LAST>
+__global__ __launch_bounds__(64, (KMAX <= 16 ? KNNQ_MINW : 2)) void knn_stage_kernel(
+    KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float4* __restrict__ qsorted,
+    const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k, int* __restrict__ idx_out, float* __restrict__ d2_out,
+    int flags, KnnStageArgs sa) {
+  static_assert(!FIRST || G == 1, "stage 0 walks one query per lane");
+  static_assert((G & (G - 1)) == 0 && G <= 64, "group size: a power of two");
+  typedef typename KP::T KT;
+  constexpr int QPW = 64 / G;  // queries per wavefront
+  const int sorted_io = flags & 1;
+  __shared__ KT queue[QD][64];
+  __shared__ int qcnt[64];
+  const int lane = threadIdx.x;
+  const int g = lane & (G - 1), own = lane & ~(G - 1);
+  const bool owner = g == 0;
+  const int64_t count = FIRST ? n_qry : (int64_t)*sa.cnt_in;
+  const int64_t nwork = (count + QPW - 1) / QPW;
+  for (int64_t wg0 = blockIdx.x; wg0 < nwork; wg0 += gridDim.x) {
+    int64_t wg = wg0;
+    if constexpr (FIRST) {  // XCD-aware order (see knn_query_queue_body)
+      const int64_t nblk = nwork, q8 = nblk >> 3, r8 = nblk & 7;
+      const int64_t xcd = wg & 7, i8 = wg >> 3;
+      wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
+    }
+    const int64_t slot = wg * QPW + (lane / G);
+    const bool valid = slot < count;
+    const int64_t sl = valid ? slot : count - 1;
+    // ---- the query and its list
+    float qx, qy, qz;
+    int t, b;
+    KT best[KMAX];
+    if constexpr (FIRST) {
+      t = (int)sl;
+      int lo = 0, hi = B;
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ptr_qry[mid] <= (int64_t)t) lo = mid; else hi = mid;
       }
-    }
-  };
-  float thr = thr0;  // = min(thr0, kth)
-  auto drain = [&]() {
-#ifdef KNNC_STATS
-    { int mx = cnt;
-      for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-      KSTAT(5, mx);
-      int sm = cnt;
-      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-      KSTAT(6, sm); }
-#endif
-    for (int i = 0; i < cnt; i += KNNQ_DRAIN) {
-      KT key[KNNQ_DRAIN];
+      b = lo;
+      const float4 q = qsorted[t];
+      qx = q.x; qy = q.y; qz = q.z;
 #pragma unroll
-      for (int u = 0; u < KNNQ_DRAIN; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
+      for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
+    } else {
+      const float4 q = sa.in.q[sl];
+      qx = q.x; qy = q.y; qz = q.z; t = __float_as_int(q.w);
+      b = sa.in.cloud[sl];
+      const KT* bi = (const KT*)sa.in.best + sl;
 #pragma unroll
-      for (int u = 0; u < KNNQ_DRAIN; ++u) chain(u == 0 || i + u < cnt ? key[u] : KP::empty());
+      for (int j = 0; j < KMAX; ++j) best[j] = owner ? bi[(size_t)j * sa.cap] : KP::empty();
     }
-    cnt = 0;
-    unsigned hw = KP::hi32(best[KMAX - 1]);
-    if (k < KMAX) {
-      hw = 0u;
+    const float* gp = w.gridp + (size_t)b * GP_STRIDE;
+    const float gx0 = gp[0], gy0 = gp[1], inv_h = gp[2], h = gp[3], eps = gp[4];
+    const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6], n = ((const int*)gp)[7];
+    const int* cs = w.cell_start + (size_t)b * (CELLS_MAX + 1);
+    const float4* sorted = w.sorted + ptr_src[b];
+    int cnt = 0;
+    float kth = __builtin_inff();
+
+    auto chain = [&](KT key) {
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {
-        const unsigned v = j < k ? KP::hi32(best[j]) : 0u;
-        hw = v > hw ? v : hw;
+        if constexpr (KP::IS_F64) {
+          KT hi2;
+          asm("v_max_f64 %0, %1, %2" : "=&v"(hi2) : "v"(best[j]), "v"(key));
+          asm("v_min_f64 %0, %0, %1" : "+v"(best[j]) : "v"(key));
+          key = hi2;
+        } else {
+          const KT cur = best[j];
+          const bool lt = key < cur;
+          best[j] = lt ? key : cur;
+          key = lt ? cur : key;
+        }
       }
-    }
-    kth = hw == KP::hi32(KP::empty()) ? __builtin_inff() : __uint_as_float(KP::d2bits_of_hi(hw));
-    thr = fminf(thr0, kth);
-  };
+    };
+    auto kth_of_list = [&]() {  // (the owner's list; G > 1: shared with the group below)
+      unsigned hw = KP::hi32(best[KMAX - 1]);
+      if (k < KMAX) {
+        hw = 0u;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          const unsigned v = j < k ? KP::hi32(best[j]) : 0u;
+          hw = v > hw ? v : hw;
+        }
+      }
+      float v = hw == KP::hi32(KP::empty()) ? __builtin_inff() : __uint_as_float(KP::d2bits_of_hi(hw));
+      if constexpr (G > 1) v = __shfl(v, own, 64);
+      kth = v;
+    };
+    auto drain = [&]() {
+      if constexpr (G == 1) {
+        for (int i = 0; i < cnt; i += KNNQ_DRAIN) {
+          KT key[KNNQ_DRAIN];
+#pragma unroll
+          for (int u = 0; u < KNNQ_DRAIN; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
+#pragma unroll
+          for (int u = 0; u < KNNQ_DRAIN; ++u) chain(u == 0 || i + u < cnt ? key[u] : KP::empty());
+        }
+      } else {
+        // the owner merges the queues of its group (same wavefront: program order is the only ordering needed; the
+        // wave barrier keeps the compiler from moving the LDS reads above the writes of the other lanes)
+        qcnt[lane] = cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (owner) {
+          for (int gg = 0; gg < G; ++gg) {
+            const int c = qcnt[own + gg];
+            for (int i = 0; i < c; ++i) chain(queue[i][own + gg]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      cnt = 0;
+      kth_of_list();
+    };
+    if constexpr (!FIRST) kth_of_list();
 
-  unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
-  KSTAT(0, 1);
-  while (todo != 0ull) {
-    KSTAT(1, 1);
-    // ---- next segment: the pending lanes that share the leader's cloud and grid row
-    const int lead = __builtin_ctzll(todo);
-    const int b0 = __builtin_amdgcn_readlane(b, lead), cy0 = __builtin_amdgcn_readlane(cy, lead);
-    const bool mine = valid && b == b0 && cy == cy0 && ((todo >> lane) & 1ull);
-    todo &= ~__builtin_amdgcn_ballot_w64(mine);
-    const float* gp = w.gridp + (size_t)b0 * GP_STRIDE;
-    const float gx0 = gp[0], gy0 = gp[1], h = gp[3], eps = gp[4];
-    const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6];
-    const int* cs = w.cell_start + (size_t)b0 * (CELLS_MAX + 1);
-    const float4* sorted = w.sorted + ptr[b0];
-    int cxmin = mine ? cx : 0x7fffffff, cxmax = mine ? cx : -1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      cxmin = min(cxmin, __shfl_xor(cxmin, o, 64));
-      cxmax = max(cxmax, __shfl_xor(cxmax, o, 64));
-    }
-    cxmin = __builtin_amdgcn_readfirstlane(cxmin);
-    cxmax = __builtin_amdgcn_readfirstlane(cxmax);
-    bool act = mine;  // lanes of this segment whose search is still open
-    for (int R = 0;; ++R) {
-      KSTAT(2, 1);
-      const int xa = max(cxmin - R, 0), xb = min(cxmax + R, Gx - 1);
-      const int ya = cy0 - R, yb = cy0 + R;
-      // ---- the runs of the sorted array this ring adds, one per lane: R = 0: the row segment itself; R >= 1: the
-      // full-width rows ya and yb, then the two single cells left and right of every row in between
-      const int nruns = R == 0 ? 1 : 4 * R;
-      for (int i0 = 0; i0 < nruns; i0 += 64) {
-        const int i = i0 + lane;
-        int yy = cy0, x0 = xa, x1 = xb;
-        bool rok = i < nruns;
-        if (R > 0) {
-          if (i < 2) {
-            yy = i == 0 ? ya : yb;
-          } else {
-            const int j = (i - 2) >> 1;
-            yy = ya + 1 + j;
-            x0 = x1 = ((i & 1) == 0) ? cxmin - R : cxmax + R;
-          }
-        }
-        rok = rok && yy >= 0 && yy < Gy && x0 >= 0 && x1 < Gx && x0 <= x1;
-        int p0 = 0, p1 = 0;
-        if (rok) { p0 = cs[yy * Gx + x0]; p1 = cs[yy * Gx + x1 + 1]; }
-        // chunk list: run r owns chunks [pre_r, pre_r + nch_r)
-        const int nch = (p1 - p0 + 63) >> 6;
-        int incl = nch;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int v = __shfl_up(incl, o, 64);
-          if (lane >= o) incl += v;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        const int excl = incl - nch;
-        auto chunk_of = [&](int c, int& base, int& count) {
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(incl > c);
-          const int r = __builtin_ctzll(m);
-          const int rp0 = __builtin_amdgcn_readlane(p0, r), rp1 = __builtin_amdgcn_readlane(p1, r);
-          base = rp0 + ((c - __builtin_amdgcn_readlane(excl, r)) << 6);
-          count = min(64, rp1 - base);
-        };
-        int nbase = 0, ncount = 0;
-        float4 nrec = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (total > 0) {
-          chunk_of(0, nbase, ncount);
-          nrec = sorted[nbase + min(lane, ncount - 1)];
-        }
-        for (int c = 0; c < total; ++c) {
-          const int count = ncount;
-          KSTAT(3, 1); KSTAT(4, count);
-          chunk[c & 1][0][lane] = nrec.x; chunk[c & 1][1][lane] = nrec.y;
-          chunk[c & 1][2][lane] = nrec.z; chunk[c & 1][3][lane] = nrec.w;
-          if (c + 1 < total) {  // next chunk's records: in flight while this one is scanned
-            chunk_of(c + 1, nbase, ncount);
-            nrec = sorted[nbase + min(lane, ncount - 1)];
-          }
-          __syncthreads();
-          const float(*ch)[64 + 4] = chunk[c & 1];
-          const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
-          for (int j = 0; j < count; j += 4) {
-            // 4 candidates per trip as 2 pairs (broadcast 8-byte LDS reads); the distance arithmetic is the packed
-            // (v_pk_*_f32) form of dist2_exact: same IEEE operations per element, same bits
-            f32x2 X[2], Y[2], Z[2], W[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              X[u] = *(const f32x2*)&ch[0][j + 2 * u]; Y[u] = *(const f32x2*)&ch[1][j + 2 * u];
-              Z[u] = *(const f32x2*)&ch[2][j + 2 * u]; W[u] = *(const f32x2*)&ch[3][j + 2 * u];
+    bool open = valid && n > 0;  // the search of this lane's query is not closed yet
+    if (open) {
+      const int cx = min(Gx - 1, max(0, (int)((qx - gx0) * inv_h)));
+      const int cy = min(Gy - 1, max(0, (int)((qy - gy0) * inv_h)));
+      for (int R = sa.r_first; LAST || R <= sa.r_last; ++R) {
+        for (int dy = -R; dy <= R; ++dy) {
+          const int yy = cy + dy;
+          if (yy < 0 || yy >= Gy) continue;
+          const bool edge = (dy == -R || dy == R);
+          for (int sg = 0; sg < (edge ? 1 : 2); ++sg) {
+            int xa, xb;
+            if (edge) {
+              xa = max(cx - R, 0); xb = min(cx + R, Gx - 1);
+            } else {
+              xa = xb = (sg == 0 ? cx - R : cx + R);
+              if (xa < 0 || xa >= Gx) continue;
             }
-            if (__builtin_amdgcn_ballot_w64(cnt > QD - 4) != 0) drain();
+            const int p0 = cs[yy * Gx + xa], p1 = cs[yy * Gx + xb + 1];
+            if (p1 <= p0) continue;
+            const int last = p1 - 1;
+            // lane g of the group takes records p0 + g, p0 + g + G, ...; KNNQ_UNROLL of them per trip, the loads of trip
+            // i + 1 issued before trip i is consumed (addresses clamped to the run: masked out below)
+            // (the trip count depends on p0 / p1 only: every lane of a group runs the same trips, so the group's lanes
+            // are always together when its owner merges their queues)
+            float4 nx[KNNQ_UNROLL];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const f32x2 d = dist2_exact_pk(q2x, q2y, q2z, X[u], Y[u], Z[u]);
+            for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[min(p0 + g + u * G, last)];
+            for (int pb = p0; pb < p1; pb += KNNQ_UNROLL * G) {
+              const int p = pb + g;
+              float4 s[KNNQ_UNROLL];
 #pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                // branch-free append: the slot is always written, the count only moves for admitted candidates
-                queue[cnt][lane] = KP::make(d[e], __float_as_int(W[u][e]));
-                cnt += (act && j + 2 * u + e < count && !(d[e] > thr)) ? 1 : 0;
+              for (int u = 0; u < KNNQ_UNROLL; ++u) s[u] = nx[u];
+#pragma unroll
+              for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[min(p + (KNNQ_UNROLL + u) * G, last)];
+#pragma unroll
+              for (int u = 0; u < KNNQ_UNROLL; ++u) asm volatile("" : "+v"(nx[u].w));  // whole 16-byte loads, issued together
+              if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
+#pragma unroll
+              for (int u = 0; u < KNNQ_UNROLL; ++u) {
+                const float d2 = dist2_exact(qx, qy, qz, s[u]);
+                // !(d2 > kth): ties with the current k-th distance go through the exact (d2, row) order in the drain
+                if (p + u * G < p1 && !(d2 > kth)) {
+                  queue[cnt][lane] = KP::make(d2, __float_as_int(s[u].w));
+                  ++cnt;
+                }
               }
             }
           }
         }
-      }
-      drain();
-      const bool covers = xa == 0 && xb == Gx - 1 && ya <= 0 && yb >= Gy - 1;
-      if (covers) break;
-      // distance from the query to the nearest side of the explored rectangle that is not a border of the grid
-      float bound = 3.4e38f;
-      if (xa > 0) bound = fminf(bound, qx - (gx0 + (float)xa * h));
-      if (xb < Gx - 1) bound = fminf(bound, (gx0 + (float)(xb + 1) * h) - qx);
-      if (ya > 0) bound = fminf(bound, qy - (gy0 + (float)ya * h));
-      if (yb < Gy - 1) bound = fminf(bound, (gy0 + (float)(yb + 1) * h) - qy);
-      bound = fmaxf(bound - eps, 0.f);
-      if (kth <= bound * bound) act = false;
-      if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
-    }
-  }
-  if (!valid) return;
-  int ids[KMAX];
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) ids[j] = KP::is_empty(best[j]) ? -1 : KP::row(best[j]);
-  if (sorted_io) {
-    int tr[KMAX];
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) tr[j] = w.inv[ids[j] < 0 ? 0 : ids[j]];
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? -1 : tr[j];
-  }
-  int* io = idx_out + orow * k;
-  if (k == KMAX && KMAX % 4 == 0 && (flags & 2)) {
-#pragma unroll
-    for (int j = 0; j < KMAX; j += 4) *(int4*)(io + j) = make_int4(ids[j], ids[j + 1], ids[j + 2], ids[j + 3]);
-    if (d2_out) {
-      float* dq = d2_out + orow * k;
-#pragma unroll
-      for (int j = 0; j < KMAX; j += 4) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          v[u] = KP::is_empty(best[j + u]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j + u]));
-        *(float4*)(dq + j) = make_float4(v[0], v[1], v[2], v[3]);
+        drain();
+        const bool covers = (cx - R <= 0) && (cx + R >= Gx - 1) && (cy - R <= 0) && (cy + R >= Gy - 1);
+        if (covers) { open = false; break; }
+        float bound = 3.4e38f;
+        if (cx - R > 0) bound = fminf(bound, qx - (gx0 + (float)(cx - R) * h));
+        if (cx + R < Gx - 1) bound = fminf(bound, (gx0 + (float)(cx + R + 1) * h) - qx);
+        if (cy - R > 0) bound = fminf(bound, qy - (gy0 + (float)(cy - R) * h));
+        if (cy + R < Gy - 1) bound = fminf(bound, (gy0 + (float)(cy + R + 1) * h) - qy);
+        bound = fmaxf(bound - eps, 0.f);
+        if (kth <= bound * bound) { open = false; break; }  // (kth = +inf while fewer than k neighbours are known)
       }
     }
-  } else {
+    // ---- open queries go to the next stage's pool: one atomic per wavefront
+    if constexpr (!LAST) {
+      const bool spill = open && owner;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(spill);
+      if (m != 0ull) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(sa.cnt_out, (unsigned)__builtin_popcountll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (spill) {
+          const size_t pos = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+          sa.out.q[pos] = make_float4(qx, qy, qz, __int_as_float(t));
+          sa.out.cloud[pos] = b;
+          KT* bo = (KT*)sa.out.best + pos;
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      if (j < k) {
-        io[j] = ids[j];
-        if (d2_out)
-          d2_out[orow * k + j] = KP::is_empty(best[j]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j]));
+          for (int j = 0; j < KMAX; ++j) bo[(size_t)j * sa.cap] = best[j];
+        }
+      }
+    }
+    // ---- closed queries: results (all slot translations in flight together, rows stored 16 bytes at a time)
+    if (valid && owner && !open) {
+      const int64_t orow = sorted_io ? (int64_t)t : (int64_t)__float_as_int(qsorted[t].w);
+      int ids[KMAX];
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) ids[j] = KP::is_empty(best[j]) ? -1 : KP::row(best[j]);
+      if (sorted_io) {  // neighbours selected by (d2, original row); reported as cell-sorted slots
+        int tr[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) tr[j] = w.inv[ids[j] < 0 ? 0 : ids[j]];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? -1 : tr[j];
+      }
+      int* io = idx_out + orow * k;
+      if (k == KMAX && KMAX % 4 == 0 && (flags & 2)) {
+#pragma unroll
+        for (int j = 0; j < KMAX; j += 4) *(int4*)(io + j) = make_int4(ids[j], ids[j + 1], ids[j + 2], ids[j + 3]);
+        if (d2_out) {
+          float* dq = d2_out + orow * k;
+#pragma unroll
+          for (int j = 0; j < KMAX; j += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              v[u] = KP::is_empty(best[j + u]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j + u]));
+            *(float4*)(dq + j) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          if (j < k) {
+            io[j] = ids[j];
+            if (d2_out)
+              d2_out[orow * k + j] = KP::is_empty(best[j]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j]));
+          }
+        }
       }
     }
   }
@@ -1002,16 +978,6 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
 #define LAUNCH_Q(KM, KP)                                                                                          \
   hipLaunchKernelGGL((knn_query_queue_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
                      w, ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags)
-  // M3D_KNN_COOP=1 (read at every call; default off): the wavefront-cooperative kernel for self-queries (queries = the
-  // sources in their own cell-sorted order: knn_graph(loop=True) of every level) with k > 4.  Bit-identical tables;
-  // measured 180-196 us against 188-193 us at level 1 and 20-50 % slower at the deeper levels (profiles/r02s_*), so it
-  // is an opt-in cross-check, not the default
-  const char* coop_s = getenv("M3D_KNN_COOP");
-  const bool self = qry_ws == ws && ptr_qry == ptr_src && n_qry == n_src && !pos_qry;
-  const bool use_coop = self && coop_s && atoi(coop_s) != 0;
-#define LAUNCH_C(KM, KP)                                                                                              \
-  hipLaunchKernelGGL((knn_query_coop_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
-                     w, ptr_src, num_clouds, n_qry, k, idx_out, d2_out, qflags)
 #define LAUNCH(KM)                       \
   do {                                   \
     if (f64_keys) LAUNCH_KP(KM, KeyF64); \
@@ -1019,10 +985,7 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   } while (0)
 #define LAUNCHQ(KM)                      \
   do {                                   \
-    if (use_coop) {                      \
-      if (f64_keys) LAUNCH_C(KM, KeyF64); \
-      else LAUNCH_C(KM, KeyU64);         \
-    } else if (!use_queue) LAUNCH(KM);   \
+    if (!use_queue) LAUNCH(KM);          \
     else if (f64_keys) LAUNCH_Q(KM, KeyF64); \
     else LAUNCH_Q(KM, KeyU64);           \
   } while (0)
@@ -1035,10 +998,144 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
 #undef LAUNCH
 #undef LAUNCHQ
 #undef LAUNCH_Q
-#undef LAUNCH_C
 #undef LAUNCH_KP
   M3D_CHECK_LAUNCH();
   return M3D_OK;
+}
+
+// ---- staged query (see knn_stage_kernel) -------------------------------------------------------------------
+// schedule: rings of stage 0, then up to KNNS_MAX_STAGES - 1 group stages "G:last_ring" (the final one "G": until
+// closed).  M3D_KNN_STAGES overrides it for A/B runs, e.g. "2,4:3,8:4,16" (the default) or "1,2:2,4:3,16".
+struct KnnSchedule {
+  int nstage;
+  int g[KNNS_MAX_STAGES];
+  int r_last[KNNS_MAX_STAGES];
+};
+static KnnSchedule knn_schedule() {
+  KnnSchedule sc;
+  const char* e = getenv("M3D_KNN_STAGES");
+  const char* txt = e && e[0] ? e : "2,4:3,8:4,16";
+  sc.nstage = 0;
+  const char* c = txt;
+  while (*c && sc.nstage < KNNS_MAX_STAGES) {
+    char* end;
+    long a = strtol(c, &end, 10);
+    int s = sc.nstage;
+    if (s == 0) { sc.g[0] = 1; sc.r_last[0] = (int)a; }
+    else {
+      sc.g[s] = (int)a; sc.r_last[s] = -1;
+      if (*end == ':') { sc.r_last[s] = (int)strtol(end + 1, &end, 10); }
+    }
+    ++sc.nstage;
+    c = end;
+    if (*c == ',') ++c; else break;
+  }
+  bool ok = sc.nstage >= 1;
+  for (int s = 1; s < sc.nstage && ok; ++s) {
+    const int g = sc.g[s];
+    ok = (g == 2 || g == 4 || g == 8 || g == 16) && (sc.r_last[s] < 0 || sc.r_last[s] > sc.r_last[s - 1]);
+    if (sc.r_last[s] < 0 && s != sc.nstage - 1) ok = false;
+  }
+  if (!ok || sc.r_last[0] < 0) {  // malformed: the default
+    sc.nstage = 4;
+    sc.g[0] = 1; sc.r_last[0] = 2; sc.g[1] = 4; sc.r_last[1] = 3; sc.g[2] = 8; sc.r_last[2] = 4; sc.g[3] = 16; sc.r_last[3] = -1;
+  }
+  sc.r_last[sc.nstage - 1] = -1;  // the final stage always runs until every query is closed
+  return sc;
+}
+
+static inline size_t knns_buf_bytes(int64_t cap, int kmax) {
+  return (size_t)m3d_align(cap * 16, 256) + (size_t)m3d_align(cap * 4, 256) + (size_t)m3d_align(cap * 8 * (int64_t)kmax, 256);
+}
+static inline int knns_kmax(int k) { return k <= 16 ? 16 : 32; }
+
+extern "C" size_t m3d_knn_staged_workspace_bytes(int64_t n_qry, int32_t k) {
+  if (n_qry <= 0 || k < 5 || k > 32) return 0;
+  return 256 + 2 * knns_buf_bytes(n_qry, knns_kmax(k));
+}
+
+// 1 when m3d_knn_query_staged takes this problem: cell-sorted queries, 4 < k <= 32, a large query set (the deep levels
+// are a few wavefronts per CU and stay on the single-launch kernels), f64 keys; M3D_KNN_STAGED=0 switches it off
+extern "C" int m3d_knn_staged_supported(int64_t n_qry, int32_t k) {
+  const char* e = getenv("M3D_KNN_STAGED");  // (read at every call: tests and A/B runs flip it inside one process)
+  const int env = e ? atoi(e) : -1;
+  static const bool f64_keys = knn_f64_keys();
+  if (env == 0 || !f64_keys || k < 5 || k > 32 || n_qry >= (1ll << 31)) return 0;
+  return (env > 0 || n_qry * (int64_t)k >= (1 << 20)) ? 1 : 0;
+}
+
+template <int KMAX, int G, bool FIRST>
+static void knns_launch(bool last, unsigned grid, hipStream_t st, const KnnWs& w, const int64_t* ptr_src, int B,
+                        const float4* qs, const int64_t* ptr_qry, int64_t n_qry, int k, int* idx_out, float* d2_out,
+                        int flags, const KnnStageArgs& sa) {
+  if (last)
+    hipLaunchKernelGGL((knn_stage_kernel<KMAX, KeyF64, KNNQ_DEPTH, G, FIRST, true>), dim3(grid), dim3(64), 0, st, w,
+                       ptr_src, B, qs, ptr_qry, n_qry, k, idx_out, d2_out, flags, sa);
+  else
+    hipLaunchKernelGGL((knn_stage_kernel<KMAX, KeyF64, KNNQ_DEPTH, G, FIRST, false>), dim3(grid), dim3(64), 0, st, w,
+                       ptr_src, B, qs, ptr_qry, n_qry, k, idx_out, d2_out, flags, sa);
+}
+
+template <int KMAX>
+static int knns_run(const KnnWs& w, const int64_t* ptr_src, int B, const float4* qs, const int64_t* ptr_qry,
+                    int64_t n_qry, int k, int* idx_out, float* d2_out, int flags, void* scratch, hipStream_t st) {
+  const KnnSchedule sc = knn_schedule();
+  char* p = (char*)scratch;
+  unsigned* cnt = (unsigned*)p;
+  p += 256;
+  KnnPoolBuf buf[2];
+  for (int i = 0; i < 2; ++i) {
+    buf[i].q = (float4*)p; p += m3d_align(n_qry * 16, 256);
+    buf[i].cloud = (int*)p; p += m3d_align(n_qry * 4, 256);
+    buf[i].best = (void*)p; p += m3d_align(n_qry * 8 * (int64_t)KMAX, 256);
+  }
+  if (sc.nstage > 1 && hipMemsetAsync(cnt, 0, 256, st) != hipSuccess) return M3D_ERR_LAUNCH;
+  // later stages: grid-stride over the pool, whose size only the device knows — enough workgroups to fill the chip at
+  // the worst case, cheap to launch when the pool turns out small
+  static const int stage_grid = getenv("M3D_KNN_STAGE_GRID") ? atoi(getenv("M3D_KNN_STAGE_GRID")) : 4096;
+  for (int s = 0; s < sc.nstage; ++s) {
+    KnnStageArgs sa;
+    sa.in = buf[(s + 1) & 1];
+    sa.out = buf[s & 1];
+    sa.cnt_in = s > 0 ? cnt + (s - 1) : nullptr;
+    sa.cnt_out = cnt + s;
+    sa.cap = n_qry;
+    sa.r_first = s > 0 ? sc.r_last[s - 1] + 1 : 0;
+    sa.r_last = sc.r_last[s];
+    const bool last = s == sc.nstage - 1;
+    if (s == 0) {
+      knns_launch<KMAX, 1, true>(last, (unsigned)m3d_cdiv(n_qry, 64), st, w, ptr_src, B, qs, ptr_qry, n_qry, k, idx_out,
+                                 d2_out, flags, sa);
+    } else {
+      const int64_t worst = m3d_cdiv(n_qry, 64 / sc.g[s]);
+      const unsigned grid = (unsigned)(worst < stage_grid ? worst : stage_grid);
+      switch (sc.g[s]) {
+        case 2: knns_launch<KMAX, 2, false>(last, grid, st, w, ptr_src, B, qs, ptr_qry, n_qry, k, idx_out, d2_out, flags, sa); break;
+        case 4: knns_launch<KMAX, 4, false>(last, grid, st, w, ptr_src, B, qs, ptr_qry, n_qry, k, idx_out, d2_out, flags, sa); break;
+        case 8: knns_launch<KMAX, 8, false>(last, grid, st, w, ptr_src, B, qs, ptr_qry, n_qry, k, idx_out, d2_out, flags, sa); break;
+        default: knns_launch<KMAX, 16, false>(last, grid, st, w, ptr_src, B, qs, ptr_qry, n_qry, k, idx_out, d2_out, flags, sa); break;
+      }
+    }
+    if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
+  }
+  return M3D_OK;
+}
+
+// m3d_knn_query for cell-sorted queries (qry_ws) through the staged kernels; ``scratch``: m3d_knn_staged_workspace_bytes
+// bytes of device memory (the pools of open queries).  Bit-identical tables.
+extern "C" int m3d_knn_query_staged(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds,
+                                    const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
+                                    int32_t sorted_io, int32_t* idx_out, float* d2_out, void* scratch, void* stream) {
+  if (!ws || !ptr_src || !ptr_qry || !idx_out || !qry_ws || num_clouds < 0 || n_qry < 0) return M3D_ERR_INVALID;
+  if (k < 5 || k > 32 || n_qry >= (1ll << 31)) return M3D_ERR_UNSUPPORTED;
+  if (n_qry == 0 || num_clouds == 0) return M3D_OK;
+  if (!scratch) return M3D_ERR_INVALID;
+  KnnWs w = ws_carve((void*)ws, num_clouds, n_src);
+  const float4* qs = ws_carve((void*)qry_ws, num_clouds, n_qry).sorted;
+  const int qflags = (sorted_io ? 1 : 0) | (((((uintptr_t)idx_out) | ((uintptr_t)d2_out)) & 15) == 0 ? 2 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (k <= 16) return knns_run<16>(w, ptr_src, num_clouds, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags, scratch, st);
+  return knns_run<32>(w, ptr_src, num_clouds, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags, scratch, st);
 }
 
 // the four K-NN tables of a forward pass (or its four 1-NN tables) in one launch: see KnnBatch

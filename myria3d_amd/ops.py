@@ -170,6 +170,12 @@ class KnnIndex:
             nq, ptr_q, qws, pq, qs = pos_qry.shape[0], ptr_qry, None, pos_qry, pos_qry.stride(0)
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.ws.device)
         d2 = torch.empty((nq, k), dtype=torch.float32, device=self.ws.device) if want_d2 else None
+        if qry is not None and lib().m3d_knn_staged_supported(nq, k):
+            # large cell-sorted query sets: the search in stages with the open queries compacted in between
+            scratch = torch.empty(lib().m3d_knn_staged_workspace_bytes(nq, k), dtype=torch.uint8, device=self.ws.device)
+            call("m3d_knn_query_staged", _p(self.ws), _p(self.ptr), self.n, self.num_clouds, _p(qws), _p(ptr_q), nq, k,
+                 int(sorted_io), _p(idx), _p(d2), _p(scratch), _st())
+            return idx, d2
         call("m3d_knn_query", _p(self.ws), _p(self.ptr), self.n, self.num_clouds, _p(pq), qs, _p(qws), _p(ptr_q), nq, k,
              int(sorted_io), _p(idx), _p(d2), _st())
         return idx, d2
@@ -776,6 +782,16 @@ def knn_query_batch(pairs, k: int, sorted_io: bool = True) -> List[Tensor]:
     launch (``m3d_knn_query_batch``); bit-identical tables."""
     import ctypes
 
+    staged = [i for i, (_, q) in enumerate(pairs) if lib().m3d_knn_staged_supported(q.n, k)]
+    if staged:  # the large jobs take the staged launches of their own; the rest share one launch
+        outs = [None] * len(pairs)
+        for i in staged:
+            outs[i] = pairs[i][0].query(k, qry=pairs[i][1], sorted_io=sorted_io)[0]
+        rest = [i for i in range(len(pairs)) if i not in staged]
+        if rest:
+            for i, o in zip(rest, knn_query_batch([pairs[i] for i in rest], k, sorted_io)):
+                outs[i] = o
+        return outs
     m = len(pairs)
     dev = pairs[0][0].ws.device
     outs = [torch.empty((q.n, k), dtype=torch.int32, device=dev) for _, q in pairs]

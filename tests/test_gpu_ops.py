@@ -60,13 +60,19 @@ def test_knn_lidar_tile_and_duplicates(device):
     _knn_case(device, line, torch.tensor([0, 300]), 16)
 
 
-def test_knn_cooperative_self_query_kernel_is_bit_identical(device, monkeypatch):
-    """M3D_KNN_COOP=1: the wavefront-cooperative self-query kernel (union-rectangle ring walk, LDS-staged records) must
-    give the oracle's table bit for bit, like the per-lane kernels: ragged clouds, row wraps, duplicates, K = 8/16/32."""
-    from oracle.randla_oracle import synthetic_batch
+@pytest.mark.parametrize("stages", ["2,4:3,8:4,16", "0,2:1,4:2,16", "1,16", "0,8", "3"])
+def test_knn_staged_query_is_bit_identical(device, monkeypatch, stages):
+    """The staged query (ring-limited stages, open queries compacted into a pool, a group of lanes per open query in the
+    later stages; the default for large query sets, forced here with M3D_KNN_STAGED=1) must give the oracle's table bit
+    for bit under every stage schedule: ragged clouds, clouds smaller than K, duplicates, K = 8 / 16 / 32, cell-sorted
+    output, queries of another point set."""
+    from myria3d_amd import ops
+    from oracle.randla_oracle import knn_exact, synthetic_batch
 
-    monkeypatch.setenv("M3D_KNN_COOP", "1")
-    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32)):
+    monkeypatch.setenv("M3D_KNN_STAGED", "1")
+    monkeypatch.setenv("M3D_KNN_STAGES", stages)
+    assert ops.lib().m3d_knn_staged_supported(100, 16) == 1
+    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32), ([700, 450], 32)):
         _, pos, _, ptr = rand_batch(sizes, seed=len(sizes) + k)
         _knn_case(device, pos, ptr, k)
     _, pos, _, ptr, _ = synthetic_batch([2500, 1800, 4000])
@@ -76,6 +82,35 @@ def test_knn_cooperative_self_query_kernel_is_bit_identical(device, monkeypatch)
     line = torch.zeros(300, 3)
     line[:, 2] = torch.linspace(0, 1, 300)
     _knn_case(device, line, torch.tensor([0, 300]), 16)
+    # cell-sorted io + a different source set (k >= 5 so that the staged path takes it)
+    sub = torch.cat([torch.randperm(2500)[:600], 2500 + torch.randperm(1800)[:450], 4300 + torch.randperm(4000)[:1000]])
+    ptr_s = torch.tensor([0, 600, 1050, 2050])
+    src = pos[sub].contiguous()
+    ref_idx, ref_d2 = knn_exact(src, ptr_s.tolist(), pos, ptr.tolist(), 8)
+    si, qi = ops.KnnIndex(src.to(device), ptr_s.to(device)), ops.KnnIndex(pos.to(device), ptr.to(device))
+    idx, d2 = si.query(8, qry=qi, want_d2=True)
+    assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(d2.cpu(), ref_d2)
+    idx_s, _ = si.query(8, qry=qi, sorted_io=True)  # rows = slots of qi, ids = slots of si
+    back = si.perm.long()[idx_s.long()][qi.inv.long()]
+    assert torch.equal(back.cpu(), ref_idx)
+
+
+def test_knn_staged_equals_single_launch_at_full_size(device, monkeypatch):
+    """BASELINE config 2 and config 5 shapes (16 x 12 800, K = 16; 4 x 40 000, K = 32): the staged query (what large
+    query sets take by default) against the single-launch deferred-insertion kernel (M3D_KNN_STAGED=0) — equal tables."""
+    from myria3d_amd import ops
+    from oracle.randla_oracle import synthetic_batch
+
+    for sizes, k in (([12800] * 16, 16), ([40000] * 4, 32)):
+        _, pos, _, ptr, _ = synthetic_batch(sizes)
+        ix = ops.KnnIndex(pos.to(device), ptr.to(device))
+        monkeypatch.setenv("M3D_KNN_STAGED", "0")
+        assert ops.lib().m3d_knn_staged_supported(ix.n, k) == 0
+        ref, ref_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True)
+        monkeypatch.delenv("M3D_KNN_STAGED")
+        assert ops.lib().m3d_knn_staged_supported(ix.n, k) == 1
+        got, got_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True)
+        assert torch.equal(got, ref) and torch.equal(got_d2, ref_d2)
 
 
 def test_batched_queries_match_the_per_level_launches(device):

@@ -46,5 +46,6 @@ for l in range(4):
     index = ops.KnnIndex(p4[l], ptrs[l])
     out.append(timeit(lambda: index.query(16, qry=index, sorted_io=True)))
 tag = os.environ.get("M3D_LIB", "default").split("libm3d_")[-1]
-print(f"knn_bench lib={tag} queue={os.environ.get('M3D_KNN_QUEUE', '1')} keys={os.environ.get('M3D_KNN_KEYS', 'f64')}: "
+print(f"knn_bench lib={tag} staged={os.environ.get('M3D_KNN_STAGED', 'auto')} stages={os.environ.get('M3D_KNN_STAGES', 'default')} "
+      f"grid={os.environ.get('M3D_KNN_STAGE_GRID', '4096')} queue={os.environ.get('M3D_KNN_QUEUE', 'auto')}: "
       + " ".join(f"L{l+1}={t:.1f}us" for l, t in enumerate(out)))
