@@ -36,6 +36,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+_T0 = time.perf_counter()
+
+
+def _progress(msg):
+    """Leg-by-leg progress on stderr (the driver's clock runs around the whole command: a slow leg must be findable)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
 
 
 def parse():
@@ -86,13 +94,14 @@ def parse():
     return ap.parse_args()
 
 
-def _leg_in_fresh_process(extra_args, timeout=600):
+def _leg_in_fresh_process(extra_args, timeout=240):
     """One training-step leg (bf16 mode, dense tiles) in a process of its own: a second net in THIS process shares the
     first one's hardware queues (torch streams are dealt round-robin onto 4 of them) and measured 10 % slower than the
     same leg alone.  Returns the leg's JSON line as a dict."""
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--skip-cpu-baseline", "--skip-roofline", "--skip-extras"] + extra_args
+    _progress("leg in a process of its own: " + " ".join(extra_args))
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -346,6 +355,7 @@ def cpu_baseline(tiles, points, K, full=False):
             res[name] = tiles * points / statistics.median(ts)
         return res
 
+    _progress(f"CPU baseline: {tiles} tiles, {picked} threads, 3 + 10 iterations")
     main = leg(picked, 3, 10)
     out = {"value": round(main["fwd_bwd"], 1), "unit": "points/s", "cores": picked, "kind": "port",
            "fwd_only": round(main["fwd_only"], 1), "host_cores": ncpu,
@@ -354,6 +364,7 @@ def cpu_baseline(tiles, points, K, full=False):
                      f"oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN); threads = {picked} (fastest of "
                      f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
     if picked != ncpu:
+        _progress(f"CPU baseline: all {ncpu} cores")
         allc = leg(ncpu, *((3, 10) if full else (1, 3)))
         out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1), "fwd_only": round(allc["fwd_only"], 1),
                             "sample": "same tiles, 3 + 10" if full else "same tiles, 1 warm-up + 3 timed (bounded)"}
@@ -652,12 +663,15 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                     fn = make(kind, "eager").step
         return fn, launch, probe
 
+    _progress("train step: launch probe")
     step_fn, launch, probe = pick("train", 40, 5)
+    _progress(f"train step: timed region ({launch})")
     for _ in range(warmup):
         step_fn()
     dt = timed(step_fn, steps, world)
     # eval forward of the trained weights (the first eval pass folds the BatchNorms / packs the attention weights; the
     # module caches them until the next training phase)
+    _progress("eval forward")
     fwd_fn, flaunch, fprobe = pick("eval", 20, 3)
     for _ in range(max(1, warmup // 2)):
         fwd_fn()
@@ -766,6 +780,7 @@ def main():
         if rank == 0:
             if not args.skip_roofline:
                 try:
+                    _progress("rooflines")
                     rl = stage_rooflines(net, pos, plan)
                     res["roofline"] = rl["dominant"]
                     res["roofline_knn_lse_stage"] = rl["knn_lse"]
@@ -776,6 +791,7 @@ def main():
             # informative extra legs of the N=1 line (BASELINE configs 3 and 5), short: they share the driver's clock
             try:
                 torch.cuda.empty_cache()
+                _progress("predict sweep (config 3)")
                 pr = predict_bench(args, dev, reps=2)
                 res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
             except Exception as e:
@@ -808,6 +824,7 @@ def main():
                 res["forced_collective_1rank"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 torch.cuda.empty_cache()
+                _progress("torch-ROCm baseline")
                 res["torch_rocm_baseline"] = torch_rocm_baseline(dev, B, N, K)
             except Exception as e:
                 res["torch_rocm_baseline"] = {"error": f"{type(e).__name__}: {e}"}
@@ -823,7 +840,9 @@ def main():
                     res["dense_tiles_config5"] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             if world == 1 and not args.skip_cpu_baseline:
+                _progress("CPU baseline")
                 res["cpu_baseline"] = cpu_baseline(args.cpu_tiles, N, K, full=args.cpu_baseline_full)
+            _progress("done")
             print(json.dumps(res), flush=True)
     if world > 1 or args.force_collective:
         dist.barrier()

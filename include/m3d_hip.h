@@ -164,7 +164,8 @@ int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float*
  *   dz = scale * (dy * act'(z*scale+shift) - s1/M - (z-mean)*invstd * s2/M)   computed as the GEMM's A fragments are loaded
  *   dx[M, Kin] = dz[M, N] w[N, Kin]     dz is also stored (the weight-gradient GEMM reads it), dbeta = s1, dgamma = s2
  * sums = the [nslots][3][N] table left by m3d_bn_bwd(..., accumulate_param_grads = 2 | nslots << 8).
- * flags: bit 0 = dgamma / dbeta are gradient sinks (added to); bit 8 = bf16 matrix-core operands (N % 32 == 0, N > 64).
+ * flags: bit 0 = dgamma / dbeta are gradient sinks (added to); bit 8 = bf16 matrix-core operands (N % 32 == 0, N > 64);
+ * bit 9 = the input gradient is ADDED to dx (and dx1) — another consumer of the same tensor wrote its gradient there.
  * N % 4 == 0, N <= 1024, contiguous dy / z / dz; M3D_ERR_UNSUPPORTED otherwise (callers then use m3d_bn_bwd + m3d_gemm_f32).
  * dx_split > 0 (the layer's input was a concatenation, FPModule: pyg_randla_net.py:249-252): columns [0, dx_split) of the
  * input gradient are stored to dx[m][.] (lddx), columns [dx_split, Kin) to dx1[m][. - dx_split] (lddx1); multiples of 4. */

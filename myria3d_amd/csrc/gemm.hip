@@ -270,7 +270,8 @@ extern "C" int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* sc
   GemmArgs g{};
   g.a0 = dy; g.lda0 = N; g.k0 = N; g.b = w; g.ldb = ldw; g.b_cm = 1; g.M = M; g.N = Kin;
   g.c = dx; g.ldc = lddx; g.splitk = 1; g.kchunk = m3d_align((int64_t)N, BK);
-  g.bf16 = (flags >> 8) & 1;  // flags: bit 0 = add into dgamma / dbeta, bit 8 = bf16 matrix-core operands
+  g.bf16 = (flags >> 8) & 1;  // flags: bit 0 = add into dgamma / dbeta, bit 8 = bf16 matrix-core operands,
+  g.accumulate = (flags >> 9) & 1;  // bit 9 = add the input gradient into dx (and dx1) instead of storing it
   g.pro_z = z; g.pro_scale = scale; g.pro_shift = shift; g.pro_mean = mean; g.pro_invstd = invstd;
   g.pro_sums = sums; g.pro_slots = nslots; g.pro_act = act & 1; g.pro_slope = slope;
   g.pro_dz = dz; g.pro_dgamma = dgamma; g.pro_dbeta = dbeta; g.pro_acc = flags & 1;

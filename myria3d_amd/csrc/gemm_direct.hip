@@ -236,18 +236,32 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
     y[r] = v;
   }
   if (!rowok) return;
+  // accumulate (plain epilogue only): C += A B^T — every element has exactly one writer (no split-K here), so a plain
+  // read-modify-write.  Used by the backward pass to add an input gradient into the buffer another consumer of the same
+  // tensor has already written (no separate elementwise add, no zero fill)
+  const bool acc_c = MODE == 0 && g.accumulate;
   if (MODE == 0 && g.c_split > 0) {  // (c_split, N multiples of 4: a lane's four columns fall on one side)
-    if (n0 < g.c_split) *(float4*)(g.c + m * g.ldc + n0) = make_float4(y[0], y[1], y[2], y[3]);
-    else if (n0 < g.N) *(float4*)(g.c1 + m * g.ldc1 + (n0 - g.c_split)) = make_float4(y[0], y[1], y[2], y[3]);
+    float4* dst = nullptr;
+    if (n0 < g.c_split) dst = (float4*)(g.c + m * g.ldc + n0);
+    else if (n0 < g.N) dst = (float4*)(g.c1 + m * g.ldc1 + (n0 - g.c_split));
+    if (dst) {
+      float4 o = make_float4(y[0], y[1], y[2], y[3]);
+      if (acc_c) { const float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      *dst = o;
+    }
     return;
   }
   float* cp = g.c + m * g.ldc + n0;
   if (cvec) {  // N % 4 == 0, ldc % 4 == 0, 16-byte aligned C
-    if (n0 < g.N) *(float4*)cp = make_float4(y[0], y[1], y[2], y[3]);
+    if (n0 < g.N) {
+      float4 o = make_float4(y[0], y[1], y[2], y[3]);
+      if (acc_c) { const float4 p = *(const float4*)cp; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      *(float4*)cp = o;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n0 + r < g.N) cp[r] = y[r];
+      if (n0 + r < g.N) cp[r] = acc_c ? cp[r] + y[r] : y[r];
   }
 }
 
@@ -593,7 +607,8 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   const int K = g.k0 + g.k1;
   // debugging aid: M3D_GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
   static const int disable = getenv("M3D_GEMM_DISABLE") ? atoi(getenv("M3D_GEMM_DISABLE")) : 0;
-  if (g.a_cm || g.accumulate || g.splitk > 1) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // column-major A / split-K: the LDS-tiled kernel
+  if (g.a_cm || g.splitk > 1) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // column-major A / split-K: the LDS-tiled kernel
+  if (g.accumulate && (g.stat_part || g.scale || g.shift || g.act)) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // plain epilogue only
   if ((disable & 2) && K <= 64) return 1;
   if ((disable & 4) && K > 64) return 1;
   if ((disable & 8) && g.stat_part) return 1;

@@ -216,11 +216,11 @@ def _splitk_for(red: int, m: int, n: int) -> int:
     return max(1, min(1024 // max(tiles, 1), red // 256))
 
 
-def linear_dgrad(dz: Tensor, w: Tensor, bf16: bool = False) -> Tensor:
-    """dX[M,K] = dZ[M,N] W[N,K]   (W stored [out,in] like torch.nn.Linear)."""
+def linear_dgrad(dz: Tensor, w: Tensor, bf16: bool = False, acc: Optional[Tensor] = None) -> Tensor:
+    """dX[M,K] = dZ[M,N] W[N,K]   (W stored [out,in] like torch.nn.Linear); ``acc``: added to this buffer instead."""
     M, N = dz.shape
     K = w.shape[1]
-    return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0), bf16=bf16)
+    return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0), bf16=bf16, out=acc, accumulate=acc is not None)
 
 
 class GradSideStream:
@@ -383,8 +383,29 @@ def gather_i32(src: Tensor, idx: Tensor) -> Tensor:
     return out
 
 
-def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int) -> Tensor:
-    out = arena.zeros((n_out, src.shape[1]), torch.float32, src.device)
+class GradSlot:
+    """Gradient meeting point of a tensor with several consumers inside the net (a block's input feeds mlp1, the shortcut
+    and — decimated levels — the FP module's skip; block 1's output feeds the decimation gather and fp1's skip).
+    Autograd would hand every consumer's input gradient to an AccumulateGrad add: one elementwise launch (and one
+    [rows, channels] round trip through HBM) per extra consumer.  Instead the consumers' backward passes, which run in a
+    fixed order (decoder first, then the block's tail, then its head), share a buffer: the first DEPOSITS its gradient
+    and tells autograd "None", the following ones ADD theirs in their GEMM / scatter epilogue, the last one (``final``)
+    returns the buffer as the tensor's gradient."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf: Optional[Tensor] = None
+
+    def take(self) -> Optional[Tensor]:
+        b, self.buf = self.buf, None
+        return b
+
+
+def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int, out: Optional[Tensor] = None) -> Tensor:
+    """``out[idx[i]] += src[i]`` (``out``: an existing ``[n_out, C]`` buffer to add into; default: zeros)."""
+    if out is None:
+        out = arena.zeros((n_out, src.shape[1]), torch.float32, src.device)
     call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], _st())
     return out
 
@@ -554,11 +575,12 @@ def bn_dgrad_ok(N: int) -> bool:
     return _pow2(N) and N <= 1024
 
 
-def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, split: int = 0):
+def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, split: int = 0, acc: Optional[Tensor] = None):
     """BatchNorm backward + input gradient of the Linear in front of it in TWO launches: the column sums
     (``m3d_bn_bwd`` pass 1, slot mode), then ``m3d_bn_dgrad_f32``, whose A fragments are dz computed on the fly.
     Returns ``(dx, dz, dgamma, dbeta)`` (the last two None with sinks).  ``split = k0 > 0``: ``dx`` is the pair
-    ``(dx[:, :k0], dx[:, k0:])`` as two contiguous matrices (the layer's input was a concatenation)."""
+    ``(dx[:, :k0], dx[:, k0:])`` as two contiguous matrices (the layer's input was a concatenation).  ``acc`` (no
+    split): an existing ``[M, Kin]`` buffer the input gradient is ADDED to (and which is returned as ``dx``)."""
     M, N = z.shape
     dev = z.device
     dy = _chk(dy)
@@ -579,10 +601,11 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, 
              _p(sums), ns, M, N, _p(w), w.stride(0), Kin, _p(dx[0]), split, _p(dz), _p(dgamma), _p(dbeta),
              int(sinks is not None) | (256 if bf16 else 0), split, _p(dx[1]), Kin - split, _st())
     else:
-        dx = torch.empty((M, Kin), dtype=torch.float32, device=dev)
+        dx = acc if acc is not None else torch.empty((M, Kin), dtype=torch.float32, device=dev)
+        assert dx.shape == (M, Kin) and dx.is_contiguous()
         call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
              _p(sums), ns, M, N, _p(w), w.stride(0), Kin, _p(dx), Kin, _p(dz), _p(dgamma), _p(dbeta),
-             int(sinks is not None) | (256 if bf16 else 0), 0, None, 0, _st())
+             int(sinks is not None) | (256 if bf16 else 0) | (512 if acc is not None else 0), 0, None, 0, _st())
     if sinks is not None:
         return dx, dz, None, None
     return dx, dz, dgamma, dbeta
@@ -619,8 +642,11 @@ class LinearFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False):
+    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False, x0_slot=None, x1_slot=None):
         # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None;  bf16: matrix-core precision of the K > 64 GEMMs
+        # x0_slot: GradSlot of x0, this layer being its LAST consumer in backward order (adds its input gradient to what
+        # the others deposited and returns the sum); x1_slot: GradSlot of x1, this layer being the FIRST (deposits)
+        ctx.slots = (x0_slot, x1_slot)
         ctx.sinks = sinks
         ctx.bf16 = bool(bf16)
         ctx.side = _grad_side if sinks is not None else None
@@ -650,6 +676,8 @@ class SharedLayerTrainFn(torch.autograd.Function):
         dx0 = dx1 = None
         want_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
         dxc = None
+        x0_slot, x1_slot = ctx.slots
+        acc0 = x0_slot.take() if (x0_slot is not None and ctx.needs_input_grad[0]) else None
         fused = want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1])
         if fused and k1 and k0 % 4 == 0 and k1 % 4 == 0:
             # concatenated input: the two column blocks of the input gradient leave the GEMM as two contiguous matrices
@@ -661,8 +689,12 @@ class SharedLayerTrainFn(torch.autograd.Function):
                 dx1 = s1
             want_dx = False
         elif fused:
+            direct = acc0 is not None and k1 == 0 and rows is None and acc0.shape == (z.shape[0], k0)
             dxc, dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
-                                              sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16)
+                                              sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16,
+                                              acc=acc0 if direct else None)
+            if direct:
+                acc0 = None  # already inside dxc
         else:
             dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act,
                                                 sinks=(sk[2], sk[3]) if sk else None)
@@ -677,15 +709,24 @@ class SharedLayerTrainFn(torch.autograd.Function):
                     dx0 = dx0.contiguous()
             if x1 is not None and ctx.needs_input_grad[1]:
                 dx1 = dxc[:, k0:].contiguous()
+        if acc0 is not None and dx0 is not None:  # (shapes the fused accumulate does not take: one torch add)
+            dx0 = acc0.add_(dx0)
+        if x1_slot is not None and dx1 is not None:
+            x1_slot.buf = dx1 if dx1.is_contiguous() else dx1.contiguous()  # deposited: the tensor's last consumer returns it
+            dx1 = None
         dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
 class ResidualTailTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None, bf16=False):
+    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns, sinks2=None, sinkss=None, bf16=False,
+                xs_slot=None):
+        # xs_slot: GradSlot of the block input xs (its gradient is deposited / added there; mlp1, the last consumer in
+        # backward order, returns the sum)
+        ctx.xs_slot = xs_slot
         ctx.sinks = (sinks2, sinkss) if sinks2 is not None else None
         ctx.bf16 = bool(bf16)
         ctx.side = _grad_side if sinks2 is not None else None
@@ -713,12 +754,21 @@ class ResidualTailTrainFn(torch.autograd.Function):
         dz2, dg2, db2, dzs, dgs, dbs = bn_bwd(dy.contiguous(), z2, sc2, sh2, mu2, is2, True, zs, scs, shs, mus, iss,
                                               sinks=(sk[0][2], sk[0][3], sk[1][2], sk[1][3]) if sk else None)
         dx2 = linear_dgrad(dz2, w2, ctx.bf16)
-        dxs = linear_dgrad(dzs, ws, ctx.bf16)
+        slot = ctx.xs_slot
+        if slot is not None and ctx.needs_input_grad[6]:
+            prev = slot.buf
+            ok = prev is not None and prev.shape == (dzs.shape[0], ws.shape[1]) and prev.is_contiguous()
+            slot.buf = linear_dgrad(dzs, ws, ctx.bf16, acc=prev if ok else None)
+            if prev is not None and not ok:
+                slot.buf.add_(prev)
+            dxs = None
+        else:
+            dxs = linear_dgrad(dzs, ws, ctx.bf16)
         dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         z0_2 = None if sk else torch.zeros_like(db2)
         z0_s = None if sk else torch.zeros_like(dbs)
-        return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None, None)
+        return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None, None, None)
 
 
 class GatherRowsFn(torch.autograd.Function):
@@ -726,17 +776,23 @@ class GatherRowsFn(torch.autograd.Function):
     gather ``dy[inverse]`` (no atomics, no zero fill) instead of a scatter-add."""
 
     @staticmethod
-    def forward(ctx, x, idx, inverse=None):
+    def forward(ctx, x, idx, inverse=None, slot=None):
+        # slot: GradSlot of x, this gather being its LAST consumer in backward order: the rows are scatter-added into
+        # the gradient another consumer deposited (no zero fill, no elementwise add)
         ctx.save_for_backward(idx, inverse)
         ctx.n = x.shape[0]
+        ctx.slot = slot
         return gather_rows(x.contiguous(), idx)
 
     @staticmethod
     def backward(ctx, dy):
         idx, inverse = ctx.saved_tensors
         if inverse is not None:
-            return gather_rows(dy.contiguous(), inverse), None, None
-        return scatter_add_rows(dy.contiguous(), idx, ctx.n), None, None
+            return gather_rows(dy.contiguous(), inverse), None, None, None
+        prev = ctx.slot.take() if ctx.slot is not None else None
+        if prev is not None and not (prev.shape == (ctx.n, dy.shape[1]) and prev.is_contiguous()):
+            return scatter_add_rows(dy.contiguous(), idx, ctx.n).add_(prev), None, None, None
+        return scatter_add_rows(dy.contiguous(), idx, ctx.n, out=prev), None, None, None
 
 
 # --------------------------------------------------------------------------------------------------

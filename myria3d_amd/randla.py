@@ -137,6 +137,9 @@ class HipRandLANet(nn.Module):
         # ``trainer.precision: bf16-mixed``), like any autocast-aware module.
         self.matmul_precision = "fp32"
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
+        # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
+        # accumulation adds; False: plain autograd (cross-check)
+        self.share_input_gradients = __import__("os").environ.get("M3D_GRAD_SLOTS", "1") != "0"
         # the K-NN tables / encoder moments / decoder 1-NN tables of the four levels as one launch each (see
         # _geometry_stages); M3D_GEO_BATCH=0: level by level (A/B and cross-check)
         self.batch_geometry = __import__("os").environ.get("M3D_GEO_BATCH", "1") != "0"
@@ -316,12 +319,12 @@ class HipRandLANet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
-                      rows: Optional[Tensor] = None, train: bool = False) -> Tensor:
+                      rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None) -> Tensor:
         lin, bn = mlp.lins[li], mlp.norms[li].module
         if train:
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
-                                                sk, self._bf16)
+                                                sk, self._bf16, x0_slot, x1_slot)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
@@ -352,9 +355,11 @@ class HipRandLANet(nn.Module):
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
                mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str,
-               wait_graph=None) -> Tensor:
+               wait_graph=None, x_slot=None) -> Tensor:
         # idx: knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
-        h = self._shared_layer(blk.mlp1, 0, x, train=train)  # does not need the graph: runs while kNN finishes
+        # x_slot (train): the block input has several consumers (mlp1, the shortcut, and on the decimated levels the FP
+        # module's skip): their input gradients meet in one buffer, mlp1 — last in backward order — returns the sum
+        h = self._shared_layer(blk.mlp1, 0, x, train=train, x0_slot=x_slot)  # does not need the graph: runs while kNN finishes
         if wait_graph is not None:
             wait_graph()
         if rec is not None:
@@ -370,7 +375,7 @@ class HipRandLANet(nn.Module):
             sk2 = self._sinks(l2.weight, l2.bias, n2.weight, n2.bias) if self._use_sinks else None
             sks = self._sinks(ls.weight, ls.bias, ns.weight, ns.bias) if self._use_sinks else None
             out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
-                                                ns.weight, ns.bias, ns, sk2, sks, self._bf16)
+                                                ns.weight, ns.bias, ns, sk2, sks, self._bf16, x_slot)
         else:
             sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2), self._bn_deps(n2))
             scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns), self._bn_deps(ns))
@@ -676,15 +681,21 @@ class HipRandLANet(nn.Module):
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
                                self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
+        # gradient meeting points (train): in_slots[l] = input of block l (hin[l]), out_slot = output of block 1
+        use_slots = train and torch.is_grad_enabled() and self.share_input_gradients
+        in_slots = [ops.GradSlot() if use_slots else None for _ in range(4)]
+        out_slot = ops.GradSlot() if use_slots else None
         for lvl, blk in enumerate(blocks):
             h = self._block(blk, h, pos4[lvl], index[lvl], geo.knn[lvl], geo.mom[lvl], plan.num_edges[lvl], train,
                             record, f"block{lvl + 1}",
-                            wait_graph=lambda s=1 + 2 * lvl: geo.wait(s))  # kNN table (+ encoder moments) of this level
+                            wait_graph=lambda s=1 + 2 * lvl: geo.wait(s),  # kNN table (+ encoder moments) of this level
+                            x_slot=in_slots[lvl])
             feats.append(h)
             self._advance_interleaved()
             self._advance_interleaved()  # (two position-only stages per level: table + moments, decimation + next grid)
             geo.wait(2 + 2 * lvl)  # decimation map into the next level
-            h = ops.GatherRowsFn.apply(h, geo.src[lvl]) if train else ops.gather_rows(h, geo.src[lvl])
+            h = ops.GatherRowsFn.apply(h, geo.src[lvl], None, out_slot if lvl == 0 else None) if train \
+                else ops.gather_rows(h, geo.src[lvl])
             hin.append(h)
         self.last_decimation_idx = dec_ref
         self._advance_interleaved()  # (the last stage; the slot copy follows it)
@@ -698,7 +709,9 @@ class HipRandLANet(nn.Module):
             nn_idx = geo.nn[lvl]  # 1-NN of every level-`lvl` point among level lvl+1 (both in sorted slots)
             skip = feats[0] if lvl == 0 else hin[lvl]  # b1_out, resp. the decimated output of block lvl
             # knn_interpolate(k=1) == x[nn] (weights cancel); fused as a row gather into the GEMM's A operand
-            h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train)
+            # (the skip tensor's other consumers run later in the backward pass: this layer deposits its gradient)
+            h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train,
+                                   x1_slot=out_slot if lvl == 0 else in_slots[lvl])
             if record is not None:
                 record[f"fp{lvl + 1}"] = h[index[lvl].inv.long()]
         h = self._shared_layer(self.mlp_classif, 0, h, train=train)

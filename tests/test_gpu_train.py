@@ -299,7 +299,10 @@ def _fresh_flat_net(device, seed=31):
     fill_params_deterministic(net, seed)
     net.mlp_classif.dropout = [0.0, 0.0]  # torch's dropout stream differs between a replayed graph and eager launches
     net = net.to(device).flatten_parameters().train()
-    return net, FusedAdam(net, lr=1e-3)
+    # eps = 0.1: the update is ~ lr * g / eps where |g| << eps, so run-to-run rounding noise in tiny gradients (atomic
+    # accumulation order) is NOT normalised to +-lr as with the default 1e-8 — the two launch forms then stay comparable
+    # over several steps (Adam itself is checked against torch.optim.Adam in test_fused_adam_matches_torch_adam)
+    return net, FusedAdam(net, lr=1e-3, eps=0.1)
 
 
 def _eager_reference_steps(device, a, b, ptr, nsteps, seed):
@@ -377,7 +380,7 @@ def test_graphed_step_matches_plain_eager_steps(device, launch, lookahead, looka
         else:
             for lvl, (d0, d1) in enumerate(zip(net.last_decimation_idx, dec_ref)):
                 assert torch.equal(d0, d1), (i, lvl)
-        assert abs(loss.item() - loss_ref) <= 2e-4 * max(1.0, abs(loss_ref)), (i, loss.item(), loss_ref)
+        assert abs(loss.item() - loss_ref) <= 5e-4 * max(1.0, abs(loss_ref)), (i, loss.item(), loss_ref)
     _assert_same_training_state(net, opt, net_ref, opt_ref, f"GraphedStep[{launch}, lookahead={lookahead}, {lookahead_mode}]")
 
 
@@ -459,7 +462,7 @@ def test_collective_path_on_a_one_rank_rccl_group(device):
         for force in (False, True):
             net, _ = _fresh_flat_net(device)
             net.grad_side = None
-            opt = FusedAdam(net, lr=1e-3, all_reduce=True, force_collective=force)
+            opt = FusedAdam(net, lr=1e-3, eps=0.1, all_reduce=True, force_collective=force)
             assert opt.uses_collective() == force
             gs = GraphedStep(net, ptr, 9, mode="train", optimizer=opt)
             assert gs.opt_in_graph == (not force)
@@ -479,3 +482,26 @@ def test_collective_path_on_a_one_rank_rccl_group(device):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_shared_input_gradient_buffers_equal_autograd_accumulation(device):
+    """ops.GradSlot: the input gradients of multiply-used tensors (block inputs, block 1's output) meet in one buffer —
+    deposited by the first consumer, added in the GEMM / scatter epilogues of the others — instead of autograd's
+    accumulation adds.  Same gradients as plain autograd (``share_input_gradients = False``)."""
+    from myria3d_amd import cross_entropy
+    from oracle.randla_oracle import fixed_decimation_indices, synthetic_batch
+
+    shared, plain = _nets(device, 17)
+    plain.share_input_gradients = False
+    assert shared.share_input_gradients
+    x, pos, batch, ptr, y = synthetic_batch([5000, 4100])
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=3)
+    mask = torch.ones(9100, 32, device=device)
+    xd = x.to(device).requires_grad_(True)
+    xp = x.to(device).requires_grad_(True)
+    shared.train(), plain.train()
+    cross_entropy(shared(xd, pos.to(device), None, ptr.to(device), decimation_idx=dec, dropout_mask=mask), y.to(device), 65).backward()
+    cross_entropy(plain(xp, pos.to(device), None, ptr.to(device), decimation_idx=dec, dropout_mask=mask), y.to(device), 65).backward()
+    assert (xd.grad - xp.grad).norm().item() <= 1e-4 * xp.grad.norm().item()
+    for (name, p), (_, q) in zip(shared.named_parameters(), plain.named_parameters()):
+        assert (p.grad - q.grad).norm().item() <= 2e-4 * q.grad.norm().item() + 1e-6, name
