@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
                     help="skip the informative extra legs of the N=1 line (eager step, predict sweep, dense tiles)")
+    ap.add_argument("--skip-legs", default="", help="comma list of informative legs to leave out of the N=1 line: "
+                    "predict,bf16,dropin,collective,torch,dense")
     ap.add_argument("--cpu-tiles", type=int, default=16, help="tiles in the CPU-baseline sample (BASELINE.md 3: 16)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md 3 protocol in full: 3 warm-up + 10 timed iterations, at the probe-picked thread "
@@ -323,14 +325,14 @@ def cpu_baseline(tiles, points, K, full=False):
         free_gb = psutil.virtual_memory().available / 2**30
     except Exception:
         free_gb = 16.0
-    tiles = tiles if full else min(tiles, 4)
+    tiles = tiles if full else min(tiles, 2)
     tiles = max(1, min(tiles, int(free_gb // 1.5)))  # ~0.7 GB of autograd intermediates per 12 800-point tile
     picked = _pick_threads()
     torch.manual_seed(0)
     net = RandLANetOracle(9, 6, num_neighbors=K, return_logits=True, knn="kdtree")
     x, pos, batch, ptr, y = synthetic_batch([points] * tiles)
 
-    def leg(threads, warm, reps):
+    def leg(threads, warm, reps, only_train=False):
         torch.set_num_threads(threads)
 
         def train_step():
@@ -345,6 +347,8 @@ def cpu_baseline(tiles, points, K, full=False):
 
         res = {}
         for name, fn in (("fwd_bwd", train_step), ("fwd_only", fwd_step)):
+            if only_train and name != "fwd_bwd":
+                continue
             for _ in range(warm):
                 fn()
             ts = []
@@ -365,9 +369,10 @@ def cpu_baseline(tiles, points, K, full=False):
                      f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
     if picked != ncpu:
         _progress(f"CPU baseline: all {ncpu} cores")
-        allc = leg(ncpu, *((3, 10) if full else (1, 3)))
-        out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1), "fwd_only": round(allc["fwd_only"], 1),
-                            "sample": "same tiles, 3 + 10" if full else "same tiles, 1 warm-up + 3 timed (bounded)"}
+        allc = leg(ncpu, *((3, 10, False) if full else (1, 2, True)))
+        out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1),
+                            **({"fwd_only": round(allc["fwd_only"], 1)} if "fwd_only" in allc else {}),
+                            "sample": "same tiles, 3 + 10" if full else "same tiles, fwd+bwd only, 1 warm-up + 2 timed (bounded)"}
     return out
 
 
@@ -787,8 +792,10 @@ def main():
                 except Exception as e:
                     res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         del net, pos, plan
+        skip = set(filter(None, args.skip_legs.split(",")))
         if extras:
             # informative extra legs of the N=1 line (BASELINE configs 3 and 5), short: they share the driver's clock
+          if "predict" not in skip:
             try:
                 torch.cuda.empty_cache()
                 _progress("predict sweep (config 3)")
@@ -796,6 +803,7 @@ def main():
                 res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
             except Exception as e:
                 res["predict_config3"] = {"error": f"{type(e).__name__}: {e}"}
+          if "bf16" not in skip:
             try:  # BASELINE config 2 names bf16: the same step with the matrix-bound layers on bf16 matrix cores (fp32
                 # accumulate; parity bar of SURVEY 8c: logits within 3e-2 of the fp32 oracle, tests/test_gpu_net.py)
                 torch.cuda.empty_cache()
@@ -808,12 +816,14 @@ def main():
                                        "softmax / BatchNorm / level-1 GEMMs fp32"}
             except Exception as e:
                 res["bf16"] = {"error": f"{type(e).__name__}: {e}"}
+          if "dropin" not in skip:
             try:  # the plain drop-in step (what model.py:79 + Lightning's loop get) in a process of its own
                 di = _leg_in_fresh_process(["--mode", "dropin", "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
                 res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
                 res["dropin"] = di
             except Exception as e:
                 res["dropin"] = {"error": f"{type(e).__name__}: {e}"}
+          if "collective" not in skip:
             try:  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)
                 fc = _leg_in_fresh_process(["--force-collective", "--steps", str(args.steps), "--warmup", str(args.warmup),
                                             "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
@@ -822,14 +832,15 @@ def main():
                     "launch": fc["config"]["launch"], "collective": fc["config"]["collective"]}
             except Exception as e:
                 res["forced_collective_1rank"] = {"error": f"{type(e).__name__}: {e}"}
+          if "torch" not in skip:
             try:
                 torch.cuda.empty_cache()
                 _progress("torch-ROCm baseline")
                 res["torch_rocm_baseline"] = torch_rocm_baseline(dev, B, N, K)
             except Exception as e:
                 res["torch_rocm_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-            torch.cuda.empty_cache()
-            if (N, K) == (12800, 16):
+          torch.cuda.empty_cache()
+          if (N, K) == (12800, 16) and "dense" not in skip:
                 try:
                     torch.cuda.empty_cache()
                     d5 = _leg_in_fresh_process(["--steps", "5", "--warmup", "2", "--tiles", "16", "--points", "40000",
