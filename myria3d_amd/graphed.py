@@ -197,8 +197,12 @@ class GraphedStep:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void it)
                         self._body(k, None, with_opt)
                     gB.append(g)
+                    # captured WITH THE NET'S SIDE STREAM AS THE ORIGIN: the position-only work is enqueued on that
+                    # stream, so the graph is one chain.  Captured from another stream it is a fork / join around an
+                    # origin that holds no node of its own — and a replay of that form let the next step start on
+                    # half-written tables (tests/test_gpu_train.py::test_graphed_step_matches_plain_eager_steps)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    with torch.cuda.graph(g, stream=net._side_stream(self.ptr.device), capture_error_mode="thread_local"):
                         self._geo(k ^ 1)
                     gA.append(g)
                 self._sA = torch.cuda.Stream()

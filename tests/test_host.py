@@ -187,7 +187,8 @@ for i, p in enumerate(net.parameters()):
 local = net.flat_grads.clone()
 opt = FusedAdam(net, lr=1e-3, all_reduce=True)            # the product path's collective: FusedAdam.reduce_gradients()
 scale = opt.reduce_gradients()                            # = what step() does before its single update launch
-assert scale == 1.0 / world
+assert scale == 1.0 / world and opt.uses_collective()
+assert not FusedAdam(net, lr=1e-3, all_reduce=False).uses_collective()   # (no exchange asked for: none made)
 for i, p in enumerate(net.parameters()):
     assert torch.all(p.grad == 3.0 * (i + 1)), i          # ranks 1 + 2
 assert torch.equal(net.flat_grads, local * 3.0 / (rank + 1))
@@ -208,6 +209,27 @@ def test_flat_bucket_broadcast_and_allreduce_world_size_2_gloo(tmp_path):
         capture_output=True, text=True, env=env, timeout=240)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_forced_collective_on_a_one_rank_group_gloo():
+    """``FusedAdam(force_collective=True)``: the all-reduce runs even on a 1-rank group (how the 1-GPU box exercises the
+    N > 1 code path, ``bench.py --force-collective``); without it a 1-rank group makes no collective."""
+    import torch
+    import torch.distributed as dist
+
+    from myria3d_amd import FusedAdam, HipRandLANet
+
+    assert not dist.is_initialized()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        net = HipRandLANet(9, 6, return_logits=True).flatten_parameters()
+        assert not FusedAdam(net, lr=1e-3, all_reduce=True).uses_collective()
+        opt = FusedAdam(net, lr=1e-3, all_reduce=True, force_collective=True)
+        assert opt.uses_collective()
+        net.flat_grads.fill_(2.0)
+        assert opt.reduce_gradients() == 1.0 and float(net.flat_grads.min()) == 2.0
+    finally:
+        dist.destroy_process_group()
 
 
 def test_knn_f64_key_trick_preserves_the_total_order():
