@@ -63,8 +63,9 @@ int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t
 /* Staged form of m3d_knn_query for CELL-SORTED queries (qry_ws) and 4 < k <= 32: the same search cut into launches by
  * ring radius — the queries whose search is still open after a stage are compacted into a pool (scratch) and get a
  * group of lanes each in the next stage — so that the launch no longer ends on its slowest wavefronts
- * (csrc/knn.hip: knn_stage_kernel).  Bit-identical tables.  m3d_knn_staged_supported: 1 when the host side should
- * route a query here (large query sets; M3D_KNN_STAGED=0/1 overrides).  scratch: m3d_knn_staged_workspace_bytes bytes
+ * (csrc/knn.hip: knn_stage_kernel).  Bit-identical tables; measured slower than the single launch on Lidar-HD-shaped
+ * tiles (profiles/r03_knn_staged.log), hence opt-in: m3d_knn_staged_supported is 1 only with M3D_KNN_STAGED=1 in the
+ * environment (and 4 < k <= 32).  scratch: m3d_knn_staged_workspace_bytes bytes
  * of device memory, contents irrelevant, must stay alive until the launches have run. */
 size_t m3d_knn_staged_workspace_bytes(int64_t n_qry, int32_t k);
 int m3d_knn_staged_supported(int64_t n_qry, int32_t k);

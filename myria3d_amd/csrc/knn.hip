@@ -1054,15 +1054,20 @@ extern "C" size_t m3d_knn_staged_workspace_bytes(int64_t n_qry, int32_t k) {
   return 256 + 2 * knns_buf_bytes(n_qry, knns_kmax(k));
 }
 
-// 1 when m3d_knn_query_staged takes this problem: cell-sorted queries, 4 < k <= 32, a large query set (the deep levels
-// are a few wavefronts per CU and stay on the single-launch kernels), f64 keys; M3D_KNN_STAGED=0 switches it off
+// 1 when the host side should route a cell-sorted query with 4 < k <= 32 through m3d_knn_query_staged: only with
+// M3D_KNN_STAGED=1 (f64 keys)
 extern "C" int m3d_knn_staged_supported(int64_t n_qry, int32_t k) {
   const char* e = getenv("M3D_KNN_STAGED");  // (read at every call: tests and A/B runs flip it inside one process)
   const int env = e ? atoi(e) : -1;
   static const bool f64_keys = knn_f64_keys();
   if (env == 0 || !f64_keys || k < 5 || k > 32 || n_qry >= (1ll << 31)) return 0;
-  return (env > 0 || n_qry * (int64_t)k >= (1 << 20)) ? 1 : 0;
+  // opt-in: measured SLOWER than the single launch on the Lidar-HD-shaped tiles (level 1 of BASELINE config 2: 203-240 us
+  // against 191 us; profiles/r03_knn_staged.log with the ring histogram that shows why: 97 % of the queries close by ring
+  // 3, so there is no long tail to cut, and a group stage costs what the idle lanes it removes cost)
+  return env > 0 ? 1 : 0;
 }
+
+__global__ void knns_zero_kernel(unsigned* __restrict__ cnt) { cnt[threadIdx.x] = 0u; }
 
 template <int KMAX, int G, bool FIRST>
 static void knns_launch(bool last, unsigned grid, hipStream_t st, const KnnWs& w, const int64_t* ptr_src, int B,
@@ -1089,7 +1094,9 @@ static int knns_run(const KnnWs& w, const int64_t* ptr_src, int B, const float4*
     buf[i].cloud = (int*)p; p += m3d_align(n_qry * 4, 256);
     buf[i].best = (void*)p; p += m3d_align(n_qry * 8 * (int64_t)KMAX, 256);
   }
-  if (sc.nstage > 1 && hipMemsetAsync(cnt, 0, 256, st) != hipSuccess) return M3D_ERR_LAUNCH;
+  // (a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph proved unreliable on this stack — csrc/lfa.hip,
+  // zero_f64_kernel — and a counter that is not reset sends the next replay's pool writes out of bounds)
+  if (sc.nstage > 1) hipLaunchKernelGGL(knns_zero_kernel, dim3(1), dim3(64), 0, st, cnt);
   // later stages: grid-stride over the pool, whose size only the device knows — enough workgroups to fill the chip at
   // the worst case, cheap to launch when the pool turns out small
   static const int stage_grid = getenv("M3D_KNN_STAGE_GRID") ? atoi(getenv("M3D_KNN_STAGE_GRID")) : 4096;

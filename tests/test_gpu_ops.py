@@ -96,18 +96,18 @@ def test_knn_staged_query_is_bit_identical(device, monkeypatch, stages):
 
 
 def test_knn_staged_equals_single_launch_at_full_size(device, monkeypatch):
-    """BASELINE config 2 and config 5 shapes (16 x 12 800, K = 16; 4 x 40 000, K = 32): the staged query (what large
-    query sets take by default) against the single-launch deferred-insertion kernel (M3D_KNN_STAGED=0) — equal tables."""
+    """BASELINE config 2 and config 5 shapes (16 x 12 800, K = 16; 4 x 40 000, K = 32): the staged query (opt-in,
+    M3D_KNN_STAGED=1) against the single-launch deferred-insertion kernel (the default) — equal tables."""
     from myria3d_amd import ops
     from oracle.randla_oracle import synthetic_batch
 
     for sizes, k in (([12800] * 16, 16), ([40000] * 4, 32)):
         _, pos, _, ptr, _ = synthetic_batch(sizes)
         ix = ops.KnnIndex(pos.to(device), ptr.to(device))
-        monkeypatch.setenv("M3D_KNN_STAGED", "0")
+        monkeypatch.delenv("M3D_KNN_STAGED", raising=False)
         assert ops.lib().m3d_knn_staged_supported(ix.n, k) == 0
         ref, ref_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True)
-        monkeypatch.delenv("M3D_KNN_STAGED")
+        monkeypatch.setenv("M3D_KNN_STAGED", "1")
         assert ops.lib().m3d_knn_staged_supported(ix.n, k) == 1
         got, got_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True)
         assert torch.equal(got, ref) and torch.equal(got_d2, ref_d2)
