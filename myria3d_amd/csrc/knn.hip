@@ -23,6 +23,9 @@
 #ifndef KNN_UNROLL
 #define KNN_UNROLL 4
 #endif
+#ifndef KNN_PIPE
+#define KNN_PIPE 1  // direct-insertion kernel: software-pipelined walk over a ring's runs (0: run by run, as in round 2)
+#endif
 #ifndef KNN_MIN_BLOCKS
 #define KNN_MIN_BLOCKS 1
 #endif
@@ -41,6 +44,9 @@
 #endif
 #ifndef KNNQ_DRAIN
 #define KNNQ_DRAIN 2
+#endif
+#ifndef KNNQ_PIPE
+#define KNNQ_PIPE 1  // deferred-insertion kernel: software-pipelined walk over a ring's runs (0: run by run, as in round 2)
 #endif
 static_assert((KNNQ_DEPTH & (KNNQ_DEPTH - 1)) == 0, "queue depth must be a power of two");
 
@@ -347,6 +353,58 @@ __device__ __forceinline__ void knn_query_direct_body(const KnnWs& w, const int6
     const int cx = min(Gx - 1, max(0, (int)((qx - gx0) * inv_h)));
     const int cy = min(Gy - 1, max(0, (int)((qy - gy0) * inv_h)));
     for (int R = 0;; ++R) {
+#if KNN_PIPE
+      // software-pipelined walk over the ring's 4R runs (see knn_query_queue_body): the bounds of run r+1 and its first
+      // records are in flight while run r is scanned — the deep-level and 1-NN launches are a few wavefronts per CU whose
+      // whole life is a chain of dependent round trips (cell bounds -> records -> next cell bounds ...)
+      const int nr = R == 0 ? 1 : 4 * R;
+      auto run_bounds = [&](int r, int& a, int& b2) {
+        int yy, xa, xb;
+        if (r < 2) {
+          yy = r == 0 ? cy - R : cy + R;
+          xa = max(cx - R, 0); xb = min(cx + R, Gx - 1);
+        } else {
+          const int m = r - 2;
+          yy = cy - R + 1 + (m >> 1);
+          xa = xb = (m & 1) ? cx + R : cx - R;
+        }
+        const bool ok = yy >= 0 && yy < Gy && xa >= 0 && xb < Gx;
+        const int ia = ok ? yy * Gx + xa : 0, ib = ok ? yy * Gx + xb + 1 : 0;
+        a = cs[ia]; b2 = cs[ib];
+      };
+      const int nlast = n - 1;
+      int p0, p1;
+      run_bounds(0, p0, p1);
+      float4 nx[KNN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < KNN_UNROLL; ++u) nx[u] = sorted[min(p0 + u, nlast)];
+      for (int r = 0; r < nr; ++r) {
+        int q0 = 0, q1 = 0;
+        if (r + 1 < nr) run_bounds(r + 1, q0, q1);
+        for (int p = p0; p < p1; p += KNN_UNROLL) {
+          float4 sv[KNN_UNROLL];
+#pragma unroll
+          for (int u = 0; u < KNN_UNROLL; ++u) sv[u] = nx[u];
+          const int pn = p + KNN_UNROLL < p1 ? p + KNN_UNROLL : q0;
+#pragma unroll
+          for (int u = 0; u < KNN_UNROLL; ++u) nx[u] = sorted[min(pn + u, nlast)];
+#pragma unroll
+          for (int u = 0; u < KNN_UNROLL; ++u) asm volatile("" : "+v"(nx[u].w));
+#pragma unroll
+          for (int u = 0; u < KNN_UNROLL; ++u) {
+            float d2 = dist2_exact(qx, qy, qz, sv[u]);
+            typename KP::T key = KP::make(d2, __float_as_int(sv[u].w));
+            if (p + u >= p1) key = KP::empty();
+            KP::template insert<KMAX>(best, key);
+          }
+        }
+        if (p1 <= p0) {
+#pragma unroll
+          for (int u = 0; u < KNN_UNROLL; ++u) nx[u] = sorted[min(q0 + u, nlast)];
+        }
+        p0 = q0; p1 = q1;
+      }
+#else
       for (int dy = -R; dy <= R; ++dy) {
         int yy = cy + dy;
         if (yy < 0 || yy >= Gy) continue;
@@ -358,6 +416,7 @@ __device__ __forceinline__ void knn_query_direct_body(const KnnWs& w, const int6
           if (cx + R < Gx) scan_range<KMAX, KP>(best, sorted, cs[yy * Gx + cx + R], cs[yy * Gx + cx + R + 1], qx, qy, qz);
         }
       }
+#endif
       const bool covers = (cx - R <= 0) && (cx + R >= Gx - 1) && (cy - R <= 0) && (cy + R >= Gy - 1);
       if (covers) break;
       float bound = 3.4e38f;
@@ -538,6 +597,64 @@ __device__ __forceinline__ void knn_query_queue_body(
     const int cx = min(Gx - 1, max(0, (int)((qx - gx0) * inv_h)));
     const int cy = min(Gy - 1, max(0, (int)((qy - gy0) * inv_h)));
     for (int R = 0;; ++R) {
+#if KNNQ_PIPE
+      // The cells a ring adds are 4R runs of the sorted array (row cy-R, row cy+R, then the two side cells of every row in
+      // between).  Walked one by one, a run costs two dependent round trips before its first candidate can be examined
+      // (the cell bounds, then the records): 26 exposed latencies for rings 0-2, a large part of a wavefront's life
+      // (profiles/r03_knn_staged.log: 175 candidates per lane take 112 us).  Here the bounds of run r+1 are loaded while run
+      // r is scanned, and the last batch of run r already fetches the first records of run r+1: one exposure per ring.
+      // (Runs outside the grid read cs[0] twice: an empty run.  Candidate order does not matter: the list is a set.)
+      const int nr = R == 0 ? 1 : 4 * R;
+      auto run_bounds = [&](int r, int& a, int& b) {
+        int yy, xa, xb;
+        if (r < 2) {
+          yy = r == 0 ? cy - R : cy + R;
+          xa = max(cx - R, 0); xb = min(cx + R, Gx - 1);
+        } else {
+          const int m = r - 2;
+          yy = cy - R + 1 + (m >> 1);
+          xa = xb = (m & 1) ? cx + R : cx - R;
+        }
+        const bool ok = yy >= 0 && yy < Gy && xa >= 0 && xb < Gx;
+        const int ia = ok ? yy * Gx + xa : 0, ib = ok ? yy * Gx + xb + 1 : 0;
+        a = cs[ia]; b = cs[ib];
+      };
+      const int nlast = n - 1;
+      int p0, p1;
+      run_bounds(0, p0, p1);
+      float4 nx[KNNQ_UNROLL];
+#pragma unroll
+      for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[min(p0 + u, nlast)];
+      for (int r = 0; r < nr; ++r) {
+        int q0 = 0, q1 = 0;
+        if (r + 1 < nr) run_bounds(r + 1, q0, q1);  // in flight while this run is scanned
+        for (int p = p0; p < p1; p += KNNQ_UNROLL) {
+          float4 s[KNNQ_UNROLL];
+#pragma unroll
+          for (int u = 0; u < KNNQ_UNROLL; ++u) s[u] = nx[u];
+          const int pn = p + KNNQ_UNROLL < p1 ? p + KNNQ_UNROLL : q0;  // last batch of the run: the next run's first records
+#pragma unroll
+          for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[min(pn + u, nlast)];
+#pragma unroll
+          for (int u = 0; u < KNNQ_UNROLL; ++u) asm volatile("" : "+v"(nx[u].w));  // whole 16-byte loads, issued together
+          if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
+#pragma unroll
+          for (int u = 0; u < KNNQ_UNROLL; ++u) {
+            const float d2 = dist2_exact(qx, qy, qz, s[u]);
+            // !(d2 > kth): ties with the current k-th distance go through the exact (d2, row) order in the drain
+            if (p + u < p1 && !(d2 > kth)) {
+              queue[cnt][lane] = KP::make(d2, __float_as_int(s[u].w));
+              ++cnt;
+            }
+          }
+        }
+        if (p1 <= p0) {  // an empty run fetched nothing for its successor
+#pragma unroll
+          for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[min(q0 + u, nlast)];
+        }
+        p0 = q0; p1 = q1;
+      }
+#else
       for (int dy = -R; dy <= R; ++dy) {
         const int yy = cy + dy;
         if (yy < 0 || yy >= Gy) continue;
@@ -578,6 +695,7 @@ __device__ __forceinline__ void knn_query_queue_body(
           }
         }
       }
+#endif
       drain();
       const bool covers = (cx - R <= 0) && (cx + R >= Gx - 1) && (cy - R <= 0) && (cy + R >= Gy - 1);
       if (covers) break;

@@ -50,8 +50,12 @@ class GraphedStep:
 
     def __init__(self, net: HipRandLANet, ptr, num_features: int, *, mode: str = "train",
                  optimizer: Optional[FusedAdam] = None, ignore_index: int = 65, lookahead: bool = True,
-                 launch: str = "graph", lookahead_mode: str = "dual", optimizer_in_graph: Optional[bool] = None,
+                 launch: str = "graph", lookahead_mode: Optional[str] = None, optimizer_in_graph: Optional[bool] = None,
                  warmup: int = 2):
+        if lookahead_mode is None:
+            # two graphs on two streams pay off when the step is longer than the position-only chain (training: 4.72 vs
+            # 4.79 ms); the eval forward is shorter than that chain and would wait for it every step (1.59 vs 1.18 ms)
+            lookahead_mode = "dual" if mode == "train" else "single"
         if mode not in ("train", "eval") or launch not in ("graph", "eager") or lookahead_mode not in ("dual", "single"):
             raise ValueError("mode: train|eval, launch: graph|eager, lookahead_mode: dual|single")
         if mode == "train" and optimizer is None:

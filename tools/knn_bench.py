@@ -41,11 +41,15 @@ if "pmc" in sys.argv:
         index.query(16, qry=index, sorted_io=True)
     torch.cuda.synchronize()
     sys.exit(0)
-out = []
+out, nn = [], []
+indices = [ops.KnnIndex(p4[l], ptrs[l]) for l in range(4)]
 for l in range(4):
-    index = ops.KnnIndex(p4[l], ptrs[l])
+    index = indices[l]
     out.append(timeit(lambda: index.query(16, qry=index, sorted_io=True)))
+for l in range(3):  # decoder 1-NN tables: every level-l point among the level l+1 points
+    src, qry = indices[l + 1], indices[l]
+    nn.append(timeit(lambda: src.query(1, qry=qry, sorted_io=True)))
 tag = os.environ.get("M3D_LIB", "default").split("libm3d_")[-1]
 print(f"knn_bench lib={tag} staged={os.environ.get('M3D_KNN_STAGED', 'auto')} stages={os.environ.get('M3D_KNN_STAGES', 'default')} "
       f"grid={os.environ.get('M3D_KNN_STAGE_GRID', '4096')} queue={os.environ.get('M3D_KNN_QUEUE', 'auto')}: "
-      + " ".join(f"L{l+1}={t:.1f}us" for l, t in enumerate(out)))
+      + " ".join(f"L{l+1}={t:.1f}us" for l, t in enumerate(out)) + " | 1-NN " + " ".join(f"{t:.1f}" for t in nn))
