@@ -24,7 +24,7 @@
 #define KNN_UNROLL 4
 #endif
 #ifndef KNN_PIPE
-#define KNN_PIPE 1  // direct-insertion kernel: software-pipelined walk over a ring's runs (0: run by run, as in round 2)
+#define KNN_PIPE 0  // direct-insertion kernel: the same pipelined walk (levels 2-4: 120 / 77 / 49 vs 108 / 68 / 45 us: slower; off)
 #endif
 #ifndef KNN_MIN_BLOCKS
 #define KNN_MIN_BLOCKS 1
@@ -46,7 +46,10 @@
 #define KNNQ_DRAIN 2
 #endif
 #ifndef KNNQ_PIPE
-#define KNNQ_PIPE 1  // deferred-insertion kernel: software-pipelined walk over a ring's runs (0: run by run, as in round 2)
+// 1: software-pipelined walk over a ring's runs (bounds of run r+1 and its first records in flight while run r is
+// scanned).  Bit-identical and measured SLOWER on the same box (level 1: 202-205 vs 188-191 us; profiles/r03_knn_pipe_ab.log):
+// the exposed round trips between runs are not what bounds the kernel.  Kept as an A/B knob.
+#define KNNQ_PIPE 0
 #endif
 static_assert((KNNQ_DEPTH & (KNNQ_DEPTH - 1)) == 0, "queue depth must be a power of two");
 
