@@ -735,6 +735,67 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     return res, net, pos, make_plan(ptr.tolist(), 4, K, dev)
 
 
+def _extra_legs(args, dev, res, B, N, K):
+    """Informative legs of the N = 1 line (BASELINE configs 3 and 5, the bf16 mode, the plain drop-in step, the N > 1 code
+    path on a 1-rank RCCL group, the stock-torch baseline): short, they share the driver's clock; ``--skip-legs`` drops any."""
+    skip = set(filter(None, args.skip_legs.split(",")))
+
+    def leg(name, key, fn):
+        if name in skip:
+            return
+        try:
+            torch.cuda.empty_cache()
+            fn()
+        except Exception as e:
+            res[key] = {"error": f"{type(e).__name__}: {e}"}
+
+    def predict():
+        _progress("predict sweep (config 3)")
+        pr = predict_bench(args, dev, reps=2)
+        res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
+
+    def bf16():
+        # BASELINE config 2 names bf16: the same step with the matrix-bound layers on bf16 matrix cores (fp32 accumulate;
+        # parity bar of SURVEY 8c: logits within 3e-2 of the fp32 oracle, tests/test_gpu_net.py)
+        b16 = _leg_in_fresh_process(["--precision", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                     "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+        res["bf16"] = {"value": b16["value"], "unit": "points/s", "ms_per_step": b16["ms_per_step"],
+                       "fwd_only": b16["fwd_only"],
+                       "what": "LFA attention GEMMs (ch >= 64, fwd + bwd) and SharedMLP GEMMs with K > 64 (fwd + "
+                               "dgrad; deep-layer wgrad) on v_mfma_f32_16x16x32_bf16, fp32 accumulate; storage / kNN / "
+                               "softmax / BatchNorm / level-1 GEMMs fp32"}
+
+    def dropin():  # the plain drop-in step (what model.py:79 + Lightning's loop get) in a process of its own
+        di = _leg_in_fresh_process(["--mode", "dropin", "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+        res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
+        res["dropin"] = di
+
+    def collective():  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)
+        fc = _leg_in_fresh_process(["--force-collective", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+        res["forced_collective_1rank"] = {k: fc[k] for k in ("ms_per_step", "allreduce_ms", "allreduce_bytes", "rccl_ranks",
+                                                             "launch_probe_ms") if k in fc} | {
+            "launch": fc["config"]["launch"], "collective": fc["config"]["collective"]}
+
+    def torch_leg():
+        _progress("torch-ROCm baseline")
+        res["torch_rocm_baseline"] = torch_rocm_baseline(dev, B, N, K)
+
+    def dense():
+        d5 = _leg_in_fresh_process(["--steps", "5", "--warmup", "2", "--tiles", "16", "--points", "40000", "--neighbors", "32"])
+        res["dense_tiles_config5"] = {"value": d5["value"], "unit": "points/s", "ms_per_step": d5["ms_per_step"],
+                                      "fwd_only": d5["fwd_only"], "workload": d5["config"]["workload"]}
+
+    leg("predict", "predict_config3", predict)
+    leg("bf16", "bf16", bf16)
+    leg("dropin", "dropin", dropin)
+    leg("collective", "forced_collective_1rank", collective)
+    leg("torch", "torch_rocm_baseline", torch_leg)
+    if (N, K) == (12800, 16):
+        leg("dense", "dense_tiles_config5", dense)
+    torch.cuda.empty_cache()
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -798,63 +859,8 @@ def main():
                 except Exception as e:
                     res["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         del net, pos, plan
-        skip = set(filter(None, args.skip_legs.split(",")))
         if extras:
-            # informative extra legs of the N=1 line (BASELINE configs 3 and 5), short: they share the driver's clock
-          if "predict" not in skip:
-            try:
-                torch.cuda.empty_cache()
-                _progress("predict sweep (config 3)")
-                pr = predict_bench(args, dev, reps=2)
-                res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
-            except Exception as e:
-                res["predict_config3"] = {"error": f"{type(e).__name__}: {e}"}
-          if "bf16" not in skip:
-            try:  # BASELINE config 2 names bf16: the same step with the matrix-bound layers on bf16 matrix cores (fp32
-                # accumulate; parity bar of SURVEY 8c: logits within 3e-2 of the fp32 oracle, tests/test_gpu_net.py)
-                torch.cuda.empty_cache()
-                b16 = _leg_in_fresh_process(["--precision", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                             "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
-                res["bf16"] = {"value": b16["value"], "unit": "points/s", "ms_per_step": b16["ms_per_step"],
-                               "fwd_only": b16["fwd_only"],
-                               "what": "LFA attention GEMMs (ch >= 64, fwd + bwd) and SharedMLP GEMMs with K > 64 (fwd + "
-                                       "dgrad; deep-layer wgrad) on v_mfma_f32_16x16x32_bf16, fp32 accumulate; storage / kNN / "
-                                       "softmax / BatchNorm / level-1 GEMMs fp32"}
-            except Exception as e:
-                res["bf16"] = {"error": f"{type(e).__name__}: {e}"}
-          if "dropin" not in skip:
-            try:  # the plain drop-in step (what model.py:79 + Lightning's loop get) in a process of its own
-                di = _leg_in_fresh_process(["--mode", "dropin", "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
-                res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
-                res["dropin"] = di
-            except Exception as e:
-                res["dropin"] = {"error": f"{type(e).__name__}: {e}"}
-          if "collective" not in skip:
-            try:  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)
-                fc = _leg_in_fresh_process(["--force-collective", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                            "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
-                res["forced_collective_1rank"] = {k: fc[k] for k in ("ms_per_step", "allreduce_ms", "allreduce_bytes",
-                                                                     "rccl_ranks") if k in fc} | {
-                    "launch": fc["config"]["launch"], "collective": fc["config"]["collective"]}
-            except Exception as e:
-                res["forced_collective_1rank"] = {"error": f"{type(e).__name__}: {e}"}
-          if "torch" not in skip:
-            try:
-                torch.cuda.empty_cache()
-                _progress("torch-ROCm baseline")
-                res["torch_rocm_baseline"] = torch_rocm_baseline(dev, B, N, K)
-            except Exception as e:
-                res["torch_rocm_baseline"] = {"error": f"{type(e).__name__}: {e}"}
-          torch.cuda.empty_cache()
-          if (N, K) == (12800, 16) and "dense" not in skip:
-                try:
-                    torch.cuda.empty_cache()
-                    d5 = _leg_in_fresh_process(["--steps", "5", "--warmup", "2", "--tiles", "16", "--points", "40000",
-                                                "--neighbors", "32"])
-                    res["dense_tiles_config5"] = {"value": d5["value"], "unit": "points/s", "ms_per_step": d5["ms_per_step"],
-                                                  "fwd_only": d5["fwd_only"], "workload": d5["config"]["workload"]}
-                except Exception as e:
-                    res["dense_tiles_config5"] = {"error": f"{type(e).__name__}: {e}"}
+            _extra_legs(args, dev, res, B, N, K)
         if rank == 0:
             if world == 1 and not args.skip_cpu_baseline:
                 _progress("CPU baseline")
