@@ -173,7 +173,8 @@ def _pmc_traffic(prefix, grid=None):
     def lookup(path, col):
         rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith(prefix)]
         if grid is not None:
-            rows = [r for r in rows if r["kernel"].rstrip().endswith(f"grid={grid}")] or rows
+            grids = grid if isinstance(grid, (tuple, list)) else (grid,)
+            rows = [r for r in rows if any(r["kernel"].rstrip().endswith(f"grid={g}") for g in grids)] or rows
         if not rows:
             raise PmcMissing(f"{os.path.basename(path)} has no row for {prefix!r}")
         return max(float(r[col]) for r in rows) * 1024.0
@@ -270,7 +271,7 @@ def stage_rooflines(net, pos, plan):
                 "m3d_knn_query", ix.ws.data_ptr(), ix.ptr.data_ptr(), n, ix.num_clouds, None, 0, ix.ws.data_ptr(),
                 ix.ptr.data_ptr(), n, K, 1, idx.data_ptr(), None, st))
             stage.append(hbm_entry(f"knn_query (self-kNN, level {lvl + 1}, n={n}, K={K})", n * (12 + 4 * K), ms_knn,
-                                   KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], (n + 63) // 64 * 64))
+                                   KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], ((n + 63) // 64 * 64, (n + 255) // 256 * 256)))
         for lfa in (net.block1.lfa1, net.block1.lfa2):
             ch1, n1, ms_f = time_lfa_fwd(lfa, 0, geo)
             stage.append(hbm_entry(f"lfa_fwd_kernel<{max(ch1, 16) if ch1 > 8 else 8},16> (level 1, ch={ch1}, n={n1}, K={K})",
