@@ -110,7 +110,10 @@ def _leg_in_fresh_process(extra_args, timeout=240):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     if out.returncode != 0:
         raise RuntimeError(f"leg {extra_args} failed: {out.stderr[-400:]}")
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]  # (RCCL prints its version banner on stdout)
+    if not lines:
+        raise RuntimeError(f"leg {extra_args} printed no JSON line: {out.stdout[-300:]}")
+    return json.loads(lines[-1])
 
 
 def timed(fn, steps, world):
