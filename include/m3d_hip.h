@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 10
+#define M3D_ABI_VERSION 11
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -216,6 +216,15 @@ int m3d_lfa_prepare(const double* mom65, int64_t num_edges, const float* w, cons
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                     float* w_folded, float* b_folded, float* mean_out, float* invstd_out, int32_t D,
                     const float* w_att, int32_t CH, void* packed, void* packed_t, int32_t bf16, void* stream);
+/* m3d_lfa_prepare (train mode: mom65 given) of up to 8 LFA layers in ONE launch; HOST arrays of length njobs.  eps / momentum
+ * are shared (every encoder BatchNorm of the net has the same, pyg_randla_net.py:94). */
+int m3d_lfa_prepare_batch(int32_t njobs, const double* const* mom65, const int64_t* num_edges, const float* const* w,
+                          const float* const* b, const float* const* gamma, const float* const* beta, float eps,
+                          float momentum, float* const* running_mean, float* const* running_var, float* const* w_folded,
+                          float* const* b_folded, float* const* mean_out, float* const* invstd_out, const int32_t* D,
+                          const float* const* w_att, const int32_t* CH, void* const* packed, void* const* packed_t,
+                          const int32_t* bf16, void* stream);
+
 
 /* bf16 matrix-core variant of m3d_lfa_fwd (CH in {32, 64, 128, 256}): the attention GEMM takes bf16 operands
  * (v_mfma_f32_16x16x32_bf16, fp32 accumulate; BASELINE config 2's "bf16"), everything else stays fp32.

@@ -57,6 +57,8 @@ SIGNATURES = {
     "m3d_lfa_pack_att": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_prepare": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _i32,
                                _p]),
+    "m3d_lfa_prepare_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                     _p]),
     "m3d_lfa_fwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
     "m3d_lfa_pack_att_bf16": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
@@ -83,7 +85,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 10  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 11  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

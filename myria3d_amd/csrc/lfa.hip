@@ -511,16 +511,16 @@ extern "C" int m3d_lfa_enc_finalize(const double* mom65, int64_t num_edges, cons
 // of ~400 graph nodes and every tiny node costs 5-9 us of it): the encoder fold of m3d_lfa_enc_finalize (blocks
 // [0, D)) and the attention-weight fragments of m3d_lfa_pack_att — fp32 W / W^T, or with bf16 != 0 the bf16 operand
 // fragments of m3d_lfa_pack_att_bf16 — in the remaining blocks.
-__global__ __launch_bounds__(64) void lfa_prepare_kernel(const double* __restrict__ mom, double E,
-                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float eps, float momentum, float* running_mean,
-                                                         float* running_var, float* wf, float* bf, float* mean_out,
-                                                         float* invstd_out, int D, const float* __restrict__ w_att, int CH,
-                                                         int CHP, void* packed, void* packed_t, int bf16) {
+__device__ __forceinline__ void lfa_prepare_body(const double* __restrict__ mom, double E,
+                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float eps, float momentum, float* running_mean,
+                                                 float* running_var, float* wf, float* bf, float* mean_out,
+                                                 float* invstd_out, int D, const float* __restrict__ w_att, int CH,
+                                                 int CHP, void* packed, void* packed_t, int bf16, int blk) {
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= D) {
-    const int t = ((int)blockIdx.x - D) * 64 + lane;
+  if (blk >= D) {
+    const int t = (blk - D) * 64 + lane;
     if (bf16) {
       if (t >= CH * CH) return;
       const int KS = CH / 32;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64) void lfa_prepare_kernel(const double* __restric
     }
     return;
   }
-  const int c = blockIdx.x;
+  const int c = blk;
   double mean, var;
   if (mom) {
     double pv = 0.0, pm = 0.0;
@@ -569,6 +569,86 @@ __global__ __launch_bounds__(64) void lfa_prepare_kernel(const double* __restric
   bf[c] = (float)(sc * ((double)b[c] - mean) + (double)beta[c]);
   if (mean_out) mean_out[c] = (float)mean;
   if (invstd_out) invstd_out[c] = (float)invstd;
+}
+
+__global__ __launch_bounds__(64) void lfa_prepare_kernel(const double* __restrict__ mom, double E,
+                                                         const float* __restrict__ w, const float* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float momentum, float* running_mean,
+                                                         float* running_var, float* wf, float* bf, float* mean_out,
+                                                         float* invstd_out, int D, const float* __restrict__ w_att, int CH,
+                                                         int CHP, void* packed, void* packed_t, int bf16) {
+  lfa_prepare_body(mom, E, w, b, gamma, beta, eps, momentum, running_mean, running_var, wf, bf, mean_out, invstd_out, D,
+                   w_att, CH, CHP, packed, packed_t, bf16, (int)blockIdx.x);
+}
+
+// m3d_lfa_prepare of several LFA layers in ONE launch (m3d_lfa_prepare_batch): with the position-only tables of a step
+// prefetched, the encoder moments of all levels exist when the forward pass starts, and the eight 5-us launches that sat in
+// the chain in front of every lfa_fwd become one at its head
+#define LFA_PREP_BATCH_MAX 8
+struct LfaPrepBatch {
+  const double* mom[LFA_PREP_BATCH_MAX]; double E[LFA_PREP_BATCH_MAX];
+  const float* w[LFA_PREP_BATCH_MAX]; const float* b[LFA_PREP_BATCH_MAX];
+  const float* gamma[LFA_PREP_BATCH_MAX]; const float* beta[LFA_PREP_BATCH_MAX];
+  float* running_mean[LFA_PREP_BATCH_MAX]; float* running_var[LFA_PREP_BATCH_MAX];
+  float* wf[LFA_PREP_BATCH_MAX]; float* bf[LFA_PREP_BATCH_MAX]; float* mean[LFA_PREP_BATCH_MAX]; float* invstd[LFA_PREP_BATCH_MAX];
+  const float* w_att[LFA_PREP_BATCH_MAX]; void* packed[LFA_PREP_BATCH_MAX]; void* packed_t[LFA_PREP_BATCH_MAX];
+  int D[LFA_PREP_BATCH_MAX], CH[LFA_PREP_BATCH_MAX], bf16[LFA_PREP_BATCH_MAX];
+  unsigned wg_start[LFA_PREP_BATCH_MAX + 1];
+  int njobs;
+  float eps, momentum;
+};
+__global__ __launch_bounds__(64) void lfa_prepare_batch_kernel(LfaPrepBatch a) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < LFA_PREP_BATCH_MAX; ++i) j += (i < a.njobs && blockIdx.x >= a.wg_start[i]) ? 1 : 0;
+  const int CH = a.CH[j], CHP = CH < 16 ? 16 : CH;
+  lfa_prepare_body(a.mom[j], a.E[j], a.w[j], a.b[j], a.gamma[j], a.beta[j], a.eps, a.momentum, a.running_mean[j],
+                   a.running_var[j], a.wf[j], a.bf[j], a.mean[j], a.invstd[j], a.D[j], a.w_att[j], CH, CHP, a.packed[j],
+                   a.packed_t[j], a.bf16[j], (int)(blockIdx.x - a.wg_start[j]));
+}
+
+extern "C" int m3d_lfa_prepare_batch(int32_t njobs, const double* const* mom65, const int64_t* num_edges,
+                                     const float* const* w, const float* const* b, const float* const* gamma,
+                                     const float* const* beta, float eps, float momentum, float* const* running_mean,
+                                     float* const* running_var, float* const* w_folded, float* const* b_folded,
+                                     float* const* mean_out, float* const* invstd_out, const int32_t* D,
+                                     const float* const* w_att, const int32_t* CH, void* const* packed,
+                                     void* const* packed_t, const int32_t* bf16, void* stream) {
+  if (njobs < 0 || njobs > LFA_PREP_BATCH_MAX) return M3D_ERR_UNSUPPORTED;
+  if (njobs == 0) return M3D_OK;
+  if (!mom65 || !num_edges || !w || !b || !gamma || !beta || !running_mean || !running_var || !w_folded || !b_folded ||
+      !mean_out || !invstd_out || !D || !w_att || !CH || !packed || !packed_t || !bf16)
+    return M3D_ERR_INVALID;
+  LfaPrepBatch a;
+  a.njobs = njobs; a.eps = eps; a.momentum = momentum;
+  unsigned total = 0;
+  for (int j = 0; j < LFA_PREP_BATCH_MAX; ++j) {
+    a.wg_start[j] = total;
+    if (j >= njobs) {
+      a.mom[j] = nullptr; a.E[j] = 1.0; a.w[j] = a.b[j] = a.gamma[j] = a.beta[j] = a.w_att[j] = nullptr;
+      a.running_mean[j] = a.running_var[j] = a.wf[j] = a.bf[j] = a.mean[j] = a.invstd[j] = nullptr;
+      a.packed[j] = a.packed_t[j] = nullptr; a.D[j] = 1; a.CH[j] = 16; a.bf16[j] = 0;
+      continue;
+    }
+    if (D[j] < 1 || CH[j] < 1 || !mom65[j] || num_edges[j] < 1 || !w[j] || !b[j] || !gamma[j] || !beta[j] || !w_folded[j] ||
+        !b_folded[j] || !w_att[j] || !packed[j])
+      return M3D_ERR_INVALID;
+    const int CHP = CH[j] < 16 ? 16 : CH[j];
+    if (CHP % 16) return M3D_ERR_UNSUPPORTED;
+    if (bf16[j] && (CH[j] % 32)) return M3D_ERR_UNSUPPORTED;
+    a.mom[j] = mom65[j]; a.E[j] = (double)num_edges[j]; a.w[j] = w[j]; a.b[j] = b[j]; a.gamma[j] = gamma[j]; a.beta[j] = beta[j];
+    a.running_mean[j] = running_mean[j]; a.running_var[j] = running_var[j]; a.wf[j] = w_folded[j]; a.bf[j] = b_folded[j];
+    a.mean[j] = mean_out[j]; a.invstd[j] = invstd_out[j]; a.w_att[j] = w_att[j]; a.packed[j] = packed[j];
+    a.packed_t[j] = packed_t[j]; a.D[j] = D[j]; a.CH[j] = CH[j]; a.bf16[j] = bf16[j];
+    const int elems = bf16[j] ? CH[j] * CH[j] : CHP * CHP;
+    total += (unsigned)(D[j] + (elems + 63) / 64);
+  }
+  a.wg_start[LFA_PREP_BATCH_MAX] = total;
+  for (int j = njobs; j < LFA_PREP_BATCH_MAX; ++j) a.wg_start[j] = total;
+  hipLaunchKernelGGL(lfa_prepare_batch_kernel, dim3(total), dim3(64), 0, (hipStream_t)stream, a);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
 }
 
 extern "C" int m3d_lfa_prepare(const double* mom65, int64_t num_edges, const float* w, const float* b,

@@ -910,6 +910,41 @@ def lfa_prepare(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int, w_att: T
     return wf, bf, mean, invstd, wp, wpt
 
 
+def lfa_prepare_batch(jobs) -> list:
+    """``lfa_prepare(enc_lin, enc_bn, mom, num_edges, w_att, bf16, True)`` (train mode) for several LFA layers in ONE launch
+    (``m3d_lfa_prepare_batch``).  ``jobs``: ``(enc_lin, enc_bn, mom, num_edges, w_att, bf16)`` tuples; returns the
+    ``(wf, bf, mean, invstd, wp, wpt)`` tuple of each."""
+    import ctypes
+
+    m = len(jobs)
+    outs = []
+    for enc_lin, enc_bn, mom, num_edges, w_att, bf16 in jobs:
+        D, ch, dev = enc_lin.weight.shape[0], w_att.shape[0], enc_lin.weight.device
+        if num_edges < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size [{num_edges}, {D}]")
+        wf = torch.empty((D, 10), dtype=torch.float32, device=dev)
+        vec = torch.empty((3, D), dtype=torch.float32, device=dev)
+        wp = torch.empty(ch * ch, dtype=torch.int16, device=dev) if bf16 else \
+            torch.empty(max(ch, 16) ** 2, dtype=torch.float32, device=dev)
+        outs.append((wf, vec[0], vec[1], vec[2], wp, torch.empty_like(wp)))
+    vp = lambda vals: (ctypes.c_void_p * m)(*vals)
+    bn0 = jobs[0][1]
+    call("m3d_lfa_prepare_batch", m, vp([j[2].data_ptr() for j in jobs]), (ctypes.c_int64 * m)(*[j[3] for j in jobs]),
+         vp([j[0].weight.data_ptr() for j in jobs]), vp([j[0].bias.data_ptr() for j in jobs]),
+         vp([j[1].weight.data_ptr() for j in jobs]), vp([j[1].bias.data_ptr() for j in jobs]), float(bn0.eps),
+         float(bn0.momentum), vp([j[1].running_mean.data_ptr() for j in jobs]),
+         vp([j[1].running_var.data_ptr() for j in jobs]), vp([o[0].data_ptr() for o in outs]),
+         vp([o[1].data_ptr() for o in outs]), vp([o[2].data_ptr() for o in outs]), vp([o[3].data_ptr() for o in outs]),
+         (ctypes.c_int32 * m)(*[j[0].weight.shape[0] for j in jobs]), vp([_chk(j[4]).data_ptr() for j in jobs]),
+         (ctypes.c_int32 * m)(*[j[4].shape[0] for j in jobs]), vp([o[4].data_ptr() for o in outs]),
+         vp([o[5].data_ptr() for o in outs]), (ctypes.c_int32 * m)(*[int(bool(j[5])) for j in jobs]), _st())
+    for enc_lin, enc_bn, *_ in jobs:
+        assert float(enc_bn.eps) == float(bn0.eps) and float(enc_bn.momentum) == float(bn0.momentum)
+        if not getattr(enc_bn, "_m3d_flat_counter", False):
+            enc_bn.num_batches_tracked += 1
+    return outs
+
+
 def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor,
                 wp: Optional[Tensor] = None, bf16: bool = False) -> Tensor:
     """``bf16``: ``wp`` holds the bf16 operand fragments and the attention GEMM runs on bf16 matrix cores."""
@@ -948,14 +983,17 @@ class LFATrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att,
-                sinks=None, bf16=False):
+                sinks=None, bf16=False, prepared=None):
         # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
+        # prepared = this layer's (wf, bf, mean, invstd, wp, wpt) from lfa_prepare_batch (one launch for all layers)
         ctx.sinks = sinks
         ctx.side = _grad_side if sinks is not None else None
         x = x.contiguous()
         K = idx.shape[1]
         bf16 = bool(bf16) and lfa_bf16_ok(w_att.shape[0], K)
-        if K <= 32:  # encoder fold + both weight packings: one launch
+        if prepared is not None:
+            wf, bf, mean, invstd, wp, wpt = prepared
+        elif K <= 32:  # encoder fold + both weight packings: one launch
             wf, bf, mean, invstd, wp, wpt = lfa_prepare(enc_lin, enc_bn, mom, num_edges, w_att, bf16, True)
         else:
             wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
@@ -991,7 +1029,7 @@ class LFATrainFn(torch.autograd.Function):
                 # layer's at the end of the backward pass (GradSideStream.flush) instead of two launches in the chain
                 ctx.side.defer_lfa((n, K, ch, ws, dw_att, G, mom, ctx.num_edges, enc_w, enc_b, enc_gamma, mean, invstd,
                                     sk[0], sk[1], sk[2], sk[3]))
-                return (dx,) + (None,) * 13
+                return (dx,) + (None,) * 14
         else:
             G = torch.empty(11 * D, dtype=torch.float64, device=dev)
             dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
@@ -1005,8 +1043,8 @@ class LFATrainFn(torch.autograd.Function):
         call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
              _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, int(sk is not None), _st())
         if sk:
-            return (dx,) + (None,) * 13
-        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None
+            return (dx,) + (None,) * 14
+        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None, None
 
 
 def _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G):

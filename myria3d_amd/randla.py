@@ -140,6 +140,7 @@ class HipRandLANet(nn.Module):
         # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
         # accumulation adds; False: plain autograd (cross-check)
         self.share_input_gradients = __import__("os").environ.get("M3D_GRAD_SLOTS", "1") != "0"
+        self.batch_lfa_prepare = __import__("os").environ.get("M3D_LFA_PREP_BATCH", "1") != "0"  # (A/B switch)
         # the K-NN tables / encoder moments / decoder 1-NN tables of the four levels as one launch each (see
         # _geometry_stages); M3D_GEO_BATCH=0: level by level (A/B and cross-check)
         self.batch_geometry = __import__("os").environ.get("M3D_GEO_BATCH", "1") != "0"
@@ -332,7 +333,7 @@ class HipRandLANet(nn.Module):
                         bf16=self._bf16)
 
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
-             train: bool) -> Tensor:
+             train: bool, prepared=None) -> Tensor:
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
         bf16 = self._bf16 and ops.lfa_bf16_ok(w_att.shape[0], idx.shape[1])
@@ -340,7 +341,7 @@ class HipRandLANet(nn.Module):
             sk = self._sinks(enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, w_att) if self._use_sinks \
                 else None
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16)
+                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16, prepared)
         else:
             if idx.shape[1] <= 32:
                 wf, bf, wp = self._cached(("lfa", id(p), bf16),
@@ -355,7 +356,7 @@ class HipRandLANet(nn.Module):
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
                mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str,
-               wait_graph=None, x_slot=None) -> Tensor:
+               wait_graph=None, x_slot=None, prepared=(None, None)) -> Tensor:
         # idx: knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
         # x_slot (train): the block input has several consumers (mlp1, the shortcut, and on the decimated levels the FP
         # module's skip): their input gradients meet in one buffer, mlp1 — last in backward order — returns the sum
@@ -365,10 +366,10 @@ class HipRandLANet(nn.Module):
         if rec is not None:
             rec[name + ".knn_idx"] = _knn_to_reference_order(idx, index)
             rec[name + ".mlp1"] = h[index.inv.long()]
-        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train)
+        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train, prepared[0])
         if rec is not None:
             rec[name + ".lfa1"] = h[index.inv.long()]
-        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train)
+        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1])
         l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
         ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
         if train:
@@ -685,11 +686,23 @@ class HipRandLANet(nn.Module):
         use_slots = train and torch.is_grad_enabled() and self.share_input_gradients
         in_slots = [ops.GradSlot() if use_slots else None for _ in range(4)]
         out_slot = ops.GradSlot() if use_slots else None
+        # with prefetched tables the encoder moments of every level exist already: fold the eight encoder BatchNorms and pack
+        # the eight attention weights in ONE launch at the head of the chain (in place of eight 5-us launches inside it)
+        prepared = [(None, None)] * 4
+        if train and geo.side is geo.main and self.num_neighbors <= 32 and self.batch_lfa_prepare:
+            jobs = []
+            for lvl, blk in enumerate(blocks):
+                for lfa in (blk.lfa1, blk.lfa2):
+                    w_att = lfa.mlp_attention.lins[0].weight
+                    jobs.append((lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module, geo.mom[lvl], plan.num_edges[lvl],
+                                 w_att, self._bf16 and ops.lfa_bf16_ok(w_att.shape[0], self.num_neighbors)))
+            outs = ops.lfa_prepare_batch(jobs)
+            prepared = [(outs[2 * l], outs[2 * l + 1]) for l in range(4)]
         for lvl, blk in enumerate(blocks):
             h = self._block(blk, h, pos4[lvl], index[lvl], geo.knn[lvl], geo.mom[lvl], plan.num_edges[lvl], train,
                             record, f"block{lvl + 1}",
                             wait_graph=lambda s=1 + 2 * lvl: geo.wait(s),  # kNN table (+ encoder moments) of this level
-                            x_slot=in_slots[lvl])
+                            x_slot=in_slots[lvl], prepared=prepared[lvl])
             feats.append(h)
             self._advance_interleaved()
             self._advance_interleaved()  # (two position-only stages per level: table + moments, decimation + next grid)
