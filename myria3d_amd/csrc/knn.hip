@@ -23,6 +23,9 @@
 #ifndef KNN_UNROLL
 #define KNN_UNROLL 4
 #endif
+#ifndef KNN_PP
+#define KNN_PP 0  // direct-insertion kernel: ping-pong register sets in scan_range (1-3 % slower at the deep levels: off)
+#endif
 #ifndef KNN_PIPE
 #define KNN_PIPE 0  // direct-insertion kernel: the same pipelined walk (levels 2-4: 120 / 77 / 49 vs 108 / 68 / 45 us: slower; off)
 #endif
@@ -44,6 +47,12 @@
 #endif
 #ifndef KNNQ_DRAIN
 #define KNNQ_DRAIN 2
+#endif
+#ifndef KNNQ_PP
+#define KNNQ_PP 1  // deferred-insertion kernel: ping-pong register sets in the candidate loop (0: round 2's loop): 192 -> 183 us
+#endif
+#ifndef KNNQ_WAVES
+#define KNNQ_WAVES 1  // independent wavefronts per workgroup of the deferred-insertion kernel (A/B knob)
 #endif
 #ifndef KNNQ_PIPE
 // 1: software-pipelined walk over a ring's runs (bounds of run r+1 and its first records in flight while run r is
@@ -299,13 +308,9 @@ __device__ __forceinline__ f32x2 dist2_exact_pk(f32x2 qx, f32x2 qy, f32x2 qz, f3
 template <int KMAX, class KP>
 __device__ __forceinline__ void scan_range(typename KP::T (&best)[KMAX], const float4* __restrict__ sorted, int p0,
                                            int p1, float qx, float qy, float qz) {
-  // KNN_UNROLL candidates per trip: that many independent 16-byte loads in flight per lane (the loop is latency-bound
-  // otherwise)
-  for (int p = p0; p < p1; p += KNN_UNROLL) {
-    const int last = p1 - 1;
-    float4 s[KNN_UNROLL];
-#pragma unroll
-    for (int u = 0; u < KNN_UNROLL; ++u) s[u] = sorted[min(p + u, last)];
+  if (p1 <= p0) return;
+  const int last = p1 - 1;
+  auto examine = [&](const float4 (&s)[KNN_UNROLL], int p) {
 #pragma unroll
     for (int u = 0; u < KNN_UNROLL; ++u) {
       float d2 = dist2_exact(qx, qy, qz, s[u]);
@@ -313,7 +318,31 @@ __device__ __forceinline__ void scan_range(typename KP::T (&best)[KMAX], const f
       if (p + u > last) key = KP::empty();
       KP::template insert<KMAX>(best, key);
     }
+  };
+#if KNN_PP
+  // KNN_UNROLL candidates per trip, two register sets used in turn: the next trip's 16-byte loads are in flight while this
+  // trip's candidates are inserted (the deep-level and 1-NN launches are a few wavefronts per CU: every exposed round trip
+  // is paid in full)
+  float4 ra[KNN_UNROLL], rb[KNN_UNROLL];
+#pragma unroll
+  for (int u = 0; u < KNN_UNROLL; ++u) ra[u] = sorted[min(p0 + u, last)];
+  for (int p = p0; p < p1; p += 2 * KNN_UNROLL) {
+#pragma unroll
+    for (int u = 0; u < KNN_UNROLL; ++u) rb[u] = sorted[min(p + KNN_UNROLL + u, last)];
+    examine(ra, p);
+#pragma unroll
+    for (int u = 0; u < KNN_UNROLL; ++u) ra[u] = sorted[min(p + 2 * KNN_UNROLL + u, last)];
+    examine(rb, p + KNN_UNROLL);
   }
+#else
+  // KNN_UNROLL candidates per trip: that many independent 16-byte loads in flight per lane
+  for (int p = p0; p < p1; p += KNN_UNROLL) {
+    float4 s[KNN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < KNN_UNROLL; ++u) s[u] = sorted[min(p + u, last)];
+    examine(s, p);
+  }
+#endif
 }
 
 // qmode 0: queries are pos_qry rows (row index = output row)
@@ -512,19 +541,19 @@ __device__ __forceinline__ void knn_query_queue_body(
     int* __restrict__ idx_out, float* __restrict__ d2_out, int flags, int64_t wg_in, int64_t nblk_in) {
   const int sorted_io = flags & 1;  // bit 1: idx_out / d2_out are 16-byte aligned (vector stores allowed)
   typedef typename KP::T KT;
-  __shared__ KT queue[QD][64];
-  const int lane = threadIdx.x;
+  __shared__ KT queue[QD][64 * KNNQ_WAVES];
+  const int lane = threadIdx.x;  // (column of the queue; KNNQ_WAVES independent wavefronts per workgroup, no barriers)
   // XCD-aware order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (observed; affects speed
   // only), so workgroup b takes the queries of chunk (b % 8): every XCD then walks one contiguous eighth of the
   // (cell-sorted) queries — two whole tiles at BASELINE config 2 — and its private L2 holds just those tiles' records
   // instead of all of them (memory waits were ~50 % of the wave cycles with the plain order, profiles/r02c_*)
-  int64_t wg = wg_in;
+  int64_t wg = wg_in * KNNQ_WAVES + (threadIdx.x >> 6);
   {
-    const int64_t nblk = nblk_in, q8 = nblk >> 3, r8 = nblk & 7;
+    const int64_t nblk = nblk_in * KNNQ_WAVES, q8 = nblk >> 3, r8 = nblk & 7;
     const int64_t xcd = wg & 7, i8 = wg >> 3;
     wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
   }
-  const int64_t t = wg * 64 + lane;
+  const int64_t t = wg * 64 + (lane & 63);
   if (t >= n_qry) return;  // (the drains below are per-lane loops: lanes that leave early are simply inactive)
   int lo = 0, hi = B;
   while (hi - lo > 1) {
@@ -674,6 +703,37 @@ __device__ __forceinline__ void knn_query_queue_body(
           // (reads run up to 2*KNNQ_UNROLL-1 records past p1: still inside the workspace — the sorted array is
           // followed by the perm / inv arrays — and masked out below).  The loads of batch i+1 are issued before batch
           // i is consumed: two batches of 16-byte loads in flight per lane
+#if KNNQ_PP
+          // two register sets used in turn: the loads of the next KNNQ_UNROLL records are in flight while the current ones
+          // are examined, with no register copies and no artificial use of the loaded values (round 2's loop pinned the
+          // prefetched registers with an empty asm statement — which made the compiler wait for them, vmcnt(0), right
+          // after issuing them: no overlap at all, and 16 v_mov per trip to rotate the registers; ISA of round 3)
+          auto examine = [&](const float4 (&s)[KNNQ_UNROLL], int p) {
+            if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
+#pragma unroll
+            for (int u = 0; u < KNNQ_UNROLL; ++u) {
+              const float d2 = dist2_exact(qx, qy, qz, s[u]);
+              if (p + u < p1 && !(d2 > kth)) {
+                queue[cnt][lane] = KP::make(d2, __float_as_int(s[u].w));
+                ++cnt;
+              }
+            }
+          };
+          if (p1 > p0) {
+            const int last = p1 - 1;
+            float4 ra[KNNQ_UNROLL], rb[KNNQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = sorted[min(p0 + u, last)];
+            for (int p = p0; p < p1; p += 2 * KNNQ_UNROLL) {
+#pragma unroll
+              for (int u = 0; u < KNNQ_UNROLL; ++u) rb[u] = sorted[min(p + KNNQ_UNROLL + u, last)];
+              examine(ra, p);
+#pragma unroll
+              for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = sorted[min(p + 2 * KNNQ_UNROLL + u, last)];
+              examine(rb, p + KNNQ_UNROLL);
+            }
+          }
+#else
           float4 nx[KNNQ_UNROLL];
 #pragma unroll
           for (int u = 0; u < KNNQ_UNROLL; ++u) nx[u] = sorted[p0 + u];
@@ -696,6 +756,7 @@ __device__ __forceinline__ void knn_query_queue_body(
               }
             }
           }
+#endif
         }
       }
 #endif
@@ -750,7 +811,7 @@ __device__ __forceinline__ void knn_query_queue_body(
 }
 
 template <int KMAX, class KP, int QD>
-__global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
+__global__ __launch_bounds__(64 * KNNQ_WAVES, KNNQ_MINW) void knn_query_queue_kernel(
     KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float* __restrict__ pos_qry, int qstride,
     const float4* __restrict__ qsorted, const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
     int* __restrict__ idx_out, float* __restrict__ d2_out, int flags) {
@@ -759,7 +820,7 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
 }
 
 template <int KMAX, class KP, int QD>
-__global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_batch_kernel(KnnBatch a, int B, int k, int flags) {
+__global__ __launch_bounds__(64 * KNNQ_WAVES, KNNQ_MINW) void knn_query_queue_batch_kernel(KnnBatch a, int B, int k, int flags) {
   const int j = knn_batch_job(a);
   knn_query_queue_body<KMAX, KP, QD>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
                                      a.idx_out[j], nullptr, flags, (int64_t)(blockIdx.x - a.wg_start[j]),
@@ -767,15 +828,277 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_batch_kernel(Kn
 }
 
 // ------------------------------------------------------------------------------------------
-// query, STAGED (round 3; the default for large cell-sorted query sets): the deferred-insertion search above, cut
-// into launches by ring radius, with the unfinished queries compacted between the launches.
+// query, LDS WINDOW (round 3): the deferred-insertion search with the candidates read from LDS.
 //
-// Why: a lane's ring walk ends when ITS k-th distance is inside the explored block, a wavefront ends with its slowest
-// lane.  On Lidar tiles most queries (ground, roofs) stop after ring 2 (25 grid columns, ~175 candidates) but a
-// vegetation point high above the ground needs ring 4-6 (~850 candidates): nearly every wavefront of 64 consecutive
-// queries holds one, so the mean lane sat idle for ~75 % of its wavefront's life and the launch ended on a tail of
-// slow wavefronts (profiles/r02c_*, r02rs_*: mean wavefront 94-100 us, launch 190 us, slowest lane 679 slots vs a mean
-// of 200).  Here
+// The 64 queries of a wavefront are consecutive in cell-sorted order: a run of ~9 cells of one grid row (two runs when
+// the wavefront wraps into the next row).  Everything their first rings touch lies in a small window of the grid: the
+// rows cy-RW .. cy+RW and the columns of the run widened by RW on both sides — 7 x ~15 cells, ~750 records, 12 KB.  The
+// wavefront copies that window into LDS ONCE with coalesced loads (each window row is one contiguous run of the sorted
+// array) together with the window's cell boundaries, and every lane then does ITS OWN ring walk — the same rings, the
+// same candidates, the same keys, the same termination test => bit-identical tables — but its candidate fetches and
+// cell-boundary look-ups are LDS reads (~100 cycles) instead of per-lane global gathers behind ~850 cycles of memory
+// wait per batch of four (profiles/r02c_*: half of a wavefront's life).  Rings that leave the window (R > RW: 2.7 % of
+// the queries at RW = 3) fall back to global loads for those runs.  Lanes of a wavefront that sit in different grid rows
+// or clouds are processed as successive segments, each with its own window.
+// ------------------------------------------------------------------------------------------
+#ifndef M3D_KNN_LDS_DEFAULT
+#define M3D_KNN_LDS_DEFAULT 0
+#endif
+#ifndef KNNL_CAP
+#define KNNL_CAP 1024   // records of a window (16 KB of LDS); a window that does not fit shrinks its RW
+#endif
+#ifndef KNNL_RW
+#define KNNL_RW 3
+#endif
+#ifndef KNNL_MINW
+#define KNNL_MINW 2
+#endif
+#define KNNL_MAXR (2 * KNNL_RW + 1)
+#define KNNL_MAXC 32
+template <int KMAX, class KP, int QD>
+__global__ __launch_bounds__(64, KNNL_MINW) void knn_query_lds_kernel(
+    KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float4* __restrict__ qsorted,
+    const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k, int* __restrict__ idx_out, float* __restrict__ d2_out,
+    int flags) {
+  const int sorted_io = flags & 1;
+  typedef typename KP::T KT;
+  __shared__ KT queue[QD][64];
+  __shared__ float4 rec[KNNL_CAP];
+  __shared__ int lcs[KNNL_MAXR][KNNL_MAXC + 1];
+  const int lane = threadIdx.x;
+  int64_t wg = blockIdx.x;
+  {  // XCD-aware order (see knn_query_queue_body)
+    const int64_t nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7;
+    const int64_t xcd = wg & 7, i8 = wg >> 3;
+    wg = xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
+  }
+  const int64_t t = wg * 64 + lane;
+  const bool valid = t < n_qry;
+  const int64_t tc = valid ? t : n_qry - 1;
+  int b;
+  {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (ptr_qry[mid] <= tc) lo = mid; else hi = mid;
+    }
+    b = lo;
+  }
+  const float4 q = qsorted[tc];
+  const float qx = q.x, qy = q.y, qz = q.z;
+  int cx, cy;
+  {
+    const float* gpl = w.gridp + (size_t)b * GP_STRIDE;
+    const int Gxl = ((const int*)gpl)[5], Gyl = ((const int*)gpl)[6];
+    cx = min(Gxl - 1, max(0, (int)((qx - gpl[0]) * gpl[2])));
+    cy = min(Gyl - 1, max(0, (int)((qy - gpl[1]) * gpl[2])));
+  }
+  KT best[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
+  int cnt = 0;
+  float kth = __builtin_inff();
+
+  auto chain = [&](KT key) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if constexpr (KP::IS_F64) {
+        KT hi2;
+        asm("v_max_f64 %0, %1, %2" : "=&v"(hi2) : "v"(best[j]), "v"(key));
+        asm("v_min_f64 %0, %0, %1" : "+v"(best[j]) : "v"(key));
+        key = hi2;
+      } else {
+        const KT cur = best[j];
+        const bool lt = key < cur;
+        best[j] = lt ? key : cur;
+        key = lt ? cur : key;
+      }
+    }
+  };
+  auto drain = [&]() {
+    for (int i = 0; i < cnt; i += KNNQ_DRAIN) {
+      KT key[KNNQ_DRAIN];
+#pragma unroll
+      for (int u = 0; u < KNNQ_DRAIN; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
+#pragma unroll
+      for (int u = 0; u < KNNQ_DRAIN; ++u) chain(u == 0 || i + u < cnt ? key[u] : KP::empty());
+    }
+    cnt = 0;
+    unsigned hw = KP::hi32(best[KMAX - 1]);
+    if (k < KMAX) {
+      hw = 0u;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const unsigned v = j < k ? KP::hi32(best[j]) : 0u;
+        hw = v > hw ? v : hw;
+      }
+    }
+    kth = hw == KP::hi32(KP::empty()) ? __builtin_inff() : __uint_as_float(KP::d2bits_of_hi(hw));
+  };
+
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+  while (todo != 0ull) {
+    // ---- next segment: the pending lanes that share the leader's cloud and grid row
+    const int lead = __builtin_ctzll(todo);
+    const int b0 = __builtin_amdgcn_readlane(b, lead), cy0 = __builtin_amdgcn_readlane(cy, lead);
+    const bool mine = valid && b == b0 && cy == cy0 && ((todo >> lane) & 1ull);
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    const float* gp = w.gridp + (size_t)b0 * GP_STRIDE;
+    const float gx0 = gp[0], gy0 = gp[1], h = gp[3], eps = gp[4];
+    const int Gx = ((const int*)gp)[5], Gy = ((const int*)gp)[6], n = ((const int*)gp)[7];
+    const int* cs = w.cell_start + (size_t)b0 * (CELLS_MAX + 1);
+    const float4* sorted = w.sorted + ptr_src[b0];
+    if (n <= 0) continue;
+    int cxmin = mine ? cx : 0x7fffffff, cxmax = mine ? cx : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cxmin = min(cxmin, __shfl_xor(cxmin, o, 64));
+      cxmax = max(cxmax, __shfl_xor(cxmax, o, 64));
+    }
+    cxmin = __builtin_amdgcn_readfirstlane(cxmin);
+    cxmax = __builtin_amdgcn_readfirstlane(cxmax);
+    // ---- the window: the largest RW <= KNNL_RW whose columns and records fit (wave-uniform)
+    int wx0 = 0, wx1 = -1, wy0 = 0, wy1 = -1, nrows = 0;
+    int ra = 0, rb = 0;  // lane r < nrows: bounds of window row r in the sorted array
+    for (int rw = KNNL_RW; rw >= 0; --rw) {
+      const int x0 = max(cxmin - rw, 0), x1 = min(cxmax + rw, Gx - 1);
+      const int y0 = max(cy0 - rw, 0), y1 = min(cy0 + rw, Gy - 1);
+      const int nr = y1 - y0 + 1;
+      if (x1 - x0 + 1 > KNNL_MAXC) continue;
+      int a = 0, bb = 0;
+      if (lane < nr) { a = cs[(y0 + lane) * Gx + x0]; bb = cs[(y0 + lane) * Gx + x1 + 1]; }
+      int tot = bb - a;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+      if (__builtin_amdgcn_readfirstlane(tot) <= KNNL_CAP) {
+        wx0 = x0; wx1 = x1; wy0 = y0; wy1 = y1; nrows = nr; ra = a; rb = bb;
+        break;
+      }
+    }
+    // ---- stage the window rows (coalesced: lane i takes record i of the run) and the local cell boundaries
+    {
+      int off = 0;
+      for (int r = 0; r < nrows; ++r) {
+        const int a = __builtin_amdgcn_readlane(ra, r), len = __builtin_amdgcn_readlane(rb, r) - a;
+        for (int i = lane; i < len; i += 64) rec[off + i] = sorted[a + i];
+        const int ncol = wx1 - wx0 + 1;
+        if (lane <= ncol) lcs[r][lane] = off + (cs[(wy0 + r) * Gx + wx0 + lane] - a);
+        off += len;
+      }
+    }
+    __syncthreads();  // (one wavefront per workgroup: orders the LDS writes before the reads below)
+    if (mine) {
+      for (int R = 0;; ++R) {
+        for (int dy = -R; dy <= R; ++dy) {
+          const int yy = cy + dy;
+          if (yy < 0 || yy >= Gy) continue;
+          const bool edge = (dy == -R || dy == R);
+          for (int sg = 0; sg < (edge ? 1 : 2); ++sg) {
+            int xa, xb;
+            if (edge) {
+              xa = max(cx - R, 0); xb = min(cx + R, Gx - 1);
+            } else {
+              xa = xb = (sg == 0 ? cx - R : cx + R);
+              if (xa < 0 || xa >= Gx) continue;
+            }
+            const bool inw = yy >= wy0 && yy <= wy1 && xa >= wx0 && xb <= wx1;
+            if (inw) {
+              const int p0 = lcs[yy - wy0][xa - wx0], p1 = lcs[yy - wy0][xb + 1 - wx0];
+              for (int p = p0; p < p1; p += KNNQ_UNROLL) {
+                float4 s[KNNQ_UNROLL];
+#pragma unroll
+                for (int u = 0; u < KNNQ_UNROLL; ++u) s[u] = rec[min(p + u, p1 - 1)];
+                if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
+#pragma unroll
+                for (int u = 0; u < KNNQ_UNROLL; ++u) {
+                  const float d2 = dist2_exact(qx, qy, qz, s[u]);
+                  if (p + u < p1 && !(d2 > kth)) {
+                    queue[cnt][lane] = KP::make(d2, __float_as_int(s[u].w));
+                    ++cnt;
+                  }
+                }
+              }
+            } else {
+              const int p0 = cs[yy * Gx + xa], p1 = cs[yy * Gx + xb + 1];
+              for (int p = p0; p < p1; p += KNNQ_UNROLL) {
+                float4 s[KNNQ_UNROLL];
+#pragma unroll
+                for (int u = 0; u < KNNQ_UNROLL; ++u) s[u] = sorted[min(p + u, p1 - 1)];
+                if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
+#pragma unroll
+                for (int u = 0; u < KNNQ_UNROLL; ++u) {
+                  const float d2 = dist2_exact(qx, qy, qz, s[u]);
+                  if (p + u < p1 && !(d2 > kth)) {
+                    queue[cnt][lane] = KP::make(d2, __float_as_int(s[u].w));
+                    ++cnt;
+                  }
+                }
+              }
+            }
+          }
+        }
+        drain();
+        const bool covers = (cx - R <= 0) && (cx + R >= Gx - 1) && (cy - R <= 0) && (cy + R >= Gy - 1);
+        if (covers) break;
+        float bound = 3.4e38f;
+        if (cx - R > 0) bound = fminf(bound, qx - (gx0 + (float)(cx - R) * h));
+        if (cx + R < Gx - 1) bound = fminf(bound, (gx0 + (float)(cx + R + 1) * h) - qx);
+        if (cy - R > 0) bound = fminf(bound, qy - (gy0 + (float)(cy - R) * h));
+        if (cy + R < Gy - 1) bound = fminf(bound, (gy0 + (float)(cy + R + 1) * h) - qy);
+        bound = fmaxf(bound - eps, 0.f);
+        if (kth <= bound * bound) break;
+      }
+    }
+    __syncthreads();  // the next segment restages the window
+  }
+  if (!valid) return;
+  const int64_t orow = sorted_io ? t : (int64_t)__float_as_int(q.w);
+  int ids[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) ids[j] = KP::is_empty(best[j]) ? -1 : KP::row(best[j]);
+  if (sorted_io) {
+    int tr[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) tr[j] = w.inv[ids[j] < 0 ? 0 : ids[j]];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? -1 : tr[j];
+  }
+  int* io = idx_out + orow * k;
+  if (k == KMAX && KMAX % 4 == 0 && (flags & 2)) {
+#pragma unroll
+    for (int j = 0; j < KMAX; j += 4) *(int4*)(io + j) = make_int4(ids[j], ids[j + 1], ids[j + 2], ids[j + 3]);
+    if (d2_out) {
+      float* dq = d2_out + orow * k;
+#pragma unroll
+      for (int j = 0; j < KMAX; j += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = KP::is_empty(best[j + u]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j + u]));
+        *(float4*)(dq + j) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < k) {
+        io[j] = ids[j];
+        if (d2_out)
+          d2_out[orow * k + j] = KP::is_empty(best[j]) ? __builtin_inff() : __uint_as_float(KP::d2bits(best[j]));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// query, STAGED (round 3; opt-in, M3D_KNN_STAGED=1): the deferred-insertion search above, cut into launches by ring
+// radius, with the unfinished queries compacted between the launches.
+//
+// Why it was built: a lane's ring walk ends when ITS k-th distance is inside the explored block, a wavefront ends with its
+// slowest lane — the mean lane scans ~200 candidates, the slowest of a wavefront ~570 (rings 0..4).  What the measurement
+// said (profiles/r03_knn_staged.log): there is no long tail to cut — 24.6 / 49.7 / 23.0 / 2.6 % of the queries of a
+// Lidar-HD-shaped tile close at ring 1 / 2 / 3 / 4 — and a group stage costs what the idle lanes it removes cost, so the
+// single launch stays the default.  The design:
 //   stage 0   every query, one lane each, rings 0 .. r0 (uniform work); a query whose search is still open leaves its
 //             state — the sorted key list, its position, cloud and query index — in a pool in HBM, appended at a slot
 //             from ONE atomic per wavefront (ballot + prefix);
@@ -1097,8 +1420,15 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   hipLaunchKernelGGL((knn_query_kernel<KM, KP>), grid, block, 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, \
                      qs, ptr_qry, n_qry, k, idx_out, d2_out, sorted_io)
 #define LAUNCH_Q(KM, KP)                                                                                          \
-  hipLaunchKernelGGL((knn_query_queue_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
-                     w, ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags)
+  hipLaunchKernelGGL((knn_query_queue_kernel<KM, KP, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64 * KNNQ_WAVES)),   \
+                     dim3(64 * KNNQ_WAVES), 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k,  \
+                     idx_out, d2_out, qflags)
+  // M3D_KNN_LDS=1 (read at every call): the LDS-window kernel for cell-sorted queries with k > 4 (f64 keys)
+  const char* lds_s = getenv("M3D_KNN_LDS");
+  const bool use_lds = qs && f64_keys && (lds_s ? atoi(lds_s) != 0 : M3D_KNN_LDS_DEFAULT != 0);
+#define LAUNCH_L(KM)                                                                                              \
+  hipLaunchKernelGGL((knn_query_lds_kernel<KM, KeyF64, KNNQ_DEPTH>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, \
+                     w, ptr_src, num_clouds, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags)
 #define LAUNCH(KM)                       \
   do {                                   \
     if (f64_keys) LAUNCH_KP(KM, KeyF64); \
@@ -1106,7 +1436,8 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   } while (0)
 #define LAUNCHQ(KM)                      \
   do {                                   \
-    if (!use_queue) LAUNCH(KM);          \
+    if (use_lds) LAUNCH_L(KM);           \
+    else if (!use_queue) LAUNCH(KM);     \
     else if (f64_keys) LAUNCH_Q(KM, KeyF64); \
     else LAUNCH_Q(KM, KeyU64);           \
   } while (0)
@@ -1119,6 +1450,7 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
 #undef LAUNCH
 #undef LAUNCHQ
 #undef LAUNCH_Q
+#undef LAUNCH_L
 #undef LAUNCH_KP
   M3D_CHECK_LAUNCH();
   return M3D_OK;
@@ -1287,7 +1619,7 @@ extern "C" int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const i
   }
   static const int queue_env = getenv("M3D_KNN_QUEUE") ? atoi(getenv("M3D_KNN_QUEUE")) : -1;
   const bool use_queue = k > 4 && (queue_env < 0 ? nmax * (int64_t)k >= (1 << 20) : queue_env != 0);
-  const int per_wg = use_queue ? 64 : 256;
+  const int per_wg = use_queue ? 64 * KNNQ_WAVES : 256;
   KnnBatch a;
   a.njobs = njobs;
   unsigned total = 0;
@@ -1314,7 +1646,7 @@ extern "C" int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const i
 #define LAUNCH_BD(KM, KP) \
   hipLaunchKernelGGL((knn_query_batch_kernel<KM, KP>), dim3(total), dim3(256), 0, st, a, num_clouds, k, sorted_io)
 #define LAUNCH_BQ(KM, KP) \
-  hipLaunchKernelGGL((knn_query_queue_batch_kernel<KM, KP, KNNQ_DEPTH>), dim3(total), dim3(64), 0, st, a, num_clouds, k, qflags)
+  hipLaunchKernelGGL((knn_query_queue_batch_kernel<KM, KP, KNNQ_DEPTH>), dim3(total), dim3(64 * KNNQ_WAVES), 0, st, a, num_clouds, k, qflags)
 #define LAUNCH_B(KM)                                            \
   do {                                                          \
     if (use_queue) { if (f64_keys) LAUNCH_BQ(KM, KeyF64); else LAUNCH_BQ(KM, KeyU64); } \

@@ -95,6 +95,44 @@ def test_knn_staged_query_is_bit_identical(device, monkeypatch, stages):
     assert torch.equal(back.cpu(), ref_idx)
 
 
+def test_knn_lds_window_kernel_is_bit_identical(device, monkeypatch):
+    """M3D_KNN_LDS=1: the deferred-insertion search with the first rings' candidates staged in LDS (one window of the grid per
+    wavefront segment, per-lane ring walks on top of it, global loads for the rings that leave the window) gives the
+    oracle's tables bit for bit: ragged clouds, row wraps, clouds smaller than K, duplicates, K = 8 / 16 / 32, another
+    source set, dense cells that overflow the window."""
+    from myria3d_amd import ops
+    from oracle.randla_oracle import knn_exact, synthetic_batch
+
+    monkeypatch.setenv("M3D_KNN_LDS", "1")
+    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32), ([700, 450], 32), ([9000, 64], 16)):
+        _, pos, _, ptr = rand_batch(sizes, seed=len(sizes) + k)
+        _knn_case(device, pos, ptr, k)
+    _, pos, _, ptr, _ = synthetic_batch([2500, 1800, 4000])
+    _knn_case(device, pos, ptr, 16)
+    pos_dup = torch.cat([pos[:40].repeat(8, 1), pos[:200]])
+    _knn_case(device, pos_dup, torch.tensor([0, pos_dup.shape[0]]), 16)
+    line = torch.zeros(300, 3)
+    line[:, 2] = torch.linspace(0, 1, 300)
+    _knn_case(device, line, torch.tensor([0, 300]), 16)
+    # a cluster denser than the window's capacity (1 500 points in one grid cell's footprint) + a sparse rest
+    dense = torch.cat([torch.rand(1500, 3) * 0.01 + 0.5, torch.rand(2000, 3)])
+    _knn_case(device, dense, torch.tensor([0, 3500]), 16)
+    sub = torch.cat([torch.randperm(2500)[:600], 2500 + torch.randperm(1800)[:450], 4300 + torch.randperm(4000)[:1000]])
+    ptr_s = torch.tensor([0, 600, 1050, 2050])
+    src = pos[sub].contiguous()
+    ref_idx, ref_d2 = knn_exact(src, ptr_s.tolist(), pos, ptr.tolist(), 8)
+    si, qi = ops.KnnIndex(src.to(device), ptr_s.to(device)), ops.KnnIndex(pos.to(device), ptr.to(device))
+    idx, d2 = si.query(8, qry=qi, want_d2=True)
+    assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(d2.cpu(), ref_d2)
+    # full size: BASELINE config 2 level 1 against the default kernel
+    _, pos, _, ptr, _ = synthetic_batch([12800] * 16)
+    ix = ops.KnnIndex(pos.to(device), ptr.to(device))
+    got, got_d2 = ix.query(16, qry=ix, want_d2=True, sorted_io=True)
+    monkeypatch.setenv("M3D_KNN_LDS", "0")
+    ref, ref_d2 = ix.query(16, qry=ix, want_d2=True, sorted_io=True)
+    assert torch.equal(got, ref) and torch.equal(got_d2, ref_d2)
+
+
 def test_knn_staged_equals_single_launch_at_full_size(device, monkeypatch):
     """BASELINE config 2 and config 5 shapes (16 x 12 800, K = 16; 4 x 40 000, K = 32): the staged query (opt-in,
     M3D_KNN_STAGED=1) against the single-launch deferred-insertion kernel (the default) — equal tables."""

@@ -51,5 +51,5 @@ for l in range(3):  # decoder 1-NN tables: every level-l point among the level l
     nn.append(timeit(lambda: src.query(1, qry=qry, sorted_io=True)))
 tag = os.environ.get("M3D_LIB", "default").split("libm3d_")[-1]
 print(f"knn_bench lib={tag} staged={os.environ.get('M3D_KNN_STAGED', 'auto')} stages={os.environ.get('M3D_KNN_STAGES', 'default')} "
-      f"grid={os.environ.get('M3D_KNN_STAGE_GRID', '4096')} queue={os.environ.get('M3D_KNN_QUEUE', 'auto')}: "
+      f"lds={os.environ.get('M3D_KNN_LDS', '0')} queue={os.environ.get('M3D_KNN_QUEUE', 'auto')}: "
       + " ".join(f"L{l+1}={t:.1f}us" for l, t in enumerate(out)) + " | 1-NN " + " ".join(f"{t:.1f}" for t in nn))
