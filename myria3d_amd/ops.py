@@ -771,6 +771,127 @@ class ResidualTailTrainFn(torch.autograd.Function):
         return (dx2, dw2, z0_2, dg2, db2, None, dxs, dws, z0_s, dgs, dbs, None, None, None, None, None)
 
 
+# --------------------------------------------------------------------------------------------------
+# autograd in EVAL mode (BatchNorm = an affine map with the running statistics; the reference's eval forward is
+# differentiable like any torch module: saliency maps, fine-tuning with frozen statistics).  Rarely used and not tuned:
+# the GEMMs / LFA kernels are the HIP ones, the BatchNorm-backward arithmetic is a few torch elementwise ops.
+# --------------------------------------------------------------------------------------------------
+def _eval_bn_terms(bn):
+    scale, shift = bn_fold_eval(bn)
+    return scale, shift, bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+
+
+def _eval_bn_backward(g, z, scale, mean, invstd):
+    """``g`` = gradient w.r.t. the BatchNorm OUTPUT (activation derivative already applied).  Returns dz, dgamma, dbeta."""
+    dgamma = (g * ((z - mean) * invstd)).sum(0)
+    return (g * scale).contiguous(), dgamma, g.sum(0)
+
+
+class SharedLayerEvalFn(torch.autograd.Function):
+    """One SharedMLP layer with eval-mode BatchNorm, differentiable (cf. SharedLayerTrainFn)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows):
+        scale, shift, mean, invstd = _eval_bn_terms(bn)
+        M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
+        k0 = x0.shape[1]
+        k1 = x1.shape[1] if x1 is not None else 0
+        x0 = x0.contiguous()
+        z = gemm(x0, w, M, w.shape[0], k0, rows=rows, a1=x1, k1=k1, bias=b)
+        y = bn_apply(z, scale, shift, act)
+        ctx.save_for_backward(x0, x1, w, z, scale, shift, mean, invstd, rows)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, w, z, scale, shift, mean, invstd, rows = ctx.saved_tensors
+        k0 = x0.shape[1]
+        k1 = x1.shape[1] if x1 is not None else 0
+        g = dy
+        if ctx.act:
+            g = dy * torch.where(z * scale + shift > 0, 1.0, LRELU_SLOPE)
+        dz, dgamma, dbeta = _eval_bn_backward(g, z, scale, mean, invstd)
+        dxc = linear_dgrad(dz, w)
+        dx0 = dxc[:, :k0].contiguous()
+        if rows is not None:
+            dx0 = scatter_add_rows(dx0, rows, x0.shape[0])
+        dx1 = dxc[:, k0:].contiguous() if x1 is not None else None
+        dw = linear_wgrad(dz, x0, k0, rows, x1, k1)
+        return dx0, dx1, dw, dz.sum(0), dgamma, dbeta, None, None, None
+
+
+class ResidualTailEvalFn(torch.autograd.Function):
+    """LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs))) with eval-mode BatchNorms, differentiable."""
+
+    @staticmethod
+    def forward(ctx, x2, w2, b2, g2, be2, bn2, xs, ws, bs, gs, bes, bns):
+        sc2, sh2, mu2, is2 = _eval_bn_terms(bn2)
+        scs, shs, mus, iss = _eval_bn_terms(bns)
+        x2, xs = x2.contiguous(), xs.contiguous()
+        M, N = x2.shape[0], w2.shape[0]
+        z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2)
+        zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs)
+        y = bn_apply(z2, sc2, sh2, True, zs, scs, shs)
+        ctx.save_for_backward(x2, w2, z2, sc2, mu2, is2, xs, ws, zs, scs, mus, iss, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2, z2, sc2, mu2, is2, xs, ws, zs, scs, mus, iss, y = ctx.saved_tensors
+        g = dy * torch.where(y > 0, 1.0, LRELU_SLOPE)
+        dz2, dg2, db2 = _eval_bn_backward(g, z2, sc2, mu2, is2)
+        dzs, dgs, dbs = _eval_bn_backward(g, zs, scs, mus, iss)
+        return (linear_dgrad(dz2, w2), linear_wgrad(dz2, x2, x2.shape[1]), dz2.sum(0), dg2, db2, None,
+                linear_dgrad(dzs, ws), linear_wgrad(dzs, xs, xs.shape[1]), dzs.sum(0), dgs, dbs, None)
+
+
+class LFAEvalFn(torch.autograd.Function):
+    """aggregate() of LocalFeatureAggregation with the encoder's BatchNorm in eval mode, differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, pos4, idx, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att):
+        x = x.contiguous()
+        K = idx.shape[1]
+        if K <= 32:
+            wf, bf, _, _, wp, wpt = lfa_prepare(enc_lin, enc_bn, None, 0, w_att, False, True)
+        else:
+            wf, bf, _, _ = lfa_enc_fold(enc_lin, enc_bn, None, 0)
+            wp = wpt = None
+        out = lfa_forward(x, pos4, idx, wf, bf, w_att, wp)
+        ctx.packed = (wp, wpt)
+        ctx.save_for_backward(x, pos4, idx, wf, bf, enc_w, enc_b, enc_gamma, w_att, enc_bn.running_mean,
+                              torch.rsqrt(enc_bn.running_var + enc_bn.eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, pos4, idx, wf, bf, enc_w, enc_b, enc_gamma, w_att, rmean, invstd = ctx.saved_tensors
+        n, K = idx.shape
+        ch = w_att.shape[0]
+        D = ch // 2
+        dev = x.device
+        dout = dout.contiguous()
+        dx = torch.zeros((n, D), dtype=torch.float32, device=dev)
+        G = torch.zeros(11 * D, dtype=torch.float64, device=dev)
+        if K <= 32:
+            dw_att = torch.empty((ch, ch), dtype=torch.float32, device=dev)
+            ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
+            wp, wpt = ctx.packed
+            call("m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE, _p(dout),
+                 _p(dx), _p(dw_att), 2, _p(G), _p(ws), _st())
+        else:
+            dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
+        # G[c] = sum over the edges of dy[e, c] * [r_e | 1], dy = gradient at the encoder BatchNorm's output
+        Gm = G.view(D, 11).to(torch.float32)
+        sc = enc_gamma * invstd
+        dw = sc[:, None] * Gm[:, :10]
+        db = sc * Gm[:, 10]
+        dgamma = invstd * ((enc_w * Gm[:, :10]).sum(1) + (enc_b - rmean) * Gm[:, 10])
+        dbeta = Gm[:, 10].clone()
+        return dx, None, None, dw, db, dgamma, dbeta, None, None, dw_att
+
+
 class GatherRowsFn(torch.autograd.Function):
     """``x[idx]``.  ``inverse``: ``idx`` is a permutation and ``inverse`` its inverse map — the backward pass is then the
     gather ``dy[inverse]`` (no atomics, no zero fill) instead of a scatter-add."""

@@ -124,7 +124,7 @@ class HipRandLANet(nn.Module):
         self.register_buffer("_decim_seed", torch.tensor([0x5DEECE66D], dtype=torch.int64), persistent=False)
         self._decim_seeded = False
         self._plans: Dict[tuple, LevelPlan] = {}
-        self._warned_eval_grad = False
+        self._grad_eval = False  # eval-mode forward that records an autograd graph (set per call)
         self._use_sinks = False
         self._streams: Dict = {}
         # eval-mode derived tensors (folded BatchNorm scale/shift, folded encoder, packed attention weights) depend on
@@ -326,6 +326,8 @@ class HipRandLANet(nn.Module):
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
                                                 sk, self._bf16, x0_slot, x1_slot)
+        if self._grad_eval:
+            return ops.SharedLayerEvalFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
         M = x1.shape[0] if x1 is not None else (rows.numel() if rows is not None else x0.shape[0])
         return ops.gemm(x0, lin.weight, M, lin.weight.shape[0], x0.shape[1], rows=rows, a1=x1,
@@ -342,6 +344,9 @@ class HipRandLANet(nn.Module):
                 else None
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
                                        enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16, prepared)
+        elif self._grad_eval:
+            agg = ops.LFAEvalFn.apply(x, pos4, idx, enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, enc_lin, enc_bn,
+                                      w_att)
         else:
             if idx.shape[1] <= 32:
                 wf, bf, wp = self._cached(("lfa", id(p), bf16),
@@ -377,6 +382,9 @@ class HipRandLANet(nn.Module):
             sks = self._sinks(ls.weight, ls.bias, ns.weight, ns.bias) if self._use_sinks else None
             out = ops.ResidualTailTrainFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
                                                 ns.weight, ns.bias, ns, sk2, sks, self._bf16, x_slot)
+        elif self._grad_eval:
+            out = ops.ResidualTailEvalFn.apply(h, l2.weight, l2.bias, n2.weight, n2.bias, n2, x, ls.weight, ls.bias,
+                                               ns.weight, ns.bias, ns)
         else:
             sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2), self._bn_deps(n2))
             scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns), self._bn_deps(ns))
@@ -408,11 +416,11 @@ class HipRandLANet(nn.Module):
         x = x.to(torch.float32).contiguous()
         pos = pos.to(torch.float32).contiguous()
         train = self.training
-        if not train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if not self._warned_eval_grad:
-                warnings.warn("HipRandLANet: eval-mode forward is inference-only (no autograd graph is recorded)")
-                self._warned_eval_grad = True
-        ctx = torch.enable_grad() if (train and torch.is_grad_enabled()) else torch.no_grad()
+        # eval mode with autograd enabled and something to differentiate: the reference's eval forward records a graph like
+        # any torch module (BatchNorm on running statistics, no dropout) — so does this one (ops.*EvalFn)
+        self._grad_eval = (not train) and torch.is_grad_enabled() and \
+            (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        ctx = torch.enable_grad() if ((train or self._grad_eval) and torch.is_grad_enabled()) else torch.no_grad()
         with ctx:
             return self._forward(x, pos, ptr.to(torch.int64).contiguous(), decimation_idx, dropout_mask, plan,
                                  record, train)
@@ -678,9 +686,10 @@ class HipRandLANet(nn.Module):
         feats: List[Tensor] = []
         hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
         geo.wait(0)
+        diff = train or self._grad_eval  # the pass records an autograd graph
         x = ops.GatherRowsFn.apply(x, index[0].perm, index[0].inv) if x.requires_grad else ops.gather_rows(x, index[0].perm)
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
-                               self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if train else \
+                               self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if diff else \
             ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
         # gradient meeting points (train): in_slots[l] = input of block l (hin[l]), out_slot = output of block 1
         use_slots = train and torch.is_grad_enabled() and self.share_input_gradients
@@ -707,7 +716,7 @@ class HipRandLANet(nn.Module):
             self._advance_interleaved()
             self._advance_interleaved()  # (two position-only stages per level: table + moments, decimation + next grid)
             geo.wait(2 + 2 * lvl)  # decimation map into the next level
-            h = ops.GatherRowsFn.apply(h, geo.src[lvl], None, out_slot if lvl == 0 else None) if train \
+            h = ops.GatherRowsFn.apply(h, geo.src[lvl], None, out_slot if lvl == 0 else None) if diff \
                 else ops.gather_rows(h, geo.src[lvl])
             hin.append(h)
         self.last_decimation_idx = dec_ref
@@ -736,7 +745,7 @@ class HipRandLANet(nn.Module):
                 h = h * (mask / (1.0 - p))
             else:
                 h = F.dropout(h, p=p, training=True)
-        if train:
+        if diff:
             logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias,
                                         self._sinks(self.fc_classif.weight, self.fc_classif.bias)
                                         if self._use_sinks else None)
