@@ -9,7 +9,7 @@ Op-for-op, unfused, pure-torch (fp32, CPU) restatement of
   ``knn``; torch_scatter ``scatter_sum``) — restated from their published behaviour because the wheels
   are absent from this image.
 
-PARITY UNPINNED by the reference's own tests (shape-only); see ``oracle/__init__.py``.
+Parity: pinned to the reference's own file through ``tests/_pyg_stub`` (round 3), third-party semantics restated; see ``oracle/__init__.py``.
 
 The parameter tree reproduces the reference's ``state_dict`` keys (``block1.lfa1.mlp_encoder.lins.0.weight``,
 ``...norms.0.module.running_mean`` ...) so a Myria3D checkpoint loads unchanged.
