@@ -23,8 +23,11 @@
 #ifndef KNN_UNROLL
 #define KNN_UNROLL 4
 #endif
+#ifndef KNN_PP_OFF_CLAMPED
+#define KNN_PP_OFF_CLAMPED 0
+#endif
 #ifndef KNN_PP
-#define KNN_PP 0  // direct-insertion kernel: ping-pong register sets in scan_range (1-3 % slower at the deep levels: off)
+#define KNN_PP 1  // direct-insertion kernel, lists of 8+ keys: ping-pong register sets in scan_range
 #endif
 #ifndef KNN_PIPE
 #define KNN_PIPE 0  // direct-insertion kernel: the same pipelined walk (levels 2-4: 120 / 77 / 49 vs 108 / 68 / 45 us: slower; off)
@@ -319,28 +322,39 @@ __device__ __forceinline__ void scan_range(typename KP::T (&best)[KMAX], const f
       KP::template insert<KMAX>(best, key);
     }
   };
-#if KNN_PP
-  // KNN_UNROLL candidates per trip, two register sets used in turn: the next trip's 16-byte loads are in flight while this
-  // trip's candidates are inserted (the deep-level and 1-NN launches are a few wavefronts per CU: every exposed round trip
-  // is paid in full)
-  float4 ra[KNN_UNROLL], rb[KNN_UNROLL];
-#pragma unroll
-  for (int u = 0; u < KNN_UNROLL; ++u) ra[u] = sorted[min(p0 + u, last)];
-  for (int p = p0; p < p1; p += 2 * KNN_UNROLL) {
-#pragma unroll
-    for (int u = 0; u < KNN_UNROLL; ++u) rb[u] = sorted[min(p + KNN_UNROLL + u, last)];
-    examine(ra, p);
-#pragma unroll
-    for (int u = 0; u < KNN_UNROLL; ++u) ra[u] = sorted[min(p + 2 * KNN_UNROLL + u, last)];
-    examine(rb, p + KNN_UNROLL);
-  }
-#else
-  // KNN_UNROLL candidates per trip: that many independent 16-byte loads in flight per lane
+#if KNN_PP_OFF_CLAMPED
+  // round 2's loop: clamped addresses, load then use
   for (int p = p0; p < p1; p += KNN_UNROLL) {
     float4 s[KNN_UNROLL];
 #pragma unroll
     for (int u = 0; u < KNN_UNROLL; ++u) s[u] = sorted[min(p + u, last)];
     examine(s, p);
+  }
+#else
+  // Unclamped addresses: one base per trip + immediate offsets (reads run up to 3*KNN_UNROLL-1 records past p1: inside the
+  // 256-byte-padded workspace, masked in examine()) — per-index clamps cost a v_min and an address computation per load in
+  // kernels whose bound is instruction issue.  Lists of 8+ keys (the insertion chain is long enough to cover a load):
+  // two register sets used in turn, the next trip's loads in flight while this trip's candidates are inserted
+  // (levels 2-4: 110 / 70 / 46 -> 99 / 65 / 44 us); the 1-NN and 4-NN queries just load and use (49 -> 46 us)
+  if constexpr (KNN_PP && KMAX >= 8) {
+    float4 ra[KNN_UNROLL], rb[KNN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < KNN_UNROLL; ++u) ra[u] = sorted[p0 + u];
+    for (int p = p0; p < p1; p += 2 * KNN_UNROLL) {
+#pragma unroll
+      for (int u = 0; u < KNN_UNROLL; ++u) rb[u] = sorted[p + KNN_UNROLL + u];
+      examine(ra, p);
+#pragma unroll
+      for (int u = 0; u < KNN_UNROLL; ++u) ra[u] = sorted[p + 2 * KNN_UNROLL + u];
+      examine(rb, p + KNN_UNROLL);
+    }
+  } else {
+    for (int p = p0; p < p1; p += KNN_UNROLL) {
+      float4 s[KNN_UNROLL];
+#pragma unroll
+      for (int u = 0; u < KNN_UNROLL; ++u) s[u] = sorted[p + u];
+      examine(s, p);
+    }
   }
 #endif
 }
@@ -720,16 +734,19 @@ __device__ __forceinline__ void knn_query_queue_body(
             }
           };
           if (p1 > p0) {
-            const int last = p1 - 1;
+            // (unclamped addresses: ONE base per trip + immediate offsets.  Reads run up to 3*KNNQ_UNROLL-1 records past p1:
+            // still inside the workspace — every array of it is padded to 256 bytes and the sorted array is followed by
+            // the perm / inv arrays — and masked out in examine().  Clamping every index cost 16 VALU instructions per
+            // trip: +29 % instructions in a kernel whose bound is instruction issue, profiles/r03m_*)
             float4 ra[KNNQ_UNROLL], rb[KNNQ_UNROLL];
 #pragma unroll
-            for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = sorted[min(p0 + u, last)];
+            for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = sorted[p0 + u];
             for (int p = p0; p < p1; p += 2 * KNNQ_UNROLL) {
 #pragma unroll
-              for (int u = 0; u < KNNQ_UNROLL; ++u) rb[u] = sorted[min(p + KNNQ_UNROLL + u, last)];
+              for (int u = 0; u < KNNQ_UNROLL; ++u) rb[u] = sorted[p + KNNQ_UNROLL + u];
               examine(ra, p);
 #pragma unroll
-              for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = sorted[min(p + 2 * KNNQ_UNROLL + u, last)];
+              for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = sorted[p + 2 * KNNQ_UNROLL + u];
               examine(rb, p + KNNQ_UNROLL);
             }
           }
