@@ -294,6 +294,17 @@ class GradSideStream:
         jobs, self.jobs = self.jobs, []
         if not jobs:
             return
+        # the bf16 switch of m3d_linear_wgrad_batch applies to a whole call: layers that asked for bf16 matrix-core
+        # operands (K > 64 in the net's "bf16" mode) and layers that did not (fc0 / fc_classif, the narrow SharedMLPs) go
+        # in separate calls, so that no layer documented as fp32 is rounded
+        lo = [j for j in jobs if not (len(j) > 7 and j[7])]
+        hi = [j for j in jobs if len(j) > 7 and j[7]]
+        for part, flag in ((lo, 0), (hi, 256)):
+            if part:
+                self._launch_wgrad_batch(part, flag)
+
+    @staticmethod
+    def _launch_wgrad_batch(jobs, bf16_flag: int) -> None:
         import ctypes
 
         m = len(jobs)
@@ -315,7 +326,7 @@ class GradSideStream:
              vp([_p(j[4]) for j in jobs]), i64([j[4].stride(0) if j[4] is not None else 0 for j in jobs]),
              i32([j[5] for j in jobs]), i64([j[0].shape[0] for j in jobs]), i32([j[0].shape[1] for j in jobs]),
              vp([j[6].data_ptr() for j in jobs]), i64([j[6].stride(0) for j in jobs]),
-             1 | (256 if any(len(j) > 7 and j[7] for j in jobs) else 0),
+             1 | bf16_flag,
              vp([base + o if nb else None for o, nb in zip(offs, need)]), _st())
 
     def join(self):
@@ -679,6 +690,8 @@ class SharedLayerTrainFn(torch.autograd.Function):
         x0_slot, x1_slot = ctx.slots
         acc0 = x0_slot.take() if (x0_slot is not None and ctx.needs_input_grad[0]) else None
         fused = want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1])
+        if fused and z.shape[0] * max(z.shape[1], w.shape[1]) * 4 >= (1 << 31) - 64:
+            fused = False  # beyond the fused kernel's 2 GiB buffer descriptors: the two-pass path handles it
         if fused and k1 and k0 % 4 == 0 and k1 % 4 == 0:
             # concatenated input: the two column blocks of the input gradient leave the GEMM as two contiguous matrices
             (s0, s1), dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
