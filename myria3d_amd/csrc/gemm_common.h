@@ -16,6 +16,8 @@ struct GemmArgs {
                                          // partial to slot w % stat_slots (fp64 atomics) -> the consumer sums a handful
                                          // of slots itself and no finalize kernel is needed
   float* c; int64_t ldc; int accumulate;
+  int acc_pre;  // (set by m3d_gemm_direct_try) accumulate: the old C tile is loaded INTO the MFMA accumulators at the top of a
+                // tile — next to the operand loads, one memory round trip per tile — instead of read-modify-written in the epilogue
   int splitk; int64_t kchunk;  // reduction elements per split (multiple of BK)
   int bf16;                    // != 0: operands rounded to bf16 on load, v_mfma_f32_16x16x32_bf16 (K % 32 == 0, K > 64)
   int ksplit;                  // k-loop kernels: != 0: the four waves of a workgroup share ONE row group and a quarter of K each

@@ -180,6 +180,19 @@ __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc
   return o;
 }
 
+// accumulate, pre-loaded (GemmArgs::acc_pre): the lane's four old output values of row m, columns n0..n0+3 (the C/D
+// fragment layout of the transposed product) as the initial accumulator; zeros where the tile has no output
+__device__ __forceinline__ f32x4 c_prev(const GemmArgs& g, rsrc_t rc, rsrc_t rc1, int64_t m, int n0) {
+  const bool ok = m < g.M && n0 < g.N;
+  if (g.c_split > 0) {
+    const bool lo = n0 < g.c_split;
+    const f32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rc, (ok && lo) ? (unsigned)((m * g.ldc + n0) * 4) : OOB, 0, 0);
+    const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rc1, (ok && !lo) ? (unsigned)((m * g.ldc1 + (n0 - g.c_split)) * 4) : OOB, 0, 0);
+    return u + v;
+  }
+  return __builtin_amdgcn_raw_buffer_load_b128(rc, ok ? (unsigned)((m * g.ldc + n0) * 4) : OOB, 0, 0);
+}
+
 // Epilogue modes (template parameter MODE): the network never needs statistics and an affine map in one launch
 //   0 PLAIN   + bias                      (dgrad, plain Linear)
 //   1 STATS   + bias, column sum/sumsq    (train-mode SharedMLP: BatchNorm statistics of the raw output)
@@ -239,7 +252,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
   // accumulate (plain epilogue only): C += A B^T — every element has exactly one writer (no split-K here), so a plain
   // read-modify-write.  Used by the backward pass to add an input gradient into the buffer another consumer of the same
   // tensor has already written (no separate elementwise add, no zero fill)
-  const bool acc_c = MODE == 0 && g.accumulate;
+  const bool acc_c = MODE == 0 && g.accumulate && !g.acc_pre;
   if (MODE == 0 && g.c_split > 0) {  // (c_split, N multiples of 4: a lane's four columns fall on one side)
     float4* dst = nullptr;
     if (n0 < g.c_split) dst = (float4*)(g.c + m * g.ldc + n0);
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * NT;
-  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b);
+  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc(g.c), rc1 = mk_rsrc(g.c1);
   __shared__ float cf[PRO ? 6 : 1][PRO ? 64 : 4];
   const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
   if constexpr (PRO) pro_setup<64>(g, (float (&)[6][64])cf);
@@ -340,7 +353,10 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
     }
     f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0 && g.acc_pre) acc[t] = c_prev(g, rc, rc1, m, nb + 16 * t + 4 * lg);
+    }
 #pragma unroll
     for (int q = 0; q < KQ; ++q)
 #pragma unroll
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
   const int K = g.k0 + g.k1;
   const int KQ = (K + 15) >> 4;
   const int nb = blockIdx.y * 16 * NTW;
-  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b);
+  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc(g.c), rc1 = mk_rsrc(g.c1);
   __shared__ float cf[PRO ? 6 : 1][PRO ? PRO_KMAX : 4];
   const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
   const bool pst = blockIdx.y == 0;  // column slice 0 stores dz
@@ -398,7 +414,12 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NTW; ++t) {
+        acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (split K: wave 0 owns the epilogue, so only its accumulators start from the old tile)
+        if (MODE == 0 && g.acc_pre && (!ks || wid == 0))
+          acc[mt][t] = c_prev(g, rc, rc1, (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg);
+      }
     if constexpr (BF) {
       const int nq = K >> 5, per = (nq + 3) >> 2;
       const int q0 = ks ? wid * per : 0, q1 = ks ? (q0 + per < nq ? q0 + per : nq) : nq;
@@ -637,10 +658,12 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   dim3 grid((unsigned)rp.wgs, (unsigned)rp.slices);
   GemmArgs gk = g;
   gk.ksplit = rp.ksplit;
+  gk.acc_pre = g.accumulate && mode == 0 && cvec && g.M * g.ldc * 4 <= lim &&
+               (g.c_split == 0 || g.M * g.ldc1 * 4 <= lim);
   if (rp.rowstream) {
-    if (rp.NT == 4) launch_rowstream<4>(g, mode, rp.KQ, variant, grid, st, cvec);
-    else if (rp.NT == 2) launch_rowstream<2>(g, mode, rp.KQ, variant, grid, st, cvec);
-    else launch_rowstream<1>(g, mode, rp.KQ, variant, grid, st, cvec);
+    if (rp.NT == 4) launch_rowstream<4>(gk, mode, rp.KQ, variant, grid, st, cvec);
+    else if (rp.NT == 2) launch_rowstream<2>(gk, mode, rp.KQ, variant, grid, st, cvec);
+    else launch_rowstream<1>(gk, mode, rp.KQ, variant, grid, st, cvec);
   } else {
     if (rp.MT == 2 && rp.NT == 4) launch_kloop<2, 4>(gk, mode, variant, grid, st, cvec);
     else if (rp.MT == 2) launch_kloop<2, 2>(gk, mode, variant, grid, st, cvec);

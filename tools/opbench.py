@@ -43,8 +43,10 @@ if "gemm" in what or "wgrad" in what:
         if "gemm" in what:
             t1 = timeit(lambda: ops.gemm(x, w, M, N, K, bias=b, stats=st))
             t2 = timeit(lambda: ops.linear_dgrad(dz, w))
+            accbuf = torch.zeros(M, K, device=dev)
+            t2a = timeit(lambda: ops.linear_dgrad(dz, w, acc=accbuf))  # input gradient ADDED to a shared buffer (GradSlot)
             byt = 4 * M * (K + N); fl = 2 * M * K * N
-            line += f"fwd+stats {t1:7.1f}us ({byt/t1/1e3:6.0f} GB/s {fl/t1/1e6:6.1f} TF)  dgrad {t2:7.1f}us ({byt/t2/1e3:6.0f} GB/s)  "
+            line += f"fwd+stats {t1:7.1f}us ({byt/t1/1e3:6.0f} GB/s {fl/t1/1e6:6.1f} TF)  dgrad {t2:7.1f}us ({byt/t2/1e3:6.0f} GB/s)  dgrad+= {t2a:7.1f}us  "
             tf += t1; td += t2
         if "wgrad" in what:
             t3 = timeit(lambda: ops.linear_wgrad(dz, x, K))
