@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--skip-extras", action="store_true",
                     help="skip the informative extra legs of the N=1 line (eager step, predict sweep, dense tiles)")
     ap.add_argument("--skip-legs", default="", help="comma list of informative legs to leave out of the N=1 line: "
-                    "predict,bf16,dropin,collective,torch,dense")
+                    "predict,bf16,dropin,collective,torch,dense,pointnet2")
     ap.add_argument("--cpu-tiles", type=int, default=16, help="tiles in the CPU-baseline sample (BASELINE.md 3: 16)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="BASELINE.md 3 protocol in full: 3 warm-up + 10 timed iterations, at the probe-picked thread "
@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launch check without GPUs: bring the N ranks up over gloo, exchange one all-reduce, print the "
                          "rank census (used by the CPU tests)")
-    ap.add_argument("--mode", choices=["train", "predict", "prepare", "dropin"], default="train",
+    ap.add_argument("--mode", choices=["train", "predict", "prepare", "dropin", "pointnet2"], default="train",
                     help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative).  "
                          "prepare: the data-preparation chain in front of the net (informative).  dropin: the plain "
                          "Lightning-style step (no plan / prefetch / graph / flat buffers, torch loss and Adam)")
@@ -469,6 +469,61 @@ def dropin_bench(args, dev):
                               "eager, no plan / prefetch_geometry / hipGraph / flat buffers"}), flush=True)
 
 
+def pointnet2_bench(args, dev):
+    """``--mode pointnet2``: BASELINE configs[4]'s second half — the PointNet++ set-abstraction variant
+    (``myria3d_amd.pointnet2.HipPointNet2``: farthest-point sampling, kNN grouping, SharedMLP over the edge rows, max
+    aggregation, FPModule decoder; no reference implementation exists, model.py:12) — one eager training step
+    (forward + CrossEntropy + backward + torch Adam) and the eval forward, with the sampler's share timed beside."""
+    from myria3d_amd import ops
+    from myria3d_amd.pointnet2 import HipPointNet2
+    from myria3d_amd.synthetic import synthetic_batch
+
+    B, N, K = args.tiles, args.points, args.neighbors
+    x, pos, batch, ptr, y = synthetic_batch([N] * B)
+    x, pos, batch, ptr, y = (t.to(dev) for t in (x, pos, batch, ptr, y))
+    torch.manual_seed(0)
+    net = HipPointNet2(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=0.003933709606504788)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=65)
+
+    def step():
+        opt.zero_grad()
+        crit(net(x, pos, batch, ptr), y).backward()
+        opt.step()
+
+    steps = max(2, min(args.steps, 10))
+    for _ in range(3):
+        step()
+    dt = timed(step, steps, 1) / steps
+    net.eval()
+
+    def fwd():
+        with torch.no_grad():
+            net(x, pos, batch, ptr)
+
+    fwd()
+    dtf = timed(fwd, steps, 1) / steps
+    plan = net.plan_for(ptr)
+    pos4 = ops.pad_pos(pos)
+    lv = [pos4]
+    for l in range(3):
+        lv.append(ops.gather_rows(lv[l], net.last_sample_idx[l]))
+
+    def sampler():
+        for l in range(3):
+            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l])
+
+    dts = timed(sampler, steps, 1) / steps
+    print(json.dumps({"metric": "points/sec fwd+bwd, PointNet++ set-abstraction variant", "value": round(B * N / dt, 1),
+                      "unit": "points/s", "ms_per_step": round(dt * 1e3, 3), "fwd_only_ms": round(dtf * 1e3, 3),
+                      "fps_ms": round(dts * 1e3, 3), "dtype": "f32", "data": "synthetic",
+                      "workload": f"HipPointNet2 train step, {B} tiles x {N} pts, K={K}, decimation 4, FPS sampling, eager "
+                                  "launches, torch Adam (BASELINE configs[4], second half; no reference implementation: "
+                                  "oracle-only parity)",
+                      "what": "fps_ms = the three farthest-point-sampling launches of one forward (one workgroup per tile: "
+                              "a serial arg-max chain of n/4 iterations)"}), flush=True)
+
+
 def predict_bench(args, dev, world=1, rank=0, reps=None):
     """BASELINE config 3 (informative, not the contract line): predict.py-shaped inference over a synthetic 1 km^2
     cloud = 400 tiles of 50 m, batches of 50 tiles (configs/experiment/predict.yaml:21-23).  Per batch: eval forward
@@ -790,6 +845,10 @@ def _extra_legs(args, dev, res, B, N, K):
         res["dense_tiles_config5"] = {"value": d5["value"], "unit": "points/s", "ms_per_step": d5["ms_per_step"],
                                       "fwd_only": d5["fwd_only"], "workload": d5["config"]["workload"]}
 
+    def pointnet2():
+        res["pointnet2_config5"] = _leg_in_fresh_process(["--mode", "pointnet2", "--steps", "3", "--tiles", "16", "--points", "40000",
+                                                          "--neighbors", "32"])
+
     leg("predict", "predict_config3", predict)
     leg("bf16", "bf16", bf16)
     leg("dropin", "dropin", dropin)
@@ -797,6 +856,7 @@ def _extra_legs(args, dev, res, B, N, K):
     leg("torch", "torch_rocm_baseline", torch_leg)
     if (N, K) == (12800, 16):
         leg("dense", "dense_tiles_config5", dense)
+        leg("pointnet2", "pointnet2_config5", pointnet2)
     torch.cuda.empty_cache()
 
 
@@ -846,6 +906,10 @@ def main():
         if world > 1:
             raise SystemExit("--mode dropin is a single-GPU run")
         dropin_bench(args, dev)
+    elif args.mode == "pointnet2":
+        if world > 1:
+            raise SystemExit("--mode pointnet2 is a single-GPU run")
+        pointnet2_bench(args, dev)
     else:
         B, N, K = args.tiles, args.points, args.neighbors
         extras = world == 1 and not args.skip_extras and not args.force_collective

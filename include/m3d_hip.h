@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 11
+#define M3D_ABI_VERSION 12
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -334,6 +334,34 @@ int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, const doubl
 int m3d_tile_normalize(float* pos, int32_t pos_stride, float* x, int64_t ldx, int32_t intensity_col, int32_t rgb_col,
                        const int64_t* ptr, int32_t num_clouds, int64_t n, int32_t center, int32_t nullify_z,
                        float pos_scale, float clamp_sigma, double* stats_ws, void* stream);
+
+/* ---- PointNet++ set-abstraction variant (BASELINE.json configs[4]; north_star "random/FPS subsampling") ----------
+ * No reference implementation exists (myria3d/models/model.py:12: MODEL_ZOO = [PyGRandLANet]; no FPS anywhere in the
+ * repository): the entry points restate the published operators the variant is built from (PointNet++ as packaged by
+ * PyG: torch_cluster.fps, PointNetConv's gathers and aggr="max"); oracle/pointnet2_oracle.py is the checker.
+ *
+ * m3d_fps: farthest-point sampling inside each cloud (torch_cluster.fps semantics, random_start=False unless `start` is
+ * given): cloud b keeps ptr_out[b+1] - ptr_out[b] points; slot 0 is point start[b] (cloud-relative; NULL: point 0), slot
+ * s + 1 the point with the largest distance to slots 0..s (d2 = (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction,
+ * ties -> smaller index).  pos4: [n, 4] rows (x, y, z, -), 16-byte aligned.  idx_out: global rows, selection order.
+ * max_points: the largest cloud (host value; <= 65 536). */
+int m3d_fps(const float* pos4, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds, int64_t max_points,
+            const int32_t* start, int32_t* idx_out, void* stream);
+/* Edge rows of a set-abstraction level over a COMPACT edge list: centre i owns edges seg[i] .. seg[i+1] - 1 (at most K;
+ * fewer when its cloud has fewer than K points, as in PyG's edge_index), edge seg[i] + k has source j = nbr[i][k]:
+ *   out[e][0..C) = x[j],  out[e][C..C+3) = pos_src[j] - pos_ctr[i],  out[e][C+3..ldo) = 0;  esrc[e] = j, ectr[e] = i. */
+int m3d_sa_group(const float* x, int64_t ldx, int32_t C, const float* pos4_src, const float* pos4_ctr,
+                 const int32_t* nbr /* [m, K] */, const int64_t* seg /* [m + 1] */, int64_t m, int32_t K, float* out,
+                 int64_t ldo, int32_t* esrc, int32_t* ectr, void* stream);
+/* transpose of the x_j gather: dx[esrc[e]][c] += de[e][c], c < C (dx zeroed or pre-loaded by the caller) */
+int m3d_sa_group_bwd(const float* de, int64_t ld, const int32_t* esrc, int64_t E, int32_t C, float* dx, int64_t lddx,
+                     void* stream);
+/* aggr="max": out[i][c] = max over the edges of centre i of y[e][c]; arg[i][c] = k of the first maximal edge */
+int m3d_seg_max(const float* y, int64_t ldy, const int64_t* seg, int64_t m, int32_t C, float* out, int32_t* arg,
+                void* stream);
+/* dy[e][c] = dout[ectr[e]][c] when e is that centre's arg-max edge for channel c, else 0 (dy [E, C] contiguous) */
+int m3d_seg_max_bwd(const float* dout, const int32_t* arg, const int64_t* seg, const int32_t* ectr, int64_t E, int32_t C,
+                    float* dy, void* stream);
 
 /* ---- training step: loss and optimizer -------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(ignore_index=65, reduction="mean") on the logits (myria3d/models/model.py:118,

@@ -1246,3 +1246,72 @@ def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> T
     fp32 logits and int64 class targets (the reference's criterion, model.py:118)."""
     assert target.dtype == torch.int64 and target.is_cuda and target.is_contiguous()
     return CrossEntropyFn.apply(logits, target, int(ignore_index))
+
+
+# --------------------------------------------------------------------------------------------------
+# PointNet++ set-abstraction variant (BASELINE.json configs[4]): farthest-point sampling, grouping, max aggregation.
+# No reference implementation exists (myria3d/models/model.py:12); csrc/sa.hip restates the published operators.
+# --------------------------------------------------------------------------------------------------
+def fps(pos4: Tensor, ptr: Tensor, ptr_out: Tensor, m: int, max_points: int, start: Optional[Tensor] = None) -> Tensor:
+    """Farthest-point sampling inside each cloud (``torch_cluster.fps`` semantics): int32 ``[m]`` global rows in selection
+    order; cloud ``b`` keeps ``ptr_out[b+1] - ptr_out[b]`` points starting from ``start[b]`` (cloud-relative; default 0)."""
+    assert pos4.shape[1] == 4 and pos4.is_contiguous()
+    idx = torch.empty(m, dtype=torch.int32, device=pos4.device)
+    if start is not None:
+        assert start.dtype == torch.int32 and start.is_contiguous() and start.numel() == ptr.numel() - 1
+    call("m3d_fps", _p(_chk(pos4)), _p(ptr), _p(ptr_out), ptr.numel() - 1, int(max_points), _p(start), _p(idx), _st())
+    return idx
+
+
+class SAGroupFn(torch.autograd.Function):
+    """Edge rows ``[x_j | pos_j - pos_i | 0-pad]`` of a set-abstraction level over the compact edge list ``seg``
+    (PointNetConv.message's gathers).  Returns ``(rows [E, ldo], esrc int32 [E], ectr int32 [E])``."""
+
+    @staticmethod
+    def forward(ctx, x, pos4_src, pos4_ctr, nbr, seg, num_edges, ldo):
+        x = _chk(x.contiguous())
+        m, K = nbr.shape
+        C = x.shape[1]
+        dev = x.device
+        out = torch.empty((num_edges, ldo), dtype=torch.float32, device=dev)
+        esrc = torch.empty(num_edges, dtype=torch.int32, device=dev)
+        ectr = torch.empty(num_edges, dtype=torch.int32, device=dev)
+        call("m3d_sa_group", _p(x), x.stride(0), C, _p(_chk(pos4_src)), _p(_chk(pos4_ctr)), _p(_chk(nbr, torch.int32)),
+             _p(seg), m, K, _p(out), ldo, _p(esrc), _p(ectr), _st())
+        ctx.save_for_backward(esrc)
+        ctx.shape = (x.shape[0], C)
+        ctx.mark_non_differentiable(esrc, ectr)
+        return out, esrc, ectr
+
+    @staticmethod
+    def backward(ctx, dout, _a, _b):
+        (esrc,) = ctx.saved_tensors
+        n, C = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.zeros((n, C), dtype=torch.float32, device=dout.device)
+        call("m3d_sa_group_bwd", _p(dout), dout.stride(0), _p(esrc), esrc.numel(), C, _p(dx), C, _st())
+        return dx, None, None, None, None, None, None
+
+
+class SegMaxFn(torch.autograd.Function):
+    """``aggr="max"`` over the edges of each centre (torch_scatter.scatter_max: gradient to the arg-max edge)."""
+
+    @staticmethod
+    def forward(ctx, y, seg, ectr, m):
+        y = _chk(y.contiguous())
+        E, C = y.shape
+        out = torch.empty((m, C), dtype=torch.float32, device=y.device)
+        arg = torch.empty((m, C), dtype=torch.int32, device=y.device)
+        call("m3d_seg_max", _p(y), y.stride(0), _p(seg), m, C, _p(out), _p(arg), _st())
+        ctx.save_for_backward(arg, seg, ectr)
+        ctx.E = E
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, seg, ectr = ctx.saved_tensors
+        dout = _chk(dout.contiguous())
+        C = dout.shape[1]
+        dy = torch.empty((ctx.E, C), dtype=torch.float32, device=dout.device)
+        call("m3d_seg_max_bwd", _p(dout), _p(arg), _p(seg), _p(ectr), ctx.E, C, _p(dy), _st())
+        return dy, None, None, None

@@ -117,8 +117,12 @@ def test_registration_shim_uses_the_reference_class_factory(monkeypatch):
     assert fake.MODEL_ZOO.count(HipRandLANet) == 1
     assert fake.get_neural_net_class("HipRandLANet") is HipRandLANet
     assert fake.get_neural_net_class("PyGRandLANet") is PyGRandLANet
+    from myria3d_amd import HipPointNet2
+
+    # (substring matching, model.py:26-29: "PointNet" now finds the set-abstraction variant — BASELINE configs[4])
+    assert fake.get_neural_net_class("HipPointNet2") is HipPointNet2 and fake.get_neural_net_class("PointNet") is HipPointNet2
     with pytest.raises(KeyError):
-        fake.get_neural_net_class("PointNet")
+        fake.get_neural_net_class("KPConv")
 
 
 def test_product_never_imports_the_oracle():
