@@ -30,12 +30,24 @@ for name, g in (("B (step)", gB[0]), ("A (position-only)", gA[0])):
         ts.append((t1 - t0) * 1e6)
     torch.cuda.synchronize()
     print(f"host time of hipGraphLaunch {name}: median {sorted(ts)[5]:.0f} us (min {min(ts):.0f})")
-gs.prime()
-for _ in range(10):
-    gs.step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(50):
-    gs.step()
-torch.cuda.synchronize()
-print(f"{(time.perf_counter() - t0) / 50 * 1e3:.4f} ms per step")
+def run(tag):
+    gs.prime()
+    for _ in range(10):
+        gs.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        gs.step()
+    torch.cuda.synchronize()
+    print(f"{tag}: {(time.perf_counter() - t0) / 50 * 1e3:.4f} ms per step")
+
+
+run("default stream")
+lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+print("stream priority range", lo, hi)
+hp = torch.cuda.Stream(priority=-1)
+hp.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(hp):  # the step's graph replayed on a high-priority stream, the position-only graph on a normal one
+    run("step graph on a high-priority stream")
+torch.cuda.current_stream().wait_stream(hp)
+run("default stream again")
