@@ -463,7 +463,36 @@ def dropin_bench(args, dev):
     for _ in range(10):
         fwd()
     dtf = timed(fwd, 15, 1) / 15
+    # the same step when EVERY batch has its own tile sizes, as Lightning's loader delivers them (points_budget.yaml:
+    # 300 ... 40 000 nodes per tile): 8 batches of B tiles with sizes drawn around N, cycled — plans, arena and
+    # geometry buffers see new shapes every step
+    import numpy as np
+
+    net.train()
+    rs = np.random.RandomState(0)
+    var = []
+    for i in range(8):
+        sizes = [int(v) for v in rs.randint(N // 2, N + N // 2 + 1, size=B)]
+        vx, vpos, vbatch, vptr, vy = synthetic_batch(sizes, first_tile_id=100 * i)
+        var.append(tuple(t.to(dev) for t in (vx, vpos, vbatch, vptr, vy)))
+    turn = [0]
+
+    def vstep():
+        vx, vpos, vbatch, vptr, vy = var[turn[0] % len(var)]
+        turn[0] += 1
+        opt.zero_grad()
+        crit(net(vx, vpos, vbatch, vptr), vy).backward()
+        opt.step()
+
+    for _ in range(16):
+        vstep()
+    dtv = timed(vstep, 16, 1) / 16
+    mean_pts = sum(int(v[3][-1]) for v in var) / len(var)
     print(json.dumps({"dropin_eager_ms_per_step": round(dt * 1e3, 4), "value": round(B * N / dt, 1),
+                      "dropin_variable_layout_ms_per_step": round(dtv * 1e3, 4),
+                      "dropin_variable_layout_points_per_s": round(mean_pts / dtv, 1),
+                      "variable_layout": f"8 batches of {B} tiles, sizes uniform in [{N // 2}, {N + N // 2}] (mean "
+                                         f"{mean_pts:.0f} points per batch), a different layout every step",
                       "fwd_only_ms": round(dtf * 1e3, 4), "unit": "points/s",
                       "what": "HipRandLANet.forward(x, pos, batch, ptr) + torch CrossEntropyLoss + backward + torch.optim.Adam, "
                               "eager, no plan / prefetch_geometry / hipGraph / flat buffers"}), flush=True)
@@ -827,6 +856,7 @@ def _extra_legs(args, dev, res, B, N, K):
     def dropin():  # the plain drop-in step (what model.py:79 + Lightning's loop get) in a process of its own
         di = _leg_in_fresh_process(["--mode", "dropin", "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
         res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
+        res["dropin_variable_layout_ms_per_step"] = di.get("dropin_variable_layout_ms_per_step")
         res["dropin"] = di
 
     def collective():  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)

@@ -143,6 +143,53 @@ def test_train_steps_follow_the_oracle(device):
     assert lg.item() < 3.0
 
 
+def test_training_loop_over_changing_tile_layouts(device):
+    """What a Lightning loop feeds the boundary (model.py:79): every batch has its own number of tiles and its own tile
+    sizes (points_budget.yaml: 300 ... 40 000 nodes).  Four steps over four different layouts through the flat path — the
+    plan cache, the zero arena (sized by the previous step), the gradient slots and the deferred launches all see shapes
+    change under them — against the CPU oracle + torch.optim.Adam on the same batches; then the first layout again, and
+    a step whose tables were prefetched for ANOTHER layout (the stale prefetch must not be consumed)."""
+    from myria3d_amd import FusedAdam, HipRandLANet, cross_entropy
+    from oracle.randla_oracle import RandLANetOracle, fixed_decimation_indices
+
+    ref = RandLANetOracle(9, 6, return_logits=True)
+    fill_params_deterministic(ref, 5)
+    net = HipRandLANet(9, 6, return_logits=True)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(device).flatten_parameters()
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    opt_g = FusedAdam(net, lr=1e-3)
+    ref.train(), net.train()
+    layouts = [[2600, 1900], [3100], [1500, 1700, 2100], [4000, 300], [2600, 1900]]
+    for step, sizes in enumerate(layouts):
+        x, pos, batch, ptr = rand_batch(sizes, seed=40 + step)
+        dec = fixed_decimation_indices(ptr.tolist(), 4, seed=step)
+        rs = np.random.RandomState(step)
+        mask = torch.from_numpy((rs.uniform(size=(sum(sizes), 32)) > 0.5).astype(np.float32))
+        y = torch.from_numpy(rs.randint(0, 6, (sum(sizes),)))
+        opt_r.zero_grad()
+        lr_ = torch.nn.functional.cross_entropy(ref(x, pos, batch, ptr, decimation_idx=dec, dropout_mask=mask), y)
+        lr_.backward()
+        opt_r.step()
+        if step == 3:  # tables of a different batch are pending when this one arrives
+            xo, po, bo, pto = rand_batch([900, 800], seed=77)
+            net.prefetch_geometry(po.to(device), pto.to(device))
+        lg = cross_entropy(net(x.to(device), pos.to(device), batch.to(device), ptr.to(device), decimation_idx=dec,
+                               dropout_mask=mask.to(device)), y.to(device), ignore_index=65)
+        lg.backward()
+        opt_g.step()
+        print(f"[parity] step {step} {sizes}: loss oracle {lr_.item():.6f} hip {lg.item():.6f}")
+        assert abs(lr_.item() - lg.item()) < (1e-3 + 2e-3 * step) * max(1.0, abs(lr_.item()))
+    got = dict(net.named_parameters())
+    worst = 0.0
+    for name, p in ref.named_parameters():  # five Adam steps later the two parameter sets still agree
+        d = (got[name].detach().cpu() - p.detach()).abs().max().item()
+        worst = max(worst, d)
+        assert d < 6e-3, (name, d)  # (5 steps x lr 1e-3: Adam moves a weight by at most lr per step)
+    print(f"[parity] largest parameter difference after 5 steps: {worst:.3e}")
+    net.join_geometry()
+
+
 def test_hipgraph_replay_matches_eager_steps(device):
     """bench.py replays the whole step as a hipGraph with parallel branches (position-only work and weight gradients on
     side streams): two replayed steps must leave the same parameters as two eager steps."""
