@@ -488,7 +488,31 @@ def dropin_bench(args, dev):
         vstep()
     dtv = timed(vstep, 16, 1) / 16
     mean_pts = sum(int(v[3][-1]) for v in var) / len(var)
+    # ... and with the opt-ins of INTEGRATION.md section 3 on the same changing layouts: flat buffers + FusedAdam + the HIP
+    # criterion + the next batch's position-only work interleaved with this step (no graph: the layouts differ)
+    from myria3d_amd import FusedAdam, cross_entropy
+
+    del opt
+    net2 = HipRandLANet(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev).train().flatten_parameters()
+    opt2 = FusedAdam(net2, lr=0.003933709606504788)
+    turn[0] = 0
+
+    def ostep():
+        vx, vpos, vbatch, vptr, vy = var[turn[0] % len(var)]
+        nxt = var[(turn[0] + 1) % len(var)]
+        turn[0] += 1
+        net2.prefetch_geometry(nxt[1], nxt[3], interleave=True)
+        cross_entropy(net2(vx, vpos, vbatch, vptr), vy, ignore_index=65).backward()
+        opt2.step()
+
+    net2.prefetch_geometry(var[0][1], var[0][3])
+    for _ in range(24):
+        ostep()
+    dto = timed(ostep, 16, 1) / 16
+    net2.join_geometry()
     print(json.dumps({"dropin_eager_ms_per_step": round(dt * 1e3, 4), "value": round(B * N / dt, 1),
+                      "optin_variable_layout_ms_per_step": round(dto * 1e3, 4),
+                      "optin_variable_layout_points_per_s": round(mean_pts / dto, 1),
                       "dropin_variable_layout_ms_per_step": round(dtv * 1e3, 4),
                       "dropin_variable_layout_points_per_s": round(mean_pts / dtv, 1),
                       "variable_layout": f"8 batches of {B} tiles, sizes uniform in [{N // 2}, {N + N // 2}] (mean "
@@ -857,6 +881,7 @@ def _extra_legs(args, dev, res, B, N, K):
         di = _leg_in_fresh_process(["--mode", "dropin", "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
         res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
         res["dropin_variable_layout_ms_per_step"] = di.get("dropin_variable_layout_ms_per_step")
+        res["optin_variable_layout_ms_per_step"] = di.get("optin_variable_layout_ms_per_step")
         res["dropin"] = di
 
     def collective():  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)
