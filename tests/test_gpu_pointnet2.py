@@ -253,3 +253,39 @@ def test_dense_tile_40000_points_k32_eval_matches_oracle(device):
     want = fps_exact(pos, [0, 40000], [0, 10000])
     assert torch.equal(net.last_sample_idx[0].cpu().long(), want)
     _report("logits", out_g, out_r, 2e-4, 2e-4)
+
+
+def test_committed_fixture_vs_hip_net(device):
+    """The HIP net against tests/golden/pointnet2_small.npz directly (no oracle run on the GPU box): sampled indices
+    bit-exact, eval / train logits, loss, four parameter gradients, a running variance."""
+    import os
+
+    from myria3d_amd.pointnet2 import HipPointNet2
+    from oracle.pointnet2_oracle import PointNet2Oracle
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pointnet2_small.npz"))
+    x, pos, ptr = (torch.from_numpy(g[k]).to(device) for k in ("x", "pos", "ptr"))
+    shell = PointNet2Oracle(9, 6, num_neighbors=int(g["k"]), return_logits=True)  # (parameter tree + deterministic fill only)
+    fill_params_deterministic(shell, int(g["param_seed"]))
+    net = HipPointNet2(9, 6, num_neighbors=int(g["k"]), return_logits=True)
+    net.load_state_dict(shell.state_dict())
+    net = net.to(device).eval()
+    with torch.no_grad():
+        out = net(x, pos, None, ptr)
+    for i in range(3):
+        assert np.array_equal(net.last_sample_idx[i].cpu().numpy().astype(np.int64), g[f"fps{i}"]), i
+    _report("fixture.logits_eval", out, torch.from_numpy(g["logits_eval"]), 2e-4, 2e-4)
+    net.train()
+    lt = net(x, pos, None, ptr, dropout_mask=torch.from_numpy(g["dropout_mask"]).to(device))
+    loss = torch.nn.functional.cross_entropy(lt, torch.from_numpy(g["y"]).to(device))
+    loss.backward()
+    _report("fixture.logits_train", lt, torch.from_numpy(g["logits_train"]), 2e-3, 2e-3)
+    assert abs(loss.item() - float(g["loss_train"])) < 1e-3
+    params = dict(net.named_parameters())
+    for name, key in (("sa1.nn.lins.0.weight", "grad_sa1_lin0"), ("sa3.nn.lins.2.weight", "grad_sa3_lin2"),
+                      ("fp1.nn.lins.0.weight", "grad_fp1_lin0"), ("fc_classif.weight", "grad_fc_classif")):
+        gr = torch.from_numpy(g[key]).double()
+        rel = (params[name].grad.cpu().double() - gr).norm().item() / gr.norm().item()
+        assert rel <= 5e-3, (name, rel)  # (fp32 on both sides)
+    assert torch.allclose(net.sa2.nn.norms[1].module.running_var.cpu(), torch.from_numpy(g["running_var_sa2_bn1"]),
+                          rtol=1e-3, atol=1e-5)

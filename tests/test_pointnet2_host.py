@@ -57,3 +57,30 @@ def test_oracle_runs_on_cpu_and_max_aggregation_routes_the_gradient():
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ref.parameters())
     assert [t.numel() for t in ref.last_sample_idx] == [15 + 1 + 8, 3 + 1 + 2, 1 + 1 + 1]
+
+
+def test_oracle_reproduces_its_committed_fixture():
+    """tests/golden/pointnet2_small.npz (make_golden_pointnet2.py): the restated oracle has not drifted.  The fixture pins
+    the oracle to itself only — there is no reference implementation of this variant (model.py:12)."""
+    import os
+
+    from oracle.pointnet2_oracle import PointNet2Oracle
+    from tests._util import fill_params_deterministic
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pointnet2_small.npz"))
+    x, pos, ptr = torch.from_numpy(g["x"]), torch.from_numpy(g["pos"]), torch.from_numpy(g["ptr"])
+    net = PointNet2Oracle(9, 6, num_neighbors=int(g["k"]), return_logits=True)
+    fill_params_deterministic(net, int(g["param_seed"]))
+    net.eval()
+    with torch.no_grad():
+        out = net(x, pos, None, ptr)
+    for i in range(3):
+        assert np.array_equal(net.last_sample_idx[i].numpy(), g[f"fps{i}"]), i
+    assert np.allclose(out.numpy(), g["logits_eval"], rtol=1e-5, atol=1e-5)
+    net.train()
+    lt = net(x, pos, None, ptr, dropout_mask=torch.from_numpy(g["dropout_mask"]))
+    loss = torch.nn.functional.cross_entropy(lt, torch.from_numpy(g["y"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss_train"])) < 1e-5
+    assert np.allclose(dict(net.named_parameters())["sa3.nn.lins.2.weight"].grad.numpy(), g["grad_sa3_lin2"], rtol=1e-3,
+                       atol=1e-6)
