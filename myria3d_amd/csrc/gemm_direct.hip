@@ -46,6 +46,12 @@
 #endif
 #include "../../include/m3d_hip.h"
 
+// (GEMM_DBG: timing ablations of the statistics epilogue, never in the product build — bit 0: no flush at all (the
+// accumulation is dead code then), bit 1: no atomics / stores at its end, bit 2: no per-element accumulation)
+#ifndef GEMM_DBG
+#define GEMM_DBG 0
+#endif
+
 __device__ __forceinline__ float f4(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 // ------------------------------------------------------------------------------------------
@@ -235,7 +241,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float z = acc[r] + f4(e.bia, r);
-    if (MODE == 1) {
+    if (MODE == 1 && !(GEMM_DBG & 4)) {
       // fp64: columns with |mean| >> std (tiny batches at the deepest level) lose the variance otherwise
       const double zd = (rowok && n0 + r < g.N) ? (double)z : 0.0;
       ssum[r] += zd;
@@ -280,17 +286,22 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
 
 // per-lane fp64 column partials -> over the 16 row lanes -> LDS over the workgroup's waves -> this workgroup's
 // partial row of stat_part.  Lane (lr, lg) holds columns nb + 16t + 4lg + r.
+// Cross-lane part: row16_sum_d (m3d_common.h) — exact fp64 sums over the 16 row lanes with DPP moves.  (__shfl_xor on a
+// double is two ds_bpermute_b32: 256 LDS-pipe round trips per wave in this flush, at the END of every workgroup, every
+// workgroup of a CU at once — the statistics epilogue cost 156 us of the 522 us the forward GEMMs of a step take, almost all
+// of it here: profiles/r03y_gemm_stats_epilogue.log.  With DPP moves: 440 us.  Accumulating in fp32 around a shared
+// per-column shift and reducing in fp32 was 420 us but gives up what the fp64 partials have: they are EXACT sums of fp32
+// values, so the fp64 atomics that combine workgroups commute and the train-mode forward is bit-reproducible.)
 template <int NT, int NWAVES>
 __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&ssum)[NT][4], double (&ssq)[NT][4]) {
+  if (GEMM_DBG & 1) return;
   __shared__ double sred[NWAVES][2][16 * NT];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double a = ssum[t][r], q = ssq[t][r];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+      const double a = row16_sum_d(ssum[t][r]), q = row16_sum_d(ssq[t][r]);
       if (lr == 0) { sred[wid][0][t * 16 + lg * 4 + r] = a; sred[wid][1][t * 16 + lg * 4 + r] = q; }
     }
   __syncthreads();
@@ -301,6 +312,7 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
       double v = 0.0;
 #pragma unroll
       for (int w = 0; w < NWAVES; ++w) v += sred[w][which][col];
+      if (GEMM_DBG & 2) return;
       if (g.stat_slots > 0) {
         // slot mode: a few fp64 atomics per address (workgroups / slots); the table was zeroed by the caller
         atomicAdd(&g.stat_part[((size_t)(blockIdx.x % g.stat_slots) * 2 + which) * g.N + n], v);

@@ -55,16 +55,33 @@ __device__ __forceinline__ float xgroup_max(float v) {
   xgroup_pair32(v, a, b); v = fmaxf(a, b);
   return v;
 }
+// fp64 sums across lanes without the LDS pipe: __shfl_xor on a double is two ds_bpermute_b32 per step; the two 32-bit halves
+// travel as DPP moves inside a row of 16 lanes (quad xor 1, quad xor 2, half mirror, mirror: every lane ends with the row
+// sum) and as row swaps across rows.  The GEMM statistics flush went from 156 to 74 us per step with it
+// (profiles/r03y_gemm_stats_epilogue.log).
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum_d(double v) {
+  v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_d<0x141>(v);  // row_half_mirror
+  v += dpp_d<0x140>(v);  // row_mirror
+  return v;
+}
 __device__ __forceinline__ double xgroup_sum_d(double v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  float alo, blo, ahi, bhi;
+  xgroup_pair16(__int_as_float(__double2loint(v)), alo, blo);
+  xgroup_pair16(__int_as_float(__double2hiint(v)), ahi, bhi);
+  v = __hiloint2double(__float_as_int(ahi), __float_as_int(alo)) + __hiloint2double(__float_as_int(bhi), __float_as_int(blo));
+  xgroup_pair32(__int_as_float(__double2loint(v)), alo, blo);
+  xgroup_pair32(__int_as_float(__double2hiint(v)), ahi, bhi);
+  return __hiloint2double(__float_as_int(ahi), __float_as_int(alo)) + __hiloint2double(__float_as_int(bhi), __float_as_int(blo));
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum_d(double v) { return xgroup_sum_d(row16_sum_d(v)); }
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -230,6 +230,34 @@ def test_gemm_forward(device, M, K, N):
     _close("gemm.affine_lrelu", got2, ref2, 1e-5, 4e-6 * K)
 
 
+
+@pytest.mark.parametrize("M,K,N,slots", [(37, 128, 64, False), (800, 512, 512, True), (3200, 256, 512, True),
+                                         (204800, 32, 32, True), (51200, 64, 128, False), (20000, 16, 8, True)])
+def test_gemm_statistics_of_columns_with_mean_far_from_zero(device, M, K, N, slots):
+    """Train-mode BatchNorm statistics from the GEMM epilogue (fp32 partial sums around a per-lane shift, fp64 across lanes)
+    for columns whose mean is 1 000 standard deviations away from zero — the case a plain fp32 sum of squares loses: the
+    variance recovered from (sum, sum of squares) stays within 1e-4 of the fp64 variance of the same fp32 outputs."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M % 97)
+    a = torch.from_numpy(rs.normal(size=(M, K)).astype(np.float32)).to(device)
+    w = torch.from_numpy((rs.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)).to(device)
+    b = torch.from_numpy(rs.uniform(-1000.0, 1000.0, N).astype(np.float32)).to(device)
+    if slots:
+        st = ops.stat_slots(N, device, M)
+        z = ops.gemm(a, w, M, N, K, bias=b, stats=st, stat_slots=True)
+    else:
+        st = ops.stat_buffer(M, N, K, device)
+        z = ops.gemm(a, w, M, N, K, bias=b, stats=st)
+    tot = st.sum(0)  # [2, N]
+    zd = z.double()
+    mean, var = tot[0] / M, tot[1] / M - (tot[0] / M) ** 2
+    ref_mean, ref_var = zd.mean(0), zd.var(0, unbiased=False)
+    assert torch.allclose(mean, ref_mean, rtol=1e-9, atol=1e-6), (mean - ref_mean).abs().max().item()
+    rel = ((var - ref_var).abs() / ref_var).max().item()
+    print(f"[parity] variance of columns with |mean| up to 1000: worst relative error {rel:.2e} (M={M})")
+    assert rel < 1e-4, rel
+
 @pytest.mark.parametrize("M,N,K", [(30000, 32, 32), (1001, 6, 32), (777, 32, 9), (1000, 128, 200), (4096, 64, 16),
                                    (3, 512, 768), (12800, 4, 32), (5, 8, 8)])
 def test_wgrad_and_dgrad(device, M, N, K):
