@@ -9,6 +9,7 @@
 //                        residual: LeakyReLU(mlp2(x) + shortcut(x)), pyg_randla_net.py:186-187)
 //   m3d_bn_bwd_reduce / m3d_bn_bwd_apply -> gradient w.r.t. the raw Linear output(s), gamma, beta.
 // All HBM-bound elementwise / column-reduction kernels: float4 accesses, fp64 column accumulators.
+#include <stdlib.h>
 #include "m3d_common.h"
 #include "../../include/m3d_hip.h"
 
@@ -455,7 +456,12 @@ static BnBwdPlan bn_bwd_plan(int64_t M, int N) {
   const int CG = N4 < 256 ? N4 : 256;
   const int rpp = 256 / CG;
   p.passes = m3d_cdiv(N4, CG);
-  int64_t blocks = m3d_cdiv(M, (int64_t)rpp * 8);  // ~8 rows per thread
+  // rows per thread: every block ends in an LDS tree + atomics that cost as much as streaming ~8 rows per thread
+  // (M3D_BN_BWD_RPT: A/B knob, tools/opbench.py bnbwd)
+  // round 3: 16 for N >= 32 (386 -> 343 us over the step's 27 layers), 8 below (narrow layers have too few blocks otherwise)
+  static const int rpt_env = getenv("M3D_BN_BWD_RPT") ? atoi(getenv("M3D_BN_BWD_RPT")) : 0;
+  const int rpt = rpt_env > 0 ? rpt_env : (N >= 32 ? 16 : 8);
+  int64_t blocks = m3d_cdiv(M, (int64_t)rpp * rpt);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   p.rows_per_block = m3d_align(m3d_cdiv(M, blocks), rpp);

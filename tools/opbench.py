@@ -1,5 +1,5 @@
 """Per-op timing at the BASELINE config-2 shapes (16 x 12 800 points): run on the GPU box via gpurun.
-usage: python tools/opbench.py [gemm] [wgrad] [knn] [lfa] [bn]"""
+usage: python tools/opbench.py [gemm] [wgrad] [knn] [lfa] [bn] [bnbwd]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myria3d_amd import ops
@@ -55,6 +55,33 @@ if "gemm" in what or "wgrad" in what:
             tw += t3
         print(line)
     print(f"TOTAL fwd {tf:.0f} us, dgrad {td:.0f} us, wgrad {tw:.0f} us")
+if "bnbwd" in what:
+    # backward of every SharedMLP layer's BatchNorm + Linear input gradient: the column-sum pass (m3d_bn_bwd, reduce only)
+    # and the fused dz-on-load input-gradient GEMM (m3d_bn_dgrad_f32), beside the plain input-gradient GEMM of the same shape
+    tr = tf_ = tp = 0.0
+    for name, lvl, k0, k1, N in FWD:
+        if name in ("fc0", "fc_cls") or not ops.bn_dgrad_ok(N):
+            continue
+        M = LEVELS[lvl]; K = k0 + k1
+        w = torch.randn(N, K, device=dev); dy = torch.randn(M, N, device=dev); z = torch.randn(M, N, device=dev)
+        sc, sh, mu, isd = (torch.rand(N, device=dev) + 0.5 for _ in range(4))
+        ns = ops.bn_bwd_slots(M)
+        sums = torch.zeros((ns, 3, N), dtype=torch.float64, device=dev)
+        def red():
+            ops.call("m3d_bn_bwd", dy.data_ptr(), z.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), None, None,
+                     None, None, None, 1, 0.2, M, N, sums.data_ptr(), None, None, None, None, None, None, 2 | (ns << 8),
+                     torch.cuda.current_stream().cuda_stream)
+        dx = torch.empty(M, K, device=dev); dz = torch.empty(M, N, device=dev); dg = torch.empty(N, device=dev); db = torch.empty(N, device=dev)
+        def fused():
+            ops.call("m3d_bn_dgrad_f32", dy.data_ptr(), z.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 1, 0.2,
+                     sums.data_ptr(), ns, M, N, w.data_ptr(), w.stride(0), K, dx.data_ptr(), K, dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                     0, 0, None, 0, torch.cuda.current_stream().cuda_stream)
+        t1, t2, t3 = timeit(red), timeit(fused), timeit(lambda: ops.linear_dgrad(dz, w))
+        byt_r = 8 * M * N; byt_f = 4 * M * (3 * N + K)
+        print(f"{name:9s} M={M:6d} N={N:4d} Kin={K:4d}  reduce {t1:6.1f}us ({byt_r/t1/1e3:5.0f} GB/s)  fused dz+dgrad {t2:6.1f}us "
+              f"({byt_f/t2/1e3:5.0f} GB/s)  plain dgrad {t3:6.1f}us")
+        tr += t1; tf_ += t2; tp += t3
+    print(f"TOTAL reduce {tr:.0f} us, fused {tf_:.0f} us, plain dgrad {tp:.0f} us")
 if "bn" in what:
     for M, N in [(204800, 32), (204800, 64), (51200, 128), (12800, 256), (3200, 512)]:
         z = torch.randn(M, N, device=dev); dy = torch.randn(M, N, device=dev)
