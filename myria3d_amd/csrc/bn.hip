@@ -458,9 +458,11 @@ static BnBwdPlan bn_bwd_plan(int64_t M, int N) {
   p.passes = m3d_cdiv(N4, CG);
   // rows per thread: every block ends in an LDS tree + atomics that cost as much as streaming ~8 rows per thread
   // (M3D_BN_BWD_RPT: A/B knob, tools/opbench.py bnbwd)
-  // round 3: 16 for N >= 32 (386 -> 343 us over the step's 27 layers), 8 below (narrow layers have too few blocks otherwise)
+  // round 3: 16 for the big layers (>= 1.5 M float4 per operand: 20 -> 16, 36 -> 29, 41 -> 30 us inside the step), 8 below —
+  // back-to-back microbenchmarks like 16 everywhere, but inside the dependent chain of the step the small layers lose
+  // 3-4 us each to the smaller grid (profiles/r03end_step_timeline.csv vs the run before)
   static const int rpt_env = getenv("M3D_BN_BWD_RPT") ? atoi(getenv("M3D_BN_BWD_RPT")) : 0;
-  const int rpt = rpt_env > 0 ? rpt_env : (N >= 32 ? 16 : 8);
+  const int rpt = rpt_env > 0 ? rpt_env : (M * N4 >= 1500000 ? 16 : 8);
   int64_t blocks = m3d_cdiv(M, (int64_t)rpp * rpt);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
