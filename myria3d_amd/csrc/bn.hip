@@ -182,24 +182,33 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
   // every block derives the N column constants ONCE (one thread per column, a few slot rows each, fp64) into LDS
   __shared__ float s_sc[BN_MAXN], s_sh[BN_MAXN], s_sc2[BN_MAXN], s_sh2[BN_MAXN];
   const bool writer = blockIdx.x == 0;
+  // the first rows of this thread are requested BEFORE the column pass: the pass is a dependent chain of its own (slot
+  // loads -> fp64 divide / sqrt -> LDS) and the small layers are nothing but latency (16 of the step's 23 launches: ~8 us)
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool has0 = i < a.total4;
+  float4 v0 = make_float4(0, 0, 0, 0), w0 = make_float4(0, 0, 0, 0);
+  if (has0) {
+    v0 = a.z[i];
+    if (a.b2.slots) w0 = a.z2[i];
+  }
   for (int n = threadIdx.x; n < a.N; n += 256) {
     bn_stats_col(a, a.b1, n, writer, s_sc[n], s_sh[n]);
     if (a.b2.slots) bn_stats_col(a, a.b2, n, writer, s_sc2[n], s_sh2[n]);
   }
   __syncthreads();
   const int N4 = a.N / 4;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.total4) return;
+  if (!has0) return;
   const int c = (int)(i % N4) * 4;  // fixed for this thread: the grid stride is a multiple of N4 (checked by the host)
   const float4 sc = *(const float4*)&s_sc[c], sh = *(const float4*)&s_sh[c];
   float4 s2 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
   if (a.b2.slots) { s2 = *(const float4*)&s_sc2[c]; h2 = *(const float4*)&s_sh2[c]; }
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (; i < a.total4; i += stride) {
-    const float4 v = a.z[i];
+  bool first = true;
+  for (; i < a.total4; i += stride, first = false) {
+    const float4 v = first ? v0 : a.z[i];
     float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
     if (a.b2.slots) {
-      const float4 w = a.z2[i];
+      const float4 w = first ? w0 : a.z2[i];
       u.x += w.x * s2.x + h2.x; u.y += w.y * s2.y + h2.y; u.z += w.z * s2.z + h2.z; u.w += w.w * s2.w + h2.w;
     }
     if (a.act) { u.x = lrelu(u.x, a.slope); u.y = lrelu(u.y, a.slope); u.z = lrelu(u.z, a.slope); u.w = lrelu(u.w, a.slope); }

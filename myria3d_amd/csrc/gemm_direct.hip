@@ -337,7 +337,6 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
   const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc(g.c), rc1 = mk_rsrc(g.c1);
   __shared__ float cf[PRO ? 6 : 1][PRO ? 64 : 4];
   const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
-  if constexpr (PRO) pro_setup<64>(g, (float (&)[6][64])cf);
   float4 w[NT][KQ];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -346,6 +345,9 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
   Epi<MODE> e[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) e[t] = epi_load<MODE>(g, nb + 16 * t + 4 * lg);
+  // (after the weight / bias loads were issued: the column pass is a dependent chain of its own — slot loads, fp64, LDS,
+  // barrier — and the small layers are nothing but latency)
+  if constexpr (PRO) pro_setup<64>(g, (float (&)[6][64])cf);
   double ssum[NT][4], ssq[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
