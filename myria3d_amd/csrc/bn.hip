@@ -471,6 +471,8 @@ static BnBwdPlan bn_bwd_plan(int64_t M, int N) {
   // back-to-back microbenchmarks like 16 everywhere, but inside the dependent chain of the step the small layers lose
   // 3-4 us each to the smaller grid (profiles/r03end_step_timeline.csv vs the run before)
   static const int rpt_env = getenv("M3D_BN_BWD_RPT") ? atoi(getenv("M3D_BN_BWD_RPT")) : 0;
+  // (tried: fewer rows per thread on the small layers for >= 512 blocks — 372 -> 439 us inside the step: more block tails
+  // and slot atomics cost more than the extra parallelism gives)
   const int rpt = rpt_env > 0 ? rpt_env : (M * N4 >= 1500000 ? 16 : 8);
   int64_t blocks = m3d_cdiv(M, (int64_t)rpp * rpt);
   if (blocks > 2048) blocks = 2048;

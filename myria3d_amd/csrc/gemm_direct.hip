@@ -406,10 +406,10 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
     if constexpr (PRO) return a_frag_pro<PRO_KMAX>(g, ra0, rz, r, k, (const float (&)[6][PRO_KMAX])cf, pst);
     else return a_frag<VEC, CAT>(g, ra0, ra1, r, k, K);
   };
-  if constexpr (PRO) pro_setup<PRO_KMAX>(g, (float (&)[6][PRO_KMAX])cf);
   Epi<MODE> e[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) e[t] = epi_load<MODE>(g, nb + 16 * t + 4 * lg);
+  if constexpr (PRO) pro_setup<PRO_KMAX>(g, (float (&)[6][PRO_KMAX])cf);
   double ssum[NTW][4], ssq[NTW][4];
 #pragma unroll
   for (int t = 0; t < NTW; ++t)
