@@ -30,7 +30,6 @@ from typing import List, Optional
 import torch
 from torch import Tensor
 
-from . import ops
 from .randla import HipRandLANet, make_plan
 from .train import FusedAdam, cross_entropy
 
