@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 12
+#define M3D_ABI_VERSION 13
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -39,7 +39,9 @@ int m3d_stream_capture_id(void* stream, uint64_t* id_out);
  * torch_cluster.knn as called by knn_graph(pos, K, batch, loop=True)
  * (myria3d/models/modules/pyg_randla_net.py:180), knn_interpolate(k=1) (pyg_randla_net.py:250) and
  * knn_interpolate(k=10) (myria3d/models/model.py:90-98).  Exact; squared-L2 within each cloud; self included;
- * ascending by (d2, source index).  k <= 64. */
+ * ascending by (d2, source index).  k <= 100, the bound the upstream CUDA kernel asserts (k > 64: two passes of the
+ * search, the 64 nearest and then the next k - 64 in the same total order).  No run-time knobs: the library reads no
+ * environment variable. */
 size_t m3d_knn_workspace_bytes(int64_t n_src, int32_t num_clouds);
 /* byte offset, inside a built workspace, of the cell-sorted arrays: which = 0: float4 [n_src] (x, y, z, bits of the
  * original row); 1: perm int32 [n_src] (sorted slot -> original row); 2: inv int32 [n_src] (original row -> slot).
@@ -54,33 +56,23 @@ int m3d_knn_build_map(const float* pos_src, int32_t pos_stride, const int64_t* p
                       int64_t n_src, void* ws, const int32_t* map_in, int32_t* map_out, void* stream);
 /* queries: either pos_qry rows (row q -> idx_out[q]) or, if qry_ws != NULL, the points of another built
  * workspace in its cell-sorted order (wave-coherent; each record carries its original row).  Self-kNN =
- * qry_ws == ws.  d2_out may be NULL.  sorted_io != 0 (needs qry_ws): output row = the query's cell-sorted slot and
- * neighbour ids = cell-sorted slots of the source workspace (selection and tie-breaking stay on original rows). */
+ * qry_ws == ws.  d2_out may be NULL.  flags bit 0 (sorted_io; needs qry_ws): output row = the query's cell-sorted slot
+ * and neighbour ids = cell-sorted slots of the source workspace (selection and tie-breaking stay on original rows).
+ * flags bits 1-2: which of the two bit-identical search kernels runs — 0: chosen by size (deferred insertion from
+ * 2^20 (query, neighbour) pairs), 1: deferred insertion (used for 4 < k <= 64), 2: direct insertion; for parity tests
+ * and A/B timing (the library has no other switch). */
 int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds, const float* pos_qry,
                   int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
-                  int32_t sorted_io, int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */,
+                  int32_t flags, int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */,
                   void* stream);
-/* Staged form of m3d_knn_query for CELL-SORTED queries (qry_ws) and 4 < k <= 32: the same search cut into launches by
- * ring radius — the queries whose search is still open after a stage are compacted into a pool (scratch) and get a
- * group of lanes each in the next stage — so that the launch no longer ends on its slowest wavefronts
- * (csrc/knn.hip: knn_stage_kernel).  Bit-identical tables; measured slower than the single launch on Lidar-HD-shaped
- * tiles (profiles/r03_knn_staged.log), hence opt-in: m3d_knn_staged_supported is 1 only with M3D_KNN_STAGED=1 in the
- * environment (and 4 < k <= 32).  scratch: m3d_knn_staged_workspace_bytes bytes
- * of device memory, contents irrelevant, must stay alive until the launches have run. */
-size_t m3d_knn_staged_workspace_bytes(int64_t n_qry, int32_t k);
-int m3d_knn_staged_supported(int64_t n_qry, int32_t k);
-int m3d_knn_query_staged(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds, const void* qry_ws,
-                         const int64_t* ptr_qry, int64_t n_qry, int32_t k, int32_t sorted_io, int32_t* idx_out,
-                         float* d2_out, void* scratch, void* stream);
-
 /* Up to 8 independent queries in ONE launch: job j searches the grid ws[j] (n_src[j] sources) for the cell-sorted queries
- * of qry_ws[j] (n_qry[j]; may be ws[j] itself) and writes idx_out[j][n_qry[j], k].  Same k, num_clouds and sorted_io
- * for every job, no distances, bit-identical to njobs calls of m3d_knn_query.  The pointer arrays are HOST arrays (read
+ * of qry_ws[j] (n_qry[j]; may be ws[j] itself) and writes idx_out[j][n_qry[j], k].  Same k (<= 64), num_clouds and
+ * flags (as m3d_knn_query) for every job, no distances, bit-identical to njobs calls of m3d_knn_query.  The pointer arrays are HOST arrays (read
  * during the call).  Used for the four K-NN tables / the four decoder 1-NN tables of a forward pass
  * (pyg_randla_net.py:180, :250), whose deep-level launches are otherwise latency-bound one after the other. */
 int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const int64_t* const* ptr_src, const int64_t* n_src,
                         const void* const* qry_ws, const int64_t* const* ptr_qry, const int64_t* n_qry,
-                        int32_t num_clouds, int32_t k, int32_t sorted_io, int32_t* const* idx_out, void* stream);
+                        int32_t num_clouds, int32_t k, int32_t flags, int32_t* const* idx_out, void* stream);
 
 /* ---- SharedMLP GEMM -------------------------------------------------------------------------------------
  * Linear of PyG MLP / torch.nn.Linear (pyg_randla_net.py:42,53,97-109), forward, dgrad and wgrad:

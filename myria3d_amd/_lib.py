@@ -25,9 +25,6 @@ SIGNATURES = {
     "m3d_knn_build_map": (_i32, [_p, _i32, _p, _i32, _i64, _p, _p, _p, _p]),
     "m3d_knn_workspace_offset": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_knn_query": (_i32, [_p, _p, _i64, _i32, _p, _i32, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
-    "m3d_knn_staged_workspace_bytes": (C.c_size_t, [_i64, _i32]),
-    "m3d_knn_staged_supported": (_i32, [_i64, _i32]),
-    "m3d_knn_query_staged": (_i32, [_p, _p, _i64, _i32, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p]),
     "m3d_gemm_stat_parts": (_i32, [_i64, _i32, _i32]),
     "m3d_gemm_f32": (_i32, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _i32,
                             _f32, _p, _i32, _p, _i64, _i32, _i32, _p]),
@@ -90,7 +87,7 @@ SIGNATURES = {
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
 }
 
-ABI_VERSION = 12  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 13  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

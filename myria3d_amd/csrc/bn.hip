@@ -148,6 +148,9 @@ struct BnStatsApplyArgs {
   const float4* z; const float4* z2; int act; float slope; float4* y; int64_t total4; int N;
 };
 
+#ifndef BN_BWD_RPT
+#define BN_BWD_RPT 0  // rows per thread of the backward column sums; 0: by layer size (see bn_bwd_plan)
+#endif
 #define BN_MAXN 1024  // widest BatchNorm the fused kernels keep in LDS (this network: 512)
 
 // scale / shift of column n from the slot sums (fp64); `writer`: also store the backward inputs and update the
@@ -466,14 +469,13 @@ static BnBwdPlan bn_bwd_plan(int64_t M, int N) {
   const int rpp = 256 / CG;
   p.passes = m3d_cdiv(N4, CG);
   // rows per thread: every block ends in an LDS tree + atomics that cost as much as streaming ~8 rows per thread
-  // (M3D_BN_BWD_RPT: A/B knob, tools/opbench.py bnbwd)
+  // (BN_BWD_RPT: compile-time A/B knob, tools/opbench.py bnbwd)
   // round 3: 16 for the big layers (>= 1.5 M float4 per operand: 20 -> 16, 36 -> 29, 41 -> 30 us inside the step), 8 below —
   // back-to-back microbenchmarks like 16 everywhere, but inside the dependent chain of the step the small layers lose
   // 3-4 us each to the smaller grid (profiles/r03end_step_timeline.csv vs the run before)
-  static const int rpt_env = getenv("M3D_BN_BWD_RPT") ? atoi(getenv("M3D_BN_BWD_RPT")) : 0;
   // (tried: fewer rows per thread on the small layers for >= 512 blocks — 372 -> 439 us inside the step: more block tails
   // and slot atomics cost more than the extra parallelism gives)
-  const int rpt = rpt_env > 0 ? rpt_env : (M * N4 >= 1500000 ? 16 : 8);
+  const int rpt = BN_BWD_RPT > 0 ? BN_BWD_RPT : (M * N4 >= 1500000 ? 16 : 8);
   int64_t blocks = m3d_cdiv(M, (int64_t)rpp * rpt);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;

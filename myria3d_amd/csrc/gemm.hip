@@ -225,9 +225,11 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   g.splitk = splitk; g.kchunk = kchunk;
   {
     // fragment-direct kernels (gemm_direct.hip) cover the network's shapes; this LDS-tiled kernel is the fallback
-    // (and, with M3D_GEMM_LEGACY=1 in the environment, the cross-check used by the tests)
-    static const bool legacy = getenv("M3D_GEMM_LEGACY") != nullptr && getenv("M3D_GEMM_LEGACY")[0] == '1';
-    if (!legacy) {
+    // (a -DGEMM_LEGACY=1 build routes everything through it: cross-check builds only)
+#ifndef GEMM_LEGACY
+#define GEMM_LEGACY 0
+#endif
+    if (!GEMM_LEGACY) {
       const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
       if (rc != 1) return rc;
     }

@@ -44,6 +44,37 @@
 #ifndef WGRAD_MINW
 #define WGRAD_MINW 1
 #endif
+// launch-geometry constants (round 3's M3D_* environment knobs, now compile time: the library reads no environment)
+#ifndef GEMM_KL_MINWAVES
+#define GEMM_KL_MINWAVES 1536
+#endif
+#ifndef GEMM_KSPLIT
+#define GEMM_KSPLIT 1
+#endif
+#ifndef GEMM_KSPLIT_MINK
+#define GEMM_KSPLIT_MINK 128
+#endif
+#ifndef GEMM_RS_CAP
+#define GEMM_RS_CAP 768
+#endif
+#ifndef GEMM_RS_TILES
+#define GEMM_RS_TILES 128
+#endif
+#ifndef GEMM_DISABLE
+#define GEMM_DISABLE 0
+#endif
+#ifndef WGRAD_WAVES
+#define WGRAD_WAVES 0
+#endif
+#ifndef WGRAD_VEC
+#define WGRAD_VEC 1
+#endif
+#ifndef WGRAD_BATCH_WAVES_BIG
+#define WGRAD_BATCH_WAVES_BIG 4096
+#endif
+#ifndef WGRAD_BATCH_WAVES_SMALL
+#define WGRAD_BATCH_WAVES_SMALL 8192
+#endif
 #include "../../include/m3d_hip.h"
 
 // (GEMM_DBG: timing ablations of the statistics epilogue, never in the product build — bit 0: no flush at all (the
@@ -597,12 +628,10 @@ static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
     // (4 x 4 tiles were measured slower: too few waves to hide the fragment-load latency; 1 536 instead of 768 waves:
     // 4.85 -> 4.80 ms per step)
     static const int cand[4][2] = {{2, 4}, {2, 2}, {1, 2}, {1, 1}};
-    static const int64_t kl_min_waves = getenv("M3D_GEMM_KL_MINWAVES") ? atoi(getenv("M3D_GEMM_KL_MINWAVES")) : 1536;
+    const int64_t kl_min_waves = GEMM_KL_MINWAVES;
     // split K over the four waves of a workgroup (GemmArgs::ksplit) when K is long: a (row group, column slice) pair
-    // then counts as four waves, so the big wave tiles stay affordable on the deep levels.  M3D_GEMM_KSPLIT=0: never
-    static const int ksplit_env = getenv("M3D_GEMM_KSPLIT") ? atoi(getenv("M3D_GEMM_KSPLIT")) : 1;
-    static const int ksplit_mink = getenv("M3D_GEMM_KSPLIT_MINK") ? atoi(getenv("M3D_GEMM_KSPLIT_MINK")) : 128;
-    const bool can_split = ksplit_env != 0 && K >= ksplit_mink;
+    // then counts as four waves, so the big wave tiles stay affordable on the deep levels.  GEMM_KSPLIT=0: never
+    const bool can_split = GEMM_KSPLIT != 0 && K >= GEMM_KSPLIT_MINK;
     p.MT = 1; p.NT = 1; p.ksplit = 0;
     for (int c = 0; c < 4; ++c) {
       const int64_t waves = m3d_cdiv(ntiles, cand[c][0]) * m3d_cdiv(ncol16, cand[c][1]);
@@ -621,8 +650,7 @@ static RowPlan plan_rows(int64_t M, int N, int K, int mode) {
   p.MT = 1;
   p.slices = m3d_cdiv(ncol16, p.NT);
   // ~4096 waves to fill 1024 SIMDs, at most 16 tiles per wave
-  static const int rs_cap = getenv("M3D_GEMM_RS_CAP") ? atoi(getenv("M3D_GEMM_RS_CAP")) : 768;
-  static const int rs_tiles = getenv("M3D_GEMM_RS_TILES") ? atoi(getenv("M3D_GEMM_RS_TILES")) : 128;
+  const int rs_cap = GEMM_RS_CAP, rs_tiles = GEMM_RS_TILES;
   int64_t wgs = m3d_cdiv(ntiles, 4);
   int64_t cap = rs_cap / p.slices;
   if (cap < m3d_cdiv(ntiles, rs_tiles)) cap = m3d_cdiv(ntiles, rs_tiles);
@@ -640,8 +668,8 @@ int m3d_gemm_direct_stat_parts(int64_t M, int N, int K) {
 
 int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   const int K = g.k0 + g.k1;
-  // debugging aid: M3D_GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
-  static const int disable = getenv("M3D_GEMM_DISABLE") ? atoi(getenv("M3D_GEMM_DISABLE")) : 0;
+  // debugging aid (compile time): GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
+  const int disable = GEMM_DISABLE;
   if (g.a_cm || g.splitk > 1) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // column-major A / split-K: the LDS-tiled kernel
   if (g.accumulate && (g.stat_part || g.scale || g.shift || g.act)) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // plain epilogue only
   if ((disable & 2) && K <= 64) return 1;
@@ -1009,7 +1037,7 @@ static WgradPlan wgrad_plan(int64_t M, int N, int K, int64_t target_waves = 0) {
   p.bz = m3d_cdiv(K, 16 * p.TK);
   const bool wgr = p.TN * p.TK < 16;  // workgroup-level partials (see wgrad2_kernel)
   const int64_t steps_total = m3d_cdiv(M > 0 ? M : 1, 4);
-  static const int target_env = getenv("M3D_WGRAD_WAVES") ? atoi(getenv("M3D_WGRAD_WAVES")) : 0;
+  const int target_env = WGRAD_WAVES;
   // target_waves > 0: this job's share of a batched launch (m3d_linear_wgrad_batch), instead of the whole chip
   const int64_t target = target_waves > 0 ? target_waves : (target_env > 0 ? target_env : (wgr ? 8192 : 2048));
   int64_t waves = m3d_cdiv(target, p.by * p.bz);  // streaming tiles: ~8 waves per SIMD over the chip
@@ -1036,7 +1064,7 @@ extern "C" size_t m3d_linear_wgrad_workspace_bytes(int64_t M, int32_t N, int32_t
 
 // permuted-column vector loads / stores (WgradArgs::vec): every row offset must stay a multiple of the vector width
 static int wgrad_vec_ok(const WgradArgs& g, int TN, int TK) {
-  static const bool off = getenv("M3D_WGRAD_VEC") && atoi(getenv("M3D_WGRAD_VEC")) == 0;
+  const bool off = WGRAD_VEC == 0;
   if (off) return 0;
   const int K = g.k0 + g.k1;
   auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
@@ -1140,8 +1168,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
   // every job gets a share of its tile class's wave budget in proportion to its flops: planned one by one (as if each
   // had the chip to itself) the 14 deep-layer jobs of a batch would split their rows 14 x finer than needed and pay
   // for it in partial-sum traffic
-  static const int budget_big = getenv("M3D_WGRAD_BATCH_WAVES_BIG") ? atoi(getenv("M3D_WGRAD_BATCH_WAVES_BIG")) : 4096;
-  static const int budget_small = getenv("M3D_WGRAD_BATCH_WAVES_SMALL") ? atoi(getenv("M3D_WGRAD_BATCH_WAVES_SMALL")) : 8192;
+  const int budget_big = WGRAD_BATCH_WAVES_BIG, budget_small = WGRAD_BATCH_WAVES_SMALL;
   double class_flops[7] = {0, 0, 0, 0, 0, 0, 0};
   std::vector<int> cls_of(njobs, -1);
   for (int j = 0; j < njobs; ++j) {

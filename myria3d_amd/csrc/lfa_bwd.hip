@@ -791,11 +791,9 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
 template <int CH>
 static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
-  // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*); M3D_LFA_BWD_PIPE=0/1
-  // forces it off / on for every ch <= 64
-  static const int pipe_env = getenv("M3D_LFA_BWD_PIPE") ? atoi(getenv("M3D_LFA_BWD_PIPE")) : -1;
-  constexpr bool pipe_default = CH == 8 ? BWD_PIPE_8 : (CH == 16 ? BWD_PIPE_16 : (CH == 32 ? BWD_PIPE_32 : BWD_PIPE_64));
-  const bool pipe = pipe_env < 0 ? pipe_default : pipe_env != 0;
+  // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*; BWD_PIPE_* at compile time)
+  constexpr bool pipe = CH <= 64 && !LFA_BWD_DBG &&
+                        (CH == 8 ? BWD_PIPE_8 : (CH == 16 ? BWD_PIPE_16 : (CH == 32 ? BWD_PIPE_32 : BWD_PIPE_64)));
   if constexpr (CH >= 64) {
     if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
       constexpr bool P = CH == 64;
@@ -805,15 +803,8 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
     }
   }
   if (bf16) return M3D_ERR_UNSUPPORTED;
-  if constexpr (CH <= 64) {
-    if (pipe && !LFA_BWD_DBG) {
-      if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-      else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-      return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
-    }
-  }
-  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, false>), dim3(p.grid), dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, false>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
 

@@ -115,6 +115,9 @@ def _chk(t: Tensor, dtype=torch.float32):
 # --------------------------------------------------------------------------------------------------
 # kNN  (torch_cluster.knn via knn_graph / knn_interpolate: pyg_randla_net.py:180,250; model.py:90)
 # --------------------------------------------------------------------------------------------------
+_KNN_KERNEL = {"auto": 0, "queue": 1, "direct": 2}
+
+
 class KnnIndex:
     """Per-cloud search grid over a set of source points (device workspace owned by a torch tensor)."""
 
@@ -158,10 +161,11 @@ class KnnIndex:
 
     def query(self, k: int, qry: Optional["KnnIndex"] = None, pos_qry: Optional[Tensor] = None,
               ptr_qry: Optional[Tensor] = None, want_d2: bool = False,
-              sorted_io: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+              sorted_io: bool = False, kernel: str = "auto") -> Tuple[Tensor, Optional[Tensor]]:
         """``qry`` (another built index, possibly ``self``) gives wave-coherent cell-sorted queries;
         otherwise ``pos_qry``/``ptr_qry`` rows are queried in order.  Returns int32 ``[nq, k]`` (+ fp32 d2).
-        ``sorted_io``: rows and neighbour ids are cell-sorted slots (of ``qry`` / of ``self``)."""
+        ``sorted_io``: rows and neighbour ids are cell-sorted slots (of ``qry`` / of ``self``).  ``kernel``: "auto" (by
+        size), "queue" (deferred insertion) or "direct" — bit-identical tables; parity tests and A/B timing."""
         if qry is not None:
             nq, ptr_q, qws, pq, qs = qry.n, qry.ptr, qry.ws, None, 0
             assert qry.num_clouds == self.num_clouds
@@ -170,14 +174,8 @@ class KnnIndex:
             nq, ptr_q, qws, pq, qs = pos_qry.shape[0], ptr_qry, None, pos_qry, pos_qry.stride(0)
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.ws.device)
         d2 = torch.empty((nq, k), dtype=torch.float32, device=self.ws.device) if want_d2 else None
-        if qry is not None and lib().m3d_knn_staged_supported(nq, k):
-            # large cell-sorted query sets: the search in stages with the open queries compacted in between
-            scratch = torch.empty(lib().m3d_knn_staged_workspace_bytes(nq, k), dtype=torch.uint8, device=self.ws.device)
-            call("m3d_knn_query_staged", _p(self.ws), _p(self.ptr), self.n, self.num_clouds, _p(qws), _p(ptr_q), nq, k,
-                 int(sorted_io), _p(idx), _p(d2), _p(scratch), _st())
-            return idx, d2
         call("m3d_knn_query", _p(self.ws), _p(self.ptr), self.n, self.num_clouds, _p(pq), qs, _p(qws), _p(ptr_q), nq, k,
-             int(sorted_io), _p(idx), _p(d2), _st())
+             int(sorted_io) | (_KNN_KERNEL[kernel] << 1), _p(idx), _p(d2), _st())
         return idx, d2
 
 
@@ -967,21 +965,11 @@ def lfa_moments_batch(pos4s, idxs) -> List[Tensor]:
     return [mom[i, :65] for i in range(m)]
 
 
-def knn_query_batch(pairs, k: int, sorted_io: bool = True) -> List[Tensor]:
+def knn_query_batch(pairs, k: int, sorted_io: bool = True, kernel: str = "auto") -> List[Tensor]:
     """``src.query(k, qry=qry, sorted_io=...)`` for up to 8 ``(src, qry)`` pairs of built ``KnnIndex`` objects in ONE
     launch (``m3d_knn_query_batch``); bit-identical tables."""
     import ctypes
 
-    staged = [i for i, (_, q) in enumerate(pairs) if lib().m3d_knn_staged_supported(q.n, k)]
-    if staged:  # the large jobs take the staged launches of their own; the rest share one launch
-        outs = [None] * len(pairs)
-        for i in staged:
-            outs[i] = pairs[i][0].query(k, qry=pairs[i][1], sorted_io=sorted_io)[0]
-        rest = [i for i in range(len(pairs)) if i not in staged]
-        if rest:
-            for i, o in zip(rest, knn_query_batch([pairs[i] for i in rest], k, sorted_io)):
-                outs[i] = o
-        return outs
     m = len(pairs)
     dev = pairs[0][0].ws.device
     outs = [torch.empty((q.n, k), dtype=torch.int32, device=dev) for _, q in pairs]
@@ -990,7 +978,8 @@ def knn_query_batch(pairs, k: int, sorted_io: bool = True) -> List[Tensor]:
     vp = lambda ts: (ctypes.c_void_p * m)(*[t.data_ptr() for t in ts])
     call("m3d_knn_query_batch", m, vp([s_.ws for s_, _ in pairs]), vp([s_.ptr for s_, _ in pairs]),
          (ctypes.c_int64 * m)(*[s_.n for s_, _ in pairs]), vp([q.ws for _, q in pairs]), vp([q.ptr for _, q in pairs]),
-         (ctypes.c_int64 * m)(*[q.n for _, q in pairs]), pairs[0][0].num_clouds, k, int(sorted_io), vp(outs), _st())
+         (ctypes.c_int64 * m)(*[q.n for _, q in pairs]), pairs[0][0].num_clouds, k, int(sorted_io) | (_KNN_KERNEL[kernel] << 1),
+         vp(outs), _st())
     return outs
 
 

@@ -60,95 +60,96 @@ def test_knn_lidar_tile_and_duplicates(device):
     _knn_case(device, line, torch.tensor([0, 300]), 16)
 
 
-@pytest.mark.parametrize("stages", ["2,4:3,8:4,16", "0,2:1,4:2,16", "1,16", "0,8", "3"])
-def test_knn_staged_query_is_bit_identical(device, monkeypatch, stages):
-    """The staged query (ring-limited stages, open queries compacted into a pool, a group of lanes per open query in the
-    later stages; the default for large query sets, forced here with M3D_KNN_STAGED=1) must give the oracle's table bit
-    for bit under every stage schedule: ragged clouds, clouds smaller than K, duplicates, K = 8 / 16 / 32, cell-sorted
-    output, queries of another point set."""
+def test_knn_deferred_insertion_kernel_is_bit_identical(device):
+    """The deferred-insertion kernel (circular rings, sorting-network drains; what the level-1 and K = 32 launches run) forced
+    on small inputs (``kernel="queue"``) must give the oracle's table bit for bit: ragged clouds, clouds smaller than K,
+    duplicates, collinear points, K = 8 / 10 / 16 / 32 / 50, a dense cluster inside a sparse cloud, cell-sorted output,
+    queries of another point set."""
     from myria3d_amd import ops
     from oracle.randla_oracle import knn_exact, synthetic_batch
 
-    monkeypatch.setenv("M3D_KNN_STAGED", "1")
-    monkeypatch.setenv("M3D_KNN_STAGES", stages)
-    assert ops.lib().m3d_knn_staged_supported(100, 16) == 1
-    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32), ([700, 450], 32)):
+    def case(pos, ptr, k):
+        ref_idx, ref_d2 = knn_exact(pos, ptr.tolist(), pos, ptr.tolist(), k)
+        ix = ops.KnnIndex(pos.to(device), ptr.to(device))
+        for kern in ("queue", "direct"):
+            idx, d2 = ix.query(k, qry=ix, want_d2=True, kernel=kern)
+            assert torch.equal(idx.cpu().long(), ref_idx), (kern, k)
+            assert torch.equal(d2.cpu(), ref_d2), (kern, k)
+        idx2, _ = ix.query(k, pos_qry=pos.to(device), ptr_qry=ptr.to(device), kernel="queue")  # row-order queries
+        assert torch.equal(idx2.cpu().long(), ref_idx)
+
+    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32), ([700, 450], 32), ([9000, 64], 16),
+                     ([2000], 10), ([800, 30], 50)):
         _, pos, _, ptr = rand_batch(sizes, seed=len(sizes) + k)
-        _knn_case(device, pos, ptr, k)
+        case(pos, ptr, k)
     _, pos, _, ptr, _ = synthetic_batch([2500, 1800, 4000])
-    _knn_case(device, pos, ptr, 16)
+    case(pos, ptr, 16)
     pos_dup = torch.cat([pos[:40].repeat(8, 1), pos[:200]])
-    _knn_case(device, pos_dup, torch.tensor([0, pos_dup.shape[0]]), 16)
+    case(pos_dup, torch.tensor([0, pos_dup.shape[0]]), 16)
     line = torch.zeros(300, 3)
     line[:, 2] = torch.linspace(0, 1, 300)
-    _knn_case(device, line, torch.tensor([0, 300]), 16)
-    # cell-sorted io + a different source set (k >= 5 so that the staged path takes it)
+    case(line, torch.tensor([0, 300]), 16)
+    same = torch.zeros(100, 3) + 0.25
+    case(same, torch.tensor([0, 100]), 16)
+    # a cluster far denser than its surroundings + a sparse rest (the disc of the cluster's queries is tiny, the others' wide)
+    dense = torch.cat([torch.rand(1500, 3) * 0.01 + 0.5, torch.rand(2000, 3)])
+    case(dense, torch.tensor([0, 3500]), 16)
+    # un-normalised coordinates (metres, Lambert-93-sized offsets): the trimming slack must scale with the magnitudes
+    big = torch.rand(3000, 3) * torch.tensor([50.0, 50.0, 20.0]) + torch.tensor([843000.0, 6519000.0, 200.0])
+    case(big, torch.tensor([0, 3000]), 16)
+    # cell-sorted io + a different source set
     sub = torch.cat([torch.randperm(2500)[:600], 2500 + torch.randperm(1800)[:450], 4300 + torch.randperm(4000)[:1000]])
     ptr_s = torch.tensor([0, 600, 1050, 2050])
     src = pos[sub].contiguous()
     ref_idx, ref_d2 = knn_exact(src, ptr_s.tolist(), pos, ptr.tolist(), 8)
     si, qi = ops.KnnIndex(src.to(device), ptr_s.to(device)), ops.KnnIndex(pos.to(device), ptr.to(device))
-    idx, d2 = si.query(8, qry=qi, want_d2=True)
+    idx, d2 = si.query(8, qry=qi, want_d2=True, kernel="queue")
     assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(d2.cpu(), ref_d2)
-    idx_s, _ = si.query(8, qry=qi, sorted_io=True)  # rows = slots of qi, ids = slots of si
+    idx_s, _ = si.query(8, qry=qi, sorted_io=True, kernel="queue")  # rows = slots of qi, ids = slots of si
     back = si.perm.long()[idx_s.long()][qi.inv.long()]
     assert torch.equal(back.cpu(), ref_idx)
 
 
-def test_knn_lds_window_kernel_is_bit_identical(device, monkeypatch):
-    """M3D_KNN_LDS=1: the deferred-insertion search with the first rings' candidates staged in LDS (one window of the grid per
-    wavefront segment, per-lane ring walks on top of it, global loads for the rings that leave the window) gives the
-    oracle's tables bit for bit: ragged clouds, row wraps, clouds smaller than K, duplicates, K = 8 / 16 / 32, another
-    source set, dense cells that overflow the window."""
+def test_knn_two_kernels_agree_at_full_size(device):
+    """BASELINE config 2 and config 5 shapes (16 x 12 800, K = 16; 4 x 40 000, K = 32): the deferred-insertion kernel (the
+    default at these sizes) against the direct-insertion kernel — equal tables and distances; one tile of each against the
+    oracle."""
     from myria3d_amd import ops
     from oracle.randla_oracle import knn_exact, synthetic_batch
-
-    monkeypatch.setenv("M3D_KNN_LDS", "1")
-    for sizes, k in (([300, 211], 16), ([1, 2, 17, 5], 16), ([3000], 8), ([50, 50], 32), ([700, 450], 32), ([9000, 64], 16)):
-        _, pos, _, ptr = rand_batch(sizes, seed=len(sizes) + k)
-        _knn_case(device, pos, ptr, k)
-    _, pos, _, ptr, _ = synthetic_batch([2500, 1800, 4000])
-    _knn_case(device, pos, ptr, 16)
-    pos_dup = torch.cat([pos[:40].repeat(8, 1), pos[:200]])
-    _knn_case(device, pos_dup, torch.tensor([0, pos_dup.shape[0]]), 16)
-    line = torch.zeros(300, 3)
-    line[:, 2] = torch.linspace(0, 1, 300)
-    _knn_case(device, line, torch.tensor([0, 300]), 16)
-    # a cluster denser than the window's capacity (1 500 points in one grid cell's footprint) + a sparse rest
-    dense = torch.cat([torch.rand(1500, 3) * 0.01 + 0.5, torch.rand(2000, 3)])
-    _knn_case(device, dense, torch.tensor([0, 3500]), 16)
-    sub = torch.cat([torch.randperm(2500)[:600], 2500 + torch.randperm(1800)[:450], 4300 + torch.randperm(4000)[:1000]])
-    ptr_s = torch.tensor([0, 600, 1050, 2050])
-    src = pos[sub].contiguous()
-    ref_idx, ref_d2 = knn_exact(src, ptr_s.tolist(), pos, ptr.tolist(), 8)
-    si, qi = ops.KnnIndex(src.to(device), ptr_s.to(device)), ops.KnnIndex(pos.to(device), ptr.to(device))
-    idx, d2 = si.query(8, qry=qi, want_d2=True)
-    assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(d2.cpu(), ref_d2)
-    # full size: BASELINE config 2 level 1 against the default kernel
-    _, pos, _, ptr, _ = synthetic_batch([12800] * 16)
-    ix = ops.KnnIndex(pos.to(device), ptr.to(device))
-    got, got_d2 = ix.query(16, qry=ix, want_d2=True, sorted_io=True)
-    monkeypatch.setenv("M3D_KNN_LDS", "0")
-    ref, ref_d2 = ix.query(16, qry=ix, want_d2=True, sorted_io=True)
-    assert torch.equal(got, ref) and torch.equal(got_d2, ref_d2)
-
-
-def test_knn_staged_equals_single_launch_at_full_size(device, monkeypatch):
-    """BASELINE config 2 and config 5 shapes (16 x 12 800, K = 16; 4 x 40 000, K = 32): the staged query (opt-in,
-    M3D_KNN_STAGED=1) against the single-launch deferred-insertion kernel (the default) — equal tables."""
-    from myria3d_amd import ops
-    from oracle.randla_oracle import synthetic_batch
 
     for sizes, k in (([12800] * 16, 16), ([40000] * 4, 32)):
         _, pos, _, ptr, _ = synthetic_batch(sizes)
         ix = ops.KnnIndex(pos.to(device), ptr.to(device))
-        monkeypatch.delenv("M3D_KNN_STAGED", raising=False)
-        assert ops.lib().m3d_knn_staged_supported(ix.n, k) == 0
-        ref, ref_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True)
-        monkeypatch.setenv("M3D_KNN_STAGED", "1")
-        assert ops.lib().m3d_knn_staged_supported(ix.n, k) == 1
+        ref, ref_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True, kernel="direct")
         got, got_d2 = ix.query(k, qry=ix, want_d2=True, sorted_io=True)
         assert torch.equal(got, ref) and torch.equal(got_d2, ref_d2)
+        n0 = sizes[0]
+        o_idx, o_d2 = knn_exact(pos[:n0], [0, n0], pos[:n0], [0, n0], k)
+        plain, plain_d2 = ix.query(k, qry=ix, want_d2=True)
+        assert torch.equal(plain[:n0].cpu().long(), o_idx) and torch.equal(plain_d2[:n0].cpu(), o_d2)
+
+
+@pytest.mark.parametrize("k", [65, 100])
+def test_knn_up_to_the_upstream_limit_of_100(device, k):
+    """torch_cluster's CUDA kNN asserts k <= 100: 64 < k <= 100 runs as two passes (the 64 nearest, then the
+    next k - 64 in the same total order) and gives the oracle's table bit for bit, including clouds with fewer than k and
+    fewer than 64 points; k = 101 is refused."""
+    from myria3d_amd import ops
+    from myria3d_amd._lib import M3DError
+    from oracle.randla_oracle import knn_exact
+
+    _, pos, _, ptr = rand_batch([400, 90, 30, 1500], seed=k)
+    ref_idx, ref_d2 = knn_exact(pos, ptr.tolist(), pos, ptr.tolist(), k)
+    ix = ops.KnnIndex(pos.to(device), ptr.to(device))
+    idx, d2 = ix.query(k, qry=ix, want_d2=True)
+    assert torch.equal(idx.cpu().long(), ref_idx) and torch.equal(d2.cpu(), ref_d2)
+    idx_r, _ = ix.query(k, pos_qry=pos.to(device), ptr_qry=ptr.to(device))
+    assert torch.equal(idx_r.cpu().long(), ref_idx)
+    idx_s, _ = ix.query(k, qry=ix, sorted_io=True)
+    back = torch.where(idx_s >= 0, ix.perm.long()[idx_s.long().clamp(min=0)], torch.full_like(idx_s, -1).long())[ix.inv.long()]
+    assert torch.equal(back.cpu(), ref_idx)
+    with pytest.raises(M3DError):
+        ix.query(101, qry=ix)
 
 
 def test_batched_queries_match_the_per_level_launches(device):
@@ -638,24 +639,6 @@ def test_lfa_backward_persistent_loop(device, ch, k, n):
     assert _lib.lib().m3d_lfa_bwd_workspace_bytes(n, k, ch) > 0
     third = n // 3
     _lfa_train_parity(device, ch, k, [third, third + 7, n - 2 * third - 7], seed=ch + k, big=True)
-
-
-@pytest.mark.parametrize("ch,k,n", [(16, 16, 34000), (64, 16, 17000)])
-def test_lfa_backward_persistent_loop_without_pipelining(ch, k, n):
-    """Same check with the software-pipelined variant switched off (M3D_LFA_BWD_PIPE=0 is read once per process, so
-    the case runs in a child interpreter)."""
-    import os
-    import subprocess
-    import sys
-
-    if not torch.cuda.is_available():
-        pytest.skip("no HIP device")
-    env = dict(os.environ, M3D_LFA_BWD_PIPE="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(root, "tests", "test_gpu_ops.py"),
-                          "-k", f"test_lfa_backward_persistent_loop and {ch}-{k}-{n} and not without"],
-                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0 and "1 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
 
 
 @pytest.mark.parametrize("ch,k,n", [(64, 16, 3000), (128, 16, 2500), (256, 16, 1500), (64, 32, 1500), (256, 32, 900),
