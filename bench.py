@@ -89,6 +89,8 @@ def parse():
                     help="train: the contract line (BASELINE config 2).  predict: BASELINE config 3 (informative).  "
                          "prepare: the data-preparation chain in front of the net (informative).  dropin: the plain "
                          "Lightning-style step (no plan / prefetch / graph / flat buffers, torch loss and Adam)")
+    ap.add_argument("--collective", choices=("captured", "eager"), default="captured",
+                    help="with a gradient exchange: the RCCL all-reduce + Adam inside the step's hipGraph (default) or after it")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: bring up a 1-rank RCCL process group and take the N > 1 code path (captured fwd + bwd, "
                          "out-of-graph all-reduce of the flat gradient bucket, eager Adam) — exercises the collective and "
@@ -564,17 +566,24 @@ def pointnet2_bench(args, dev):
 
     def sampler():
         for l in range(3):
-            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l])
+            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l], min_selected=min(plan.sizes[l + 1]))
 
     dts = timed(sampler, steps, 1) / steps
+
+    def sampler_single():  # round 3's form: one workgroup per cloud
+        for l in range(3):
+            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l], multi=False)
+
+    dts1 = timed(sampler_single, max(1, steps // 2), 1) / max(1, steps // 2)
     print(json.dumps({"metric": "points/sec fwd+bwd, PointNet++ set-abstraction variant", "value": round(B * N / dt, 1),
                       "unit": "points/s", "ms_per_step": round(dt * 1e3, 3), "fwd_only_ms": round(dtf * 1e3, 3),
-                      "fps_ms": round(dts * 1e3, 3), "dtype": "f32", "data": "synthetic",
+                      "fps_ms": round(dts * 1e3, 3), "fps_single_workgroup_ms": round(dts1 * 1e3, 3), "dtype": "f32", "data": "synthetic",
                       "workload": f"HipPointNet2 train step, {B} tiles x {N} pts, K={K}, decimation 4, FPS sampling, eager "
                                   "launches, torch Adam (BASELINE configs[4], second half; no reference implementation: "
                                   "oracle-only parity)",
-                      "what": "fps_ms = the three farthest-point-sampling launches of one forward (one workgroup per tile: "
-                              "a serial arg-max chain of n/4 iterations)"}), flush=True)
+                      "what": "fps_ms = the three farthest-point-sampling launches of one forward (several workgroups per tile "
+                              "that exchange one candidate per iteration; fps_single_workgroup_ms: one workgroup per tile, a "
+                              "serial arg-max chain of n/4 iterations on one CU)"}), flush=True)
 
 
 def predict_bench(args, dev, world=1, rank=0, reps=None):
@@ -756,9 +765,13 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     def make(kind, launch):
         # (the eval forward is shorter than the position-only chain it would wait for in the two-graph form: one graph)
         gs = GraphedStep(net, ptr, x.shape[1], mode=kind, optimizer=opt if kind == "train" else None, ignore_index=65,
-                         lookahead=look, launch=launch, lookahead_mode=args.lookahead_mode if kind == "train" else "single")
+                         lookahead=look, launch=launch, lookahead_mode=args.lookahead_mode if kind == "train" else "single",
+                         collective=args.collective)
         gs.load_all(x, pos, y)
+        made[kind, launch] = gs
         return gs
+
+    made = {}
 
     def pick(kind, eager_warm, graph_warm):
         """(step function, launch name, probe timings): the replayed hipGraphs, the eager launcher, or (``auto``)
@@ -819,7 +832,9 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                                f"K={K}, F=9, C=6, decimation 4 ({_baseline_config(N, K)}, {precision})",
                    "tiles_per_gpu": B, "points_per_tile": N, "num_neighbors": K, "parallelism": f"dp{world} over tiles",
                    "collective": ("one flat 4.45 MB fp32 gradient all-reduce per step (RCCL)" +
-                                  (" — forced on a 1-rank group" if world == 1 else "")) if collective else "none (1 rank)",
+                                  (" — forced on a 1-rank group" if world == 1 else "") +
+                                  (f"; {made['train', 'graph'].collective} in the step's hipGraph form" if ("train", "graph") in made and launch == "hipgraph" else "")
+                                  ) if collective else "none (1 rank)",
                    "launch": launch + (" (myria3d_amd.GraphedStep)"), **({"geometry_lookahead": args.lookahead_mode} if look else {})},
         "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
                      "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad", "launch": flaunch},
@@ -890,6 +905,10 @@ def _extra_legs(args, dev, res, B, N, K):
         res["forced_collective_1rank"] = {k: fc[k] for k in ("ms_per_step", "allreduce_ms", "allreduce_bytes", "rccl_ranks",
                                                              "launch_probe_ms") if k in fc} | {
             "launch": fc["config"]["launch"], "collective": fc["config"]["collective"]}
+        # round 3's form of the same step (all-reduce + Adam after the graph), for the A/B
+        fe = _leg_in_fresh_process(["--force-collective", "--collective", "eager", "--launch", "graph", "--steps", str(args.steps),
+                                    "--warmup", str(args.warmup), "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+        res["forced_collective_1rank"]["eager_collective_ms_per_step"] = fe["ms_per_step"]
 
     def torch_leg():
         _progress("torch-ROCm baseline")

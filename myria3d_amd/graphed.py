@@ -16,8 +16,11 @@ and the feature chain starts ~0.8 ms late, hence two graph
 
 Data pipeline: two input buffer sets; ``load_next(x, pos, y)`` fills the set of the step AFTER the coming one while the
 coming one still reads its own (``load(x, pos, y)`` fills the coming one and rebuilds its tables eagerly — first batch,
-or after a gap).  With N > 1 ranks the gradient all-reduce (RCCL) and the Adam launch stay outside the graphs; they
-run on the step's stream beside ``A_i``.
+or after a gap).  With N > 1 ranks the gradient all-reduce (RCCL, capturable) and the Adam launch are PART of ``B[k]``
+since round 4 (``collective="captured"``, the default): run outside the graphs — after ``B``, beside ``A`` — they cost
+0.44 ms of graph start / stop bubbles per 4.6 ms step on one rank (round 3's ``forced_collective_1rank`` leg), i.e. 9 % of
+per-GPU throughput the moment ``world_size > 1``.  If the stack refuses to capture the collective, ``prepare()`` falls
+back to that form (``collective="eager"`` asks for it) and says so in ``self.collective``.
 
 ``launch="eager"`` runs the same step kernel by kernel (lookahead interleaved between the blocks of the forward);
 ``lookahead=False`` builds the tables inside the step (one graph, one buffer set).  Results are the same in every
@@ -50,7 +53,7 @@ class GraphedStep:
     def __init__(self, net: HipRandLANet, ptr, num_features: int, *, mode: str = "train",
                  optimizer: Optional[FusedAdam] = None, ignore_index: int = 65, lookahead: bool = True,
                  launch: str = "graph", lookahead_mode: Optional[str] = None, optimizer_in_graph: Optional[bool] = None,
-                 warmup: int = 2):
+                 warmup: int = 2, collective: str = "captured"):
         if lookahead_mode is None:
             # two graphs on two streams pay off when the step is longer than the position-only chain (training: 4.72 vs
             # 4.79 ms); the eval forward is shorter than that chain and would wait for it every step (1.59 vs 1.18 ms)
@@ -71,11 +74,17 @@ class GraphedStep:
         n = host_ptr[-1]
         self.sets: List[_BufferSet] = [_BufferSet(n, num_features, dev, mode == "train")
                                        for _ in range(2 if self.lookahead else 1)]
+        if collective not in ("captured", "eager"):
+            raise ValueError("collective: captured|eager")
         multi = mode == "train" and optimizer.uses_collective()
-        # a collective is never captured: with a gradient exchange the optimizer runs after the graph
-        self.opt_in_graph = (not multi) if optimizer_in_graph is None else bool(optimizer_in_graph)
-        if multi and self.opt_in_graph:
-            raise ValueError("optimizer_in_graph=True would capture the RCCL all-reduce")
+        # with a gradient exchange the all-reduce is captured together with Adam (RCCL collectives are stream-ordered
+        # kernels; torch's process group enqueues them on the capturing stream's side) unless collective="eager"
+        self.collective = ("captured" if collective == "captured" else "eager") if multi else "none"
+        self.opt_in_graph = (not multi or collective == "captured") if optimizer_in_graph is None else bool(optimizer_in_graph)
+        if multi and self.opt_in_graph and collective == "eager":
+            raise ValueError("optimizer_in_graph=True with collective='eager': the optimizer step contains the all-reduce")
+        if multi and not self.opt_in_graph:
+            self.collective = "eager"
         self.turn = 0
         self._warmup = max(1, warmup)
         self._graphs = None  # (gB, gA) once captured
@@ -187,45 +196,18 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.launch == "graph":
-            net._finish_interleaved()
-            net._look_queue.clear()
-            gB, gA = [], []
-            with_opt = self.mode == "train" and self.opt_in_graph
-            if self.lookahead:
-                self._geo(0)  # pending tables for the first captured step
+            try:
+                self._capture()
+            except Exception as exc:  # noqa: BLE001 — any capture failure of the collective form falls back to the eager one
+                if self.collective != "captured":
+                    raise
+                import warnings
+
+                warnings.warn(f"GraphedStep: capturing the gradient all-reduce failed ({type(exc).__name__}: {exc}); "
+                              "the all-reduce and the optimizer step run after the graph instead")
                 torch.cuda.synchronize()
-            if self.lookahead and self.lookahead_mode == "dual":
-                for k in range(2):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void it)
-                        self._body(k, None, with_opt)
-                    gB.append(g)
-                    # captured WITH THE NET'S SIDE STREAM AS THE ORIGIN: the position-only work is enqueued on that
-                    # stream, so the graph is one chain.  Captured from another stream it is a fork / join around an
-                    # origin that holds no node of its own — and a replay of that form let the next step start on
-                    # half-written tables (tests/test_gpu_train.py::test_graphed_step_matches_plain_eager_steps)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=net._side_stream(self.ptr.device), capture_error_mode="thread_local"):
-                        self._geo(k ^ 1)
-                    gA.append(g)
-                self._sA = torch.cuda.Stream()
-            elif self.lookahead:  # one graph per buffer set holding both branches
-                for k in range(2):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._body(k, k ^ 1, with_opt)
-                    gB.append(g)
-            else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._body(0, None, with_opt)
-                gB.append(g)
-            net._finish_interleaved()
-            net._look_queue.clear()  # (consumed inside the captures: nothing is pending for eager callers)
-            self._graphs = (gB, gA)
-            self._evA, self._evReady = torch.cuda.Event(), torch.cuda.Event()
-            self._evA.record()
-            self._evReady.record()
+                self.collective, self.opt_in_graph = "eager", False
+                self._capture()
         if saved is not None:
             with torch.no_grad():
                 for t, v in zip(self._state(), saved):
@@ -234,6 +216,48 @@ class GraphedStep:
         self._primed = False
         torch.cuda.synchronize()
         return self
+
+    def _capture(self) -> None:
+        net = self.net
+        net._finish_interleaved()
+        net._look_queue.clear()
+        gB, gA = [], []
+        with_opt = self.mode == "train" and self.opt_in_graph
+        if self.lookahead:
+            self._geo(0)  # pending tables for the first captured step
+            torch.cuda.synchronize()
+        if self.lookahead and self.lookahead_mode == "dual":
+            for k in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (RCCL's watchdog thread must not void it)
+                    self._body(k, None, with_opt)
+                gB.append(g)
+                # captured WITH THE NET'S SIDE STREAM AS THE ORIGIN: the position-only work is enqueued on that
+                # stream, so the graph is one chain.  Captured from another stream it is a fork / join around an
+                # origin that holds no node of its own — and a replay of that form let the next step start on
+                # half-written tables (tests/test_gpu_train.py::test_graphed_step_matches_plain_eager_steps)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=net._side_stream(self.ptr.device), capture_error_mode="thread_local"):
+                    self._geo(k ^ 1)
+                gA.append(g)
+            self._sA = torch.cuda.Stream()
+        elif self.lookahead:  # one graph per buffer set holding both branches
+            for k in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._body(k, k ^ 1, with_opt)
+                gB.append(g)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._body(0, None, with_opt)
+            gB.append(g)
+        net._finish_interleaved()
+        net._look_queue.clear()  # (consumed inside the captures: nothing is pending for eager callers)
+        self._graphs = (gB, gA)
+        self._evA, self._evReady = torch.cuda.Event(), torch.cuda.Event()
+        self._evA.record()
+        self._evReady.record()
 
     def prime(self) -> None:
         """Eagerly build the position-only tables of the coming step (first step, after ``load()``, after a seed
@@ -251,6 +275,9 @@ class GraphedStep:
 
     # ------------------------------------------------------------------------------------------
     def step(self) -> Tensor:
+        """One step; returns the loss (train) / logits (eval) tensor of this step's buffer set.  LIFETIME: the tensor lives in
+        the captured graph's memory and is overwritten by the next step on the same buffer set (two steps later with
+        lookahead, the very next step without) — read it (``.item()``) or ``.clone()`` it before then."""
         self._set_mode()
         if self._graphs is None and self.launch == "graph":
             self.prepare()

@@ -1241,14 +1241,28 @@ def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> T
 # PointNet++ set-abstraction variant (BASELINE.json configs[4]): farthest-point sampling, grouping, max aggregation.
 # No reference implementation exists (myria3d/models/model.py:12); csrc/sa.hip restates the published operators.
 # --------------------------------------------------------------------------------------------------
-def fps(pos4: Tensor, ptr: Tensor, ptr_out: Tensor, m: int, max_points: int, start: Optional[Tensor] = None) -> Tensor:
+_FPS_WS: dict = {}  # (device, clouds) -> zero-filled exchange workspace of the multi-workgroup sampler (reusable as is)
+
+
+def fps(pos4: Tensor, ptr: Tensor, ptr_out: Tensor, m: int, max_points: int, start: Optional[Tensor] = None,
+        min_selected: int = 0, multi: bool = True) -> Tensor:
     """Farthest-point sampling inside each cloud (``torch_cluster.fps`` semantics): int32 ``[m]`` global rows in selection
-    order; cloud ``b`` keeps ``ptr_out[b+1] - ptr_out[b]`` points starting from ``start[b]`` (cloud-relative; default 0)."""
+    order; cloud ``b`` keeps ``ptr_out[b+1] - ptr_out[b]`` points starting from ``start[b]`` (cloud-relative; default 0).
+    ``min_selected``: the smallest number of points a cloud keeps (host value); with ``multi`` and ``min_selected >= 64``
+    big clouds are sampled by several workgroups each (same index lists)."""
     assert pos4.shape[1] == 4 and pos4.is_contiguous()
     idx = torch.empty(m, dtype=torch.int32, device=pos4.device)
     if start is not None:
         assert start.dtype == torch.int32 and start.is_contiguous() and start.numel() == ptr.numel() - 1
-    call("m3d_fps", _p(_chk(pos4)), _p(ptr), _p(ptr_out), ptr.numel() - 1, int(max_points), _p(start), _p(idx), _st())
+    B = ptr.numel() - 1
+    ws = None
+    if multi and min_selected >= 64:
+        key = (pos4.device, B, _st())  # (one exchange buffer per stream: launches on different streams may overlap)
+        ws = _FPS_WS.get(key)
+        if ws is None:
+            ws = _FPS_WS[key] = torch.zeros(lib().m3d_fps_workspace_bytes(B), dtype=torch.uint8, device=pos4.device)
+    call("m3d_fps", _p(_chk(pos4)), _p(ptr), _p(ptr_out), B, int(max_points), int(min_selected), _p(start), _p(idx), _p(ws),
+         _st())
     return idx
 
 

@@ -491,9 +491,9 @@ def test_stale_prefetch_is_not_consumed(device):
 
 
 def test_collective_path_on_a_one_rank_rccl_group(device):
-    """The N > 1 code path on the 1-GPU box: a 1-rank RCCL ("nccl") process group, ``FusedAdam(force_collective=True)``:
-    fwd + bwd captured (capture_error_mode thread_local beside RCCL's watchdog), the flat-bucket all-reduce and Adam
-    outside the graph — 3 steps must leave the same state as the N = 1 path (optimizer inside the graph)."""
+    """The N > 1 code path on the 1-GPU box: a 1-rank RCCL ("nccl") process group, ``FusedAdam(force_collective=True)``, in
+    both launch forms — the flat-bucket all-reduce and Adam CAPTURED in the step's hipGraph (round 4, the default) and
+    after the graph (round 3's form, ``collective="eager"``) — 3 steps must leave the same state as the N = 1 path."""
     import torch.distributed as dist
 
     from myria3d_amd import FusedAdam, GraphedStep
@@ -506,22 +506,27 @@ def test_collective_path_on_a_one_rank_rccl_group(device):
         created = True
     try:
         states = []
-        for force in (False, True):
+        for force, form in ((False, "captured"), (True, "captured"), (True, "eager")):
             net, _ = _fresh_flat_net(device)
             net.grad_side = None
             opt = FusedAdam(net, lr=1e-3, eps=0.1, all_reduce=True, force_collective=force)
             assert opt.uses_collective() == force
-            gs = GraphedStep(net, ptr, 9, mode="train", optimizer=opt)
-            assert gs.opt_in_graph == (not force)
+            gs = GraphedStep(net, ptr, 9, mode="train", optimizer=opt, collective=form)
+            assert gs.collective == (form if force else "none")
+            assert gs.opt_in_graph == (not force or form == "captured")
             gs.load_all(*a)
             gs.load_next(*b)
             gs.prepare()
             net.set_decimation_seed(99)
+            if force and form == "captured":
+                # (a stack that cannot capture the collective falls back with a warning; the leg in bench.py records which)
+                print(f"[collective] requested captured, got {gs.collective}")
             for _ in range(3):
                 gs.step()
             torch.cuda.synchronize()
             states.append((net, opt))
-        _assert_same_training_state(states[1][0], states[1][1], states[0][0], states[0][1], "1-rank RCCL path vs N=1 path")
+        _assert_same_training_state(states[1][0], states[1][1], states[0][0], states[0][1], "1-rank RCCL, captured vs N=1 path")
+        _assert_same_training_state(states[2][0], states[2][1], states[0][0], states[0][1], "1-rank RCCL, eager vs N=1 path")
         g = states[1][0].flat_grads
         g.fill_(1.0)
         dist.all_reduce(g)

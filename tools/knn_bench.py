@@ -50,6 +50,6 @@ for l in range(3):  # decoder 1-NN tables: every level-l point among the level l
     src, qry = indices[l + 1], indices[l]
     nn.append(timeit(lambda: src.query(1, qry=qry, sorted_io=True)))
 tag = os.environ.get("M3D_LIB", "default").split("libm3d_")[-1]
-print(f"knn_bench lib={tag} staged={os.environ.get('M3D_KNN_STAGED', 'auto')} stages={os.environ.get('M3D_KNN_STAGES', 'default')} "
-      f"lds={os.environ.get('M3D_KNN_LDS', '0')} queue={os.environ.get('M3D_KNN_QUEUE', 'auto')}: "
-      + " ".join(f"L{l+1}={t:.1f}us" for l, t in enumerate(out)) + " | 1-NN " + " ".join(f"{t:.1f}" for t in nn))
+direct = [timeit(lambda: indices[l].query(16, qry=indices[l], sorted_io=True, kernel="direct")) for l in range(2)]
+print(f"knn_bench lib={tag}: " + " ".join(f"L{l+1}={t:.1f}us" for l, t in enumerate(out)) + " | 1-NN " + " ".join(f"{t:.1f}" for t in nn)
+      + " | direct-insertion kernel L1/L2 " + " ".join(f"{t:.1f}" for t in direct))
