@@ -52,6 +52,12 @@
 #ifndef KNNQ_NET
 #define KNNQ_NET 1   // sorting-network drains for 16-key lists (0: insertion chains; same results)
 #endif
+#ifndef KNNQ_NET_BIG
+#define KNNQ_NET_BIG 8    // a lane with more queued keys than this: the 16-slot network
+#endif
+#ifndef KNNQ_NET_SMALL
+#define KNNQ_NET_SMALL 3  // ... more than this (and at most KNNQ_NET_BIG): the 8-slot network (>= 8: never); else chains
+#endif
 // query sets with at least this many (query, neighbour) pairs take the deferred-insertion kernel (level 1 of BASELINE
 // config 2, the K = 32 tiles); the small deep-level launches (a few wavefronts per CU: latency-bound) the direct one
 #ifndef KNNQ_MIN_PAIRS
@@ -569,8 +575,8 @@ __device__ __forceinline__ void knn_query_queue_body(
   auto drain = [&]() {
     bool done = false;
     if constexpr (NET) {
-      const bool big = __builtin_amdgcn_ballot_w64(cnt > 8) != 0;
-      if (big || __builtin_amdgcn_ballot_w64(cnt > 3) != 0) {
+      const bool big = __builtin_amdgcn_ballot_w64(cnt > KNNQ_NET_BIG) != 0;
+      if (big || (KNNQ_NET_SMALL < 8 && __builtin_amdgcn_ballot_w64(cnt > KNNQ_NET_SMALL) != 0)) {
         if (big) {
           KT q[16];
 #pragma unroll

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int K = a.K;
-  const int64_t c0 = (int64_t)blockIdx.x * TC;
+  const int64_t c0 = xcd_major(blockIdx.x, gridDim.x) * TC;  // (XCD-aware: m3d_common.h)
 
   // ---- phase 1a: neighbour ids
   for (int e = tid; e < ROWS; e += 256) {

@@ -185,6 +185,11 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 
   const int64_t ngroups = (a.n + TC - 1) / TC;
   const int64_t nlast = a.n - 1;
+  // this workgroup's groups: g0, g0 + gs, ... < gend — the contiguous eighth of its XCD (m3d_common.h: the dx atomics of a
+  // tile then all come from ONE XCD and stay in its L2; round 3's order, group b, b + gridDim.x, ..., sent every XCD to every
+  // tile and every atomic to the memory side: 97 / 113 MB written for 3.3 / 6.6 MB of dx at level 1)
+  int64_t g0, gs, gend;
+  xcd_range(blockIdx.x, gridDim.x, ngroups, g0, gs, gend);
   // ---- software pipeline over the persistent loop: everything a group needs from HBM (neighbour ids, x_j rows,
   // positions, dout) is loaded one group ahead into registers, so the loads fly during the MFMA phases of the
   // previous group.  All prefetch loads are unconditional (clamped addresses); validity is applied on use.
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   int jn = -1;
   auto load_idx = [&](int64_t g) -> int {
     int j = -1;
-    if (tid < ROWS && g < ngroups) {
+    if (tid < ROWS && g < gend) {
       const int ci = tid / KP, k = tid % KP;
       const int64_t i = g * TC + ci;
       if (i < a.n && k < K) j = a.idx[i * K + k];
@@ -227,14 +232,14 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     }
   };
   int cur = 0;
-  if (PIPE && (int64_t)blockIdx.x < ngroups) {
-    const int j0 = load_idx(blockIdx.x);
+  if (PIPE && g0 < gend) {
+    const int j0 = load_idx(g0);
     if (tid < ROWS) nbr2[0][tid] = j0;
     __syncthreads();
-    prefetch(blockIdx.x, nbr2[0]);
-    jn = load_idx((int64_t)blockIdx.x + gridDim.x);
+    prefetch(g0, nbr2[0]);
+    jn = load_idx(g0 + gs);
   }
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, cur ^= (PIPE ? 1 : 0)) {
+  for (int64_t grp = g0; grp < gend; grp += gs, cur ^= (PIPE ? 1 : 0)) {
     const int64_t c0 = grp * TC;
     int* nbr = nbr2[cur];
     if constexpr (PIPE) {
@@ -520,9 +525,9 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
         }
         if constexpr (PIPE) {
-          if (ks == 0 && grp + gridDim.x < ngroups) {  // next group's loads (see the fp32 branch below)
-            prefetch(grp + gridDim.x, nbr2[cur ^ 1]);
-            jn = load_idx(grp + 2 * (int64_t)gridDim.x);
+          if (ks == 0 && grp + gs < gend) {  // next group's loads (see the fp32 branch below)
+            prefetch(grp + gs, nbr2[cur ^ 1]);
+            jn = load_idx(grp + 2 * gs);
           }
         }
       }
@@ -548,9 +553,9 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           }
           if (first) {
             first = false;
-            if (grp + gridDim.x < ngroups) {
-              prefetch(grp + gridDim.x, nbr2[cur ^ 1]);
-              jn = load_idx(grp + 2 * (int64_t)gridDim.x);
+            if (grp + gs < gend) {
+              prefetch(grp + gs, nbr2[cur ^ 1]);
+              jn = load_idx(grp + 2 * gs);
             }
           }
         }

@@ -28,6 +28,30 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// XCD-aware work order.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs (observed; speed only, never
+// correctness), each XCD has an L2 of its own, and the points of a batch are stored tile after tile: workgroup b of nblk takes
+// work item xcd_major(b, nblk), so that every XCD walks ONE contiguous eighth of the items (two whole tiles at BASELINE
+// config 2).  Its L2 then holds just those tiles' rows — and every atomic on a row comes from one XCD, i.e. is resolved in
+// that L2 instead of bouncing the line between the chiplets.
+#ifndef M3D_XCD_ORDER
+#define M3D_XCD_ORDER 1
+#endif
+__device__ __forceinline__ int64_t xcd_major(int64_t b, int64_t nblk) {
+  if (!M3D_XCD_ORDER) return b;
+  const int64_t q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, i8 = b >> 3;
+  return xcd * q8 + (xcd < r8 ? xcd : r8) + i8;
+}
+// persistent kernels: workgroup b of nwg walks the items [g0, gend) with stride gs — the contiguous eighth of its XCD,
+// shared with the other workgroups dealt to that XCD
+__device__ __forceinline__ void xcd_range(int64_t b, int64_t nwg, int64_t nitems, int64_t& g0, int64_t& gs, int64_t& gend) {
+  if (!M3D_XCD_ORDER || nwg < 8) { g0 = b; gs = nwg; gend = nitems; return; }
+  const int64_t xcd = b & 7;
+  const int64_t lo = nitems * xcd / 8, hi = nitems * (xcd + 1) / 8;
+  gs = (nwg + 7 - xcd) >> 3;  // workgroups with b % 8 == xcd
+  g0 = lo + (b >> 3);
+  gend = hi;
+}
+
 // reduce over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48): all lanes get the result.
 // gfx950 row swaps instead of __shfl_xor (which lowers to ds_bpermute_b32: an LDS-pipe round trip per step — the
 // softmax of the LFA kernels does six of them per centre): v_permlane16_swap exchanges the odd 16-lane rows of its first

@@ -53,8 +53,13 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
                                                                const int32_t* __restrict__ idx,
                                                                float* __restrict__ out, int64_t ldo, int64_t m,
                                                                int C) {
+  // XCD-aware (m3d_common.h): the rows of a tile — sources and targets — stay with one XCD, its atomics in that L2
+  int64_t b0, bs, bend;
+  xcd_range(blockIdx.x, gridDim.x, (m * C + 255) / 256, b0, bs, bend);
   const int64_t total = m * C;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t blk = b0; blk < bend; blk += bs) {
+    const int64_t i = blk * 256 + threadIdx.x;
+    if (i >= total) break;
     int64_t r = i / C;
     int c = (int)(i % C);
     int64_t d = (int64_t)idx[r];

@@ -178,7 +178,13 @@ __global__ __launch_bounds__(FPSM_THREADS) void fps_multi_kernel(const float4* _
                                                                 const int64_t* __restrict__ ptr_out,
                                                                 const int32_t* __restrict__ start, int32_t* __restrict__ idx_out,
                                                                 FpsSlot* __restrict__ slots, int G) {
-  const int b = blockIdx.x / G, g = blockIdx.x % G, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  // the G workgroups of a cloud sit on ONE XCD where the numbers allow (consecutive workgroups are dealt round-robin over the
+  // 8 XCDs; in XCD-major numbering a cloud's workgroups are neighbours): their per-iteration exchange then goes through that XCD's L2 instead of
+  // crossing the chiplets (first version, workgroups of a cloud on 8 different XCDs + agent-scope release / acquire
+  // fences = an L2 write-back and invalidate per iteration: 10 us per selected point, slower than ONE workgroup)
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int pos = (int)xcd_major(blockIdx.x, gridDim.x);  // a bijection on the workgroup ids: XCD-major numbering
+  const int b = pos / G, g = pos % G;                     // (a cloud whose workgroups straddle two XCDs is slower, not wrong)
   const int64_t s0 = ptr_src[b], o0 = ptr_out[b];
   const int n = (int)(ptr_src[b + 1] - s0), m = (int)(ptr_out[b + 1] - o0);
   if (m <= 0 || n <= 0) return;
@@ -255,14 +261,20 @@ __global__ __launch_bounds__(FPSM_THREADS) void fps_multi_kernel(const float4* _
       __hip_atomic_store(&d->x, c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&d->y, c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&d->z, c.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&d->flag, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // payload before flag: every access to a slot is an agent-scope atomic (served by L2 / the memory side, never by a
+      // non-coherent cache), so the order of THIS thread's stores is all that matters: wait for them, then raise the flag —
+      // no L2 write-back / invalidate as an agent-scope release / acquire pair would issue every iteration
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_store(&d->flag, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // gather: lanes 0..G-1 of every wave poll one slot each until it carries this iteration's number
     float cb = -3.f; int ci = INT_MAX; float cx = 0.f, cy = 0.f, cz = 0.f;
     const int sl = lane & (FPSM_MAXG - 1);
     if (sl < G) {
       const FpsSlot* d = row + sl;
-      while (__hip_atomic_load(&d->flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != s + 1) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&d->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s + 1) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       cb = __hip_atomic_load(&d->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ci = __hip_atomic_load(&d->besti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cx = __hip_atomic_load(&d->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
