@@ -835,7 +835,8 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
                                   (" — forced on a 1-rank group" if world == 1 else "") +
                                   (f"; {made['train', 'graph'].collective} in the step's hipGraph form" if ("train", "graph") in made and launch == "hipgraph" else "")
                                   ) if collective else "none (1 rank)",
-                   "launch": launch + (" (myria3d_amd.GraphedStep)"), **({"geometry_lookahead": args.lookahead_mode} if look else {})},
+                   "launch": launch + (" (myria3d_amd.GraphedStep)"), **({"geometry_lookahead": args.lookahead_mode} if look else {}),
+                   **({"side_stream_overlaps": made["train", "graph"].side_stream_overlaps} if ("train", "graph") in made else {})},
         "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
                      "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad", "launch": flaunch},
     }

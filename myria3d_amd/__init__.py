@@ -13,6 +13,7 @@ from .model_forward import SimpleBatch, collate_tiles, forward_like_model  # noq
 from .train import FusedAdam, cross_entropy  # noqa: F401
 from .graphed import GraphedStep  # noqa: F401
 from . import tiling, transforms  # noqa: F401
+from .predict import predict_cloud  # noqa: F401
 
-__all__ = ["HipRandLANet", "HipPointNet2", "make_plan", "knn_interpolate", "scatter_sum", "predict_reduce", "DeviceInterpolator",
+__all__ = ["predict_cloud", "HipRandLANet", "HipPointNet2", "make_plan", "knn_interpolate", "scatter_sum", "predict_reduce", "DeviceInterpolator",
            "register_in_model_zoo", "forward_like_model", "collate_tiles", "SimpleBatch", "FusedAdam", "cross_entropy", "GraphedStep", "transforms", "tiling"]

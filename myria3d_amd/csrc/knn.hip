@@ -19,8 +19,8 @@
 //   * circular rings: a ring's runs are trimmed to the disc of the lane's current k-th distance (rows cut to the chord,
 //     side cells outside the disc skipped): -34 % candidates per query, -25 % lock-step candidate slots per wavefront
 //     on the Lidar-HD-shaped tiles (tools/sim/knn_trim_sim.py);
-//   * the drain of the per-lane candidate queues is a SORTING NETWORK + bitonic merge (60 + 16 + 32 compare-exchanges
-//     for up to 16 queued keys, 19 + 8 + 32 for up to 8) instead of one 16-deep insertion chain per queued key.
+//   (a sorting-network drain of the candidate queues — 60 + 16 + 32 compare-exchanges for up to 16 queued keys instead of a
+//   16-deep insertion chain per key — was built, bit-identical, and measured 6-7 % SLOWER: profiles/r04b_knn_ab.log; removed.)
 // No run-time knobs: tuning constants are compile-time macros (tools/build_variant.sh NAME knn.hip -D...).
 #include "m3d_common.h"
 #include "../../include/m3d_hip.h"
@@ -41,22 +41,13 @@
 // (waves per SIMD), candidates per batch
 #define KNNQ_DEPTH 16
 #ifndef KNNQ_MINW
-#define KNNQ_MINW 3  // 168 VGPRs: the 16-key sorting network needs 32 registers beside the list (spill-free; 128 spills in the candidate loop)
+#define KNNQ_MINW 3  // 168 VGPRs: spill-free with the trimming arithmetic (a 128-register cap spills inside the candidate loop: 193 vs 138 us)
 #endif
 #ifndef KNNQ_UNROLL
 #define KNNQ_UNROLL 4
 #endif
 #ifndef KNNQ_TRIM
 #define KNNQ_TRIM 1  // circular rings (0: square rings, the round-3 walk; same results)
-#endif
-#ifndef KNNQ_NET
-#define KNNQ_NET 1   // sorting-network drains for 16-key lists (0: insertion chains; same results)
-#endif
-#ifndef KNNQ_NET_BIG
-#define KNNQ_NET_BIG 8    // a lane with more queued keys than this: the 16-slot network
-#endif
-#ifndef KNNQ_NET_SMALL
-#define KNNQ_NET_SMALL 3  // ... more than this (and at most KNNQ_NET_BIG): the 8-slot network (>= 8: never); else chains
 #endif
 // query sets with at least this many (query, neighbour) pairs take the deferred-insertion kernel (level 1 of BASELINE
 // config 2, the K = 32 tiles); the small deep-level launches (a few wavefronts per CU: latency-bound) the direct one
@@ -238,18 +229,7 @@ struct KeyF64 {
   static __device__ __forceinline__ unsigned hi32(T k) { return (unsigned)__double2hiint(k); }
   static __device__ __forceinline__ unsigned d2bits_of_hi(unsigned hw) { return hw - BIAS; }
   static __device__ __forceinline__ int row(T k) { return __double2loint(k); }
-  // a <- min(a, b), b <- max(a, b).  Raw instructions: fmin() / fmax() would add a canonicalising v_max_f64 per operand in
-  // IEEE mode
-  static __device__ __forceinline__ void cex(T& a, T& b) {
-    T lo, hi;
-    asm("v_max_f64 %1, %2, %3\n\tv_min_f64 %0, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b));
-    a = lo; b = hi;
-  }
-  static __device__ __forceinline__ T kmin(T a, T b) {
-    T lo;
-    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
-    return lo;
-  }
+  // (raw instructions: fmin() / fmax() would add a canonicalising v_max_f64 per operand in IEEE mode)
   // sorted insertion: the key sinks through the list, every slot keeps the smaller of (slot, carried key)
   template <int KMAX>
   static __device__ __forceinline__ void chain(T (&best)[KMAX], T key) {
@@ -268,32 +248,6 @@ struct KeyF64 {
 };
 typedef KeyF64 KP;
 typedef KeyF64::T KT;
-
-// sorting networks over register arrays (indices are compile-time after unrolling).  16 inputs: 60 compare-exchanges in 10
-// layers (the best known size; verified with the 0-1 principle by tools/sim/sortnet_check.py), 8 inputs: 19.
-__device__ __forceinline__ void sort16(KT (&q)[16]) {
-  constexpr unsigned char N[60][2] = {
-      {0, 13}, {1, 12}, {2, 15}, {3, 14}, {4, 8}, {5, 6}, {7, 11}, {9, 10}, {0, 5}, {1, 7}, {2, 9}, {3, 4}, {6, 13}, {8, 14}, {10, 15},
-      {11, 12}, {0, 1}, {2, 3}, {4, 5}, {6, 8}, {7, 9}, {10, 11}, {12, 13}, {14, 15}, {0, 2}, {1, 3}, {4, 10}, {5, 11}, {6, 7}, {8, 9},
-      {12, 14}, {13, 15}, {1, 2}, {3, 12}, {4, 6}, {5, 7}, {8, 10}, {9, 11}, {13, 14}, {1, 4}, {2, 6}, {5, 8}, {7, 10}, {9, 13}, {11, 14},
-      {2, 4}, {3, 6}, {9, 12}, {11, 13}, {3, 5}, {6, 8}, {7, 9}, {10, 12}, {3, 4}, {5, 6}, {7, 8}, {9, 10}, {11, 12}, {6, 7}, {8, 9}};
-#pragma unroll
-  for (int c = 0; c < 60; ++c) KP::cex(q[N[c][0]], q[N[c][1]]);
-}
-__device__ __forceinline__ void sort8(KT (&q)[8]) {
-  constexpr unsigned char N[19][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {0, 2}, {1, 3}, {4, 6}, {5, 7}, {1, 2}, {5, 6},
-                                      {0, 4}, {3, 7}, {1, 5}, {2, 6}, {1, 4}, {3, 6}, {2, 4}, {3, 5}, {3, 4}};
-#pragma unroll
-  for (int c = 0; c < 19; ++c) KP::cex(q[N[c][0]], q[N[c][1]]);
-}
-// a bitonic sequence of 16 keys -> ascending (4 half-cleaner stages, 32 compare-exchanges)
-__device__ __forceinline__ void bitonic_merge16(KT (&v)[16]) {
-#pragma unroll
-  for (int s = 8; s >= 1; s >>= 1)
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if ((i & s) == 0) KP::cex(v[i], v[i + s]);
-}
 
 __device__ __forceinline__ float dist2_exact(float qx, float qy, float qz, float4 s) {
 #pragma clang fp contract(off)
@@ -524,10 +478,6 @@ __global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_batch_kernel(Kn
 //     skipped, the others are cut to the chord |dx| <= sqrt(kth - gap_y^2), a side cell is skipped when its nearest corner
 //     lies outside the disc.  All comparisons are made conservative (kth inflated by 2^-16, gaps shrunk by the grid's
 //     rounding slack eps), so that no point a square ring would have admitted is lost: bit-identical tables.
-//   * sorting-network drain (KNNQ_NET, 16-key lists).  Invariant: queue slots at and above a lane's count hold +inf.
-//     Any lane with more than 8 queued keys: all 16 slots are sorted (60 compare-exchanges) and merged into the list with
-//     one bitonic merge (16 + 32); more than 3: the same with 8 slots (19 + 8 + 32); otherwise insertion chains.  A
-//     drain of m keys used to cost 34 m instructions with m = the fullest lane's count (13-16 when a queue fills).
 // ------------------------------------------------------------------------------------------
 template <int KMAX>
 __device__ __forceinline__ void knn_query_queue_body(
@@ -535,7 +485,6 @@ __device__ __forceinline__ void knn_query_queue_body(
     const float4* __restrict__ qsorted, const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
     int* __restrict__ idx_out, float* __restrict__ d2_out, int flags, int64_t wg_in, int64_t nblk) {
   constexpr int QD = KNNQ_DEPTH;
-  constexpr bool NET = KNNQ_NET && KMAX == 16;
   const int sorted_io = flags & 1;  // bit 1: idx_out / d2_out are 16-byte aligned (vector stores allowed)
   __shared__ KT queue[QD][64];
   const int lane = threadIdx.x;
@@ -565,56 +514,18 @@ __device__ __forceinline__ void knn_query_queue_body(
   KT best[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) best[j] = KP::empty();
-  if constexpr (NET) {
-#pragma unroll
-    for (int i = 0; i < QD; ++i) queue[i][lane] = KP::empty();
-  }
   int cnt = 0;                       // entries in this lane's queue
   float kth = __builtin_inff();      // this lane's current k-th squared distance (+inf while the list is not full)
 
   auto drain = [&]() {
-    bool done = false;
-    if constexpr (NET) {
-      const bool big = __builtin_amdgcn_ballot_w64(cnt > KNNQ_NET_BIG) != 0;
-      if (big || (KNNQ_NET_SMALL < 8 && __builtin_amdgcn_ballot_w64(cnt > KNNQ_NET_SMALL) != 0)) {
-        if (big) {
-          KT q[16];
+    // divergent trip count: the wavefront runs max(cnt) insertion chains, all lanes in step, two keys per trip (their chains
+    // are independent up to a one-slot skew, so the scheduler can interleave them)
+    for (int i = 0; i < cnt; i += 2) {
+      KT key[2];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) q[i] = queue[i][lane];
+      for (int u = 0; u < 2; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) queue[i][lane] = KP::empty();
-          sort16(q);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) best[i] = KP::kmin(best[i], q[15 - i]);
-        } else {
-          KT q[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) q[i] = queue[i][lane];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) queue[i][lane] = KP::empty();
-          sort8(q);
-          // (best ascending, 8 x +inf, q descending) is bitonic: its first half-cleaner leaves best[0..7] as they are
-#pragma unroll
-          for (int i = 8; i < 16; ++i) best[i] = KP::kmin(best[i], q[15 - i]);
-        }
-        bitonic_merge16(best);
-        done = true;
-      }
-    }
-    if (!done) {
-      // divergent trip count: the wavefront runs max(cnt) insertion chains, all lanes in step, two keys per trip (their
-      // chains are independent up to a one-slot skew, so the scheduler can interleave them)
-      for (int i = 0; i < cnt; i += 2) {
-        KT key[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) key[u] = queue[(i + u) & (QD - 1)][lane];
-        if constexpr (NET) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) queue[(i + u) & (QD - 1)][lane] = KP::empty();
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) KP::chain<KMAX>(best, u == 0 || i + u < cnt ? key[u] : KP::empty());
-      }
+      for (int u = 0; u < 2; ++u) KP::chain<KMAX>(best, u == 0 || i + u < cnt ? key[u] : KP::empty());
     }
     cnt = 0;
     // k-th key = the largest of the first k (the list is ascending; empty slots sort above every key).  Written as a max
@@ -651,8 +562,7 @@ __device__ __forceinline__ void knn_query_queue_body(
 #pragma unroll
       for (int u = 0; u < KNNQ_UNROLL; ++u) ra[u] = g.sorted[p0 + u];
       for (int p = p0; p < p1; p += 2 * KNNQ_UNROLL) {
-        // the drain check sits BEFORE the other register set is requested: one set of candidates is live across a drain
-        // (the sorting network needs 32 registers of its own; with both sets live the kernel spilled in this loop)
+        // (the drain check sits BEFORE the other register set is requested: one set of candidates is live across a drain)
         if (__builtin_amdgcn_ballot_w64(cnt > QD - KNNQ_UNROLL) != 0) drain();
 #pragma unroll
         for (int u = 0; u < KNNQ_UNROLL; ++u) rb[u] = g.sorted[p + KNNQ_UNROLL + u];

@@ -91,6 +91,7 @@ class GraphedStep:
         self._sA: Optional[torch.cuda.Stream] = None
         self._evA = self._evReady = None
         self._primed = False
+        self.side_stream_overlaps: Optional[bool] = None  # probe result for graph A's replay stream (dual lookahead)
 
     # ------------------------------------------------------------------------------------------
     def _cur(self) -> _BufferSet:
@@ -185,6 +186,8 @@ class GraphedStep:
         net = self.net
         saved = [t.clone() for t in self._state()] if preserve_state else None
         nsets = len(self.sets)
+        if self.lookahead:
+            net._side_stream(self.ptr.device)  # created (and probed) against the stream the steps will be launched on
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # (warm-up off the default stream, as torch's graph recipe asks)
@@ -240,7 +243,11 @@ class GraphedStep:
                 with torch.cuda.graph(g, stream=net._side_stream(self.ptr.device), capture_error_mode="thread_local"):
                     self._geo(k ^ 1)
                 gA.append(g)
-            self._sA = torch.cuda.Stream()
+            # the replay stream of graph A must sit on another hardware queue than the step's stream (ops.concurrent_stream)
+            from . import ops as _ops
+
+            self._sA = _ops.concurrent_stream(self.ptr.device)
+            self.side_stream_overlaps = _ops._STREAM_PROBE.get((torch.cuda.current_stream().cuda_stream, self._sA.cuda_stream))
         elif self.lookahead:  # one graph per buffer set holding both branches
             for k in range(2):
                 g = torch.cuda.CUDAGraph()

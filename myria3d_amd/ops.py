@@ -221,6 +221,56 @@ def linear_dgrad(dz: Tensor, w: Tensor, bf16: bool = False, acc: Optional[Tensor
     return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0), bf16=bf16, out=acc, accumulate=acc is not None)
 
 
+_STREAM_PROBE: dict = {}  # id(stream pair) -> bool, for reporting
+
+
+def streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream", cycles: int = 300_000) -> bool:
+    """Do kernels on ``a`` and ``b`` really run side by side?  HIP maps streams onto a few hardware queues (4 by default);
+    two streams that share one execute in enqueue order, however independent their work is.  Measured with two spin kernels
+    (``torch.cuda._sleep``): together they take about as long as one when the streams sit on different queues, twice as
+    long when they share one."""
+    torch.cuda.synchronize(a.device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    with torch.cuda.stream(a):
+        ev[0].record(a)
+        torch.cuda._sleep(cycles)
+        ev[1].record(a)
+    torch.cuda.synchronize(a.device)
+    one = ev[0].elapsed_time(ev[1])
+    with torch.cuda.stream(a):
+        ev[2].record(a)
+    b.wait_event(ev[2])
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(cycles)
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+        a.wait_stream(b)
+        ev[3].record(a)
+    torch.cuda.synchronize(a.device)
+    both = ev[2].elapsed_time(ev[3])
+    return both < 1.5 * one
+
+
+def concurrent_stream(device, beside: Optional["torch.cuda.Stream"] = None, tries: int = 8) -> "torch.cuda.Stream":
+    """A side stream that runs BESIDE ``beside`` (default: the current stream), chosen by probing.  Round 4: with an RCCL
+    process group alive (its communicator owns streams of its own) the stream ``torch.cuda.Stream()`` handed out for the
+    position-only graph landed on the hardware queue of the step's stream: the two graphs of ``GraphedStep`` ran one after
+    the other — 4.45 + 0.69 = 5.14 ms instead of 4.60 — which is all of the "+0.44 ms of the N > 1 form" round 3 measured
+    (``tools/collective_probe.py``: the slowdown appears with the process group alone, without any collective in the step)."""
+    beside = torch.cuda.current_stream(device) if beside is None else beside
+    if torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=device)
+    first = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device)
+        ok = streams_overlap(beside, cand)
+        _STREAM_PROBE[(beside.cuda_stream, cand.cuda_stream)] = ok
+        if ok:
+            return cand
+        first = first or cand
+    return first
+
+
 class GradSideStream:
     """Weight-gradient kernels are leaves of the backward pass (nothing downstream reads dW before the optimizer), so
     with gradient sinks they can run on a side stream next to the dgrad / BatchNorm / LFA chain.  The stream rejoins the

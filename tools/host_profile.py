@@ -1,4 +1,6 @@
-"""Where the HOST time of an eagerly launched training step goes (cProfile over 20 steps): python tools/host_profile.py"""
+"""Where the HOST time of an eagerly launched training step goes (cProfile over 20 steps): python tools/host_profile.py [variable]
+``variable``: a different tile layout every step (the opt-in path of INTEGRATION.md section 3: flat buffers, FusedAdam, HIP
+criterion, the next batch's position-only work interleaved) — what a loop with per-batch layouts pays on the host."""
 import cProfile, os, pstats, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myria3d_amd import HipRandLANet, make_plan
@@ -24,6 +26,29 @@ def step():
     opt.step()
 
 
+if "variable" in sys.argv:
+    import numpy as np
+
+    rs = np.random.RandomState(0)
+    var = []
+    for i in range(8):
+        sizes = [int(v) for v in rs.randint(6400, 19201, size=16)]
+        vx, vpos, vbatch, vptr, vy = synthetic_batch(sizes, first_tile_id=100 * i)
+        var.append(tuple(t.to(dev) for t in (vx, vpos, vbatch, vptr, vy)))
+    turn = [0]
+    net.train()
+
+    def step():  # noqa: F811
+        vx, vpos, vbatch, vptr, vy = var[turn[0] % len(var)]
+        nxt = var[(turn[0] + 1) % len(var)]
+        turn[0] += 1
+        net.prefetch_geometry(nxt[1], nxt[3], interleave=True)
+        cross_entropy(net(vx, vpos, vbatch, vptr), vy, ignore_index=65).backward()
+        opt.step()
+
+    net.prefetch_geometry(var[0][1], var[0][3])
+
+
 for _ in range(5):
     step()
 torch.cuda.synchronize()
@@ -41,4 +66,4 @@ for _ in range(20):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(40)
