@@ -342,6 +342,12 @@ int m3d_tile_normalize(float* pos, int32_t pos_stride, float* x, int64_t ldx, in
  * through ws (csrc/sa.hip: fps_multi_kernel; used when min_selected >= 64 and the grid stays co-resident).  Same index lists
  * either way. */
 size_t m3d_fps_workspace_bytes(int32_t num_clouds);
+/* The same sampling with EXACT bucket skipping (csrc/sa.hip: fps_bucket_kernel): sorted_ws = the BUILT kNN workspace of the
+ * same points and ptr_src (m3d_knn_build; n_src points in all) — its cell-sorted records are cut into buckets of 64 whose
+ * bounding boxes let an iteration skip every bucket the new point cannot reach.  max_points <= 40 000 (the running minima of
+ * a cloud live in LDS).  idx_out: original global rows, selection order; identical to m3d_fps. */
+int m3d_fps_sorted(const void* sorted_ws, int64_t n_src, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds,
+                   int64_t max_points, const int32_t* start, int32_t* idx_out, void* stream);
 int m3d_fps(const float* pos4, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds, int64_t max_points,
             int64_t min_selected, const int32_t* start, int32_t* idx_out, void* ws, void* stream);
 /* Edge rows of a set-abstraction level over a COMPACT edge list: centre i owns edges seg[i] .. seg[i+1] - 1 (at most K;

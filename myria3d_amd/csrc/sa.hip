@@ -294,6 +294,152 @@ __global__ __launch_bounds__(FPSM_THREADS) void fps_multi_kernel(const float4* _
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// farthest-point sampling with EXACT bucket skipping (round 4; the "block order for exact sub-set skipping" of DESIGN r3).
+// The serial chain of m iterations stays, but an iteration no longer touches every point: the points of a cloud are taken in
+// the cell-sorted order of its kNN grid (csrc/knn.hip: float4 records x, y, z, original row — spatially compact runs) and cut
+// into buckets of 64 consecutive records.  A bucket keeps its bounding box, the largest running minimum distance of its
+// points (bmax) and that point.  Selecting q can lower a point's minimum only if d2(q, p) < mind[p]; for a whole bucket
+//     d2(q, p) >= d2(q, box) for every p inside      (the same fp32 expression on both sides: subtraction, squares and sums
+//                                                     are monotonic, so the inequality holds for the ROUNDED values too)
+// so a bucket with d2(q, box) >= bmax is skipped without loading a point — after the first few hundred selections that is
+// all but the handful of buckets around q.  Bucket b is owned by lane b / 16 of wave b % 16 (neighbouring buckets — affected
+// together — go to different waves); the owner wave updates the 64 points (positions: one coalesced 1 KB load from L2;
+// running minima: LDS, 40 000 x 4 bytes = all of it), reduces (value, original row) with the total order of the oracle
+// (larger distance, then smaller ORIGINAL row) and leaves the result in the owner lane's registers.  The arg-max over the
+// bucket maxima is the two-stage reduction of fps_kernel.  Same arithmetic, same order => bit-identical index lists.
+// Clouds of 4 097 ... 40 000 points (LDS bound); others take fps_kernel.
+// ------------------------------------------------------------------------------------------
+#define FPSB_MAXN 40000
+#define FPSB_BS 64
+template <int CTRL>
+__device__ __forceinline__ void fpsb_step(float& best, int& besti, int& tag) {  // (value desc, original row asc); tag rides along
+  const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xF, 0xF, false));
+  const int oi = __builtin_amdgcn_update_dpp(0, besti, CTRL, 0xF, 0xF, false);
+  const int ot = __builtin_amdgcn_update_dpp(0, tag, CTRL, 0xF, 0xF, false);
+  if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; tag = ot; }
+}
+__device__ __forceinline__ void fpsb_wave_argmax(float& best, int& besti, int& tag) {
+  fpsb_step<0xB1>(best, besti, tag);
+  fpsb_step<0x4E>(best, besti, tag);
+  fpsb_step<0x141>(best, besti, tag);
+  fpsb_step<0x140>(best, besti, tag);
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {  // across the four rows of 16 lanes
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64), ot = __shfl_xor(tag, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; tag = ot; }
+  }
+}
+
+__global__ __launch_bounds__(FPS_THREADS) void fps_bucket_kernel(const float4* __restrict__ sorted4, const int32_t* __restrict__ inv,
+                                                                const int64_t* __restrict__ ptr_src,
+                                                                const int64_t* __restrict__ ptr_out,
+                                                                const int32_t* __restrict__ start, int32_t* __restrict__ idx_out) {
+  __shared__ float mind[FPSB_MAXN];
+  constexpr int NW = FPS_THREADS / 64;
+  __shared__ float wbest[2][NW];
+  __shared__ int wbesti[2][NW];
+  __shared__ float4 wq[2][NW];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int64_t s0 = ptr_src[b], o0 = ptr_out[b];
+  const int n = (int)(ptr_src[b + 1] - s0), m = (int)(ptr_out[b + 1] - o0);
+  if (m <= 0 || n <= 0) return;
+  const float4* p = sorted4 + s0;  // cell-sorted records of this cloud; .w = original GLOBAL row
+  const int nb = (n + FPSB_BS - 1) / FPSB_BS;
+  for (int i = t; i < nb * FPSB_BS; i += FPS_THREADS) mind[i] = i < n ? __builtin_inff() : -1.f;
+  // my bucket: lane l of wave w owns bucket l * 16 + w
+  const int mb = lane * NW + wid;
+  const bool has = mb < nb;
+  float lox = 0.f, loy = 0.f, loz = 0.f, hix = 0.f, hiy = 0.f, hiz = 0.f;
+  float bmax = has ? __builtin_inff() : -2.f;  // +inf: every bucket is updated by the first selection
+  int barg = INT_MAX;                          // original cloud-relative row of the bucket's farthest point
+  float bx = 0.f, by = 0.f, bz = 0.f;          // ... and its coordinates
+  // bounding boxes: the owner wave scans its buckets (64 records = one coalesced load each)
+  for (int l = 0; l < 64; ++l) {
+    const int bb = l * NW + wid;
+    if (bb >= nb) break;  // (wave-uniform)
+    const int i = bb * FPSB_BS + lane;
+    const float4 v = p[i < n ? i : n - 1];
+    float ax = v.x, ay = v.y, az = v.z, cx = v.x, cy = v.y, cz = v.z;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ax = fminf(ax, __shfl_xor(ax, o, 64)); ay = fminf(ay, __shfl_xor(ay, o, 64)); az = fminf(az, __shfl_xor(az, o, 64));
+      cx = fmaxf(cx, __shfl_xor(cx, o, 64)); cy = fmaxf(cy, __shfl_xor(cy, o, 64)); cz = fmaxf(cz, __shfl_xor(cz, o, 64));
+    }
+    if (lane == l) { lox = ax; loy = ay; loz = az; hix = cx; hiy = cy; hiz = cz; }
+  }
+  int cur = start ? start[b] : 0;
+  cur = cur < 0 ? 0 : (cur >= n ? n - 1 : cur);
+  float4 q = sorted4[inv[s0 + cur]];  // (inv: original global row -> global cell-sorted slot)
+  __syncthreads();
+  int32_t mine = 0;
+  for (int s = 0; s < m; ++s) {
+    if (t == (s & (FPS_THREADS - 1))) mine = (int32_t)(s0 + cur);
+    if ((s & (FPS_THREADS - 1)) == FPS_THREADS - 1 || s == m - 1) {
+      const int base = s & ~(FPS_THREADS - 1);
+      if (base + t <= s) idx_out[o0 + base + t] = mine;
+    }
+    if (s == m - 1) break;
+    // ---- which of this wave's buckets can the new point reach?
+    bool aff = false;
+    if (has) {
+      const float4 c = make_float4(fminf(fmaxf(q.x, lox), hix), fminf(fmaxf(q.y, loy), hiy), fminf(fmaxf(q.z, loz), hiz), 0.f);
+      aff = fps_d2(c, q) < bmax;  // c = the box's nearest point to q: |c - q| <= |p - q| per axis for every p in the box
+    }
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(aff);
+    while (mask) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int bb = l * NW + wid;
+      const int i = bb * FPSB_BS + lane;
+      const float4 v = p[i < n ? i : n - 1];
+      const float d = fps_d2(v, q);
+      float nm = mind[i];
+      if (i < n) { nm = fminf(nm, d); mind[i] = nm; }
+      float best = nm;
+      int besti = i < n ? (int)(__float_as_int(v.w) - (int)s0) : INT_MAX;
+      int tag = lane;
+      fpsb_wave_argmax(best, besti, tag);
+      const int tl = __builtin_amdgcn_readfirstlane(tag);
+      const float wx = __shfl(v.x, tl, 64), wy = __shfl(v.y, tl, 64), wz = __shfl(v.z, tl, 64);
+      if (lane == l) { bmax = best; barg = besti; bx = wx; by = wy; bz = wz; }
+    }
+    // ---- arg-max over the bucket maxima: wave, then the 16 wave candidates
+    float best = bmax;
+    int besti = barg, tag = lane;
+    fpsb_wave_argmax(best, besti, tag);
+    const int par = s & 1;
+    if (lane == __builtin_amdgcn_readfirstlane(tag)) { wbest[par][wid] = best; wbesti[par][wid] = besti; wq[par][wid] = make_float4(bx, by, bz, 0.f); }
+    __syncthreads();
+    int bw = lane & 15;
+    best = wbest[par][bw]; besti = wbesti[par][bw];
+    fps_step_dpp3<0xB1>(best, besti, bw);
+    fps_step_dpp3<0x4E>(best, besti, bw);
+    fps_step_dpp3<0x141>(best, besti, bw);
+    fps_step_dpp3<0x140>(best, besti, bw);
+    cur = besti;
+    q = wq[par][bw];
+  }
+}
+
+// sorted_ws: the cloud set's BUILT kNN workspace (m3d_knn_build over the same points / ptr_src) or NULL.  With it, clouds of
+// 4 097 ... 40 000 points are sampled by fps_bucket_kernel (exact bucket skipping); index lists are identical either way
+extern "C" int m3d_fps_sorted(const void* sorted_ws, int64_t n_src, const int64_t* ptr_src, const int64_t* ptr_out,
+                              int32_t num_clouds, int64_t max_points, const int32_t* start, int32_t* idx_out, void* stream) {
+  if (num_clouds < 0 || max_points < 0 || n_src < 0) return M3D_ERR_INVALID;
+  if (num_clouds == 0 || max_points == 0) return M3D_OK;
+  if (!sorted_ws || !ptr_src || !ptr_out || !idx_out) return M3D_ERR_INVALID;
+  if (max_points > FPSB_MAXN) return M3D_ERR_UNSUPPORTED;
+  const char* base = (const char*)sorted_ws;
+  const float4* sorted4 = (const float4*)(base + m3d_knn_workspace_offset(n_src, num_clouds, 0));
+  const int32_t* inv = (const int32_t*)(base + m3d_knn_workspace_offset(n_src, num_clouds, 2));
+  hipLaunchKernelGGL(fps_bucket_kernel, dim3((unsigned)num_clouds), dim3(FPS_THREADS), 0, (hipStream_t)stream, sorted4, inv,
+                     ptr_src, ptr_out, start, idx_out);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
 // ws: m3d_fps_workspace_bytes(num_clouds) bytes, ZERO-FILLED once by the caller (the kernels leave it reusable: a slot's flag
 // holds iteration numbers >= m - 2 >= 62 afterwards, which the first iterations of the next launch cannot mistake for theirs);
 // NULL: the single-workgroup kernel for every size

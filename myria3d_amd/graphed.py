@@ -53,7 +53,7 @@ class GraphedStep:
     def __init__(self, net: HipRandLANet, ptr, num_features: int, *, mode: str = "train",
                  optimizer: Optional[FusedAdam] = None, ignore_index: int = 65, lookahead: bool = True,
                  launch: str = "graph", lookahead_mode: Optional[str] = None, optimizer_in_graph: Optional[bool] = None,
-                 warmup: int = 2, collective: str = "captured"):
+                 warmup: int = 2, collective: str = "captured", tune_streams: int = 6):
         if lookahead_mode is None:
             # two graphs on two streams pay off when the step is longer than the position-only chain (training: 4.72 vs
             # 4.79 ms); the eval forward is shorter than that chain and would wait for it every step (1.59 vs 1.18 ms)
@@ -86,12 +86,13 @@ class GraphedStep:
         if multi and not self.opt_in_graph:
             self.collective = "eager"
         self.turn = 0
+        self._tune_streams = int(tune_streams)
         self._warmup = max(1, warmup)
         self._graphs = None  # (gB, gA) once captured
         self._sA: Optional[torch.cuda.Stream] = None
         self._evA = self._evReady = None
         self._primed = False
-        self.side_stream_overlaps: Optional[bool] = None  # probe result for graph A's replay stream (dual lookahead)
+        self.side_stream_ms: Optional[List[float]] = None  # ms per step measured for each candidate replay stream of graph A
 
     # ------------------------------------------------------------------------------------------
     def _cur(self) -> _BufferSet:
@@ -186,8 +187,6 @@ class GraphedStep:
         net = self.net
         saved = [t.clone() for t in self._state()] if preserve_state else None
         nsets = len(self.sets)
-        if self.lookahead:
-            net._side_stream(self.ptr.device)  # created (and probed) against the stream the steps will be launched on
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # (warm-up off the default stream, as torch's graph recipe asks)
@@ -211,6 +210,8 @@ class GraphedStep:
                 torch.cuda.synchronize()
                 self.collective, self.opt_in_graph = "eager", False
                 self._capture()
+        if self._graphs is not None and self._graphs[1] and self._tune_streams > 1:
+            self._pick_side_stream()
         if saved is not None:
             with torch.no_grad():
                 for t, v in zip(self._state(), saved):
@@ -219,6 +220,35 @@ class GraphedStep:
         self._primed = False
         torch.cuda.synchronize()
         return self
+
+    def _pick_side_stream(self) -> None:
+        """Which stream should graph ``A`` be replayed on?  HIP maps streams onto a few hardware queues (4 by default), and two
+        streams that share one execute in enqueue order however independent their work is.  Which queue a new stream lands
+        on depends on every stream created before it in the process — with an RCCL communicator alive (it owns streams of its
+        own) the stream ``torch.cuda.Stream()`` hands out next sat on the step's queue, and the two graphs of a step ran one
+        after the other: 4.45 + 0.69 = 5.14 ms instead of 4.60 (``tools/collective_probe.py``: the slowdown appears with the
+        process group ALONE, no collective in the step — that, not the all-reduce, was round 3's "+0.44 ms of the N > 1 form").
+        So the choice is measured: a few steps on each of ``tune_streams`` candidate streams, the fastest one is kept."""
+        import time
+
+        cands = [self._sA] + [torch.cuda.Stream() for _ in range(self._tune_streams - 1)]
+        ms = []
+        for c in cands:
+            self._sA = c
+            self._primed = False
+            for _ in range(2):
+                self.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                self.step()
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) / 4 * 1e3)
+        best = min(range(len(cands)), key=lambda i: ms[i])
+        self._sA = cands[best]
+        self.side_stream_ms = [round(v, 3) for v in ms]
+        self._evA.record()
+        self._evReady.record()
 
     def _capture(self) -> None:
         net = self.net
@@ -243,11 +273,7 @@ class GraphedStep:
                 with torch.cuda.graph(g, stream=net._side_stream(self.ptr.device), capture_error_mode="thread_local"):
                     self._geo(k ^ 1)
                 gA.append(g)
-            # the replay stream of graph A must sit on another hardware queue than the step's stream (ops.concurrent_stream)
-            from . import ops as _ops
-
-            self._sA = _ops.concurrent_stream(self.ptr.device)
-            self.side_stream_overlaps = _ops._STREAM_PROBE.get((torch.cuda.current_stream().cuda_stream, self._sA.cuda_stream))
+            self._sA = torch.cuda.Stream()
         elif self.lookahead:  # one graph per buffer set holding both branches
             for k in range(2):
                 g = torch.cuda.CUDAGraph()

@@ -221,56 +221,6 @@ def linear_dgrad(dz: Tensor, w: Tensor, bf16: bool = False, acc: Optional[Tensor
     return gemm(dz, w, M, K, N, b_cm=True, ldb=w.stride(0), bf16=bf16, out=acc, accumulate=acc is not None)
 
 
-_STREAM_PROBE: dict = {}  # id(stream pair) -> bool, for reporting
-
-
-def streams_overlap(a: "torch.cuda.Stream", b: "torch.cuda.Stream", cycles: int = 300_000) -> bool:
-    """Do kernels on ``a`` and ``b`` really run side by side?  HIP maps streams onto a few hardware queues (4 by default);
-    two streams that share one execute in enqueue order, however independent their work is.  Measured with two spin kernels
-    (``torch.cuda._sleep``): together they take about as long as one when the streams sit on different queues, twice as
-    long when they share one."""
-    torch.cuda.synchronize(a.device)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    with torch.cuda.stream(a):
-        ev[0].record(a)
-        torch.cuda._sleep(cycles)
-        ev[1].record(a)
-    torch.cuda.synchronize(a.device)
-    one = ev[0].elapsed_time(ev[1])
-    with torch.cuda.stream(a):
-        ev[2].record(a)
-    b.wait_event(ev[2])
-    with torch.cuda.stream(b):
-        torch.cuda._sleep(cycles)
-    with torch.cuda.stream(a):
-        torch.cuda._sleep(cycles)
-        a.wait_stream(b)
-        ev[3].record(a)
-    torch.cuda.synchronize(a.device)
-    both = ev[2].elapsed_time(ev[3])
-    return both < 1.5 * one
-
-
-def concurrent_stream(device, beside: Optional["torch.cuda.Stream"] = None, tries: int = 8) -> "torch.cuda.Stream":
-    """A side stream that runs BESIDE ``beside`` (default: the current stream), chosen by probing.  Round 4: with an RCCL
-    process group alive (its communicator owns streams of its own) the stream ``torch.cuda.Stream()`` handed out for the
-    position-only graph landed on the hardware queue of the step's stream: the two graphs of ``GraphedStep`` ran one after
-    the other — 4.45 + 0.69 = 5.14 ms instead of 4.60 — which is all of the "+0.44 ms of the N > 1 form" round 3 measured
-    (``tools/collective_probe.py``: the slowdown appears with the process group alone, without any collective in the step)."""
-    beside = torch.cuda.current_stream(device) if beside is None else beside
-    if torch.cuda.is_current_stream_capturing():
-        return torch.cuda.Stream(device=device)
-    first = None
-    for _ in range(tries):
-        cand = torch.cuda.Stream(device=device)
-        ok = streams_overlap(beside, cand)
-        _STREAM_PROBE[(beside.cuda_stream, cand.cuda_stream)] = ok
-        if ok:
-            return cand
-        first = first or cand
-    return first
-
-
 class GradSideStream:
     """Weight-gradient kernels are leaves of the backward pass (nothing downstream reads dW before the optimizer), so
     with gradient sinks they can run on a side stream next to the dgrad / BatchNorm / LFA chain.  The stream rejoins the
@@ -1295,16 +1245,22 @@ _FPS_WS: dict = {}  # (device, clouds) -> zero-filled exchange workspace of the 
 
 
 def fps(pos4: Tensor, ptr: Tensor, ptr_out: Tensor, m: int, max_points: int, start: Optional[Tensor] = None,
-        min_selected: int = 0, multi: bool = True) -> Tensor:
+        min_selected: int = 0, multi: bool = True, index: Optional["KnnIndex"] = None) -> Tensor:
     """Farthest-point sampling inside each cloud (``torch_cluster.fps`` semantics): int32 ``[m]`` global rows in selection
     order; cloud ``b`` keeps ``ptr_out[b+1] - ptr_out[b]`` points starting from ``start[b]`` (cloud-relative; default 0).
     ``min_selected``: the smallest number of points a cloud keeps (host value); with ``multi`` and ``min_selected >= 64``
-    big clouds are sampled by several workgroups each (same index lists)."""
+    big clouds are sampled by several workgroups each (same index lists).  ``index``: the built ``KnnIndex`` of the same
+    points and ``ptr`` — clouds of 4 097 ... 40 000 points are then sampled with exact bucket skipping over its cell-sorted
+    records (``m3d_fps_sorted``; same index lists)."""
     assert pos4.shape[1] == 4 and pos4.is_contiguous()
     idx = torch.empty(m, dtype=torch.int32, device=pos4.device)
     if start is not None:
         assert start.dtype == torch.int32 and start.is_contiguous() and start.numel() == ptr.numel() - 1
     B = ptr.numel() - 1
+    if index is not None and 4096 < max_points <= 40000:
+        assert index.n == pos4.shape[0] and index.num_clouds == B
+        call("m3d_fps_sorted", _p(index.ws), index.n, _p(ptr), _p(ptr_out), B, int(max_points), _p(start), _p(idx), _st())
+        return idx
     ws = None
     if multi and min_selected >= 64:
         key = (pos4.device, B, _st())  # (one exchange buffer per stream: launches on different streams may overlap)

@@ -136,7 +136,7 @@ class HipPointNet2(nn.Module):
         return ops.gemm(x0, w, M, w.shape[0], x0.shape[1], rows=rows, a1=x1, k1=0 if x1 is None else x1.shape[1],
                         bias=lin.bias, scale=scale, shift=shift, act=mlp.act, bf16=self._bf16)
 
-    def _sample(self, lvl: int, pos4: Tensor, plan: SAPlan, train: bool) -> Tensor:
+    def _sample(self, lvl: int, pos4: Tensor, plan: SAPlan, train: bool, index=None) -> Tensor:
         m = plan.totals[lvl + 1]
         dev = pos4.device
         if self.subsampling == "fps":
@@ -145,7 +145,7 @@ class HipPointNet2(nn.Module):
                 sizes = (plan.ptrs[lvl][1:] - plan.ptrs[lvl][:-1]).to(torch.float32)
                 start = (torch.rand(sizes.numel(), device=dev) * sizes).to(torch.int32)
             return ops.fps(pos4, plan.ptrs[lvl], plan.ptrs[lvl + 1], m, plan.max_points[lvl], start,
-                           min_selected=min(plan.sizes[lvl + 1]) if plan.sizes[lvl + 1] else 0)
+                           min_selected=min(plan.sizes[lvl + 1]) if plan.sizes[lvl + 1] else 0, index=index)
         seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=dev)
         return ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], m, seed, lvl)
 
@@ -184,7 +184,7 @@ class HipPointNet2(nn.Module):
                 if sel.numel() != m:
                     raise ValueError(f"level {lvl}: {sel.numel()} sample indices given, {m} expected")
             else:
-                sel = self._sample(lvl, pos4[lvl], plan, train)
+                sel = self._sample(lvl, pos4[lvl], plan, train, index[lvl])
             self.last_sample_idx.append(sel)
             ctr = ops.gather_rows(pos4[lvl], sel)
             nbr, _ = index[lvl].query(K, pos_qry=ctr, ptr_qry=plan.ptrs[lvl + 1])

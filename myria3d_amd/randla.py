@@ -643,8 +643,7 @@ class HipRandLANet(nn.Module):
     def _side_stream(self, device) -> "torch.cuda.Stream":
         st = self._streams.get(device)
         if st is None:
-            # (a stream that really runs beside the current one: ops.concurrent_stream probes the hardware-queue mapping)
-            st = self._streams[device] = ops.concurrent_stream(device)
+            st = self._streams[device] = torch.cuda.Stream(device=device)
         return st
 
     def _forward(self, x, pos, ptr, decimation_idx, dropout_mask, plan, record, train):

@@ -75,6 +75,10 @@ def test_fps_over_several_workgroups_is_bit_exact(device, sizes, keep, starts):
     pos4 = ops.pad_pos(pos.to(device))
     st = torch.tensor(starts, dtype=torch.int32, device=device) if starts is not None else None
     single = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, multi=False)
+    if 4096 < max(sizes) <= 40000:  # exact bucket skipping over the cell-sorted records of the kNN grid
+        ix = ops.KnnIndex(pos4, ptr.to(device))
+        bucketed = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, index=ix)
+        assert torch.equal(bucketed, single), "bucket-skipping sampler vs the plain one"
     for _ in range(2):
         got = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, min_selected=min(keep))
         assert torch.equal(got, single)
@@ -102,6 +106,13 @@ def test_fps_on_duplicates_and_lattice_ties(device):
     want2 = fps_exact(pos2, [0, n2], [0, 900])
     got2 = ops.fps(ops.pad_pos(pos2.to(device)), _ptr([n2]).to(device), _ptr([900]).to(device), 900, n2, min_selected=900)
     assert torch.equal(got2.cpu().long(), want2)
+    # ... and more slots than distinct points on a cloud big enough for the bucket-skipping sampler (all minima reach 0)
+    pos3 = torch.from_numpy(np.concatenate([g2] * 2))
+    n3 = pos3.shape[0]
+    p3 = ops.pad_pos(pos3.to(device))
+    want3 = fps_exact(pos3, [0, n3], [0, 3300])
+    got3 = ops.fps(p3, _ptr([n3]).to(device), _ptr([3300]).to(device), 3300, n3, index=ops.KnnIndex(p3, _ptr([n3]).to(device)))
+    assert torch.equal(got3.cpu().long(), want3)
 
 
 def test_fps_spreads_points(device):

@@ -42,6 +42,6 @@ for rep in range(3):
         gs.step()
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) / 20 * 1e3)
-print(f"collective_probe {case}: {min(ts):.3f} ms per step (runs {', '.join(f'{t:.3f}' for t in ts)}); collective={gs.collective} opt_in_graph={gs.opt_in_graph}", flush=True)
+print(f"collective_probe {case}: {min(ts):.3f} ms per step (runs {', '.join(f'{t:.3f}' for t in ts)}); collective={gs.collective} opt_in_graph={gs.opt_in_graph} side-stream candidates {gs.side_stream_ms}", flush=True)
 if dist.is_initialized():
     dist.destroy_process_group()

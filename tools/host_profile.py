@@ -7,6 +7,8 @@ from myria3d_amd import HipRandLANet, make_plan
 from myria3d_amd.synthetic import synthetic_batch
 from myria3d_amd.train import FusedAdam, cross_entropy
 
+if "st" in sys.argv:  # backward nodes run on the calling thread (no hand-off to the autograd device thread per node)
+    torch.autograd.set_multithreading_enabled(False)
 dev = torch.device("cuda:0")
 x, pos, batch, ptr, y = synthetic_batch([12800] * 16)
 x, pos, ptr, y = x.to(dev), pos.to(dev), ptr.to(dev), y.to(dev)
