@@ -1,24 +1,23 @@
-"""Pins the oracle to the REAL reference — runs only where the reference's third-party stack is importable.
+"""Pins the oracle (and, on the GPU box, the HIP net) to the reference's OWN file: generates ``randla_reference.npz``.
 
     python tests/golden/make_golden_from_reference.py  [/path/to/myria3d checkout, default /root/reference]
 
-Needs ``torch_geometric`` (pyg 2.4), ``torch_cluster``, ``torch_scatter``, ``torchmetrics`` (environment.yml:14-22 of
-the reference).  None of them is installed in the build image of rounds 1-2, so this script has NOT been run yet and
-``tests/golden/randla_reference.npz`` does not exist: the oracle's parity with the reference stays UNPINNED until it
-does (oracle/__init__.py).  The day the wheels exist:
+The script imports ``PyGRandLANet`` from ``myria3d/models/modules/pyg_randla_net.py`` of the checkout (by file path: the
+package ``__init__`` pulls in Lightning / hydra, which the net itself does not need).  The six third-party symbols that file
+imports come from the real wheels (``torch_geometric`` 2.4, ``torch_cluster``, ``torch_scatter``; environment.yml:14-22 of the
+reference) where they are installed, else from ``tests/_pyg_stub`` (a restatement of exactly those symbols, SURVEY Appendix
+A); the ``stack`` entry of the file records which.  HAS BEEN RUN in the build container (rounds 3 and 4, stub stack: the wheels
+cannot be installed there); the committed file is its output and ``tests/test_reference_pin.py`` regenerates and diffs it.
 
-  1. this script imports ``PyGRandLANet`` from ``myria3d/models/modules/pyg_randla_net.py`` of the checkout (by file
-     path: the package ``__init__`` pulls in Lightning / hydra, which the net itself does not need),
-  2. loads the same deterministic weights as ``tests/_util.fill_params_deterministic`` (state_dict keys are shared by
-     construction), injects the same decimation indices by replacing the module-level
-     ``decimation_indices`` (pyg_randla_net.py:192-231) and switches the classifier dropout off (PyG ``MLP.dropout``
-     is a plain list) because torch's dropout stream cannot be injected,
-  3. writes the reference's OWN outputs — eval logits, train-mode logits, loss, a handful of parameter gradients,
-     running statistics, the level-1 kNN edge list as sorted per-centre squared distances — to
-     ``tests/golden/randla_reference.npz``.
-
-``tests/test_reference_pin.py`` then compares ``oracle.randla_oracle.RandLANetOracle`` with that file on every run
-(and, where the stack is importable, with the live reference as well).
+For every size set it
+  1. loads the deterministic weights of ``tests/_util.fill_params_deterministic`` (state_dict keys are shared by construction,
+     SURVEY 8b), injects fixed decimation indices by replacing the module-level ``decimation_indices``
+     (pyg_randla_net.py:192-231) and switches the classifier dropout off (PyG ``MLP.dropout`` is a plain list; torch's
+     dropout stream cannot be injected),
+  2. writes the reference's outputs: eval logits, train-mode logits, loss, EVERY parameter gradient (141 tensors, round 4;
+     seven in round 3), running statistics, the level-1 kNN edge list as per-centre squared distances.
+Size sets: ``[700, 333, 50]`` (keys without prefix) and, round 4, ``[300, 9, 1, 120]`` (prefix ``b/``): a cloud with fewer
+points than K = 16 and a one-point cloud (CHANGELOG 3.4.0 of the reference: tiles down to one point).
 """
 import importlib.util
 import os
@@ -32,6 +31,7 @@ sys.path.insert(0, ROOT)
 from tests._util import fill_params_deterministic, rand_batch  # noqa: E402
 
 SIZES = [700, 333, 50]
+SIZE_SETS = {"": [700, 333, 50], "b/": [300, 9, 1, 120]}  # key prefix -> tile sizes
 PARAM_SEED = 77
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "randla_reference.npz")
 GRAD_KEYS = ["fc0.weight", "block1.lfa1.mlp_attention.lins.0.weight", "block1.lfa2.mlp_encoder.lins.0.weight",
@@ -128,21 +128,23 @@ def main():
     ref_root = sys.argv[1] if len(sys.argv) > 1 else os.environ.get("M3D_REFERENCE_ROOT", "/root/reference")
     mod = load_reference_module(ref_root)
     torch.set_num_threads(1)
-    x, pos, batch, ptr = rand_batch(SIZES, seed=2025)
-    dec = fixed_decimation(ptr.tolist(), 4, 4, seed=8)
-    y = torch.from_numpy(np.random.RandomState(3).randint(0, 6, (sum(SIZES),)))
-    r = run_reference(mod, x, pos, batch, ptr, dec, y)
-    out = dict(x=x.numpy(), pos=pos.numpy(), ptr=ptr.numpy(), y=y.numpy(), param_seed=np.int64(PARAM_SEED),
-               logits_eval=r["logits_eval"].numpy(), logits_train=r["logits_train"].numpy(),
-               loss_train=np.float64(r["loss"].item()), knn_src=r["knn_src"].numpy(), knn_dst=r["knn_dst"].numpy(),
-               knn_d2=r["knn_d2"].numpy(), stack=np.array(mod.M3D_STACK))
-    for i, d in enumerate(dec):
-        out[f"dec{i}"] = d.numpy().astype(np.int64)
-    for k in GRAD_KEYS:
-        out["grad:" + k] = r["grads"][k].numpy()
-    for k, b in r["bufs"].items():
-        if k.startswith(("block1.lfa1.mlp_encoder", "block3.mlp2", "mlp_summit")):
-            out["buf:" + k] = b.numpy()
+    out = dict(param_seed=np.int64(PARAM_SEED), stack=np.array(mod.M3D_STACK), sets=np.array(list(SIZE_SETS)))
+    for pre, sizes in SIZE_SETS.items():
+        x, pos, batch, ptr = rand_batch(sizes, seed=2025 + len(pre))
+        dec = fixed_decimation(ptr.tolist(), 4, 4, seed=8)
+        y = torch.from_numpy(np.random.RandomState(3).randint(0, 6, (sum(sizes),)))
+        r = run_reference(mod, x, pos, batch, ptr, dec, y)
+        out.update({pre + "x": x.numpy(), pre + "pos": pos.numpy(), pre + "ptr": ptr.numpy(), pre + "y": y.numpy(),
+                    pre + "logits_eval": r["logits_eval"].numpy(), pre + "logits_train": r["logits_train"].numpy(),
+                    pre + "loss_train": np.float64(r["loss"].item()), pre + "knn_src": r["knn_src"].numpy(),
+                    pre + "knn_dst": r["knn_dst"].numpy(), pre + "knn_d2": r["knn_d2"].numpy()})
+        for i, d in enumerate(dec):
+            out[f"{pre}dec{i}"] = d.numpy().astype(np.int64)
+        for k, g in r["grads"].items():  # every parameter gradient
+            out[pre + "grad:" + k] = g.numpy()
+        for k, b in r["bufs"].items():
+            if k.startswith(("block1.lfa1.mlp_encoder", "block3.mlp2", "mlp_summit")):
+                out[pre + "buf:" + k] = b.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes — generated from the reference at", ref_root, "on:", mod.M3D_STACK)
 

@@ -45,7 +45,7 @@ def _oracle_run(x, pos, batch, ptr, dec, y, param_seed):
     return net, logits_eval, logits_train.detach(), loss.detach(), idx, d2
 
 
-def _compare(ref, net, logits_eval, logits_train, loss, idx, d2, n):
+def _compare(ref, net, logits_eval, logits_train, loss, idx, d2, n, grad_tol=5e-3):
     """``ref``: dict of the reference's outputs (tensors).  SURVEY 8c parity statement."""
     assert torch.allclose(logits_eval, ref["logits_eval"], rtol=1e-4, atol=1e-4)
     assert (logits_eval.argmax(1) == ref["logits_eval"].argmax(1)).float().mean().item() >= 0.9999
@@ -53,9 +53,14 @@ def _compare(ref, net, logits_eval, logits_train, loss, idx, d2, n):
     assert abs(float(loss) - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"])))
     params = dict(net.named_parameters())
     for k, g in ref["grads"].items():
+        if _noise_gradient(k):
+            continue
         got = params[k].grad
-        # (fp32 on both sides, different thread counts / summation orders: 2e-3; observed up to 1.3e-3)
-        assert (got - g).norm().item() <= 2e-3 * g.norm().item() + 1e-7, k
+        # (fp32 on both sides, different thread counts / summation orders: with EVERY gradient compared the worst of the first size set is 2.3e-3 — mlp_classif.norms.0.module.bias — so 5e-3;  The encoder parameters
+        # of the LFA layers sit behind a train-mode BatchNorm over the edges — ill-conditioned when a level holds a few dozen
+        # points, as in the second size set: 3.4e-3 observed between two fp32 CPU runs of the same arithmetic, 1e-2 allowed)
+        tol = max(1e-2, grad_tol) if "mlp_encoder." in k else grad_tol
+        assert (got - g).norm().item() <= tol * g.norm().item() + 1e-7, k
     bufs = dict(net.named_buffers())
     for k, b in ref["bufs"].items():
         assert torch.allclose(bufs[k], b, rtol=1e-4, atol=1e-6), k
@@ -70,6 +75,12 @@ def _compare(ref, net, logits_eval, logits_train, loss, idx, d2, n):
     ref_d2[rows, col] = ref["knn_d2"][order]
     ref_d2 = ref_d2.sort(dim=1).values
     assert torch.allclose(d2[valid], ref_d2[valid], rtol=1e-5, atol=1e-9)
+
+
+def _noise_gradient(k: str) -> bool:
+    """A bias in front of a BatchNorm (every SharedMLP Linear; fc0's feeds two Linear + BatchNorm layers) has a gradient of
+    exactly 0 in exact arithmetic: both sides hold rounding noise there, a relative comparison is meaningless."""
+    return (".lins." in k and k.endswith(".bias")) or k == "fc0.bias"
 
 
 def _reference_module():
@@ -88,13 +99,16 @@ def test_oracle_matches_the_live_reference():
     mod = _reference_module()
     from tests._util import rand_batch
 
-    x, pos, batch, ptr = rand_batch(gen.SIZES, seed=2025)
-    dec = gen.fixed_decimation(ptr.tolist(), 4, 4, seed=8)
-    y = torch.from_numpy(np.random.RandomState(3).randint(0, 6, (sum(gen.SIZES),)))
-    r = gen.run_reference(mod, x, pos, batch, ptr, dec, y)
-    ref = dict(logits_eval=r["logits_eval"], logits_train=r["logits_train"], loss=r["loss"],
-               grads={k: r["grads"][k] for k in gen.GRAD_KEYS}, bufs=r["bufs"], knn_dst=r["knn_dst"], knn_d2=r["knn_d2"])
-    _compare(ref, *_oracle_run(x, pos, batch, ptr, dec, y, gen.PARAM_SEED), n=x.shape[0])
+    for pre, sizes in gen.SIZE_SETS.items():  # every parameter gradient; the second set holds a 9-point and a 1-point cloud
+        x, pos, batch, ptr = rand_batch(sizes, seed=2025 + len(pre))
+        dec = gen.fixed_decimation(ptr.tolist(), 4, 4, seed=8)
+        y = torch.from_numpy(np.random.RandomState(3).randint(0, 6, (sum(sizes),)))
+        r = gen.run_reference(mod, x, pos, batch, ptr, dec, y)
+        ref = dict(logits_eval=r["logits_eval"], logits_train=r["logits_train"], loss=r["loss"], grads=r["grads"],
+                   bufs=r["bufs"], knn_dst=r["knn_dst"], knn_d2=r["knn_d2"])
+        # (the second set is 430 points: every statistic is a sum over a few hundred rows at most and two fp32 runs of the same
+        # arithmetic — the generator runs single-threaded — differ by 2-4e-3 in several gradients: 1e-2 there)
+        _compare(ref, *_oracle_run(x, pos, batch, ptr, dec, y, gen.PARAM_SEED), n=x.shape[0], grad_tol=1e-2 if pre else 5e-3)
 
 
 @pytest.mark.parametrize("sizes", [[50, 50], [1250, 1000], [7, 300, 1]])
@@ -164,14 +178,17 @@ def test_oracle_matches_vectors_generated_from_the_reference():
         pytest.skip("tests/golden/randla_reference.npz has not been generated: oracle parity with the reference is UNPINNED")
     g = np.load(FIXTURE)
     print(f"[pin] fixture generated on: {g['stack']}")
-    t = lambda k: torch.from_numpy(g[k])
-    x, pos, ptr, y = t("x"), t("pos"), t("ptr"), t("y")
-    batch = torch.repeat_interleave(torch.arange(ptr.numel() - 1), ptr[1:] - ptr[:-1])
-    dec = [t(f"dec{i}") for i in range(4)]
-    ref = dict(logits_eval=t("logits_eval"), logits_train=t("logits_train"), loss=torch.tensor(float(g["loss_train"])),
-               grads={k[5:]: t(k) for k in g.files if k.startswith("grad:")},
-               bufs={k[4:]: t(k) for k in g.files if k.startswith("buf:")}, knn_dst=t("knn_dst"), knn_d2=t("knn_d2"))
-    _compare(ref, *_oracle_run(x, pos, batch, ptr, dec, y, int(g["param_seed"])), n=x.shape[0])
+    for pre in [str(s) for s in g["sets"]]:
+        t = lambda k: torch.from_numpy(g[pre + k])
+        x, pos, ptr, y = t("x"), t("pos"), t("ptr"), t("y")
+        batch = torch.repeat_interleave(torch.arange(ptr.numel() - 1), ptr[1:] - ptr[:-1])
+        dec = [t(f"dec{i}") for i in range(4)]
+        grads = {k[len(pre) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + "grad:")}
+        assert len(grads) == 152, "every parameter gradient of the reference run is in the fixture"
+        ref = dict(logits_eval=t("logits_eval"), logits_train=t("logits_train"), loss=torch.tensor(float(g[pre + "loss_train"])),
+                   grads=grads, bufs={k[len(pre) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + "buf:")},
+                   knn_dst=t("knn_dst"), knn_d2=t("knn_d2"))
+        _compare(ref, *_oracle_run(x, pos, batch, ptr, dec, y, int(g["param_seed"])), n=x.shape[0], grad_tol=1e-2 if pre else 5e-3)
 
 
 def test_pin_machinery_is_self_consistent():
