@@ -316,10 +316,9 @@ def _pick_threads():
 def cpu_baseline(tiles, points, K, full=False):
     """The CPU oracle (op-for-op restatement of the reference path; kNN through cKDTree like torch_cluster's CPU
     path), BASELINE.md section 3 protocol: fwd+bwd in train mode (CE loss) and fwd-only in eval mode, 3 warm-up + 10
-    timed iterations, median, at the thread count a micro-probe picks; then on every host core (bounded: 1 warm-up + 3
-    timed — some hosts are several times slower oversubscribed).  Default sample: 4 of the GPU line's 16 tiles (every
-    op is per point or per tile, the time per point does not depend on the tile count; ~40-60 s of CPU work so the
-    driver's default run stays short); ``full``: all ``tiles`` tiles, 3 + 10 at both thread counts."""
+    timed iterations, median, at the thread count a micro-probe picks.  Default sample (round 4): ALL of the GPU line's 16
+    tiles — the same batch the GPU steps on — with 1 warm-up + 3 timed iterations per leg (~30 s of CPU work at 16 threads,
+    so the driver's default run stays short); ``full``: 3 + 10 iterations, and the same on every host core."""
     import statistics
 
     from oracle.randla_oracle import RandLANetOracle
@@ -331,7 +330,6 @@ def cpu_baseline(tiles, points, K, full=False):
         free_gb = psutil.virtual_memory().available / 2**30
     except Exception:
         free_gb = 16.0
-    tiles = tiles if full else min(tiles, 2)
     tiles = max(1, min(tiles, int(free_gb // 1.5)))  # ~0.7 GB of autograd intermediates per 12 800-point tile
     picked = _pick_threads()
     torch.manual_seed(0)
@@ -365,12 +363,13 @@ def cpu_baseline(tiles, points, K, full=False):
             res[name] = tiles * points / statistics.median(ts)
         return res
 
-    _progress(f"CPU baseline: {tiles} tiles, {picked} threads, 3 + 10 iterations")
-    main = leg(picked, 3, 10)
+    warm, reps = (3, 10) if full else (1, 3)
+    _progress(f"CPU baseline: {tiles} tiles, {picked} threads, {warm} + {reps} iterations")
+    main = leg(picked, warm, reps)
     out = {"value": round(main["fwd_bwd"], 1), "unit": "points/s", "cores": picked, "kind": "port",
            "fwd_only": round(main["fwd_only"], 1), "host_cores": ncpu,
-           "sample": f"{tiles} tiles x {points} pts (of the GPU line's batch), median of 10 timed iterations after 3 "
-                     f"warm-up (BASELINE.md 3); fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
+           "sample": f"{tiles} tiles x {points} pts (the GPU line's whole batch), median of {reps} timed iterations after {warm} "
+                     f"warm-up (BASELINE.md 3 asks for 3 + 10: --cpu-baseline-full); fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
                      f"oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN); threads = {picked} (fastest of "
                      f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
     if full and picked != ncpu:
@@ -380,10 +379,6 @@ def cpu_baseline(tiles, points, K, full=False):
         allc = leg(ncpu, 3, 10, False)
         out["all_cores"] = {"cores": ncpu, "value": round(allc["fwd_bwd"], 1), "fwd_only": round(allc["fwd_only"], 1),
                             "sample": "same tiles, 3 + 10"}
-    elif picked != ncpu:
-        out["all_cores"] = {"cores": ncpu, "value": None,
-                            "note": "not run by default: with every core of this host the same sample did not finish within "
-                                    "460 s (oversubscribed torch CPU ops + cKDTree workers); --cpu-baseline-full runs it"}
     return out
 
 
@@ -512,11 +507,33 @@ def dropin_bench(args, dev):
         ostep()
     dto = timed(ostep, 16, 1) / 16
     net2.join_geometry()
+    # ... and with the backward pass on the calling thread (one line at program start; one device per
+    # process leaves the autograd engine's device thread nothing to overlap, and the hand-off costs ~10 us per node)
+    torch.autograd.set_multithreading_enabled(False)
+    for _ in range(8):
+        ostep()
+    dto_st = timed(ostep, 16, 1) / 16
+    net2.join_geometry()
+    opt3 = torch.optim.Adam(net.parameters(), lr=0.003933709606504788)
+
+    def vstep_st():
+        vx, vpos, vbatch, vptr, vy = var[turn[0] % len(var)]
+        turn[0] += 1
+        opt3.zero_grad()
+        crit(net(vx, vpos, vbatch, vptr), vy).backward()
+        opt3.step()
+
+    for _ in range(8):
+        vstep_st()
+    dtv_st = timed(vstep_st, 16, 1) / 16
+    torch.autograd.set_multithreading_enabled(True)
     print(json.dumps({"dropin_eager_ms_per_step": round(dt * 1e3, 4), "value": round(B * N / dt, 1),
                       "optin_variable_layout_ms_per_step": round(dto * 1e3, 4),
                       "optin_variable_layout_points_per_s": round(mean_pts / dto, 1),
                       "dropin_variable_layout_ms_per_step": round(dtv * 1e3, 4),
                       "dropin_variable_layout_points_per_s": round(mean_pts / dtv, 1),
+                      "optin_variable_layout_single_thread_autograd_ms_per_step": round(dto_st * 1e3, 4),
+                      "dropin_variable_layout_single_thread_autograd_ms_per_step": round(dtv_st * 1e3, 4),
                       "variable_layout": f"8 batches of {B} tiles, sizes uniform in [{N // 2}, {N + N // 2}] (mean "
                                          f"{mean_pts:.0f} points per batch), a different layout every step",
                       "fwd_only_ms": round(dtf * 1e3, 4), "unit": "points/s",
@@ -564,33 +581,28 @@ def pointnet2_bench(args, dev):
     for l in range(3):
         lv.append(ops.gather_rows(lv[l], net.last_sample_idx[l]))
 
-    def sampler():
-        for l in range(3):
-            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l], min_selected=min(plan.sizes[l + 1]))
-
-    dts = timed(sampler, steps, 1) / steps
-
-    def sampler_single():  # round 3's form: one workgroup per cloud
-        for l in range(3):
-            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l], multi=False)
-
-    dts1 = timed(sampler_single, max(1, steps // 2), 1) / max(1, steps // 2)
     ixs = [ops.KnnIndex(lv[l], plan.ptrs[l]) for l in range(3)]
 
-    def sampler_bucket():  # exact bucket skipping over the kNN grid's cell-sorted records (what the net uses)
+    def sampler():  # what the net runs: exact bucket skipping above 16 384 points per cloud, the register-resident sampler below
         for l in range(3):
             ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l], index=ixs[l])
 
-    dtsb = timed(sampler_bucket, steps, 1) / steps
+    dts = timed(sampler, steps, 1) / steps
+
+    def sampler_single():  # round 3's sampler: every point in every iteration
+        for l in range(3):
+            ops.fps(lv[l], plan.ptrs[l], plan.ptrs[l + 1], plan.totals[l + 1], plan.max_points[l])
+
+    dts1 = timed(sampler_single, max(1, steps // 2), 1) / max(1, steps // 2)
     print(json.dumps({"metric": "points/sec fwd+bwd, PointNet++ set-abstraction variant", "value": round(B * N / dt, 1),
                       "unit": "points/s", "ms_per_step": round(dt * 1e3, 3), "fwd_only_ms": round(dtf * 1e3, 3),
-                      "fps_ms": round(dts * 1e3, 3), "fps_single_workgroup_ms": round(dts1 * 1e3, 3), "fps_bucket_skipping_ms": round(dtsb * 1e3, 3), "dtype": "f32", "data": "synthetic",
+                      "fps_ms": round(dts * 1e3, 3), "fps_plain_ms": round(dts1 * 1e3, 3), "dtype": "f32", "data": "synthetic",
                       "workload": f"HipPointNet2 train step, {B} tiles x {N} pts, K={K}, decimation 4, FPS sampling, eager "
                                   "launches, torch Adam (BASELINE configs[4], second half; no reference implementation: "
                                   "oracle-only parity)",
-                      "what": "fps_ms = the three farthest-point-sampling launches of one forward (several workgroups per tile "
-                              "that exchange one candidate per iteration; fps_single_workgroup_ms: one workgroup per tile, a "
-                              "serial arg-max chain of n/4 iterations on one CU)"}), flush=True)
+                      "what": "fps_ms = the three farthest-point-sampling launches of one forward (one workgroup per tile; exact "
+                              "bucket skipping over the kNN grid's cell-sorted records above 16 384 points per tile); "
+                              "fps_plain_ms: every point visited in every iteration (round 3's sampler)"}), flush=True)
 
 
 def predict_bench(args, dev, world=1, rank=0, reps=None):
@@ -648,6 +660,39 @@ def predict_bench(args, dev, world=1, rank=0, reps=None):
                                    f"batch {bs}, K=16, C={C}, interpolation k=10; batches sharded over {world} rank(s), "
                                    "no data-path collective",
                        "launch": "eager"}}
+
+
+def predict_e2e_bench(args, dev, side_m=1000.0, density=10.0, reps=2):
+    """BASELINE config 3 END TO END: one synthetic 1 km^2 cloud (10 M points at 10 pts/m^2; raw Lambert-style coordinates minus a
+    file offset, raw Intensity / colour features) in HBM through the whole ``predict.py`` chain on the device —
+    ``myria3d_amd.predict_cloud``: tile selection (400 samples of 50 m) -> GridSampling(0.25) -> node budget -> Center /
+    NullifyLowestZ / NormalizePos / StandardizeRGBAndIntensity -> forward (batches of 50 samples) -> knn_interpolate(k=10) onto
+    every original point -> scatter_sum merge -> softmax / argmax / entropy.  The timed call starts from the resident cloud
+    and ends with the per-point predictions on the device (LAS reading / writing is pdal's: storage, out of scope)."""
+    import numpy as np
+
+    from myria3d_amd import HipRandLANet, predict_cloud
+
+    rs = np.random.RandomState(0)
+    n = int(side_m * side_m * density)
+    xy = rs.uniform(0, side_m, (n, 2)).astype(np.float32)
+    z0 = 2.0 * np.sin(2 * np.pi * xy[:, 0] / 50.0) + 1.5 * np.cos(2 * np.pi * xy[:, 1] / 37.0)
+    u = rs.uniform(size=n).astype(np.float32)
+    z = np.where(u < 0.5, z0 + 0.05 * rs.standard_normal(n), np.where(u < 0.85, z0 + 15 * rs.uniform(size=n), z0 + 3 + 6 * rs.uniform(size=n)))
+    pos = torch.from_numpy(np.concatenate([xy, z[:, None].astype(np.float32)], 1)).to(dev)
+    x = torch.rand((n, 9), device=dev)
+    x[:, 0] = torch.from_numpy(rs.gamma(2.0, 300.0, n).astype(np.float32)).to(dev)
+    x[:, 7] = x[:, 7] * 255.0
+    torch.manual_seed(0)
+    net = HipRandLANet(9, 7, num_neighbors=16, return_logits=True).to(dev).eval()
+    out = predict_cloud(net, pos, x, tile_width=side_m, subtile_width=50, batch_size=50)  # warm-up (allocator, plans)
+    assert out["idx_in_full_cloud"].numel() == n and int(out["idx_in_full_cloud"].unique().numel()) == n  # every point once
+    assert bool(torch.isfinite(out["probas"]).all()) and float((out["probas"].sum(1) - 1).abs().max()) < 1e-4
+    del out
+    dt = timed(lambda: predict_cloud(net, pos, x, tile_width=side_m, subtile_width=50, batch_size=50), reps, 1) / reps
+    return {"value": round(n / dt, 1), "unit": "points/s", "ms_per_cloud": round(dt * 1e3, 1), "points": n,
+            "workload": f"BASELINE config 3 end to end: {n} points over {side_m:.0f} m x {side_m:.0f} m, 400 samples of 50 m, batch 50, "
+                        "GridSampling 0.25 m, K=16, C=7, interpolation k=10 (myria3d_amd.predict_cloud)"}
 
 
 def prepare_bench(args, dev):
@@ -889,6 +934,10 @@ def _extra_legs(args, dev, res, B, N, K):
         pr = predict_bench(args, dev, reps=2)
         res["predict_config3"] = {k: pr[k] for k in ("value", "unit", "ms_per_sweep")} | {"workload": pr["config"]["workload"]}
 
+    def predict_e2e():
+        _progress("predict chain end to end (config 3)")
+        res["predict_config3_end_to_end"] = predict_e2e_bench(args, dev)
+
     def bf16():
         # BASELINE config 2 names bf16: the same step with the matrix-bound layers on bf16 matrix cores (fp32 accumulate;
         # parity bar of SURVEY 8c: logits within 3e-2 of the fp32 oracle, tests/test_gpu_net.py)
@@ -905,6 +954,8 @@ def _extra_legs(args, dev, res, B, N, K):
         res["dropin_eager_ms_per_step"] = di["dropin_eager_ms_per_step"]
         res["dropin_variable_layout_ms_per_step"] = di.get("dropin_variable_layout_ms_per_step")
         res["optin_variable_layout_ms_per_step"] = di.get("optin_variable_layout_ms_per_step")
+        res["optin_variable_layout_single_thread_autograd_ms_per_step"] = di.get("optin_variable_layout_single_thread_autograd_ms_per_step")
+        res["dropin_variable_layout_single_thread_autograd_ms_per_step"] = di.get("dropin_variable_layout_single_thread_autograd_ms_per_step")
         res["dropin"] = di
 
     def collective():  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)
@@ -932,6 +983,7 @@ def _extra_legs(args, dev, res, B, N, K):
                                                           "--neighbors", "32"])
 
     leg("predict", "predict_config3", predict)
+    leg("predict", "predict_config3_end_to_end", predict_e2e)
     leg("bf16", "bf16", bf16)
     leg("dropin", "dropin", dropin)
     leg("collective", "forced_collective_1rank", collective)

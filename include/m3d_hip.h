@@ -336,20 +336,16 @@ int m3d_tile_normalize(float* pos, int32_t pos_stride, float* x, int64_t ldx, in
  * given): cloud b keeps ptr_out[b+1] - ptr_out[b] points; slot 0 is point start[b] (cloud-relative; NULL: point 0), slot
  * s + 1 the point with the largest distance to slots 0..s (d2 = (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction,
  * ties -> smaller index).  pos4: [n, 4] rows (x, y, z, -), 16-byte aligned.  idx_out: global rows, selection order.
- * max_points: the largest cloud (host value; <= 65 536); min_selected: the smallest ptr_out difference (host value).
- * ws: NULL, or m3d_fps_workspace_bytes(num_clouds) bytes that were ZERO-FILLED once (reusable afterwards without refilling):
- * clouds of >= 2 048 points are then sampled by several workgroups each, which exchange one candidate per iteration
- * through ws (csrc/sa.hip: fps_multi_kernel; used when min_selected >= 64 and the grid stays co-resident).  Same index lists
- * either way. */
-size_t m3d_fps_workspace_bytes(int32_t num_clouds);
+ * max_points: the largest cloud (host value; <= 65 536). */
+int m3d_fps(const float* pos4, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds, int64_t max_points,
+            const int32_t* start, int32_t* idx_out, void* stream);
 /* The same sampling with EXACT bucket skipping (csrc/sa.hip: fps_bucket_kernel): sorted_ws = the BUILT kNN workspace of the
  * same points and ptr_src (m3d_knn_build; n_src points in all) — its cell-sorted records are cut into buckets of 64 whose
- * bounding boxes let an iteration skip every bucket the new point cannot reach.  max_points <= 40 000 (the running minima of
+ * bounding boxes let an iteration skip every bucket the new point cannot reach (2x faster at 40 000 points per cloud; no
+ * gain below ~16 000, where m3d_fps keeps every position in registers).  max_points <= 40 000 (the running minima of
  * a cloud live in LDS).  idx_out: original global rows, selection order; identical to m3d_fps. */
 int m3d_fps_sorted(const void* sorted_ws, int64_t n_src, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds,
                    int64_t max_points, const int32_t* start, int32_t* idx_out, void* stream);
-int m3d_fps(const float* pos4, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds, int64_t max_points,
-            int64_t min_selected, const int32_t* start, int32_t* idx_out, void* ws, void* stream);
 /* Edge rows of a set-abstraction level over a COMPACT edge list: centre i owns edges seg[i] .. seg[i+1] - 1 (at most K;
  * fewer when its cloud has fewer than K points, as in PyG's edge_index), edge seg[i] + k has source j = nbr[i][k]:
  *   out[e][0..C) = x[j],  out[e][C..C+3) = pos_src[j] - pos_ctr[i],  out[e][C+3..ldo) = 0;  esrc[e] = j, ectr[e] = i. */

@@ -77,9 +77,8 @@ SIGNATURES = {
     "m3d_tile_select_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_tile_select": (_i32, [_p, _i32, _i64, _p, _i32, C.c_double, C.c_double, C.c_double, _p, _i32, _p, _p, _p]),
     "m3d_tile_normalize": (_i32, [_p, _i32, _p, _i64, _i32, _i32, _p, _i32, _i64, _i32, _i32, _f32, _f32, _p, _p]),
-    "m3d_fps_workspace_bytes": (C.c_size_t, [_i32]),
     "m3d_fps_sorted": (_i32, [_p, _i64, _p, _p, _i32, _i64, _p, _p, _p]),
-    "m3d_fps": (_i32, [_p, _p, _p, _i32, _i64, _i64, _p, _p, _p, _p]),
+    "m3d_fps": (_i32, [_p, _p, _p, _i32, _i64, _p, _p, _p]),
     "m3d_sa_group": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "m3d_sa_group_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "m3d_seg_max": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p]),

@@ -19,10 +19,11 @@
 // variance of W r + b over all edges follow from the first and second moments of r (m3d_lfa_moments, 65
 // numbers per level, fp64), see m3d_lfa_enc_finalize.
 //
-// Backward (round 1): recompute-based but unfused — m3d_lfa_edge_features materialises F, the generic GEMM
-// recomputes A, m3d_lfa_edge_softmax_bwd / m3d_lfa_edge_features_bwd do the per-edge calculus, and the
-// encoder's parameter gradients (through its train-mode BatchNorm) are reconstructed analytically from 11*d
-// accumulated numbers in m3d_lfa_enc_bwd_finalize.
+// Backward: the fused kernel of lfa_bwd.hip (nothing of size [E,.] in HBM either).  The per-edge entry points further down
+// (m3d_lfa_edge_features / _edge_softmax_* / _edge_features_bwd: round 1's unfused backward, which materialises F and the
+// logits) serve neighbour counts above 32, which the fused kernels are not instantiated for, and are the step-by-step
+// cross-check the parity tests run against the fused kernels.  The encoder's parameter gradients (through its train-mode BatchNorm) are reconstructed analytically from
+// 11*d accumulated numbers in m3d_lfa_enc_bwd_finalize.
 #include "m3d_common.h"
 #include "lfa_common.h"
 #include "../../include/m3d_hip.h"

@@ -151,150 +151,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float4* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// farthest-point sampling over G workgroups per cloud (round 4).  The single-workgroup kernel above is a serial chain of
-// m iterations on ONE CU: 6.4 us per selected point at 40 000 points (16 waves on 4 SIMDs: 1.4 us of reductions + barrier,
-// 40 points per thread re-read from L2) — 64 ms of the PointNet++ variant's 94 ms step at 16 x 40 000 points, on 16 of the
-// chip's 256 CUs.  Here workgroup g of a cloud owns the contiguous slice [g * chunk, (g + 1) * chunk) of its points with
-// positions AND running minima in registers (256 threads, <= 24 points per thread), finds its own farthest point, and the G
-// candidates (distance, index, coordinates: 32 bytes) meet in L2: every workgroup publishes its candidate into slot
-// [iteration parity][g] of a small workspace and then reads all G slots of that parity (acquire loads, lanes 0..G-1 of every
-// wave poll one slot each; the arg-max over the G candidates is a DPP reduction; no second barrier).  A slot's flag carries
-// the iteration number, so double buffering by parity is enough: a workgroup can only be one iteration ahead of the
-// slowest one (it needs everybody's candidate of iteration s to finish s).  Same arithmetic and the same total order
-// (larger distance, then smaller index) as the single-workgroup kernel: bit-identical index lists.  All G workgroups of a
-// cloud spin on each other, so the launch keeps the grid small enough to be co-resident (<= 1024 workgroups of 256 threads).
-// ------------------------------------------------------------------------------------------
-#define FPSM_THREADS 256
-#define FPSM_MAXG 16
-struct FpsSlot {  // 32 bytes
-  float best; int besti; float x, y, z; int flag; int pad0, pad1;
-};
-extern "C" size_t m3d_fps_workspace_bytes(int32_t num_clouds) {
-  return num_clouds < 0 ? 0 : (size_t)num_clouds * 2 * FPSM_MAXG * sizeof(FpsSlot) + 256;
-}
-
-template <int PPT>
-__global__ __launch_bounds__(FPSM_THREADS) void fps_multi_kernel(const float4* __restrict__ pos4, const int64_t* __restrict__ ptr_src,
-                                                                const int64_t* __restrict__ ptr_out,
-                                                                const int32_t* __restrict__ start, int32_t* __restrict__ idx_out,
-                                                                FpsSlot* __restrict__ slots, int G) {
-  // the G workgroups of a cloud sit on ONE XCD where the numbers allow (consecutive workgroups are dealt round-robin over the
-  // 8 XCDs; in XCD-major numbering a cloud's workgroups are neighbours): their per-iteration exchange then goes through that XCD's L2 instead of
-  // crossing the chiplets (first version, workgroups of a cloud on 8 different XCDs + agent-scope release / acquire
-  // fences = an L2 write-back and invalidate per iteration: 10 us per selected point, slower than ONE workgroup)
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int pos = (int)xcd_major(blockIdx.x, gridDim.x);  // a bijection on the workgroup ids: XCD-major numbering
-  const int b = pos / G, g = pos % G;                     // (a cloud whose workgroups straddle two XCDs is slower, not wrong)
-  const int64_t s0 = ptr_src[b], o0 = ptr_out[b];
-  const int n = (int)(ptr_src[b + 1] - s0), m = (int)(ptr_out[b + 1] - o0);
-  if (m <= 0 || n <= 0) return;
-  constexpr int NW = FPSM_THREADS / 64;
-  __shared__ float wbest[2][NW];
-  __shared__ int wbesti[2][NW];
-  __shared__ float4 wq[2][NW];
-  const float4* p = pos4 + s0;
-  const int chunk = (n + G - 1) / G;
-  const int lo = g * chunk, hi = min(n, lo + chunk);
-  FpsSlot* my = slots + (size_t)b * 2 * FPSM_MAXG;  // [2][FPSM_MAXG]
-  float mind[PPT];
-  float4 pc[PPT];
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    const int i = lo + t + FPSM_THREADS * j;
-    mind[j] = i < hi ? __builtin_inff() : -1.f;  // (a valid point's distance is >= 0: padding never wins)
-    pc[j] = i < hi ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  int cur = start ? start[b] : 0;
-  cur = cur < 0 ? 0 : (cur >= n ? n - 1 : cur);
-  float4 q = p[cur];
-  int32_t mine = 0;  // (workgroup 0 of the cloud records the selections: thread s % 256 keeps selection s, stored in blocks)
-  for (int s = 0; s < m; ++s) {
-    if (g == 0) {
-      if (t == (s & (FPSM_THREADS - 1))) mine = (int32_t)(s0 + cur);
-      if ((s & (FPSM_THREADS - 1)) == FPSM_THREADS - 1 || s == m - 1) {
-        const int base = s & ~(FPSM_THREADS - 1);
-        if (base + t <= s) idx_out[o0 + base + t] = mine;
-      }
-    }
-    if (s == m - 1) break;
-    float best = -2.f;
-    int besti = INT_MAX;
-    float bx = 0.f, by = 0.f, bz = 0.f;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int i = lo + t + FPSM_THREADS * j;
-      const float d = fps_d2(pc[j], q);
-      if (i < hi) mind[j] = fminf(mind[j], d);
-      if (mind[j] > best) {  // (ascending i inside a thread: '>' keeps the first)
-        best = mind[j]; besti = i; bx = pc[j].x; by = pc[j].y; bz = pc[j].z;
-      }
-    }
-    const int own = besti;
-    fps_step_dpp<0xB1>(best, besti);
-    fps_step_dpp<0x4E>(best, besti);
-    fps_step_dpp<0x141>(best, besti);
-    fps_step_dpp<0x140>(best, besti);
-    {
-      float a, c, ia, ic;
-      xgroup_pair16(best, a, c); xgroup_pair16(__int_as_float(besti), ia, ic);
-      fps_pick(a, __float_as_int(ia), c, __float_as_int(ic), best, besti);
-      xgroup_pair32(best, a, c); xgroup_pair32(__int_as_float(besti), ia, ic);
-      fps_pick(a, __float_as_int(ia), c, __float_as_int(ic), best, besti);
-    }
-    const int par = s & 1;
-    // (a wave whose points are all padding has best = -2 / besti = INT_MAX in every lane: lane 0 writes that candidate)
-    if (own == besti && (besti != INT_MAX || lane == 0)) {
-      wbest[par][wid] = best; wbesti[par][wid] = besti; wq[par][wid] = make_float4(bx, by, bz, 0.f);
-    }
-    __syncthreads();
-    // the workgroup's candidate: every wave reduces the NW wave candidates itself (lane l takes candidate l % NW)
-    int bw = lane & (NW - 1);
-    best = wbest[par][bw]; besti = wbesti[par][bw];
-    fps_step_dpp3<0xB1>(best, besti, bw);
-    fps_step_dpp3<0x4E>(best, besti, bw);
-    FpsSlot* row = my + par * FPSM_MAXG;
-    if (t == 0) {  // publish: payload, then the flag (release at agent scope: the other workgroups run on other CUs / XCDs)
-      const float4 c = wq[par][bw];
-      FpsSlot* d = row + g;
-      __hip_atomic_store(&d->best, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&d->besti, besti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&d->x, c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&d->y, c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&d->z, c.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // payload before flag: every access to a slot is an agent-scope atomic (served by L2 / the memory side, never by a
-      // non-coherent cache), so the order of THIS thread's stores is all that matters: wait for them, then raise the flag —
-      // no L2 write-back / invalidate as an agent-scope release / acquire pair would issue every iteration
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_s_waitcnt(0);
-      __hip_atomic_store(&d->flag, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // gather: lanes 0..G-1 of every wave poll one slot each until it carries this iteration's number
-    float cb = -3.f; int ci = INT_MAX; float cx = 0.f, cy = 0.f, cz = 0.f;
-    const int sl = lane & (FPSM_MAXG - 1);
-    if (sl < G) {
-      const FpsSlot* d = row + sl;
-      while (__hip_atomic_load(&d->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != s + 1) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      cb = __hip_atomic_load(&d->best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ci = __hip_atomic_load(&d->besti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cx = __hip_atomic_load(&d->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cy = __hip_atomic_load(&d->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cz = __hip_atomic_load(&d->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // arg-max over the 16 lanes of a DPP row (every row of every wave holds the same 16 slots); the winner's lane-in-row
-    // travels along as a tag and its coordinates are fetched with a row-local permutation
-    int tag = sl;
-    fps_step_dpp3<0xB1>(cb, ci, tag);
-    fps_step_dpp3<0x4E>(cb, ci, tag);
-    fps_step_dpp3<0x141>(cb, ci, tag);
-    fps_step_dpp3<0x140>(cb, ci, tag);
-    cur = ci;
-    const int srcl = (lane & ~(FPSM_MAXG - 1)) | tag;
-    q = make_float4(__shfl(cx, srcl, 64), __shfl(cy, srcl, 64), __shfl(cz, srcl, 64), 0.f);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // farthest-point sampling with EXACT bucket skipping (round 4; the "block order for exact sub-set skipping" of DESIGN r3).
 // The serial chain of m iterations stays, but an iteration no longer touches every point: the points of a cloud are taken in
 // the cell-sorted order of its kNN grid (csrc/knn.hip: float4 records x, y, z, original row — spatially compact runs) and cut
@@ -308,7 +164,11 @@ __global__ __launch_bounds__(FPSM_THREADS) void fps_multi_kernel(const float4* _
 // running minima: LDS, 40 000 x 4 bytes = all of it), reduces (value, original row) with the total order of the oracle
 // (larger distance, then smaller ORIGINAL row) and leaves the result in the owner lane's registers.  The arg-max over the
 // bucket maxima is the two-stage reduction of fps_kernel.  Same arithmetic, same order => bit-identical index lists.
-// Clouds of 4 097 ... 40 000 points (LDS bound); others take fps_kernel.
+// Clouds of 16 385 ... 40 000 points (below, fps_kernel keeps every position in registers and is as fast; above, the minima
+// no longer fit in LDS).  16 x 40 000 -> 10 000 -> 2 500 -> 625 points: 71.5 -> 36.6 ms for the three launches (r04d), ...
+// (Also built in round 4 and removed: G workgroups per cloud that exchange one candidate per iteration through L2 — 70 ms, no
+// better than one workgroup: an agent-scope round trip per iteration costs what the 40 points per thread cost;
+// profiles/r04c_bench.json.)
 // ------------------------------------------------------------------------------------------
 #define FPSB_MAXN 40000
 #define FPSB_BS 64
@@ -319,17 +179,40 @@ __device__ __forceinline__ void fpsb_step(float& best, int& besti, int& tag) {  
   const int ot = __builtin_amdgcn_update_dpp(0, tag, CTRL, 0xF, 0xF, false);
   if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; tag = ot; }
 }
+__device__ __forceinline__ void fpsb_pick3(float a, int ia, int ta, float b, int ib, int tb, float& best, int& besti, int& tag) {
+  const bool t = b > a || (b == a && ib < ia);
+  best = t ? b : a; besti = t ? ib : ia; tag = t ? tb : ta;
+}
 __device__ __forceinline__ void fpsb_wave_argmax(float& best, int& besti, int& tag) {
   fpsb_step<0xB1>(best, besti, tag);
   fpsb_step<0x4E>(best, besti, tag);
   fpsb_step<0x141>(best, besti, tag);
   fpsb_step<0x140>(best, besti, tag);
-#pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {  // across the four rows of 16 lanes
-    const float ob = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(besti, o, 64), ot = __shfl_xor(tag, o, 64);
-    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; tag = ot; }
-  }
+  // across the four rows of 16 lanes: row swaps (VALU), not __shfl_xor (an LDS-pipe round trip per value and step)
+  float a, c, ia, ic, ta, tc;
+  xgroup_pair16(best, a, c); xgroup_pair16(__int_as_float(besti), ia, ic); xgroup_pair16(__int_as_float(tag), ta, tc);
+  fpsb_pick3(a, __float_as_int(ia), __float_as_int(ta), c, __float_as_int(ic), __float_as_int(tc), best, besti, tag);
+  xgroup_pair32(best, a, c); xgroup_pair32(__int_as_float(besti), ia, ic); xgroup_pair32(__int_as_float(tag), ta, tc);
+  fpsb_pick3(a, __float_as_int(ia), __float_as_int(ta), c, __float_as_int(ic), __float_as_int(tc), best, besti, tag);
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {  // (the builtin moves 32 raw bits: reinterpret, do not convert)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// one affected bucket: lane-wise minimum update of its 64 records, the bucket's new (max, original row, coordinates) into the
+// owner lane's registers
+__device__ __forceinline__ void fpsb_update(const float4 v, int i, int l, int n, int64_t s0, int lane, const float4 q, float* mind,
+                                            float& bmax, int& barg, float& bx, float& by, float& bz) {
+  const float d = fps_d2(v, q);
+  float nm = mind[i];
+  if (i < n) { nm = fminf(nm, d); mind[i] = nm; }
+  float best = nm;
+  int besti = i < n ? (int)(__float_as_int(v.w) - (int)s0) : INT_MAX;
+  int tag = lane;
+  fpsb_wave_argmax(best, besti, tag);
+  const int tl = __builtin_amdgcn_readfirstlane(tag);
+  const float wx = readlane_f(v.x, tl), wy = readlane_f(v.y, tl), wz = readlane_f(v.z, tl);
+  if (lane == l) { bmax = best; barg = besti; bx = wx; by = wy; bz = wz; }
 }
 
 __global__ __launch_bounds__(FPS_THREADS) void fps_bucket_kernel(const float4* __restrict__ sorted4, const int32_t* __restrict__ inv,
@@ -374,6 +257,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_bucket_kernel(const float4* _
   float4 q = sorted4[inv[s0 + cur]];  // (inv: original global row -> global cell-sorted slot)
   __syncthreads();
   int32_t mine = 0;
+  float cbest = -2.f, cqx = 0.f, cqy = 0.f, cqz = 0.f;  // this wave's candidate (wave-uniform), kept across iterations
+  int cbesti = INT_MAX;
   for (int s = 0; s < m; ++s) {
     if (t == (s & (FPS_THREADS - 1))) mine = (int32_t)(s0 + cur);
     if ((s & (FPS_THREADS - 1)) == FPS_THREADS - 1 || s == m - 1) {
@@ -388,32 +273,39 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_bucket_kernel(const float4* _
       aff = fps_d2(c, q) < bmax;  // c = the box's nearest point to q: |c - q| <= |p - q| per axis for every p in the box
     }
     unsigned long long mask = __builtin_amdgcn_ballot_w64(aff);
+    const bool touched = mask != 0;
     while (mask) {
+      // two buckets per trip: both position loads are in flight before the first one is reduced
       const int l = __builtin_ctzll(mask);
       mask &= mask - 1;
+      const int l2 = mask ? __builtin_ctzll(mask) : l;
+      const int i2 = (l2 * NW + wid) * FPSB_BS + lane;
       const int bb = l * NW + wid;
       const int i = bb * FPSB_BS + lane;
-      const float4 v = p[i < n ? i : n - 1];
-      const float d = fps_d2(v, q);
-      float nm = mind[i];
-      if (i < n) { nm = fminf(nm, d); mind[i] = nm; }
-      float best = nm;
-      int besti = i < n ? (int)(__float_as_int(v.w) - (int)s0) : INT_MAX;
-      int tag = lane;
+      float4 v = p[i < n ? i : n - 1];
+      const float4 v2 = p[i2 < n ? i2 : n - 1];
+      fpsb_update(v, i, l, n, s0, lane, q, mind, bmax, barg, bx, by, bz);
+      if (mask) {
+        mask &= mask - 1;
+        fpsb_update(v2, i2, l2, n, s0, lane, q, mind, bmax, barg, bx, by, bz);
+      }
+    }
+    // ---- arg-max over the bucket maxima: this wave's candidate (recomputed only when one of its buckets changed — the
+    // bucket of the point just selected always does), then the 16 wave candidates
+    if (touched || s == 0) {
+      float best = bmax;
+      int besti = barg, tag = lane;
       fpsb_wave_argmax(best, besti, tag);
       const int tl = __builtin_amdgcn_readfirstlane(tag);
-      const float wx = __shfl(v.x, tl, 64), wy = __shfl(v.y, tl, 64), wz = __shfl(v.z, tl, 64);
-      if (lane == l) { bmax = best; barg = besti; bx = wx; by = wy; bz = wz; }
+      cbest = best; cbesti = besti;
+      cqx = readlane_f(bx, tl); cqy = readlane_f(by, tl); cqz = readlane_f(bz, tl);
     }
-    // ---- arg-max over the bucket maxima: wave, then the 16 wave candidates
-    float best = bmax;
-    int besti = barg, tag = lane;
-    fpsb_wave_argmax(best, besti, tag);
     const int par = s & 1;
-    if (lane == __builtin_amdgcn_readfirstlane(tag)) { wbest[par][wid] = best; wbesti[par][wid] = besti; wq[par][wid] = make_float4(bx, by, bz, 0.f); }
+    if (lane == 0) { wbest[par][wid] = cbest; wbesti[par][wid] = cbesti; wq[par][wid] = make_float4(cqx, cqy, cqz, 0.f); }
     __syncthreads();
     int bw = lane & 15;
-    best = wbest[par][bw]; besti = wbesti[par][bw];
+    float best = wbest[par][bw];
+    int besti = wbesti[par][bw];
     fps_step_dpp3<0xB1>(best, besti, bw);
     fps_step_dpp3<0x4E>(best, besti, bw);
     fps_step_dpp3<0x141>(best, besti, bw);
@@ -440,35 +332,14 @@ extern "C" int m3d_fps_sorted(const void* sorted_ws, int64_t n_src, const int64_
   return M3D_OK;
 }
 
-// ws: m3d_fps_workspace_bytes(num_clouds) bytes, ZERO-FILLED once by the caller (the kernels leave it reusable: a slot's flag
-// holds iteration numbers >= m - 2 >= 62 afterwards, which the first iterations of the next launch cannot mistake for theirs);
-// NULL: the single-workgroup kernel for every size
 extern "C" int m3d_fps(const float* pos4, const int64_t* ptr_src, const int64_t* ptr_out, int32_t num_clouds,
-                       int64_t max_points, int64_t min_selected, const int32_t* start, int32_t* idx_out, void* ws,
-                       void* stream) {
+                       int64_t max_points, const int32_t* start, int32_t* idx_out, void* stream) {
   if (num_clouds < 0 || max_points < 0) return M3D_ERR_INVALID;
   if (num_clouds == 0 || max_points == 0) return M3D_OK;
   if (!pos4 || !ptr_src || !ptr_out || !idx_out || (((uintptr_t)pos4) & 15)) return M3D_ERR_INVALID;
   if (max_points > (int64_t)FPS_THREADS * 64) return M3D_ERR_UNSUPPORTED;  // 65 536 points per cloud
   hipStream_t st = (hipStream_t)stream;
   const float4* p = (const float4*)pos4;
-  // several workgroups per cloud when the clouds are big enough to be split (>= 2 048 points), every cloud selects enough
-  // points for the flag protocol (min_selected >= 64: host value, the smallest ptr_out difference) and the grid stays
-  // co-resident
-  int G = (int)m3d_cdiv(max_points, FPSM_THREADS * 8);  // ~8 points per thread ...
-  if (max_points > (int64_t)FPSM_THREADS * 8 * FPSM_MAXG) G = (int)m3d_cdiv(max_points, FPSM_THREADS * 24);  // ... up to 24
-  if (G > FPSM_MAXG) G = FPSM_MAXG;
-  while (G > 1 && (int64_t)G * num_clouds > 1024) --G;
-  if (ws && G >= 2 && min_selected >= 64 && m3d_cdiv(max_points, G) <= (int64_t)FPSM_THREADS * 24) {
-    const int64_t chunk = m3d_cdiv(max_points, G);
-    const dim3 grid((unsigned)(num_clouds * G)), block(FPSM_THREADS);
-    FpsSlot* sl = (FpsSlot*)ws;
-    if (chunk <= FPSM_THREADS * 8) hipLaunchKernelGGL((fps_multi_kernel<8>), grid, block, 0, st, p, ptr_src, ptr_out, start, idx_out, sl, G);
-    else if (chunk <= FPSM_THREADS * 16) hipLaunchKernelGGL((fps_multi_kernel<16>), grid, block, 0, st, p, ptr_src, ptr_out, start, idx_out, sl, G);
-    else hipLaunchKernelGGL((fps_multi_kernel<24>), grid, block, 0, st, p, ptr_src, ptr_out, start, idx_out, sl, G);
-    M3D_CHECK_LAUNCH();
-    return M3D_OK;
-  }
   const dim3 grid((unsigned)num_clouds), block(FPS_THREADS);
   if (max_points <= FPS_THREADS * 4) hipLaunchKernelGGL((fps_kernel<4, true>), grid, block, 0, st, p, ptr_src, ptr_out, start, idx_out);
   else if (max_points <= FPS_THREADS * 16) hipLaunchKernelGGL((fps_kernel<16, true>), grid, block, 0, st, p, ptr_src, ptr_out, start, idx_out);

@@ -146,7 +146,10 @@ class GraphedStep:
                                       slot=prefetch, owner=id(self))
             out = net(s.x, s.pos, None, self.ptr, plan=self.plan)
             loss = cross_entropy(out, s.y, ignore_index=self.ignore_index)  # model.py:118
-            loss.backward()
+            # backward nodes on THIS thread: one device per process leaves the engine's device thread nothing to overlap, and the
+            # hand-off costs ~10 us for each of the ~190 nodes (2 ms -> 0.4 ms of host time per step: tools/host_profile.py st)
+            with torch.autograd.set_multithreading_enabled(False):
+                loss.backward()
             if net.grad_side is not None:
                 net.grad_side.join()  # (inside a capture the deferred leaf launches must be part of it)
             if self.lookahead:
@@ -210,7 +213,8 @@ class GraphedStep:
                 torch.cuda.synchronize()
                 self.collective, self.opt_in_graph = "eager", False
                 self._capture()
-        if self._graphs is not None and self._graphs[1] and self._tune_streams > 1:
+        if self._tune_streams > 1 and self.lookahead and (
+                (self._graphs is not None and self._graphs[1]) or (self._graphs is None and self.mode == "train")):
             self._pick_side_stream()
         if saved is not None:
             with torch.no_grad():
@@ -231,10 +235,19 @@ class GraphedStep:
         So the choice is measured: a few steps on each of ``tune_streams`` candidate streams, the fastest one is kept."""
         import time
 
-        cands = [self._sA] + [torch.cuda.Stream() for _ in range(self._tune_streams - 1)]
+        eager = self._graphs is None  # eager launching: the net's side stream carries the interleaved position-only work
+        dev = self.ptr.device
+        first = self.net._side_stream(dev) if eager else self._sA
+        cands = [first] + [torch.cuda.Stream() for _ in range(self._tune_streams - 1)]
         ms = []
         for c in cands:
-            self._sA = c
+            if eager:
+                self.net._finish_interleaved()
+                self.net._look_queue.clear()
+                torch.cuda.synchronize()
+                self.net._streams[dev] = c
+            else:
+                self._sA = c
             self._primed = False
             for _ in range(2):
                 self.step()
@@ -245,8 +258,14 @@ class GraphedStep:
             torch.cuda.synchronize()
             ms.append((time.perf_counter() - t0) / 4 * 1e3)
         best = min(range(len(cands)), key=lambda i: ms[i])
-        self._sA = cands[best]
         self.side_stream_ms = [round(v, 3) for v in ms]
+        if eager:
+            self.net._finish_interleaved()
+            self.net._look_queue.clear()
+            torch.cuda.synchronize()
+            self.net._streams[dev] = cands[best]
+            return
+        self._sA = cands[best]
         self._evA.record()
         self._evReady.record()
 

@@ -144,8 +144,7 @@ class HipPointNet2(nn.Module):
             if train and self.random_start:
                 sizes = (plan.ptrs[lvl][1:] - plan.ptrs[lvl][:-1]).to(torch.float32)
                 start = (torch.rand(sizes.numel(), device=dev) * sizes).to(torch.int32)
-            return ops.fps(pos4, plan.ptrs[lvl], plan.ptrs[lvl + 1], m, plan.max_points[lvl], start,
-                           min_selected=min(plan.sizes[lvl + 1]) if plan.sizes[lvl + 1] else 0, index=index)
+            return ops.fps(pos4, plan.ptrs[lvl], plan.ptrs[lvl + 1], m, plan.max_points[lvl], start, index=index)
         seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=dev)
         return ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], m, seed, lvl)
 

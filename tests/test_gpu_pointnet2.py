@@ -56,33 +56,29 @@ def test_fps_is_bit_exact(device, sizes, keep, starts):
 
 
 @pytest.mark.parametrize("sizes,keep,starts", [
-    ([5000, 2100, 9000], [1250, 525, 2250], None),     # 2-5 workgroups per cloud; a cloud below the split size in the batch
-    ([40000], [10000], [777]),                         # the 40 000-point node budget: 7 workgroups x 23 points per thread
-    ([12800] * 4, [3200] * 4, [5, 0, 12799, 640]),     # BASELINE tile size: 7 workgroups x 8 points per thread
-    ([65536], [300], None),                            # the largest supported cloud: 11 workgroups
-    ([3000, 64], [750, 64], None),                     # a tiny cloud beside a split one (its slices are mostly empty)
+    ([20000, 2100, 17000], [5000, 525, 4250], None),   # a cloud below the bucket size in the batch
+    ([40000], [10000], [777]),                         # the 40 000-point node budget: 625 buckets of 64 records
+    ([16385, 30000], [4096, 7500], [5, 29999]),        # just above the register-resident sampler's range
+    ([39999], [300], None),                            # a last bucket with one record missing
 ])
-def test_fps_over_several_workgroups_is_bit_exact(device, sizes, keep, starts):
-    """fps_multi_kernel (several workgroups per cloud, one candidate exchange per iteration through L2): the index lists
-    of the oracle, bit for bit; run twice on the same exchange workspace (the flags of a finished launch must not confuse the
-    next one) and against the single-workgroup kernel."""
+def test_fps_with_bucket_skipping_is_bit_exact(device, sizes, keep, starts):
+    """fps_bucket_kernel (the points in the cell-sorted order of the kNN grid, buckets of 64 with bounding boxes, every bucket
+    the new point cannot reach skipped): the index lists of the plain sampler and of the oracle, bit for bit."""
     from myria3d_amd import ops
     from oracle.pointnet2_oracle import fps_exact
 
     rs = np.random.RandomState(sum(sizes) + 1)
     pos = torch.from_numpy(rs.uniform(-1, 1, (sum(sizes), 3)).astype(np.float32))
+    pos[:, 2] *= 0.3  # (flat clouds, like Lidar tiles)
     ptr, ptr_out = _ptr(sizes), _ptr(keep)
     pos4 = ops.pad_pos(pos.to(device))
     st = torch.tensor(starts, dtype=torch.int32, device=device) if starts is not None else None
-    single = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, multi=False)
-    if 4096 < max(sizes) <= 40000:  # exact bucket skipping over the cell-sorted records of the kNN grid
-        ix = ops.KnnIndex(pos4, ptr.to(device))
-        bucketed = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, index=ix)
-        assert torch.equal(bucketed, single), "bucket-skipping sampler vs the plain one"
+    plain = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st)
+    ix = ops.KnnIndex(pos4, ptr.to(device))
     for _ in range(2):
-        got = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, min_selected=min(keep))
-        assert torch.equal(got, single)
-    if sum(sizes) <= 45000:  # (the pure-Python oracle loop is slow: the big case is pinned by the single-workgroup kernel)
+        got = ops.fps(pos4, ptr.to(device), ptr_out.to(device), int(ptr_out[-1]), max(sizes), st, index=ix)
+        assert torch.equal(got, plain), "bucket-skipping sampler vs the plain one"
+    if sum(keep) <= 11000:  # (the pure-Python oracle loop is slow)
         want = fps_exact(pos, ptr.tolist(), ptr_out.tolist(), starts)
         assert torch.equal(got.cpu().long(), want)
 
@@ -99,20 +95,17 @@ def test_fps_on_duplicates_and_lattice_ties(device):
     want = fps_exact(pos, ptr.tolist(), ptr_out.tolist())
     got = ops.fps(ops.pad_pos(pos.to(device)), ptr.to(device), ptr_out.to(device), sizes[0], sizes[0])
     assert torch.equal(got.cpu().long(), want)
-    # the same on a lattice big enough to be split over workgroups (ties across workgroup borders)
-    g2 = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
-    pos2 = torch.from_numpy(np.concatenate([g2, g2[:500]]))
-    n2 = pos2.shape[0]
-    want2 = fps_exact(pos2, [0, n2], [0, 900])
-    got2 = ops.fps(ops.pad_pos(pos2.to(device)), _ptr([n2]).to(device), _ptr([900]).to(device), 900, n2, min_selected=900)
-    assert torch.equal(got2.cpu().long(), want2)
-    # ... and more slots than distinct points on a cloud big enough for the bucket-skipping sampler (all minima reach 0)
-    pos3 = torch.from_numpy(np.concatenate([g2] * 2))
+    # more slots than distinct points on a cloud big enough for the bucket-skipping sampler (all minima reach 0; exactly
+    # equal distances across bucket borders)
+    g2 = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    pos3 = torch.from_numpy(np.concatenate([g2, g2[:6000]]))
     n3 = pos3.shape[0]
     p3 = ops.pad_pos(pos3.to(device))
-    want3 = fps_exact(pos3, [0, n3], [0, 3300])
-    got3 = ops.fps(p3, _ptr([n3]).to(device), _ptr([3300]).to(device), 3300, n3, index=ops.KnnIndex(p3, _ptr([n3]).to(device)))
-    assert torch.equal(got3.cpu().long(), want3)
+    plain3 = ops.fps(p3, _ptr([n3]).to(device), _ptr([13000]).to(device), 13000, n3)
+    got3 = ops.fps(p3, _ptr([n3]).to(device), _ptr([13000]).to(device), 13000, n3, index=ops.KnnIndex(p3, _ptr([n3]).to(device)))
+    assert torch.equal(got3, plain3)
+    want3 = fps_exact(pos3[:4000], [0, 4000], [0, 600])  # (the plain sampler itself against the oracle on a lattice)
+    assert torch.equal(ops.fps(ops.pad_pos(pos3[:4000].to(device)), _ptr([4000]).to(device), _ptr([600]).to(device), 600, 4000).cpu().long(), want3)
 
 
 def test_fps_spreads_points(device):
