@@ -686,11 +686,15 @@ def predict_e2e_bench(args, dev, side_m=1000.0, density=10.0, reps=2):
     torch.manual_seed(0)
     net = HipRandLANet(9, 7, num_neighbors=16, return_logits=True).to(dev).eval()
     out = predict_cloud(net, pos, x, tile_width=side_m, subtile_width=50, batch_size=50)  # warm-up (allocator, plans)
-    assert out["idx_in_full_cloud"].numel() == n and int(out["idx_in_full_cloud"].unique().numel()) == n  # every point once
+    # every point is predicted (a point exactly ON a sample border belongs to both samples — the reference's closed ball — and
+    # is predicted twice, its logits summed: a handful among 10 M fp32 coordinates)
+    dup = out["idx_in_full_cloud"].numel() - n
+    assert 0 <= dup < 1000 and int(out["idx_in_full_cloud"].unique().numel()) == n
     assert bool(torch.isfinite(out["probas"]).all()) and float((out["probas"].sum(1) - 1).abs().max()) < 1e-4
     del out
     dt = timed(lambda: predict_cloud(net, pos, x, tile_width=side_m, subtile_width=50, batch_size=50), reps, 1) / reps
     return {"value": round(n / dt, 1), "unit": "points/s", "ms_per_cloud": round(dt * 1e3, 1), "points": n,
+            "points_on_sample_borders_predicted_twice": dup,
             "workload": f"BASELINE config 3 end to end: {n} points over {side_m:.0f} m x {side_m:.0f} m, 400 samples of 50 m, batch 50, "
                         "GridSampling 0.25 m, K=16, C=7, interpolation k=10 (myria3d_amd.predict_cloud)"}
 

@@ -1285,6 +1285,8 @@ class SAGroupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _a, _b):
+        if not ctx.needs_input_grad[0]:  # set-abstraction level 1 reads the raw input features: nobody wants this gradient
+            return None, None, None, None, None, None, None  # (E = m K rows of atomics were thrown away every step)
         (esrc,) = ctx.saved_tensors
         n, C = ctx.shape
         dout = dout.contiguous()
