@@ -32,9 +32,6 @@
 #ifndef LFA_B_PREFETCH
 #define LFA_B_PREFETCH 0
 #endif
-#ifndef LFA_ROW_SPLIT
-#define LFA_ROW_SPLIT 1
-#endif
 
 // CH is a template parameter: with a runtime channel count the index arithmetic of the gather / encoder loops
 // (f / D4, f % D4, ...) compiled to integer divisions and made the ch <= 32 kernels VALU-issue-bound
@@ -51,13 +48,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   constexpr int KT = KP / 16;            // MFMA M-tiles per centre
   constexpr int STR = CHP + 2;           // LDS row stride (floats): bank = 2*row + k for fragment reads
   constexpr int MT = ROWS / 16, NT = CHP / 16;
-  // tile ownership of the four waves: rows first (round 4, LFA_ROW_SPLIT) — a wave takes as few centre tiles and as many column
-  // tiles as the shapes allow, so that an A fragment read from LDS feeds NTW MFMAs (ch = 64: one LDS read per FOUR MFMAs
-  // instead of one per MFMA: the column split of rounds 1-3 had all four waves read the same A fragments); see lfa_bwd.hip
-  constexpr int WM_ROWS = (MT / KT) < 4 ? (MT / KT) : 4;
-  constexpr int WN = LFA_ROW_SPLIT ? 4 / WM_ROWS : (NT < 4 ? NT : 4);
-  constexpr int WM = 4 / WN;
-  static_assert(WN >= 1 && NT % WN == 0 && MT % WM == 0, "tile ownership");
+  constexpr int WN = NT < 4 ? NT : 4, WM = 4 / WN;
   constexpr int NTW = NT / WN, MTW = MT / WM;
   constexpr int S4 = CHP / 16;           // groups of 4 k-steps
   static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");

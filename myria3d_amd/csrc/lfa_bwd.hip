@@ -46,13 +46,6 @@ struct LfaBwdArgs {
 #ifndef BWD_B_PREFETCH
 #define BWD_B_PREFETCH 0
 #endif
-#ifndef BWD_ROW_SPLIT
-#define BWD_ROW_SPLIT 1  // 1: a wave owns few centre tiles x many column tiles (LDS reads per MFMA / NTW); 0: rounds 1-3
-#endif
-#define S4_OF(chp) ((chp) / 16)
-#ifndef BWD_SQUARE3
-#define BWD_SQUARE3 1
-#endif
 #ifndef BWD_PIPE_8
 #define BWD_PIPE_8 1
 #endif
@@ -148,32 +141,22 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   constexpr int TC = ROWS / KP, KT = KP / 16;
   constexpr int STR = CHP + 2, RSTR = 18;
   constexpr int MT = ROWS / 16, NT = CHP / 16;
-  // Which 16 x 16 tiles of the [ROWS, CHP] products a wave owns.  Round 4: rows first (BWD_ROW_SPLIT) — a wave takes as few
-  // centre tiles and as many column tiles as possible, so that an A fragment read from LDS (one ds_read_b32 per lane) feeds
-  // NTW MFMAs instead of one: with the column split of rounds 1-3 (ch = 64: four waves, one column tile each, all four
-  // reading the same four A fragments per k-step) the three GEMMs needed one LDS read per MFMA — 1 KB per wave per 128 MFMA
-  // cycles x 16 waves per CU = the 128 B/clk the LDS delivers at best, before bank conflicts: the GEMMs ran "at the MFMA
-  // floor" only because nothing else could use the LDS meanwhile, which is also why the VALU / LDS phases of the other
-  // workgroups on the CU never overlapped them (stagger experiment).
-  constexpr int WM_ROWS = (MT / KT) < NW ? (MT / KT) : NW;  // most row splits that keep a centre's tiles in one wave
-  constexpr int WN = BWD_ROW_SPLIT ? NW / WM_ROWS : (NT < NW ? NT : NW);
-  constexpr int WM = NW / WN;
-  static_assert(WN >= 1 && NT % WN == 0 && MT % WM == 0, "tile ownership");
+  // tile ownership: columns first (a wave owns one or two column tiles and every centre tile of the group).  Round 4 tried rows
+  // first — few centre tiles x many column tiles per wave, one LDS read of an A fragment feeding 4-8 MFMAs instead of 1-2, on
+  // the theory that the GEMM phases are bound by the LDS pipe — and square dW_att blocks: bit-identical and SLOWER at every
+  // deep level (ch = 64 / 128 / 256: 265 -> 292, 247 -> 278, 287 -> 325 us; the forward kernel likewise, 79 -> 89 and 89 -> 107
+  // us; profiles/r04f_lfa_tile_ownership_ab.log): the wider B-fragment sets cost more registers and loads than the LDS reads
+  // they save.  Removed.
+  constexpr int WN = NT < NW ? NT : NW, WM = NW / WN;
   constexpr int NTW = NT / WN, MTW = MT / WM;
-  constexpr bool BREG = S4_OF(CHP) * NTW <= 8;  // PIPE: all B fragments of a GEMM held in registers (else streamed per k-step group)
   constexpr int S4 = CHP / 16;
   static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
   // GEMM-3 (dW_att) tile ownership
   constexpr int T3 = NT * NT;
   constexpr int KSPL3 = T3 >= NW ? 1 : NW / T3;
   constexpr int TPW3 = T3 >= NW ? T3 / NW : 1;
-  // a wave's TPW3 tiles of dW_att as a CTW3 x KTW3 block: a DA fragment feeds KTW3 MFMAs, an F fragment CTW3.  Round 4
-  // (BWD_SQUARE3): the block is made as square as the tile counts allow (ch = 128: 2 x 4 instead of 1 x 8 — 6 LDS reads per 8
-  // MFMAs instead of 9; ch = 64: 2 x 2 instead of 1 x 4)
-  constexpr int CSQ = TPW3 >= 16 ? 4 : (TPW3 >= 4 ? 2 : 1);
-  constexpr int KTW3 = (BWD_SQUARE3 && KSPL3 == 1) ? TPW3 / CSQ : (TPW3 < NT ? TPW3 : NT);
+  constexpr int KTW3 = TPW3 < NT ? TPW3 : NT;
   constexpr int CTW3 = TPW3 / KTW3;
-  static_assert(KTW3 <= NT && NT % KTW3 == 0 && NT % CTW3 == 0, "dW_att block ownership");
   // GEMM-4 (G) tile ownership: GT tiles of 16 encoder channels
   constexpr int DP = CHP / 2 < 16 ? 16 : CHP / 2;  // padded encoder width
   constexpr int GT = DP / 16;
@@ -183,6 +166,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   constexpr int GPT = (ROWS * D4 + NTHR - 1) / NTHR;  // prefetched x_j segments (float4) per thread
   constexpr int NCW = MTW / KT;                       // centres per wave in the softmax phase
   static_assert(!PIPE || ROWS <= NTHR, "one neighbour id per thread");
+  static_assert(!PIPE || S4 * NTW <= 8, "B fragments of one GEMM are held in registers");
 
   __shared__ float F[ROWS * STR];
   __shared__ float DA[ROWS * STR];
@@ -201,9 +185,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 #pragma unroll
     for (int k = 0; k < KTW3; ++k) acc3[c][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 accg = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int blk3 = wid / KSPL3, ks3 = wid % KSPL3;
-  constexpr int KB3 = NT / KTW3;  // blocks per tile row
-  const int ct0 = (blk3 / KB3) * CTW3, kt0 = (blk3 % KB3) * KTW3;
+  const int t0 = (wid / KSPL3) * TPW3;
+  const int ct0 = t0 / NT, kt0 = t0 % NT, ks3 = wid % KSPL3;
   const int gt = wid / KSPL4, ks4 = wid % KSPL4;
 
   const int64_t ngroups = (a.n + TC - 1) / TC;
@@ -401,7 +384,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
         }
       }
-    } else     if constexpr (PIPE && BREG) {
+    } else     if constexpr (PIPE) {
       {
         const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
         float4 b[S4][NTW];  // every B fragment of this wave's column tiles: one latency exposure, not one per k-step
@@ -464,8 +447,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
     }
     // B fragments of GEMM-2 (W_att^T): issued now, they arrive during the softmax phase
-    float4 b4[(PIPE && !BF && BREG) ? S4 : 1][NTW];
-    if constexpr (PIPE && !BF && BREG) {
+    float4 b4[(PIPE && !BF) ? S4 : 1][NTW];
+    if constexpr (PIPE && !BF) {
 #pragma unroll
       for (int s4 = 0; s4 < S4; ++s4)
 #pragma unroll
@@ -549,41 +532,6 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         }
         if constexpr (PIPE) {
           if (ks == 0 && grp + gs < gend) {  // next group's loads (see the fp32 branch below)
-            prefetch(grp + gs, nbr2[cur ^ 1]);
-            jn = load_idx(grp + 2 * gs);
-          }
-        }
-      }
-    } else if constexpr (PIPE && !BREG) {
-      {
-        // (many column tiles per wave: the B fragments are streamed per group of four k-steps, double-buffered)
-        const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg];
-        float4 bn[NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4) * 64 + lane];
-#pragma unroll 1
-        for (int s4 = 0; s4 < S4; ++s4) {
-          float4 b[NTW];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) b[t] = bn[t];
-          {
-            const int sn = s4 + 1 < S4 ? s4 + 1 : s4;  // last trip: a harmless re-load
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) bn[t] = a.wpt[((size_t)(wn * NTW + t) * S4 + sn) * 64 + lane];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float av[MTW];
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) av[m] = da[m * 16 * STR + (s4 * 4 + i) * 4];
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-              const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
-#pragma unroll
-              for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
-            }
-          }
-          if (s4 == 0 && grp + gs < gend) {  // next group's loads (see the register-resident branch below)
             prefetch(grp + gs, nbr2[cur ^ 1]);
             jn = load_idx(grp + 2 * gs);
           }
