@@ -44,6 +44,9 @@
 #ifndef WGRAD_MINW
 #define WGRAD_MINW 1
 #endif
+#ifndef GEMM_RS_PREFETCH
+#define GEMM_RS_PREFETCH 0
+#endif
 // launch-geometry constants (round 3's M3D_* environment knobs, now compile time: the library reads no environment)
 #ifndef GEMM_KL_MINWAVES
 #define GEMM_KL_MINWAVES 1536
@@ -195,12 +198,19 @@ __device__ __forceinline__ void pro_setup(const GemmArgs& g, float (&cf)[6][KP])
 }
 
 // dz[m][k .. k+3] from dy and z (same arithmetic as bn_bwd_apply_kernel); `store`: also write it to pro_dz
+struct ProRaw { float4 gy, zv; unsigned f0; };  // the two loads of a prologue fragment (issued ahead by the row-stream kernel)
+__device__ __forceinline__ ProRaw pro_load(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k) {
+  ProRaw p;
+  p.f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
+  p.gy = ld4(ra0, p.f0);
+  p.zv = ld4(rz, p.f0);
+  return p;
+}
 template <int KP>
-__device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k,
-                                             const float (&cf)[6][KP], bool store) {
-  const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
-  float4 gy = ld4(ra0, f0);
-  const float4 zv = ld4(rz, f0);
+__device__ __forceinline__ float4 pro_finish(const GemmArgs& g, const ProRaw& p, int k, const float (&cf)[6][KP], bool store) {
+  const unsigned f0 = p.f0;
+  float4 gy = p.gy;
+  const float4 zv = p.zv;
   const float4 sc = *(const float4*)&cf[0][k], mu = *(const float4*)&cf[2][k], is = *(const float4*)&cf[3][k];
   const float4 m1 = *(const float4*)&cf[4][k], m2 = *(const float4*)&cf[5][k];
   if (g.pro_act) {
@@ -215,6 +225,11 @@ __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc
   o.w = sc.w * (gy.w - m1.w - (zv.w - mu.w) * is.w * m2.w);
   if (store && f0 != OOB) *(float4*)((char*)g.pro_dz + f0) = o;
   return o;
+}
+template <int KP>
+__device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k,
+                                             const float (&cf)[6][KP], bool store) {
+  return pro_finish<KP>(g, pro_load(g, ra0, rz, r, k), k, cf, store);
 }
 
 // accumulate, pre-loaded (GemmArgs::acc_pre): the lane's four old output values of row m, columns n0..n0+3 (the C/D
@@ -387,14 +402,46 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 
   const int64_t ntiles = (g.M + 15) >> 4;
   const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += stride) {
-    const int64_t m = tile * 16 + lr;
-    const ARow row = a_row(g, m);
-    float4 a[KQ];
+  // software pipeline (GEMM_RS_PREFETCH bit 0: plain operands, bit 1: the dz-on-load prologue's dy / z): the fragments of the wave's NEXT tile are in flight while
+  // this tile's MFMAs and stores run.  A wave owns ~4 tiles of a 204 800-row layer and three waves share a SIMD: with one
+  // tile per wave in flight the chip holds ~6 MB of loads, which at ~2 us of loaded latency is 3 TB/s — what these
+  // launches measured (Little's law), against 5-6 TB/s for the BatchNorm apply over the same bytes.
+  constexpr bool PF = (GEMM_RS_PREFETCH & 1) && !PRO, PFP = (GEMM_RS_PREFETCH & 2) && PRO;
+  float4 an[PF ? KQ : 1];
+  ProRaw pn[PFP ? KQ : 1];
+  if constexpr (PF || PFP) {
+    const ARow r0 = a_row(g, ((int64_t)blockIdx.x * 4 + wid) * 16 + lr);
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
-      else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
+      if constexpr (PF) an[q] = a_frag<VEC, CAT>(g, ra0, ra1, r0, 16 * q + 4 * lg, K);
+      else pn[q] = pro_load(g, ra0, rz, r0, 16 * q + 4 * lg);
+    }
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += stride) {
+    const int64_t m = tile * 16 + lr;
+    float4 a[KQ];
+    if constexpr (PF) {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) a[q] = an[q];
+      const ARow rn = a_row(g, m + stride * 16);  // (past the last tile: every offset is OOB, nothing is read)
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) an[q] = a_frag<VEC, CAT>(g, ra0, ra1, rn, 16 * q + 4 * lg, K);
+    } else if constexpr (PFP) {
+      ProRaw pc[KQ];
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) pc[q] = pn[q];
+      const ARow rn = a_row(g, m + stride * 16);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) pn[q] = pro_load(g, ra0, rz, rn, 16 * q + 4 * lg);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) a[q] = pro_finish<64>(g, pc[q], 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
+    } else {
+      const ARow row = a_row(g, m);
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+        if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
+        else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
+      }
     }
     f32x4 acc[NT];
 #pragma unroll

@@ -119,6 +119,17 @@ struct LfaBwdArgs {
 #ifndef BWD_MINW_256
 #define BWD_MINW_256 1
 #endif
+// wave priority by phase (s_setprio; the workgroups that share a CU sit in different phases, and fp32 MFMA runs at the
+// vector rate on the SIMD the VALU phases need): a mask of the phases that run at priority LFA_BWD_PRIO_LVL, the others
+// at 0.  bit 0 = gather / encoder (phase 1), 1 = logits GEMM (2), 2 = softmax / dA (3'), 3 = dF and dW GEMMs (4, 5),
+// 4 = scatter / dy / encoder sums (6, 7).
+#ifndef LFA_BWD_SETPRIO
+#define LFA_BWD_SETPRIO 21  // the VALU phases first: level 1 247 -> 222 and 254 -> 233 us, ch = 64 265 -> 254 us, -0.065 ms per step (profiles/r04g_*)
+#endif
+#ifndef LFA_BWD_PRIO_LVL
+#define LFA_BWD_PRIO_LVL 1
+#endif
+#define BWD_PRIO(bit) do { if (LFA_BWD_SETPRIO) __builtin_amdgcn_s_setprio((LFA_BWD_SETPRIO & (bit)) ? LFA_BWD_PRIO_LVL : 0); } while (0)
 template <int CHP> struct BwdCfg {};
 template <> struct BwdCfg<16> { static constexpr int ROWS = BWD_ROWS_16, NW = BWD_NW_16, CAP = BWD_CAP_16, MINW = BWD_MINW_16; };
 template <> struct BwdCfg<32> { static constexpr int ROWS = BWD_ROWS_32, NW = BWD_NW_32, CAP = BWD_CAP_32, MINW = BWD_MINW_32; };
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   for (int64_t grp = g0; grp < gend; grp += gs, cur ^= (PIPE ? 1 : 0)) {
     const int64_t c0 = grp * TC;
     int* nbr = nbr2[cur];
+    BWD_PRIO(1);
     if constexpr (PIPE) {
       // ---- phase 1 (from the prefetched registers): x_j -> F[:, 0:D]
       {
@@ -363,6 +375,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 
     if (LFA_BWD_DBG & 2) continue;   // timing experiment: phase 1 only
     // ---- phase 2: A = F * W_att^T
+    BWD_PRIO(2);
     f32x4 acc[MTW][NTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
@@ -455,6 +468,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         for (int t = 0; t < NTW; ++t) b4[s4][t] = a.wpt[((size_t)(wn * NTW + t) * S4 + s4) * 64 + lane];
     }
 
+    BWD_PRIO(4);
     if (LFA_BWD_DBG & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
 #pragma unroll
@@ -515,6 +529,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 
     if (LFA_BWD_DBG & 8) continue;   // timing experiment: phases 1-3
     // ---- phase 4: dF = dout*s + DA * W_att
+    BWD_PRIO(8);
     if constexpr (BF) {
       constexpr int KS = CHP / 32;
       const uint4* wptb = (const uint4*)a.wpt;
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           for (int k = 0; k < KTW3; ++k) acc3[c][k] = mfma16(av[c], bv[k], acc3[c][k]);
       }
     }
+    BWD_PRIO(16);
     __syncthreads();
     if (LFA_BWD_DBG & 16) continue;  // timing experiment: phases 1-5
     // ---- phase 6: scatter dx; dy -> DA[:, D:2D]

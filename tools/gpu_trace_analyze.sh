@@ -24,7 +24,12 @@ if len(adam) >= 4:
     with open(os.path.join(os.environ.get("OUT", "."), "step_timeline_" + os.environ.get("TAG", "t") + ".csv"), "w") as fh:
         fh.write("start_us,dur_us,queue,grid_x,kernel\n")
         for s_, e_, n_, q_, g_ in seg:
-            fh.write(f"{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f},{q_},{g_},{n_.split('(')[0][:70]}\n")
+            short = n_.split('(')[0][:70]
+            if "at::native" in n_:  # torch kernels: the functor says what it is (the template head does not)
+                import re
+                m_ = re.search(r"(CUDAFunctor\w+<[\w ]+>|FillFunctor<[\w ]+>|fused_dropout\w+|masked_scale\w+|\w+Functor\w*<[\w ]+>|normal_kernel|CatArray\w+)", n_)
+                short = "torch:" + (m_.group(1) if m_ else n_[:70].replace(",", ";"))
+            fh.write(f"{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.1f},{q_},{g_},{short}\n")
     wall = (t1 - t0) / 1e3
     # union of intervals
     busy = 0; cur_s, cur_e = seg[0][0], seg[0][1]
