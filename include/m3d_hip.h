@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define M3D_ABI_VERSION 13
+#define M3D_ABI_VERSION 14
+#define M3D_ADAM_STATE_WORDS 66
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -93,6 +94,16 @@ int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_
                  int64_t M, int32_t N, const float* bias, const float* scale, const float* shift, int32_t act,
                  float slope, double* stat_part, int32_t stat_parts, float* c, int64_t ldc, int32_t accumulate,
                  int32_t splitk, void* stream);
+/* two products with ONE output shape, C_i[M, N] (+)= A_i[M, k_i] B_i^T (+ bias_i), i = 0, 1, as one launch when the
+ * fragment-direct k-loop kernel takes both (k_i > 64, 16-byte aligned rows, same tile plan), as two m3d_gemm_f32 launches
+ * otherwise: the mlp2 / shortcut Linears of a DilatedResidualBlock (pyg_randla_net.py:172-188) and their input
+ * gradients on the deep levels.  Every array argument has two entries.  stat_part (nullable; entries nullable together):
+ * slot-mode statistics tables as in m3d_gemm_f32 (stat_parts < 0).  flags: bit 0 = column-major B_i (the dgrad pattern),
+ * bit 8 = bf16 matrix-core operands. */
+int m3d_gemm_pair_f32(const float* const* a, const int64_t* lda, const int32_t* k, const float* const* b,
+                      const int64_t* ldb, int64_t M, int32_t N, const float* const* bias, double* const* stat_part,
+                      int32_t stat_parts, float* const* c, const int64_t* ldc, const int32_t* accumulate, int32_t flags,
+                      void* stream);
 /* Linear weight gradient  dW[N, k0+k1] (+)= dZ[M,N]^T [X0[x0_rows] | X1]   (autograd transpose of the Linear in
  * SharedMLP / FPModule, pyg_randla_net.py:97-109,249-252).  The rows are split over workgroups; the splits meet in
  * the workspace (m3d_linear_wgrad_workspace_bytes(M, N, k0+k1) bytes, may be 0), not in same-address atomics.
@@ -364,22 +375,27 @@ int m3d_seg_max_bwd(const float* dout, const int32_t* arg, const int64_t* seg, c
 
 /* ---- training step: loss and optimizer -------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(ignore_index=65, reduction="mean") on the logits (myria3d/models/model.py:118,
- * configs/model/criterion/CrossEntropyLoss.yaml:1-3).  lse: [n] scratch kept for the backward; acc2: fp64 [2]
- * (sum of row losses, number of non-ignored rows; zeroed inside); loss: fp32 [1]. */
+ * configs/model/criterion/CrossEntropyLoss.yaml:1-3).  lse: [n] scratch kept for the backward; acc4: fp64 [4]
+ * ([0] sum of row losses, [1] number of non-ignored rows, [2] arrival ticket of the workgroups, [3] unused; zeroed
+ * inside unless flags bit 0 says the caller passes zeros); loss: fp32 [1], written by the last workgroup to arrive. */
 int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
-                    int64_t ignore_index, float* lse, double* acc2, float* loss, void* stream);
+                    int64_t ignore_index, float* lse, double* acc4, float* loss, int32_t flags, void* stream);
 /* dlogits[n, C] (contiguous) = gout[0] * d loss / d logits */
 int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
-                    int64_t ignore_index, const float* lse, const double* acc2, const float* gout, float* dlogits,
+                    int64_t ignore_index, const float* lse, const double* acc4, const float* gout, float* dlogits,
                     void* stream);
 /* torch.optim.Adam (configs/model/optimizer/Adam.yaml:1-4; lr from configs/model/pyg_randla_net_model.yaml:4) in ONE
- * launch over flat, 16-byte aligned fp32 buffers of n (multiple of 4) elements.  state: fp32 [1] step counter on
- * the device (incremented inside, so a replayed hipGraph keeps counting).  lr_dev: optional device fp32 [1]
+ * launch over flat, 16-byte aligned fp32 buffers of n (multiple of 4) elements.  state: [M3D_ADAM_STATE_WORDS] x 4
+ * bytes on the device: [0] fp32 step counter (incremented inside, so a replayed hipGraph keeps counting), the rest
+ * uint32 arrival tickets of the update's workgroups (zero before the first call; left zero).  lr_dev: optional device fp32 [1]
  * overriding `lr` (schedulers under graph replay).  grad_scale multiplies the gradient on the way in (1/world
  * after a SUM all-reduce); zero_grad != 0 clears the gradient buffer after it has been consumed. */
 int m3d_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* state, const float* lr_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   int32_t zero_grad, int64_t n, void* stream);
+/* start of a training step: zero-fill of `nbytes` (multiple of 16, 16-byte aligned: the step's accumulation arena) and
+ * counters[0 .. ncounters) += 1 (the BatchNorm layers' num_batches_tracked, int64) in one launch */
+int m3d_zero_bump(void* buf, int64_t nbytes, int64_t* counters, int32_t ncounters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "m3d_gemm_stat_parts": (_i32, [_i64, _i32, _i32]),
     "m3d_gemm_f32": (_i32, [_p, _i64, _i32, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _i32,
                             _f32, _p, _i32, _p, _i64, _i32, _i32, _p]),
+    "m3d_gemm_pair_f32": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _i32, _p]),
     "m3d_linear_wgrad_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_linear_wgrad_f32": (_i32, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _i64, _i32, _p, _i64, _i32, _p, _p]),
     "m3d_linear_wgrad_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
@@ -83,12 +84,13 @@ SIGNATURES = {
     "m3d_sa_group_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _p, _i64, _p]),
     "m3d_seg_max": (_i32, [_p, _i64, _p, _i64, _i32, _p, _p, _p]),
     "m3d_seg_max_bwd": (_i32, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
-    "m3d_ce_loss_fwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p]),
+    "m3d_ce_loss_fwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _i32, _p]),
     "m3d_ce_loss_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p]),
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
+    "m3d_zero_bump": (_i32, [_p, _i64, _p, _i32, _p]),
 }
 
-ABI_VERSION = 13  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 14  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

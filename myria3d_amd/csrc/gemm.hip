@@ -23,6 +23,9 @@
 
 #include <stdlib.h>
 #include "gemm_common.h"
+#ifndef GEMM_LEGACY
+#define GEMM_LEGACY 0  // 1: cross-check builds route every product through the LDS-tiled kernel below
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -226,9 +229,6 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   {
     // fragment-direct kernels (gemm_direct.hip) cover the network's shapes; this LDS-tiled kernel is the fallback
     // (a -DGEMM_LEGACY=1 build routes everything through it: cross-check builds only)
-#ifndef GEMM_LEGACY
-#define GEMM_LEGACY 0
-#endif
     if (!GEMM_LEGACY) {
       const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
       if (rc != 1) return rc;
@@ -252,6 +252,44 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   else if (NT == 2) hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, st, g);
   else hipLaunchKernelGGL(gemm_kernel<4>, grid, block, 0, st, g);
   M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// Two independent products C_i[M, N] (+)= A_i[M, K_i] B_i^T with one output shape as ONE launch when the fragment-direct
+// k-loop kernel covers both (K_i > 64, 16-byte aligned rows, same tile plan); otherwise two ordinary launches.  The mlp2 /
+// shortcut Linears of a DilatedResidualBlock (/root/reference/myria3d/models/modules/pyg_randla_net.py:172-188) and their
+// input gradients on the deep levels, where each product alone leaves most of the chip idle.
+// flags: bit 0 = column-major B (the dgrad pattern: element (n, k) of B_i at b_i[k * ldb_i + n]), bit 8 = bf16 operands.
+extern "C" int m3d_gemm_pair_f32(const float* const* a, const int64_t* lda, const int32_t* k, const float* const* b,
+                                 const int64_t* ldb, int64_t M, int32_t N, const float* const* bias,
+                                 double* const* stat_part, int32_t stat_parts, float* const* c, const int64_t* ldc,
+                                 const int32_t* accumulate, int32_t flags, void* stream) {
+  if (!a || !lda || !k || !b || !ldb || !c || !ldc || !accumulate) return M3D_ERR_INVALID;
+  if (M < 0 || N < 0) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  const int b_cm = flags & 1, bf16 = (flags >> 8) & 1;
+  GemmArgs g[2];
+  for (int i = 0; i < 2; ++i) {
+    if (!a[i] || !b[i] || !c[i] || k[i] < 1) return M3D_ERR_INVALID;
+    double* sp = stat_part ? stat_part[i] : nullptr;
+    if (sp && stat_parts >= 0) return M3D_ERR_INVALID;  // statistics: slot mode only (a pre-zeroed [-stat_parts][2][N] table)
+    if (sp && (accumulate[i] || b_cm)) return M3D_ERR_INVALID;
+    GemmArgs z{};
+    z.a0 = a[i]; z.lda0 = lda[i]; z.k0 = k[i]; z.b = b[i]; z.ldb = ldb[i]; z.b_cm = b_cm; z.M = M; z.N = N;
+    z.bias = bias ? bias[i] : nullptr; z.slope = 0.f;
+    z.stat_part = sp; z.stat_sum = sp; z.stat_sumsq = sp ? sp + N : nullptr; z.stat_slots = sp ? -stat_parts : 0;
+    z.c = c[i]; z.ldc = ldc[i]; z.accumulate = accumulate[i]; z.bf16 = bf16; z.splitk = 1; z.kchunk = m3d_align(k[i], BK);
+    g[i] = z;
+  }
+  int rc = 1;
+  if (!GEMM_LEGACY) rc = m3d_gemm_direct_pair_try(g[0], g[1], (hipStream_t)stream);
+  if (rc != 1) return rc;
+  for (int i = 0; i < 2; ++i) {
+    rc = m3d_gemm_f32(a[i], lda[i], 0, nullptr, k[i], nullptr, 0, 0, b[i], ldb[i], b_cm, M, N, bias ? bias[i] : nullptr,
+                      nullptr, nullptr, bf16 << 8, 0.f, stat_part ? stat_part[i] : nullptr, stat_parts, c[i], ldc[i],
+                      accumulate[i], 1, stream);
+    if (rc != M3D_OK) return rc;
+  }
   return M3D_OK;
 }
 

@@ -39,5 +39,7 @@ struct GemmArgs {
 
 // gemm_direct.hip: returns M3D_OK when it handled the problem, 1 when the shape is not covered (caller falls back)
 int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st);
+// two products of one output shape as ONE launch (deep levels: the mlp2 / shortcut pair of a block); 1: launch them singly
+int m3d_gemm_direct_pair_try(const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 // number of statistics partial rows the direct kernels write for a forward GEMM of this shape (>= 1)
 int m3d_gemm_direct_stat_parts(int64_t M, int N, int K);

@@ -44,9 +44,6 @@
 #ifndef WGRAD_MINW
 #define WGRAD_MINW 1
 #endif
-#ifndef GEMM_RS_PREFETCH
-#define GEMM_RS_PREFETCH 0
-#endif
 // launch-geometry constants (round 3's M3D_* environment knobs, now compile time: the library reads no environment)
 #ifndef GEMM_KL_MINWAVES
 #define GEMM_KL_MINWAVES 1536
@@ -198,19 +195,12 @@ __device__ __forceinline__ void pro_setup(const GemmArgs& g, float (&cf)[6][KP])
 }
 
 // dz[m][k .. k+3] from dy and z (same arithmetic as bn_bwd_apply_kernel); `store`: also write it to pro_dz
-struct ProRaw { float4 gy, zv; unsigned f0; };  // the two loads of a prologue fragment (issued ahead by the row-stream kernel)
-__device__ __forceinline__ ProRaw pro_load(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k) {
-  ProRaw p;
-  p.f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
-  p.gy = ld4(ra0, p.f0);
-  p.zv = ld4(rz, p.f0);
-  return p;
-}
 template <int KP>
-__device__ __forceinline__ float4 pro_finish(const GemmArgs& g, const ProRaw& p, int k, const float (&cf)[6][KP], bool store) {
-  const unsigned f0 = p.f0;
-  float4 gy = p.gy;
-  const float4 zv = p.zv;
+__device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k,
+                                             const float (&cf)[6][KP], bool store) {
+  const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
+  float4 gy = ld4(ra0, f0);
+  const float4 zv = ld4(rz, f0);
   const float4 sc = *(const float4*)&cf[0][k], mu = *(const float4*)&cf[2][k], is = *(const float4*)&cf[3][k];
   const float4 m1 = *(const float4*)&cf[4][k], m2 = *(const float4*)&cf[5][k];
   if (g.pro_act) {
@@ -225,11 +215,6 @@ __device__ __forceinline__ float4 pro_finish(const GemmArgs& g, const ProRaw& p,
   o.w = sc.w * (gy.w - m1.w - (zv.w - mu.w) * is.w * m2.w);
   if (store && f0 != OOB) *(float4*)((char*)g.pro_dz + f0) = o;
   return o;
-}
-template <int KP>
-__device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k,
-                                             const float (&cf)[6][KP], bool store) {
-  return pro_finish<KP>(g, pro_load(g, ra0, rz, r, k), k, cf, store);
 }
 
 // accumulate, pre-loaded (GemmArgs::acc_pre): the lane's four old output values of row m, columns n0..n0+3 (the C/D
@@ -339,7 +324,8 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
 // per-column shift and reducing in fp32 was 420 us but gives up what the fp64 partials have: they are EXACT sums of fp32
 // values, so the fp64 atomics that combine workgroups commute and the train-mode forward is bit-reproducible.)
 template <int NT, int NWAVES>
-__device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&ssum)[NT][4], double (&ssq)[NT][4]) {
+__device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&ssum)[NT][4], double (&ssq)[NT][4],
+                                            const unsigned bx) {
   if (GEMM_DBG & 1) return;
   __shared__ double sred[NWAVES][2][16 * NT];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
@@ -361,11 +347,11 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
       if (GEMM_DBG & 2) return;
       if (g.stat_slots > 0) {
         // slot mode: a few fp64 atomics per address (workgroups / slots); the table was zeroed by the caller
-        atomicAdd(&g.stat_part[((size_t)(blockIdx.x % g.stat_slots) * 2 + which) * g.N + n], v);
+        atomicAdd(&g.stat_part[((size_t)(bx % g.stat_slots) * 2 + which) * g.N + n], v);
       } else {
         // plain store of this workgroup's partial (summed by m3d_bn_finalize): no same-address atomics, no
         // zero-fill, bitwise reproducible
-        g.stat_part[((size_t)blockIdx.x * 2 + which) * g.N + n] = v;
+        g.stat_part[((size_t)bx * 2 + which) * g.N + n] = v;
       }
     }
   }
@@ -402,46 +388,14 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 
   const int64_t ntiles = (g.M + 15) >> 4;
   const int64_t stride = (int64_t)gridDim.x * 4;
-  // software pipeline (GEMM_RS_PREFETCH bit 0: plain operands, bit 1: the dz-on-load prologue's dy / z): the fragments of the wave's NEXT tile are in flight while
-  // this tile's MFMAs and stores run.  A wave owns ~4 tiles of a 204 800-row layer and three waves share a SIMD: with one
-  // tile per wave in flight the chip holds ~6 MB of loads, which at ~2 us of loaded latency is 3 TB/s — what these
-  // launches measured (Little's law), against 5-6 TB/s for the BatchNorm apply over the same bytes.
-  constexpr bool PF = (GEMM_RS_PREFETCH & 1) && !PRO, PFP = (GEMM_RS_PREFETCH & 2) && PRO;
-  float4 an[PF ? KQ : 1];
-  ProRaw pn[PFP ? KQ : 1];
-  if constexpr (PF || PFP) {
-    const ARow r0 = a_row(g, ((int64_t)blockIdx.x * 4 + wid) * 16 + lr);
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) {
-      if constexpr (PF) an[q] = a_frag<VEC, CAT>(g, ra0, ra1, r0, 16 * q + 4 * lg, K);
-      else pn[q] = pro_load(g, ra0, rz, r0, 16 * q + 4 * lg);
-    }
-  }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += stride) {
     const int64_t m = tile * 16 + lr;
+    const ARow row = a_row(g, m);
     float4 a[KQ];
-    if constexpr (PF) {
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) a[q] = an[q];
-      const ARow rn = a_row(g, m + stride * 16);  // (past the last tile: every offset is OOB, nothing is read)
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) an[q] = a_frag<VEC, CAT>(g, ra0, ra1, rn, 16 * q + 4 * lg, K);
-    } else if constexpr (PFP) {
-      ProRaw pc[KQ];
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) pc[q] = pn[q];
-      const ARow rn = a_row(g, m + stride * 16);
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) pn[q] = pro_load(g, ra0, rz, rn, 16 * q + 4 * lg);
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) a[q] = pro_finish<64>(g, pc[q], 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
-    } else {
-      const ARow row = a_row(g, m);
-#pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
-        else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
-      }
+    for (int q = 0; q < KQ; ++q) {
+      if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
+      else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
     }
     f32x4 acc[NT];
 #pragma unroll
@@ -458,7 +412,7 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 #pragma unroll
     for (int t = 0; t < NT; ++t) epi_store<MODE>(g, e[t], acc[t], m, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
   }
-  if (MODE == 1) stats_flush<NT, 4>(g, nb, ssum, ssq);
+  if (MODE == 1) stats_flush<NT, 4>(g, nb, ssum, ssq, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -468,8 +422,10 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 // and the product runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (K a multiple of 32): the deep SharedMLP
 // layers in the net's "bf16" matmul precision.  Epilogue, statistics and storage stay fp32.
 #define PRO_KMAX 1024  // widest BatchNorm the prologue keeps in LDS (this network: 512)
-template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false, bool PRO = false>
-__global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
+// (bx, gx): this workgroup's index among the gx row workgroups of ITS problem — the launch's own blockIdx.x / gridDim.x, or
+// a sub-range of them when one launch carries two problems (gemm_kloop_pair_kernel)
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF, bool PRO>
+__device__ __forceinline__ void gemm_kloop_body(const GemmArgs& g, int cvec, const unsigned bx, const unsigned gx) {
   // a wave owns MTW x NTW tiles of 16x16: every A / W fragment it loads feeds NTW / MTW MFMAs (these shapes are
   // L2-bandwidth bound on operand re-reads when MTW = NTW = 1)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
@@ -497,8 +453,8 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
   const int64_t ngroups = (g.M + 16 * MTW - 1) / (16 * MTW);
   const bool ks = g.ksplit != 0;  // (uniform) split K over the four waves: same group, a quarter of the chunks each
   __shared__ float kred[3][MTW * NTW * 4 * 64];
-  const int64_t stride = ks ? (int64_t)gridDim.x : (int64_t)gridDim.x * 4;
-  for (int64_t grp = ks ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wid; grp < ngroups; grp += stride) {
+  const int64_t stride = ks ? (int64_t)gx : (int64_t)gx * 4;
+  for (int64_t grp = ks ? (int64_t)bx : (int64_t)bx * 4 + wid; grp < ngroups; grp += stride) {
     ARow row[MTW];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) row[mt] = a_row(g, (grp * MTW + mt) * 16 + lr);
@@ -586,7 +542,22 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs 
     }
     if (ks) __syncthreads();  // kred is reused by the next group
   }
-  if (MODE == 1) stats_flush<NTW, 4>(g, nb, ssum, ssq);
+  if (MODE == 1) stats_flush<NTW, 4>(g, nb, ssum, ssq, bx);
+}
+
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false, bool PRO = false>
+__global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
+  gemm_kloop_body<MTW, NTW, MODE, VEC, CAT, BCM, BF, PRO>(g, cvec, blockIdx.x, gridDim.x);
+}
+
+// TWO independent products with the same output shape and tile plan in one launch: row workgroups [0, wgs0) work on g0,
+// the rest on g1 (same column slices).  The mlp2 and shortcut Linears of a DilatedResidualBlock (pyg_randla_net.py:172-188)
+// — forward, and their input gradients — on the deep levels: each alone is 400-800 workgroups of a few microseconds.
+template <int MTW, int NTW, int MODE, bool BCM, bool BF>
+__global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_pair_kernel(GemmArgs g0, GemmArgs g1, int cvec0, int cvec1,
+                                                                            unsigned wgs0) {
+  if (blockIdx.x < wgs0) gemm_kloop_body<MTW, NTW, MODE, true, false, BCM, BF, false>(g0, cvec0, blockIdx.x, wgs0);
+  else gemm_kloop_body<MTW, NTW, MODE, true, false, BCM, BF, false>(g1, cvec1, blockIdx.x - wgs0, gridDim.x - wgs0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -759,6 +730,61 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
     else if (rp.NT == 2) launch_kloop<1, 2>(gk, mode, variant, grid, st, cvec);
     else launch_kloop<1, 1>(gk, mode, variant, grid, st, cvec);
   }
+  return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+}
+
+// ---- two products in one launch (gemm_kloop_pair_kernel) ----
+template <int MTW, int NTW>
+static void launch_kl_pair(const GemmArgs& g0, const GemmArgs& g1, int mode, bool bcm, bool bf, dim3 grid, hipStream_t st,
+                           int cvec0, int cvec1, unsigned wgs0) {
+#define M3D_PAIR(MODE_, BCM_, BF_) \
+  hipLaunchKernelGGL((gemm_kloop_pair_kernel<MTW, NTW, MODE_, BCM_, BF_>), grid, dim3(256), 0, st, g0, g1, cvec0, cvec1, wgs0)
+  if (mode == 1) { if (bf) M3D_PAIR(1, false, true); else M3D_PAIR(1, false, false); }
+  else if (bcm) { if (bf) M3D_PAIR(0, true, true); else M3D_PAIR(0, true, false); }
+  else { if (bf) M3D_PAIR(0, false, true); else M3D_PAIR(0, false, false); }
+#undef M3D_PAIR
+}
+
+// M3D_OK when both products went out as one launch; 1 when the pair does not fit (the caller launches them one by one):
+// K > 64 on both sides, plain row-major operands with 16-byte rows, the same output shape, epilogue (plain, or slot-mode
+// statistics) and tile plan.
+int m3d_gemm_direct_pair_try(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+  const GemmArgs* gs[2] = {&a, &b};
+  if (a.M != b.M || a.N != b.N || a.b_cm != b.b_cm || a.bf16 != b.bf16) return 1;
+  if ((a.stat_part != nullptr) != (b.stat_part != nullptr)) return 1;
+  const int mode = a.stat_part ? 1 : 0;
+  int cvec[2];
+  RowPlan rp[2];
+  GemmArgs gk[2];
+  const int64_t lim = (int64_t)M3D_BUF_BYTES - 64;
+  for (int i = 0; i < 2; ++i) {
+    const GemmArgs& g = *gs[i];
+    const int K = g.k0;
+    if (g.k1 != 0 || g.a0_rows || g.a_cm || g.splitk > 1 || g.pro_z || g.c_split > 0 || K <= 64) return 1;
+    if (g.scale || g.shift || g.act) return 1;
+    if (g.accumulate && g.stat_part) return 1;
+    if (g.b_cm && mode != 0) return 1;
+    if (g.stat_part && g.stat_slots <= 0) return 1;  // (per-workgroup partial rows are sized for the single launch)
+    const bool vec = ((g.lda0 & 3) == 0) && ((K & 3) == 0) && al16(g.a0) && (g.b_cm || (((g.ldb & 3) == 0) && al16(g.b)));
+    if (!vec) return 1;
+    if (g.bf16 && (K & 31)) return 1;
+    if (g.M * g.lda0 * 4 > lim || (int64_t)(g.b_cm ? K : g.N) * g.ldb * 4 > lim) return 1;
+    cvec[i] = ((g.ldc & 3) == 0) && al16(g.c) && ((g.N & 3) == 0);
+    rp[i] = plan_rows(g.M, g.N, K, mode);
+    if (rp[i].rowstream) return 1;
+    gk[i] = g;
+    gk[i].ksplit = rp[i].ksplit;
+    gk[i].acc_pre = g.accumulate && mode == 0 && cvec[i] && g.M * g.ldc * 4 <= lim;
+  }
+  if (rp[0].MT != rp[1].MT || rp[0].NT != rp[1].NT || rp[0].slices != rp[1].slices || rp[0].slices > 65535) return 1;
+  if ((GEMM_DISABLE) & 4) return 1;
+  dim3 grid((unsigned)(rp[0].wgs + rp[1].wgs), (unsigned)rp[0].slices);
+  const bool bcm = a.b_cm != 0, bf = a.bf16 != 0;
+  const unsigned w0 = (unsigned)rp[0].wgs;
+  if (rp[0].MT == 2 && rp[0].NT == 4) launch_kl_pair<2, 4>(gk[0], gk[1], mode, bcm, bf, grid, st, cvec[0], cvec[1], w0);
+  else if (rp[0].MT == 2) launch_kl_pair<2, 2>(gk[0], gk[1], mode, bcm, bf, grid, st, cvec[0], cvec[1], w0);
+  else if (rp[0].NT == 2) launch_kl_pair<1, 2>(gk[0], gk[1], mode, bcm, bf, grid, st, cvec[0], cvec[1], w0);
+  else launch_kl_pair<1, 1>(gk[0], gk[1], mode, bcm, bf, grid, st, cvec[0], cvec[1], w0);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
 

@@ -26,15 +26,6 @@
 // 11*d accumulated numbers in m3d_lfa_enc_bwd_finalize.
 #include "m3d_common.h"
 #include "lfa_common.h"
-// wave priority by phase (like LFA_BWD_SETPRIO in lfa_bwd.hip): mask of the phases at priority LFA_FWD_PRIO_LVL,
-// bit 0 = gather / encoder, 1 = logits GEMM, 2 = softmax / aggregation
-#ifndef LFA_FWD_SETPRIO
-#define LFA_FWD_SETPRIO 0
-#endif
-#ifndef LFA_FWD_PRIO_LVL
-#define LFA_FWD_PRIO_LVL 1
-#endif
-#define FWD_PRIO(bit) do { if (LFA_FWD_SETPRIO) __builtin_amdgcn_s_setprio((LFA_FWD_SETPRIO & (bit)) ? LFA_FWD_PRIO_LVL : 0); } while (0)
 #include "../../include/m3d_hip.h"
 
 // 1: double-buffer the attention-weight fragments of the MFMA loop (untuned knob for a same-box A/B; default off)
@@ -69,7 +60,6 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   const int K = a.K;
   const int64_t c0 = xcd_major(blockIdx.x, gridDim.x) * TC;  // (XCD-aware: m3d_common.h)
 
-  FWD_PRIO(1);
   // ---- phase 1a: neighbour ids
   for (int e = tid; e < ROWS; e += 256) {
     int ci = e / KP, k = e % KP;
@@ -120,7 +110,6 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   __syncthreads();
 
   // ---- phase 2: A = F * W_att^T on MFMA
-  FWD_PRIO(2);
   const int wn = wid % WN, wm = wid / WN;
   f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -182,7 +171,6 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
     }
   }
 
-  FWD_PRIO(4);
   // ---- phase 3: softmax over each centre's neighbours + weighted sum, in the MFMA C layout
 #pragma unroll
   for (int cc = 0; cc < MTW / KT; ++cc) {

@@ -124,7 +124,7 @@ struct LfaBwdArgs {
 // at 0.  bit 0 = gather / encoder (phase 1), 1 = logits GEMM (2), 2 = softmax / dA (3'), 3 = dF and dW GEMMs (4, 5),
 // 4 = scatter / dy / encoder sums (6, 7).
 #ifndef LFA_BWD_SETPRIO
-#define LFA_BWD_SETPRIO 21  // the VALU phases first: level 1 247 -> 222 and 254 -> 233 us, ch = 64 265 -> 254 us, -0.065 ms per step (profiles/r04g_*)
+#define LFA_BWD_SETPRIO 17  // gather / encoder and scatter phases first: -2.5 ... -5 % per launch at levels 1-2, -0.03 ms per step (profiles/r04h_*, r04i_*)
 #endif
 #ifndef LFA_BWD_PRIO_LVL
 #define LFA_BWD_PRIO_LVL 1

@@ -13,11 +13,13 @@
 
 #define CE_MAXC 64
 
-// acc[0] += sum of per-row losses, acc[1] += number of rows with target != ignore_index; lse[i] = logsumexp(row i)
+// acc[0] += sum of per-row losses, acc[1] += number of rows with target != ignore_index; lse[i] = logsumexp(row i).
+// acc[2] (its first 4 bytes) is an arrival ticket: the workgroup that arrives last reads the finished sums and writes the
+// mean — the finalize step without a launch of its own (5 us apiece in a replayed graph).
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld,
                                                      const int64_t* __restrict__ target, int64_t n, int C,
                                                      int64_t ignore_index, float* __restrict__ lse,
-                                                     double* __restrict__ acc) {
+                                                     double* __restrict__ acc, float* __restrict__ loss) {
   __shared__ double red[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   double ls = 0.0, cnt = 0.0;
@@ -48,12 +50,20 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   if (tid == 0) {
     atomicAdd(&acc[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     atomicAdd(&acc[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    __threadfence();
+    unsigned* ticket = (unsigned*)&acc[2];
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      // every other workgroup's two atomics precede its ticket: the sums are final (read where the atomics ran, in L2)
+      const double s = __hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double c = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      loss[0] = (float)(s / c);  // mean over the non-ignored rows (0/0 = NaN when every row is ignored, like torch)
+      *ticket = 0u;
+    }
   }
 }
 
 __global__ void ce_finalize_kernel(const double* __restrict__ acc, float* __restrict__ loss) {
-  // mean over the non-ignored rows (0/0 = NaN when every row is ignored, like torch)
-  loss[0] = (float)(acc[0] / acc[1]);
+  loss[0] = (float)(acc[0] / acc[1]);  // (n == 0: no forward workgroup exists)
 }
 
 // dlogits[i, c] = gout * (softmax(i)[c] - [c == target_i]) / count   (0 for ignored rows)
@@ -75,19 +85,21 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 }
 
 extern "C" int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
-                               int64_t ignore_index, float* lse, double* acc2, float* loss, void* stream) {
+                               int64_t ignore_index, float* lse, double* acc4, float* loss, int32_t flags, void* stream) {
   if (n < 0 || C < 1) return M3D_ERR_INVALID;
-  if (!acc2 || !loss) return M3D_ERR_INVALID;
+  if (!acc4 || !loss) return M3D_ERR_INVALID;
   if (n > 0 && (!logits || !target || !lse)) return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc2, 0, 2 * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
+  // flags bit 0: acc4 is already zero (a slice of the caller's pre-zeroed arena): no memset node
+  if (!(flags & 1) && hipMemsetAsync(acc4, 0, 4 * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
   if (n > 0) {
     int64_t gx = m3d_cdiv(n, 256);
     if (gx > 256) gx = 256;  // every block ends in two same-address fp64 atomics: one block per CU, not 800 of them
     hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)gx), dim3(256), 0, st, logits, ld, target, n, C, ignore_index, lse,
-                       acc2);
+                       acc4, loss);
+  } else {
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, st, acc4, loss);
   }
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, st, acc2, loss);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
@@ -114,13 +126,19 @@ extern "C" int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* t
 // grad_scale multiplies g on the way in (1/world_size after a SUM all-reduce); zero_grad != 0 clears g.
 // ------------------------------------------------------------------------------------------
 __global__ void adam_tick_kernel(float* __restrict__ state) { state[0] += 1.f; }
+#define ADAM_SUBTICKETS 64
 
+// state[0] = steps done so far (fp32), state[1 .. 1 + ADAM_TICKETS] = arrival tickets (uint32, zero between launches):
+// every workgroup reads state[0] when it starts and takes a ticket when it is done; the last one stores the new count —
+// the counter bump without a 1-thread launch in front of the update (a replayed graph pays ~5 us per node).  Two levels of
+// tickets (workgroup b -> counter 2 + b % 64, the last arriver of each counter -> the master counter 1): ~1 100 arrivals at ONE
+// address are ~15 ns apiece, one after the other (+8 us on a 10-us kernel when they all sit on the master).
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float4* __restrict__ g,
                                                    float4* __restrict__ m, float4* __restrict__ v,
-                                                   const float* __restrict__ state, const float* __restrict__ lr_dev,
+                                                   float* __restrict__ state, const float* __restrict__ lr_dev,
                                                    float lr, float b1, float b2, float eps, float wd, float gscale,
                                                    int zero_grad, int64_t n4) {
-  const float t = state[0];
+  const float t = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1.f;
   const float lrv = lr_dev ? lr_dev[0] : lr;
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float step = lrv / bc1, rs = 1.f / sqrtf(bc2);
@@ -137,6 +155,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float
     p[i] = pv; m[i] = mv; v[i] = vv;
     if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  __syncthreads();  // every thread of this workgroup has used its copy of the count
+  if (threadIdx.x == 0) {
+    unsigned* tk = (unsigned*)&state[1];
+    const unsigned sub = blockIdx.x % ADAM_SUBTICKETS;
+    const unsigned members = gridDim.x / ADAM_SUBTICKETS + (sub < gridDim.x % ADAM_SUBTICKETS ? 1u : 0u);
+    if (atomicAdd(&tk[1 + sub], 1u) == members - 1) {
+      tk[1 + sub] = 0u;
+      const unsigned groups = gridDim.x < ADAM_SUBTICKETS ? gridDim.x : ADAM_SUBTICKETS;
+      if (atomicAdd(&tk[0], 1u) == groups - 1) {
+        __hip_atomic_store(&state[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tk[0] = 0u;
+      }
+    }
+  }
 }
 
 extern "C" int m3d_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* state,
@@ -148,7 +180,7 @@ extern "C" int m3d_adam_step(float* params, float* grads, float* exp_avg, float*
   if ((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15)
     return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, state);
+  if (n == 0) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, state);
   if (n > 0) {
     int64_t gx = m3d_cdiv(n / 4, 256);
     if (gx > 2048) gx = 2048;
@@ -156,6 +188,32 @@ extern "C" int m3d_adam_step(float* params, float* grads, float* exp_avg, float*
                        (float4*)exp_avg, (float4*)exp_avg_sq, state, lr_dev, lr, beta1, beta2, eps, weight_decay,
                        grad_scale, zero_grad, n / 4);
   }
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// start of a training step: zero-fill of the step's accumulation arena (one buffer: the dx targets of the LFA backward
+// atomics, the row scatter-add outputs, the statistics slots) and the "+ 1" of the BatchNorm step counters
+// (torch.nn.BatchNorm1d.num_batches_tracked, one int64 per layer) in ONE launch.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_bump_kernel(float4* __restrict__ buf, int64_t n16, int64_t* __restrict__ counters,
+                                                        int ncounters) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+    buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < ncounters; c += 256) counters[c] += 1;
+}
+
+extern "C" int m3d_zero_bump(void* buf, int64_t nbytes, int64_t* counters, int32_t ncounters, void* stream) {
+  if (nbytes < 0 || (nbytes & 15) || ncounters < 0) return M3D_ERR_INVALID;
+  if ((nbytes > 0 && (!buf || (((uintptr_t)buf) & 15))) || (ncounters > 0 && !counters)) return M3D_ERR_INVALID;
+  if (nbytes == 0 && ncounters == 0) return M3D_OK;
+  int64_t gx = m3d_cdiv(nbytes / 16, 256 * 4);
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(zero_bump_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (float4*)buf, nbytes / 16,
+                     counters, ncounters);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

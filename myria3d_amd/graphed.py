@@ -149,7 +149,7 @@ class GraphedStep:
             # backward nodes on THIS thread: one device per process leaves the engine's device thread nothing to overlap, and the
             # hand-off costs ~10 us for each of the ~190 nodes (2 ms -> 0.4 ms of host time per step: tools/host_profile.py st)
             with torch.autograd.set_multithreading_enabled(False):
-                loss.backward()
+                loss.backward(gradient=self._unit(loss))  # (a persistent 1: no ones_like fill node per step)
             if net.grad_side is not None:
                 net.grad_side.join()  # (inside a capture the deferred leaf launches must be part of it)
             if self.lookahead:
@@ -165,6 +165,12 @@ class GraphedStep:
                 s.out = net(s.x, s.pos, None, self.ptr, plan=self.plan)
                 if self.lookahead:
                     net.join_geometry()
+
+    def _unit(self, like: Tensor) -> Tensor:
+        u = getattr(self, "_one", None)
+        if u is None or u.device != like.device or u.dtype != like.dtype:
+            u = self._one = torch.ones((), dtype=like.dtype, device=like.device)
+        return u
 
     def _geo(self, k: int) -> None:
         """The position-only work for buffer set ``k`` as a unit of its own (graph ``A``; also the eager priming)."""

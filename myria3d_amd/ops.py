@@ -57,10 +57,19 @@ class ZeroArena:
         self.need = 0
         self.active = False
 
-    def begin(self, device) -> None:
+    def begin(self, device, bump: Optional[Tensor] = None) -> None:
+        """``bump``: int64 counters incremented by the same launch (the BatchNorm layers' ``num_batches_tracked``)."""
         self._learn()
         self.active = True
-        self.buf = torch.zeros(self.need, dtype=torch.uint8, device=device) if self.need else None
+        if torch.device(device).type != "cuda":  # (bookkeeping exercised on the host by tests/test_host.py; no kernels there)
+            self.buf = torch.zeros(self.need, dtype=torch.uint8, device=device) if self.need else None
+            if bump is not None:
+                bump += 1
+        elif self.need or bump is not None:
+            self.buf = torch.empty(self.need, dtype=torch.uint8, device=device) if self.need else None
+            call("m3d_zero_bump", _p(self.buf), self.need, _p(bump), 0 if bump is None else bump.numel(), _st())
+        else:
+            self.buf = None
 
     def stop(self) -> None:
         self._learn()  # (an eval pass between two training steps must not forget what the last step needed)
@@ -200,6 +209,25 @@ def gemm(a0: Tensor, b: Tensor, M: int, N: int, k0: int, *, lda0: Optional[int] 
          0 if stats is None else (-stats.shape[0] if stat_slots else stats.shape[0]),
          _p(out), ldc, int(accumulate), splitk, _st())
     return out
+
+
+def gemm_pair(a, b, M: int, N: int, *, bias=None, stats=None, out=None, accumulate=(False, False), b_cm: bool = False,
+              bf16: bool = False):
+    """Two products with one output shape, ``C_i[M,N] (+)= A_i B_i^T`` (``b_cm``: ``A_i B_i``, the input-gradient
+    pattern), as ONE launch where the k-loop kernel takes both (``m3d_gemm_pair_f32``; two launches otherwise).
+    ``stats``: a pair of slot-mode tables (``stat_slots``).  Returns the two outputs."""
+    import ctypes
+
+    dev = a[0].device
+    outs = [o if o is not None else torch.empty((M, N), dtype=torch.float32, device=dev) for o in (out or (None, None))]
+    vp = lambda ts: (ctypes.c_void_p * 2)(*[_p(t) for t in ts])
+    i64 = lambda vs: (ctypes.c_int64 * 2)(*vs)
+    i32 = lambda vs: (ctypes.c_int32 * 2)(*vs)
+    call("m3d_gemm_pair_f32", vp(a), i64([t.stride(0) for t in a]), i32([t.shape[1] for t in a]), vp(b),
+         i64([t.stride(0) for t in b]), M, N, vp(bias) if bias is not None else None,
+         vp(stats) if stats is not None else None, -stats[0].shape[0] if stats is not None else 0, vp(outs),
+         i64([t.stride(0) for t in outs]), i32([int(x) for x in accumulate]), int(b_cm) | (256 if bf16 else 0), _st())
+    return outs
 
 
 def stat_buffer(M: int, N: int, K: int, device) -> Tensor:
@@ -477,6 +505,8 @@ def bn_finalize(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d):
 # instead of one GEMM + one reduce per layer on the side stream; M3D_DEFER_WGRAD=0: the per-layer launches (A/B)
 DEFER_WGRAD = os.environ.get("M3D_DEFER_WGRAD", "1") != "0"
 FUSE_BN_DGRAD = os.environ.get("M3D_FUSE_BN_DGRAD", "1") != "0"  # A/B switch for bn_dgrad (see its docstring)
+FUSE_MIN_ROWS = 1600
+PAIR_GEMMS = os.environ.get("M3D_PAIR_GEMMS", "1") != "0"  # mlp2 / shortcut Linears of a block as one launch (A/B switch)
 BN_SLOTS = 16  # slot-mode statistics: workgroups add their column partials into (at most) this many fp64 rows
 # slot rows by layer size: (rows threshold, slots) pairs, first match wins; M3D_BN_SLOTS="100000:8,25000:4,0:2"
 _SLOT_TABLE = tuple((int(a), int(b)) for a, b in
@@ -687,7 +717,9 @@ class SharedLayerTrainFn(torch.autograd.Function):
         dxc = None
         x0_slot, x1_slot = ctx.slots
         acc0 = x0_slot.take() if (x0_slot is not None and ctx.needs_input_grad[0]) else None
-        fused = want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1])
+        # (a few hundred rows x wide layers — mlp_summit: 800 x 512 -> 512 — the prologue, repeated in every column slice,
+        # costs more than the apply launch it replaces: 35 vs 23 us, profiles/r04h_gemm_*.log)
+        fused = want_dx and FUSE_BN_DGRAD and bn_dgrad_ok(z.shape[1]) and (z.shape[0] >= FUSE_MIN_ROWS or k1 > 0)
         if fused and z.shape[0] * max(z.shape[1], w.shape[1]) * 4 >= (1 << 31) - 64:
             fused = False  # beyond the fused kernel's 2 GiB buffer descriptors: the two-pass path handles it
         if fused and k1 and k0 % 4 == 0 and k1 % 4 == 0:
@@ -744,8 +776,12 @@ class ResidualTailTrainFn(torch.autograd.Function):
         M, N = x2.shape[0], w2.shape[0]
         if _pow2(N):
             st2, sts = stat_slots(N, w2.device, M), stat_slots(N, w2.device, M)
-            z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, stat_slots=True, bf16=bf16)
-            zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts, stat_slots=True, bf16=bf16)
+            if PAIR_GEMMS and min(x2.shape[1], xs.shape[1]) > 64 and st2.shape == sts.shape:
+                # deep levels: both Linears in one launch (each alone is a few hundred workgroups)
+                z2, zs = gemm_pair((x2.contiguous(), xs.contiguous()), (w2, ws), M, N, bias=(b2, bs), stats=(st2, sts), bf16=bf16)
+            else:
+                z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, stat_slots=True, bf16=bf16)
+                zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts, stat_slots=True, bf16=bf16)
             y, (sc2, sh2, mu2, is2), (scs, shs, mus, iss) = bn_stats_apply(st2, M, bn2, z2, True, sts, bns, zs)
         else:
             st2 = stat_buffer(M, N, x2.shape[1], w2.device)
@@ -764,17 +800,22 @@ class ResidualTailTrainFn(torch.autograd.Function):
         sk = ctx.sinks
         dz2, dg2, db2, dzs, dgs, dbs = bn_bwd(dy.contiguous(), z2, sc2, sh2, mu2, is2, True, zs, scs, shs, mus, iss,
                                               sinks=(sk[0][2], sk[0][3], sk[1][2], sk[1][3]) if sk else None)
-        dx2 = linear_dgrad(dz2, w2, ctx.bf16)
         slot = ctx.xs_slot
-        if slot is not None and ctx.needs_input_grad[6]:
-            prev = slot.buf
-            ok = prev is not None and prev.shape == (dzs.shape[0], ws.shape[1]) and prev.is_contiguous()
-            slot.buf = linear_dgrad(dzs, ws, ctx.bf16, acc=prev if ok else None)
+        use_slot = slot is not None and ctx.needs_input_grad[6]
+        prev = slot.buf if use_slot else None
+        ok = prev is not None and prev.shape == (dzs.shape[0], ws.shape[1]) and prev.is_contiguous()
+        if PAIR_GEMMS and w2.shape[1] == ws.shape[1] and dz2.shape[1] > 64:
+            # dX_i[M, K] = dZ_i[M, N] W_i: the same output shape on both sides (deep levels: K_in of mlp2 = K_in of the shortcut)
+            dx2, dxs = gemm_pair((dz2, dzs), (w2, ws), dz2.shape[0], w2.shape[1], out=(None, prev if ok else None),
+                                 accumulate=(False, ok), b_cm=True, bf16=ctx.bf16)
+        else:
+            dx2 = linear_dgrad(dz2, w2, ctx.bf16)
+            dxs = linear_dgrad(dzs, ws, ctx.bf16, acc=prev if ok else None)
+        if use_slot:
+            slot.buf = dxs
             if prev is not None and not ok:
                 slot.buf.add_(prev)
             dxs = None
-        else:
-            dxs = linear_dgrad(dzs, ws, ctx.bf16)
         dw2 = linear_wgrad(dz2, x2, x2.shape[1], out=sk[0][0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         dws = linear_wgrad(dzs, xs, xs.shape[1], out=sk[1][0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         z0_2 = None if sk else torch.zeros_like(db2)
@@ -1211,10 +1252,11 @@ class CrossEntropyFn(torch.autograd.Function):
         n, C = logits.shape
         dev = logits.device
         lse = torch.empty(n, dtype=torch.float32, device=dev)
-        acc = torch.empty(2, dtype=torch.float64, device=dev)
+        pre_zeroed = arena.active and arena.buf is not None
+        acc = arena.zeros((4,), torch.float64, dev) if pre_zeroed else torch.empty(4, dtype=torch.float64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         call("m3d_ce_loss_fwd", _p(logits), logits.stride(0), _p(target), n, C, ignore_index, _p(lse), _p(acc), _p(loss),
-             _st())
+             1 if pre_zeroed else 0, _st())
         ctx.save_for_backward(logits, target, lse, acc)
         ctx.ignore_index = ignore_index
         return loss.view(())

@@ -671,14 +671,16 @@ class HipRandLANet(nn.Module):
             raise ValueError(f"matmul_precision must be 'fp32' or 'bf16', got {self.matmul_precision!r}")
         self._bf16 = self.matmul_precision == "bf16" or (
             torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+        bump = self._nbt_flat if (train and self._flat is not None) else None  # BatchNorm step counters (one int64 vector)
         if train and torch.is_grad_enabled():
-            ops.arena.begin(pos.device)  # one zero fill for every accumulation target of the coming backward pass
+            # one launch: zero fill of every accumulation target of the coming backward pass + the counters' "+ 1"
+            ops.arena.begin(pos.device, bump=bump)
         else:
             ops.arena.stop()
+            if bump is not None:
+                bump += 1
         if train:
             self._eval_cache.clear()  # this pass updates the running statistics (and an optimizer step follows)
-        if train and self._flat is not None:
-            self._nbt_flat += 1
         # weight gradients on a side stream: only with gradient sinks and an optimizer that joins the stream
         ops._grad_side = self.grad_side if self._use_sinks else None
         blocks = (self.block1, self.block2, self.block3, self.block4)

@@ -43,7 +43,9 @@ class FusedAdam(torch.optim.Optimizer):
         flat = net.flat_parameters
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        # device-side state of m3d_adam_step: [0] the step counter (fp32), then the arrival tickets of the update's workgroups
+        self._adam_state = torch.zeros(66, dtype=torch.float32, device=flat.device)  # (M3D_ADAM_STATE_WORDS)
+        self.step_count = self._adam_state[:1]
         self.lr_dev: Optional[torch.Tensor] = None  # optional device-side learning rate (graph-replay safe)
         self.all_reduce = all_reduce
         # run the gradient all-reduce even on a 1-rank process group (exercises RCCL and its interplay with hipGraph
@@ -142,7 +144,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._bound_ptr = flat_p.data_ptr()
         g = self.param_groups[0]
         call("m3d_adam_step", flat_p.data_ptr(), flat_g.data_ptr(), self.exp_avg.data_ptr(),
-             self.exp_avg_sq.data_ptr(), self.step_count.data_ptr(),
+             self.exp_avg_sq.data_ptr(), self._adam_state.data_ptr(),
              None if self.lr_dev is None else self.lr_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
              float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), scale, 1, flat_p.numel(),
              torch.cuda.current_stream().cuda_stream)

@@ -232,6 +232,41 @@ def test_gemm_forward(device, M, K, N):
 
 
 
+@pytest.mark.parametrize("M,K0,K1,N", [(3200, 256, 256, 512), (12800, 128, 128, 256), (801, 128, 256, 128), (3200, 512, 96, 64),
+                                       (5000, 64, 32, 128), (300, 256, 256, 20)])
+def test_gemm_pair_equals_two_launches(device, M, K0, K1, N):
+    """``m3d_gemm_pair_f32`` (the mlp2 / shortcut Linears of a block as ONE launch on the deep levels, pyg_randla_net.py:172-188):
+    outputs and slot-mode statistics are the BITS two ``m3d_gemm_f32`` launches give — the forward pattern with bias and
+    statistics, and the input-gradient pattern with one side added into an existing buffer; shapes the pair kernel does not
+    take (K <= 64) go through the two-launch fallback inside the same entry point."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M + K0 + N)
+    t = lambda *shape: torch.from_numpy(rs.uniform(-1, 1, shape).astype(np.float32)).to(device)
+    a, w, b = (t(M, K0), t(M, K1)), (t(N, K0), t(N, K1)), (t(N), t(N))
+    pow2 = N >= 4 and (N & (N - 1)) == 0
+    st_ref = [torch.zeros((ops.bn_slots(M), 2, N), dtype=torch.float64, device=device) for _ in range(2)] if pow2 else None
+    st_got = [torch.zeros_like(x) for x in st_ref] if pow2 else None
+    ref = [ops.gemm(a[i], w[i], M, N, a[i].shape[1], bias=b[i], stats=st_ref[i] if pow2 else None, stat_slots=pow2)
+           for i in range(2)]
+    got = ops.gemm_pair(a, w, M, N, bias=b, stats=st_got)
+    for i in range(2):
+        assert torch.equal(got[i], ref[i]), (i, (got[i] - ref[i]).abs().max().item())
+        if pow2:
+            # (fp64 sums of the same fp32 outputs, grouped into slots by a different workgroup count)
+            assert torch.allclose(st_got[i].sum(0), st_ref[i].sum(0), rtol=1e-12, atol=1e-9), i
+    # input-gradient pattern: dX_i[M, Kin] = dZ_i[M, N] W_i[N, Kin], the second one added into an existing buffer
+    Kin = K0
+    dz, wd = (t(M, N), t(M, N)), (t(N, Kin), t(N, Kin))
+    base = t(M, Kin)
+    r0 = ops.linear_dgrad(dz[0], wd[0])
+    r1 = ops.linear_dgrad(dz[1], wd[1], acc=base.clone())
+    acc = base.clone()
+    g0, g1 = ops.gemm_pair(dz, wd, M, Kin, out=(None, acc), accumulate=(False, True), b_cm=True)
+    assert g1.data_ptr() == acc.data_ptr()
+    assert torch.equal(g0, r0) and torch.equal(g1, r1)
+
+
 @pytest.mark.parametrize("M,K,N,slots", [(37, 128, 64, False), (800, 512, 512, True), (3200, 256, 512, True),
                                          (204800, 32, 32, True), (51200, 64, 128, False), (20000, 16, 8, True)])
 def test_gemm_statistics_of_columns_with_mean_far_from_zero(device, M, K, N, slots):
