@@ -25,8 +25,14 @@
 extern "C" {
 #endif
 
+/* torch.nn.Dropout(p) fused into a SharedMLP layer's BatchNorm kernels (mlp_classif, pyg_randla_net.py:49-52): the mask
+ * of m3d_dropout — a hash of (seed, counter[0], element) — applied to the layer's output in the forward pass and to the
+ * incoming gradient in the backward pass.  A null pointer, a null counter or p == 0 mean "no dropout". */
+typedef struct { const int64_t* counter; uint64_t seed; float p; } M3DDropout;
+
 #define M3D_ABI_VERSION 14
 #define M3D_ADAM_STATE_WORDS 66
+#define M3D_CE_ACC_DOUBLES 516
 int m3d_abi_version(void);
 
 /* count <= 48 device-to-device copies (dst[i] <- src[i], bytes[i] bytes; 16-byte aligned pointers) in ONE launch;
@@ -149,7 +155,7 @@ int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t count, const
                        float* mean_out, float* invstd_out, const float* z, const double* slots2, const float* gamma2,
                        const float* beta2, float* running_mean2, float* running_var2, float* scale2, float* shift2,
                        float* mean_out2, float* invstd_out2, const float* z2, int32_t act, float slope, float* y,
-                       int64_t M, int32_t N, void* stream);
+                       int64_t M, int32_t N, const M3DDropout* drop, void* stream);
 /* backward of m3d_bn_apply in train mode: dz (and dz2), dgamma/dbeta (and dgamma2/dbeta2).
  * sums_ws: m3d_bn_bwd_workspace_bytes(M, N) bytes of scratch (per-block partial column sums, no atomics).
  * accumulate_param_grads: bit 0 = dgamma/dbeta are gradient sinks (e.g. slices of the flat gradient buffer) and are added
@@ -162,7 +168,7 @@ int m3d_bn_bwd(const float* dy, const float* z, const float* scale, const float*
                const float* invstd, const float* z2, const float* scale2, const float* shift2, const float* mean2,
                const float* invstd2, int32_t act, float slope, int64_t M, int32_t N, double* sums_ws, float* dz,
                float* dz2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
-               int32_t accumulate_param_grads, void* stream);
+               int32_t accumulate_param_grads, const M3DDropout* drop, void* stream);
 /* Pass 2 of the BatchNorm backward fused into the input-gradient GEMM of the Linear in front of it (SharedMLP layer,
  * pyg_randla_net.py:97-109: torch autograd runs BatchNorm1d.backward, then Linear.backward):
  *   dz = scale * (dy * act'(z*scale+shift) - s1/M - (z-mean)*invstd * s2/M)   computed as the GEMM's A fragments are loaded
@@ -177,7 +183,7 @@ int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* scale, const 
                      const float* invstd, int32_t act, float slope, const double* sums, int32_t nslots, int64_t M,
                      int32_t N, const float* w, int64_t ldw, int32_t Kin, float* dx, int64_t lddx, float* dz,
                      float* dgamma, float* dbeta, int32_t flags, int32_t dx_split, float* dx1, int64_t lddx1,
-                     void* stream);
+                     const M3DDropout* drop, void* stream);
 
 /* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
 int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,
@@ -375,9 +381,10 @@ int m3d_seg_max_bwd(const float* dout, const int32_t* arg, const int64_t* seg, c
 
 /* ---- training step: loss and optimizer -------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(ignore_index=65, reduction="mean") on the logits (myria3d/models/model.py:118,
- * configs/model/criterion/CrossEntropyLoss.yaml:1-3).  lse: [n] scratch kept for the backward; acc4: fp64 [4]
- * ([0] sum of row losses, [1] number of non-ignored rows, [2] arrival ticket of the workgroups, [3] unused; zeroed
- * inside unless flags bit 0 says the caller passes zeros); loss: fp32 [1], written by the last workgroup to arrive. */
+ * configs/model/criterion/CrossEntropyLoss.yaml:1-3).  lse: [n] scratch kept for the backward; acc4: fp64
+ * [M3D_CE_ACC_DOUBLES] ([0] sum of row losses, [1] number of non-ignored rows — both kept for the backward —, [2]
+ * arrival ticket of the workgroups, [4 ...] their partial sums; the first four are zeroed inside unless flags bit 0 says
+ * the caller passes zeros); loss: fp32 [1], written by the last workgroup to arrive. */
 int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
                     int64_t ignore_index, float* lse, double* acc4, float* loss, int32_t flags, void* stream);
 /* dlogits[n, C] (contiguous) = gout[0] * d loss / d logits */
@@ -393,6 +400,11 @@ int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* target, int6
 int m3d_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* state, const float* lr_dev,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   int32_t zero_grad, int64_t n, void* stream);
+/* torch.nn.Dropout(p), train mode (mlp_classif: pyg_randla_net.py:49-52): y[i] = x[i] * keep(i) / (1 - p'), keep(i) a hash
+ * of (seed, counter[0], i) with P(keep) = 1 - p' = 1 - p rounded to 2^-16; n a multiple of 4, 16-byte aligned buffers
+ * (y may be x).  The same call with dy in place of x is the backward pass (the mask is recomputed, not stored);
+ * counter: a device int64 the caller advances once per training forward (graph-replay safe). */
+int m3d_dropout(const float* x, float* y, int64_t n, float p, const int64_t* counter, uint64_t seed, void* stream);
 /* start of a training step: zero-fill of `nbytes` (multiple of 16, 16-byte aligned: the step's accumulation arena) and
  * counters[0 .. ncounters) += 1 (the BatchNorm layers' num_batches_tracked, int64) in one launch */
 int m3d_zero_bump(void* buf, int64_t nbytes, int64_t* counters, int32_t ncounters, void* stream);

@@ -37,12 +37,12 @@ SIGNATURES = {
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
     "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
     "m3d_bn_stats_apply": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                  _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
+                                  _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p, _p]),
     "m3d_bn_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "m3d_bn_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _f32, _i64, _i32, _p, _p, _p, _p, _p,
-                          _p, _p, _i32, _p]),
+                          _p, _p, _i32, _p, _p]),
     "m3d_bn_dgrad_f32": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i32, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p,
-                                _p, _i32, _i32, _p, _i64, _p]),
+                                _p, _i32, _i32, _p, _i64, _p, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
     "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
@@ -88,7 +88,13 @@ SIGNATURES = {
     "m3d_ce_loss_bwd": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _p, _p]),
     "m3d_adam_step": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _i64, _p]),
     "m3d_zero_bump": (_i32, [_p, _i64, _p, _i32, _p]),
+    "m3d_dropout": (_i32, [_p, _p, _i64, _f32, _p, C.c_uint64, _p]),
 }
+
+class M3DDropout(C.Structure):
+    """``M3DDropout`` of include/m3d_hip.h (read by the library on the host, at call time)."""
+    _fields_ = [("counter", C.c_void_p), ("seed", C.c_uint64), ("p", C.c_float)]
+
 
 ABI_VERSION = 14  # M3D_ABI_VERSION in include/m3d_hip.h
 

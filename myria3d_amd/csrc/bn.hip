@@ -146,6 +146,7 @@ struct BnStatsApplyArgs {
   BnStatsArgs b1, b2;  // b2.slots == nullptr: no residual branch
   int nslots; double count; float eps, momentum;
   const float4* z; const float4* z2; int act; float slope; float4* y; int64_t total4; int N;
+  DropArgs drop;  // thr16 != 0: y = dropout(activation) (m3d_common.h)
 };
 
 #ifndef BN_BWD_RPT
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
   if (a.b2.slots) { s2 = *(const float4*)&s_sc2[c]; h2 = *(const float4*)&s_sh2[c]; }
   const int64_t stride = (int64_t)gridDim.x * 256;
   bool first = true;
+  const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
   for (; i < a.total4; i += stride, first = false) {
     const float4 v = first ? v0 : a.z[i];
     float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
@@ -215,6 +217,10 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
       u.x += w.x * s2.x + h2.x; u.y += w.y * s2.y + h2.y; u.z += w.z * s2.z + h2.z; u.w += w.w * s2.w + h2.w;
     }
     if (a.act) { u.x = lrelu(u.x, a.slope); u.y = lrelu(u.y, a.slope); u.z = lrelu(u.z, a.slope); u.w = lrelu(u.w, a.slope); }
+    if (a.drop.thr16) {
+      const float4 m = drop_mul4(dkey, i, a.drop.thr16, a.drop.scale);
+      u.x *= m.x; u.y *= m.y; u.z *= m.z; u.w *= m.w;
+    }
     a.y[i] = u;
   }
 }
@@ -225,7 +231,7 @@ extern "C" int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t c
                                   const double* slots2, const float* gamma2, const float* beta2, float* running_mean2,
                                   float* running_var2, float* scale2, float* shift2, float* mean_out2,
                                   float* invstd_out2, const float* z2, int32_t act, float slope, float* y, int64_t M,
-                                  int32_t N, void* stream) {
+                                  int32_t N, const M3DDropout* drop, void* stream) {
   if (M < 0 || N < 0 || nslots < 1 || count < 1) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
   if (!slots || !scale || !shift || !z || !y) return M3D_ERR_INVALID;
@@ -237,6 +243,7 @@ extern "C" int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t c
   a.nslots = nslots; a.count = (double)count; a.eps = eps; a.momentum = momentum;
   a.z = (const float4*)z; a.z2 = (const float4*)z2; a.act = act; a.slope = slope; a.y = (float4*)y;
   a.total4 = M * (N / 4); a.N = N;
+  a.drop = drop_args(drop);
   int64_t gx = m3d_cdiv(a.total4, 256 * 8);  // ~8 float4 per thread: the per-block column pass is amortised
   if (gx > 1024) gx = 1024;
   if (gx < 1) gx = 1;
@@ -259,10 +266,15 @@ struct BnBwdArgs {
   float* dz; float* dz2; float* dgamma; float* dbeta; float* dgamma2; float* dbeta2;
   int acc_pg;  // != 0: add into dgamma/dbeta (gradient sinks) instead of overwriting
   int nslots;  // > 0: sums is a pre-zeroed [nslots][3][N] table (reduce adds, apply sums; no finalize kernel)
+  DropArgs drop; uint32_t dkey;  // thr16 != 0: the layer's output went through dropout: dy is masked first (dkey: set in-kernel)
 };
 
 __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, float4 zv, float4& z2v) {
   float4 g = ((const float4*)a.dy)[i];
+  if (a.drop.thr16) {
+    const float4 m = drop_mul4(a.dkey, i, a.drop.thr16, a.drop.scale);
+    g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+  }
   if (a.act) {
     float4 sc = *(const float4*)(a.scale + c), sh = *(const float4*)(a.shift + c);
     float4 u = make_float4(zv.x * sc.x + sh.x, zv.y * sc.y + sh.y, zv.z * sc.z + sh.z, zv.w * sc.w + sh.w);
@@ -281,6 +293,7 @@ __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, 
 // one plain-stored partial row per block: part[x][3][N]  (summed by bn_bwd_finalize_kernel — no atomics).
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int rows_per_block, double* __restrict__ part) {
   __shared__ double red[256 * 12];
+  if (a.drop.thr16) a.dkey = drop_key(a.drop);
   const int tid = threadIdx.x;
   const int N4 = a.N / 4;
   const int CG = N4 < 256 ? N4 : 256;  // column groups per block
@@ -385,6 +398,7 @@ __device__ __forceinline__ float4 bn_dz(const BnCol& k, float4 g, float4 zv) {
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  if (a.drop.thr16) a.dkey = drop_key(a.drop);
   const int N4 = a.N / 4;
   const int64_t total4 = a.M * N4;
   const double invM = 1.0 / (double)a.M;
@@ -493,7 +507,7 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
                           const float* invstd, const float* z2, const float* scale2, const float* shift2,
                           const float* mean2, const float* invstd2, int32_t act, float slope, int64_t M, int32_t N,
                           double* sums_ws, float* dz, float* dz2, float* dgamma, float* dbeta, float* dgamma2,
-                          float* dbeta2, int32_t accumulate_param_grads, void* stream) {
+                          float* dbeta2, int32_t accumulate_param_grads, const M3DDropout* drop, void* stream) {
   if (M < 0 || N < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
   // bit 1 of accumulate_param_grads: pass 1 only (slot mode; pass 2 is the A-prologue of m3d_bn_dgrad_f32)
@@ -511,6 +525,7 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   // (slot mode: two launches instead of three; N must be a power of two)
   a.acc_pg = accumulate_param_grads & 1;
   a.nslots = (accumulate_param_grads >> 8) & 0xff;
+  a.drop = drop_args(drop); a.dkey = 0u;
   if (a.nslots > 0 && ((N & (N - 1)) || N > BN_MAXN)) return M3D_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const BnBwdPlan pl = bn_bwd_plan(M, N);

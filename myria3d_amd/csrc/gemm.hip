@@ -302,7 +302,7 @@ extern "C" int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* sc
                                 const float* mean, const float* invstd, int32_t act, float slope, const double* sums,
                                 int32_t nslots, int64_t M, int32_t N, const float* w, int64_t ldw, int32_t Kin,
                                 float* dx, int64_t lddx, float* dz, float* dgamma, float* dbeta, int32_t flags,
-                                int32_t dx_split, float* dx1, int64_t lddx1, void* stream) {
+                                int32_t dx_split, float* dx1, int64_t lddx1, const M3DDropout* drop, void* stream) {
   if (M < 0 || N < 0 || Kin < 0 || nslots < 1 || dx_split < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0 || Kin == 0) return M3D_OK;
   if (!dy || !z || !scale || !shift || !mean || !invstd || !sums || !w || !dx || !dz) return M3D_ERR_INVALID;
@@ -315,6 +315,7 @@ extern "C" int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* sc
   g.pro_z = z; g.pro_scale = scale; g.pro_shift = shift; g.pro_mean = mean; g.pro_invstd = invstd;
   g.pro_sums = sums; g.pro_slots = nslots; g.pro_act = act & 1; g.pro_slope = slope;
   g.pro_dz = dz; g.pro_dgamma = dgamma; g.pro_dbeta = dbeta; g.pro_acc = flags & 1;
+  g.pro_drop = drop_args(drop); g.pro_dkey = 0u;
   g.c_split = dx_split; g.c1 = dx1; g.ldc1 = lddx1;
   const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
   return rc == 1 ? M3D_ERR_UNSUPPORTED : rc;

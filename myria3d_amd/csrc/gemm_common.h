@@ -31,6 +31,7 @@ struct GemmArgs {
   const float* pro_z; const float* pro_scale; const float* pro_shift; const float* pro_mean; const float* pro_invstd;
   const double* pro_sums; int pro_slots; int pro_act; float pro_slope;
   float* pro_dz; float* pro_dgamma; float* pro_dbeta; int pro_acc;
+  DropArgs pro_drop; uint32_t pro_dkey;  // the layer's output went through dropout (thr16 != 0): dy is masked on load
   // split output (input gradient of a layer whose input was cat([x0[rows], x1]), FPModule): columns [0, c_split) go to
   // c[m][.] (ldc), columns [c_split, N) to c1[m][. - c_split] (ldc1) — two contiguous matrices instead of one that has to
   // be sliced and copied.  c_split = 0: plain output.  Direct kernels, plain epilogue only.

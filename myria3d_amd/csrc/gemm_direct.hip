@@ -193,6 +193,7 @@ __device__ __forceinline__ void pro_setup(const GemmArgs& g, float (&cf)[6][KP])
   }
   __syncthreads();
 }
+__device__ __forceinline__ uint32_t pro_key(const GemmArgs& g) { return g.pro_drop.thr16 ? drop_key(g.pro_drop) : 0u; }
 
 // dz[m][k .. k+3] from dy and z (same arithmetic as bn_bwd_apply_kernel); `store`: also write it to pro_dz
 template <int KP>
@@ -201,6 +202,10 @@ __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc
   const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
   float4 gy = ld4(ra0, f0);
   const float4 zv = ld4(rz, f0);
+  if (g.pro_drop.thr16) {  // (f0 / 16 = number of this float4 in the row-major [M, k0] output: lda0 == k0 is checked by the host)
+    const float4 m = drop_mul4(g.pro_dkey, (int64_t)(f0 >> 4), g.pro_drop.thr16, g.pro_drop.scale);
+    gy.x *= m.x; gy.y *= m.y; gy.z *= m.z; gy.w *= m.w;
+  }
   const float4 sc = *(const float4*)&cf[0][k], mu = *(const float4*)&cf[2][k], is = *(const float4*)&cf[3][k];
   const float4 m1 = *(const float4*)&cf[4][k], m2 = *(const float4*)&cf[5][k];
   if (g.pro_act) {
@@ -363,6 +368,7 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
 // ------------------------------------------------------------------------------------------
 template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM, bool PRO = false>
 __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
+  if constexpr (PRO) g.pro_dkey = pro_key(g);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * NT;
@@ -547,6 +553,7 @@ __device__ __forceinline__ void gemm_kloop_body(const GemmArgs& g, int cvec, con
 
 template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false, bool PRO = false>
 __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
+  if constexpr (PRO) g.pro_dkey = pro_key(g);
   gemm_kloop_body<MTW, NTW, MODE, VEC, CAT, BCM, BF, PRO>(g, cvec, blockIdx.x, gridDim.x);
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/m3d_hip.h"
 
 #define M3D_OK 0
 #define M3D_ERR_INVALID (-1)      // bad argument (null pointer, negative size, unsupported k ...)
@@ -35,6 +36,36 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // that L2 instead of bouncing the line between the chiplets.
 #ifndef M3D_XCD_ORDER
 #define M3D_XCD_ORDER 1
+
+// ---- counter-based dropout mask (torch.nn.Dropout of mlp_classif, pyg_randla_net.py:49-52; see m3d_dropout in rows.hip) ----
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// thr16 == 0: no dropout.  keep(element) <=> its 16 random bits >= thr16; kept values are multiplied by scale = 1 / P(keep)
+struct DropArgs { const int64_t* counter; uint64_t seed; uint32_t thr16; float scale; };
+__device__ __forceinline__ uint32_t drop_key(const DropArgs& d) {
+  const uint64_t c = (uint64_t)d.counter[0];
+  return mix32((uint32_t)d.seed ^ mix32((uint32_t)(d.seed >> 32) + 0x85ebca6bu * ((uint32_t)c + 1u)) ^
+               mix32((uint32_t)(c >> 32) * 0xc2b2ae35u + 0x27d4eb2fu));
+}
+// multipliers (0 or scale) of the four elements of float4 number i of the row-major tensor
+__device__ __forceinline__ float4 drop_mul4(uint32_t key, int64_t i, uint32_t thr16, float scale) {
+  const uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+  const uint32_t r0 = mix32(key ^ mix32(2u * lo + 0x9e3779b9u * hi)), r1 = mix32(key ^ mix32(2u * lo + 1u + 0x9e3779b9u * hi));
+  return make_float4((r0 & 0xffffu) >= thr16 ? scale : 0.f, (r0 >> 16) >= thr16 ? scale : 0.f,
+                     (r1 & 0xffffu) >= thr16 ? scale : 0.f, (r1 >> 16) >= thr16 ? scale : 0.f);
+}
+// host side: the C ABI's M3DDropout (nullable) -> kernel arguments
+static inline DropArgs drop_args(const M3DDropout* d) {
+  DropArgs a{nullptr, 0, 0u, 1.f};
+  if (d && d->counter && d->p > 0.f) {
+    uint32_t thr = (uint32_t)(d->p * 65536.f + 0.5f);
+    if (thr > 65535u) thr = 65535u;
+    a.counter = d->counter; a.seed = d->seed; a.thr16 = thr; a.scale = 1.f / (1.f - (float)thr / 65536.f);
+  }
+  return a;
+}
 #endif
 __device__ __forceinline__ int64_t xcd_major(int64_t b, int64_t nblk) {
   if (!M3D_XCD_ORDER) return b;

@@ -105,11 +105,6 @@ extern "C" int m3d_pad_pos(const float* pos, int32_t stride, float* out4, int64_
 // ------------------------------------------------------------------------------------------
 // decimation indices
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
-}
-
 __device__ __forceinline__ uint32_t feistel_perm(uint32_t r, uint32_t n, uint32_t key) {
   if (n <= 1) return 0;
   int bits = 32 - __clz(n - 1);  // ceil(log2 n), n >= 2
@@ -128,6 +123,40 @@ __device__ __forceinline__ uint32_t feistel_perm(uint32_t r, uint32_t n, uint32_
     x = (L << half) | R;
   } while (x >= n);
   return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// torch.nn.Dropout(p) in train mode (the second layer of mlp_classif: MLP(..., dropout=[0.0, 0.5]),
+// /root/reference/myria3d/models/modules/pyg_randla_net.py:49-52): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p).
+// Counter-based: keep(i) is a hash of (seed, step counter, i), so the backward pass recomputes the mask with the same
+// launch (dx = dy * keep / (1 - p)) instead of storing it, and a replayed hipGraph draws a new mask every step because the
+// step counter lives on the device (torch's own dropout under graph capture costs two extra fill launches per replay
+// for its Philox state).  16 random bits per element: P(keep) is 1 - p rounded to 2^-16.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_kernel(const float4* __restrict__ x, float4* __restrict__ y, int64_t n4,
+                                                      DropArgs d) {
+  const uint32_t key = drop_key(d);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = x[i], m = drop_mul4(key, i, d.thr16, d.scale);
+    y[i] = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+  }
+}
+
+extern "C" int m3d_dropout(const float* x, float* y, int64_t n, float p, const int64_t* counter, uint64_t seed,
+                           void* stream) {
+  if (n < 0 || (n & 3) || !(p >= 0.f && p < 1.f)) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!x || !y || !counter || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return M3D_ERR_INVALID;
+  const M3DDropout md{counter, seed, p};
+  DropArgs d = drop_args(&md);
+  if (d.thr16 == 0) { d.counter = counter; d.seed = seed; }  // p rounds to 0: the identity (every 16-bit draw is >= 0)
+  int64_t gx = m3d_cdiv(n / 4, 256 * 4);
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y,
+                     n / 4, d);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
 }
 
 __global__ __launch_bounds__(256) void decimation_kernel(const int64_t* __restrict__ ptr,

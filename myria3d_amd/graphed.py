@@ -184,6 +184,8 @@ class GraphedStep:
         keep = [t for t in (net.flat_parameters, net.flat_grads) if t is not None] if net.flat_parameters is not None \
             else [p.data for p in net.parameters()]
         keep += [b for b in net.buffers()]
+        if getattr(net, "_nbt_flat", None) is not None:
+            keep.append(net._nbt_flat)  # (its last slot, the dropout step counter, is no registered buffer)
         if self.opt is not None:
             keep += [self.opt.exp_avg, self.opt.exp_avg_sq, self.opt.step_count]
         return keep

@@ -545,8 +545,19 @@ def stat_slots(N: int, device, M: int = 1 << 30) -> Tensor:
     return arena.zeros((bn_slots(M), 2, N), torch.float64, device)
 
 
+def _drop_ref(drop):
+    """``drop = (p, counter, seed)`` or None -> a by-reference ``M3DDropout`` argument (None: a null pointer)."""
+    if drop is None:
+        return None
+    import ctypes
+    from ._lib import M3DDropout
+
+    p, counter, seed = drop
+    return ctypes.byref(M3DDropout(counter.data_ptr(), int(seed), float(p)))
+
+
 def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tensor, act: bool, stats2=None, bn2=None,
-                   z2=None):
+                   z2=None, drop=None):
     """``bn_finalize`` + ``bn_apply`` in one launch (``m3d_bn_stats_apply``) from slot-mode statistics.  Returns
     ``(y, (scale, shift, mean, invstd)[, (scale2, shift2, mean2, invstd2)])``."""
     if count < 2:
@@ -563,7 +574,7 @@ def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tenso
          _p(_chk(z)), _p(stats2), _p(bn2.weight if bn2 is not None else None),
          _p(bn2.bias if bn2 is not None else None), _p(bn2.running_mean if bn2 is not None else None),
          _p(bn2.running_var if bn2 is not None else None), _p(p2[0]), _p(p2[1]), _p(p2[2]), _p(p2[3]), _p(z2), int(act),
-         LRELU_SLOPE, _p(y), z.shape[0], z.shape[1], _st())
+         LRELU_SLOPE, _p(y), z.shape[0], z.shape[1], _drop_ref(drop), _st())
     for b in (bn, bn2):
         if b is not None and not getattr(b, "_m3d_flat_counter", False):  # flattened nets bump all counters at once
             b.num_batches_tracked += 1
@@ -579,7 +590,7 @@ def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Te
 
 
 def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=None, mean2=None, invstd2=None,
-           sinks=None):
+           sinks=None, drop=None):
     """``sinks = (dgamma, dbeta[, dgamma2, dbeta2])``: gradient sinks that are added to (None is returned for them).
     Power-of-two widths take the slot mode of ``m3d_bn_bwd`` (two launches, pre-zeroed sums from the zero arena)."""
     M, N = z.shape
@@ -603,7 +614,7 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
         dz2 = torch.empty_like(z2)
     call("m3d_bn_bwd", _p(_chk(dy)), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), _p(z2), _p(scale2),
          _p(shift2), _p(mean2), _p(invstd2), int(act), LRELU_SLOPE, M, N, _p(sums), _p(dz), _p(dz2), _p(dgamma),
-         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None) | (slots << 8), _st())
+         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None) | (slots << 8), _drop_ref(drop), _st())
     if sinks is not None:
         return dz, None, None, dz2, None, None
     return dz, dgamma, dbeta, dz2, dgamma2, dbeta2
@@ -614,7 +625,8 @@ def bn_dgrad_ok(N: int) -> bool:
     return _pow2(N) and N <= 1024
 
 
-def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, split: int = 0, acc: Optional[Tensor] = None):
+def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, split: int = 0, acc: Optional[Tensor] = None,
+             drop=None):
     """BatchNorm backward + input gradient of the Linear in front of it in TWO launches: the column sums
     (``m3d_bn_bwd`` pass 1, slot mode), then ``m3d_bn_dgrad_f32``, whose A fragments are dz computed on the fly.
     Returns ``(dx, dz, dgamma, dbeta)`` (the last two None with sinks).  ``split = k0 > 0``: ``dx`` is the pair
@@ -626,7 +638,7 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, 
     ns = bn_bwd_slots(M)
     sums = arena.zeros((ns, 3, N), torch.float64, dev)
     call("m3d_bn_bwd", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), None, None, None, None, None,
-         int(act), LRELU_SLOPE, M, N, _p(sums), None, None, None, None, None, None, 2 | (ns << 8), _st())
+         int(act), LRELU_SLOPE, M, N, _p(sums), None, None, None, None, None, None, 2 | (ns << 8), _drop_ref(drop), _st())
     if sinks is not None:
         dgamma, dbeta = sinks
     else:
@@ -638,13 +650,14 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, 
               torch.empty((M, Kin - split), dtype=torch.float32, device=dev))
         call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
              _p(sums), ns, M, N, _p(w), w.stride(0), Kin, _p(dx[0]), split, _p(dz), _p(dgamma), _p(dbeta),
-             int(sinks is not None) | (256 if bf16 else 0), split, _p(dx[1]), Kin - split, _st())
+             int(sinks is not None) | (256 if bf16 else 0), split, _p(dx[1]), Kin - split, _drop_ref(drop), _st())
     else:
         dx = acc if acc is not None else torch.empty((M, Kin), dtype=torch.float32, device=dev)
         assert dx.shape == (M, Kin) and dx.is_contiguous()
         call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
              _p(sums), ns, M, N, _p(w), w.stride(0), Kin, _p(dx), Kin, _p(dz), _p(dgamma), _p(dbeta),
-             int(sinks is not None) | (256 if bf16 else 0) | (512 if acc is not None else 0), 0, None, 0, _st())
+             int(sinks is not None) | (256 if bf16 else 0) | (512 if acc is not None else 0), 0, None, 0, _drop_ref(drop),
+             _st())
     if sinks is not None:
         return dx, dz, None, None
     return dx, dz, dgamma, dbeta
@@ -681,11 +694,15 @@ class LinearFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False, x0_slot=None, x1_slot=None):
+    def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False, x0_slot=None, x1_slot=None,
+                drop=None):
         # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None;  bf16: matrix-core precision of the K > 64 GEMMs
         # x0_slot: GradSlot of x0, this layer being its LAST consumer in backward order (adds its input gradient to what
         # the others deposited and returns the sum); x1_slot: GradSlot of x1, this layer being the FIRST (deposits)
+        # drop = (p, counter, seed): the layer's output goes through Dropout(p) (mlp_classif, pyg_randla_net.py:49-52) inside the
+        # BatchNorm kernels — masked on the way out here, the incoming gradient masked on load in the backward pass
         ctx.slots = (x0_slot, x1_slot)
+        ctx.drop = drop
         ctx.sinks = sinks
         ctx.bf16 = bool(bf16)
         ctx.side = _grad_side if sinks is not None else None
@@ -696,8 +713,10 @@ class SharedLayerTrainFn(torch.autograd.Function):
         if _pow2(N):  # slot-mode statistics: GEMM + ONE fused finalize/apply launch
             stats = stat_slots(N, w.device, M)
             z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, stat_slots=True, bf16=bf16)
-            y, (scale, shift, mean, invstd) = bn_stats_apply(stats, M, bn, z, act)
+            y, (scale, shift, mean, invstd) = bn_stats_apply(stats, M, bn, z, act, drop=drop)
         else:
+            if drop is not None:
+                raise ValueError("fused dropout needs a power-of-two layer width")
             stats = stat_buffer(M, N, k0 + k1, w.device)
             z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, bf16=bf16)
             scale, shift, mean, invstd = bn_finalize(stats, M, bn)
@@ -725,7 +744,8 @@ class SharedLayerTrainFn(torch.autograd.Function):
         if fused and k1 and k0 % 4 == 0 and k1 % 4 == 0:
             # concatenated input: the two column blocks of the input gradient leave the GEMM as two contiguous matrices
             (s0, s1), dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
-                                                   sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16, split=k0)
+                                                   sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16, split=k0,
+                                                   drop=ctx.drop)
             if ctx.needs_input_grad[0]:
                 dx0 = scatter_add_rows(s0, rows, x0.shape[0]) if rows is not None else s0
             if ctx.needs_input_grad[1]:
@@ -735,12 +755,12 @@ class SharedLayerTrainFn(torch.autograd.Function):
             direct = acc0 is not None and k1 == 0 and rows is None and acc0.shape == (z.shape[0], k0)
             dxc, dz, dgamma, dbeta = bn_dgrad(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act, w,
                                               sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16,
-                                              acc=acc0 if direct else None)
+                                              acc=acc0 if direct else None, drop=ctx.drop)
             if direct:
                 acc0 = None  # already inside dxc
         else:
             dz, dgamma, dbeta, _, _, _ = bn_bwd(dy.contiguous(), z, scale, shift, mean, invstd, ctx.act,
-                                                sinks=(sk[2], sk[3]) if sk else None)
+                                                sinks=(sk[2], sk[3]) if sk else None, drop=ctx.drop)
         if want_dx:
             if dxc is None:
                 dxc = linear_dgrad(dz, w, ctx.bf16)
@@ -759,7 +779,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
             dx1 = None
         dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
@@ -1253,7 +1273,7 @@ class CrossEntropyFn(torch.autograd.Function):
         dev = logits.device
         lse = torch.empty(n, dtype=torch.float32, device=dev)
         pre_zeroed = arena.active and arena.buf is not None
-        acc = arena.zeros((4,), torch.float64, dev) if pre_zeroed else torch.empty(4, dtype=torch.float64, device=dev)
+        acc = arena.zeros((516,), torch.float64, dev) if pre_zeroed else torch.empty(516, dtype=torch.float64, device=dev)  # M3D_CE_ACC_DOUBLES
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         call("m3d_ce_loss_fwd", _p(logits), logits.stride(0), _p(target), n, C, ignore_index, _p(lse), _p(acc), _p(loss),
              1 if pre_zeroed else 0, _st())
@@ -1270,6 +1290,28 @@ class CrossEntropyFn(torch.autograd.Function):
         call("m3d_ce_loss_bwd", _p(logits), logits.stride(0), _p(target), n, C, ctx.ignore_index, _p(lse), _p(acc),
              _p(gout), _p(d), _st())
         return d, None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    """``torch.nn.functional.dropout(x, p, training=True)`` with a counter-based mask (``m3d_dropout``): ``counter`` is a
+    device int64 the net advances once per training forward, so a replayed hipGraph draws a fresh mask every step and the
+    backward pass recomputes the forward's mask instead of reading a stored one."""
+
+    @staticmethod
+    def forward(ctx, x, p, counter, seed):
+        x = _chk(x.contiguous())
+        y = torch.empty_like(x)
+        call("m3d_dropout", _p(x), _p(y), x.numel(), float(p), _p(counter), int(seed), _st())
+        ctx.args = (float(p), counter, int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, counter, seed = ctx.args
+        dy = _chk(dy.contiguous())
+        dx = torch.empty_like(dy)
+        call("m3d_dropout", _p(dy), _p(dx), dy.numel(), p, _p(counter), seed, _st())
+        return dx, None, None, None
 
 
 def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = -100) -> Tensor:

@@ -169,6 +169,15 @@ class HipRandLANet(nn.Module):
             self._decim_seed.fill_(seed)
         self._decim_seeded = True
 
+    def _dropout_seed(self) -> int:
+        s = getattr(self, "_drop_seed", None)
+        if s is None:
+            import torch.distributed as dist
+
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            s = self._drop_seed = ((torch.initial_seed() & 0xFFFFFFFFFFFF) * 1024 + rank) * 0x9E3779B97F4A7C15 % (1 << 64)
+        return s
+
     def _seed_decimation(self) -> None:
         if self._decim_seeded:
             return
@@ -204,7 +213,9 @@ class HipRandLANet(nn.Module):
                 off += sz
         # BatchNorm step counters: views of one int64 vector, bumped by a single add per training forward
         bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm1d)]
-        self._nbt_flat = torch.stack([m.num_batches_tracked.to(dev) for m in bns]).contiguous()
+        # (one extra slot at the end: the step counter of the classifier's dropout mask, ops.DropoutFn)
+        self._nbt_flat = torch.stack([m.num_batches_tracked.to(dev) for m in bns]
+                                     + [torch.zeros((), dtype=torch.int64, device=dev)]).contiguous()
         for i, m in enumerate(bns):
             m.num_batches_tracked = self._nbt_flat[i]  # registered buffer: same state_dict key, now a view
             m._m3d_flat_counter = True
@@ -332,12 +343,12 @@ class HipRandLANet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
-                      rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None) -> Tensor:
+                      rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None, drop=None) -> Tensor:
         lin, bn = mlp.lins[li], mlp.norms[li].module
         if train:
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
-                                                sk, self._bf16, x0_slot, x1_slot)
+                                                sk, self._bf16, x0_slot, x1_slot, drop)
         if self._grad_eval:
             return ops.SharedLayerEvalFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
@@ -751,12 +762,22 @@ class HipRandLANet(nn.Module):
             if record is not None:
                 record[f"fp{lvl + 1}"] = h[index[lvl].inv.long()]
         h = self._shared_layer(self.mlp_classif, 0, h, train=train)
-        h = self._shared_layer(self.mlp_classif, 1, h, train=train)
         p = self.mlp_classif.dropout[1]
-        if train and p > 0.0:
+        # Dropout(p) behind the layer (pyg_randla_net.py:49-52).  Flattened nets: a counter-based mask on the device step counter
+        # the step prologue advances (seeded like the decimation: torch's global seed and the rank), applied INSIDE the
+        # layer's BatchNorm kernels, forward and backward (no launches of its own)
+        fused_drop = (train and p > 0.0 and dropout_mask is None and self._flat is not None and torch.is_grad_enabled()
+                      and ops._pow2(self.mlp_classif.lins[1].weight.shape[0]))
+        h = self._shared_layer(self.mlp_classif, 1, h, train=train,
+                               drop=(p, self._nbt_flat[-1:], self._dropout_seed()) if fused_drop else None)
+        if train and p > 0.0 and not fused_drop:
             if dropout_mask is not None:  # given in the caller's row order
                 mask = ops.gather_rows(dropout_mask.to(h.dtype).contiguous(), index[0].perm)
                 h = h * (mask / (1.0 - p))
+            elif self._flat is not None and h.numel() % 4 == 0:
+                # counter-based mask on the device step counter the step prologue advances (seeded like the decimation:
+                # torch's global seed and the rank)
+                h = ops.DropoutFn.apply(h, p, self._nbt_flat[-1:], self._dropout_seed())
             else:
                 h = F.dropout(h, p=p, training=True)
         if diff:

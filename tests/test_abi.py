@@ -12,7 +12,7 @@ HEADER = os.path.join(ROOT, "include", "m3d_hip.h")
 
 _CTYPE = {
     "int": ctypes.c_int32, "int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "int64_t": ctypes.c_int64,
-    "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+    "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64,
 }
 
 

@@ -232,6 +232,69 @@ def test_gemm_forward(device, M, K, N):
 
 
 
+def test_dropout_counter_based_mask(device):
+    """``m3d_dropout`` (mlp_classif's Dropout(0.5), pyg_randla_net.py:49-52): kept elements are scaled by 1 / (1 - p), the kept
+    fraction is 1 - p, the mask is a function of (seed, device step counter, element) — the same call on dy reproduces the
+    forward's mask (the backward pass stores nothing), a bumped counter or another seed draws a new one."""
+    from myria3d_amd import ops
+
+    n, c = 204800, 32
+    x = torch.rand(n, c, device=device) + 0.5
+    counter = torch.zeros(1, dtype=torch.int64, device=device)
+    for p in (0.5, 0.1):
+        xr = x.clone().requires_grad_(True)
+        y = ops.DropoutFn.apply(xr, p, counter, 1234)
+        keep = y != 0
+        frac = keep.float().mean().item()
+        assert abs(frac - (1 - p)) < 2e-3, frac
+        assert torch.allclose(y[keep], (x / (1 - p))[keep], rtol=1e-5)
+        assert abs(keep.float().mean(0) - (1 - p)).max().item() < 0.01  # no column is favoured
+        g = torch.rand_like(x) + 0.5
+        y.backward(g)
+        assert torch.equal(xr.grad != 0, keep) and torch.allclose(xr.grad[keep], (g / (1 - p))[keep], rtol=1e-5)
+        y2 = ops.DropoutFn.apply(x, p, counter, 1234)
+        assert torch.equal(y2, y.detach())
+        other = ops.DropoutFn.apply(x, p, counter + 1, 1234) != 0
+        agree = (other == keep).float().mean().item()
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 5e-3, agree  # independent masks
+        other = ops.DropoutFn.apply(x, p, counter, 99) != 0
+        assert abs((other == keep).float().mean().item() - ((1 - p) ** 2 + p ** 2)) < 5e-3
+
+
+@pytest.mark.parametrize("M,K,N,k1", [(20000, 64, 32, 0), (4000, 256, 64, 0), (6000, 32, 32, 32)])
+def test_shared_layer_with_fused_dropout_equals_layer_then_dropout(device, M, K, N, k1):
+    """Dropout fused into a SharedMLP layer's BatchNorm kernels (``SharedLayerTrainFn(..., drop=...)``: mask applied by
+    ``m3d_bn_stats_apply`` on the way out, to the incoming gradient by the column-sum pass and the dz-on-load prologue) gives what the
+    layer followed by ``DropoutFn`` gives: output, input gradients and every parameter gradient."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M + K)
+    t = lambda *shape: torch.from_numpy(rs.uniform(-1, 1, shape).astype(np.float32)).to(device)
+    counter = torch.full((1,), 7, dtype=torch.int64, device=device)
+    outs = []
+    for fused in (False, True):
+        x0 = t(M, K).requires_grad_(True)
+        x1 = t(M, k1).requires_grad_(True) if k1 else None
+        w = t(N, K + k1).requires_grad_(True)
+        b, gamma, beta = t(N).requires_grad_(True), (t(N) + 2).requires_grad_(True), t(N).requires_grad_(True)
+        bn = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+        drop = (0.5, counter, 4242)
+        y = ops.SharedLayerTrainFn.apply(x0, x1, w, b, gamma, beta, bn, True, None, None, False, None, None,
+                                         drop if fused else None)
+        if not fused:
+            y = ops.DropoutFn.apply(y, *drop)
+        g = t(M, N)
+        y.backward(g)
+        outs.append([y.detach(), x0.grad, x1.grad if k1 else None, w.grad, gamma.grad, beta.grad])
+        rs = np.random.RandomState(M + K)  # same draws for the second arm
+    for a_, b_, name in zip(outs[0], outs[1], ("y", "dx0", "dx1", "dw", "dgamma", "dbeta")):
+        if a_ is None:
+            continue
+        assert torch.allclose(a_, b_, rtol=2e-5, atol=2e-6 * max(1.0, a_.abs().max().item())), \
+            (name, (a_ - b_).abs().max().item())
+    assert (outs[1][0] == 0).float().mean().item() > 0.4  # the mask was applied
+
+
 @pytest.mark.parametrize("M,K0,K1,N", [(3200, 256, 256, 512), (12800, 128, 128, 256), (801, 128, 256, 128), (3200, 512, 96, 64),
                                        (5000, 64, 32, 128), (300, 256, 256, 20)])
 def test_gemm_pair_equals_two_launches(device, M, K0, K1, N):

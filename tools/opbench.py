@@ -70,12 +70,12 @@ if "bnbwd" in what:
         def red():
             ops.call("m3d_bn_bwd", dy.data_ptr(), z.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), None, None,
                      None, None, None, 1, 0.2, M, N, sums.data_ptr(), None, None, None, None, None, None, 2 | (ns << 8),
-                     torch.cuda.current_stream().cuda_stream)
+                     None, torch.cuda.current_stream().cuda_stream)
         dx = torch.empty(M, K, device=dev); dz = torch.empty(M, N, device=dev); dg = torch.empty(N, device=dev); db = torch.empty(N, device=dev)
         def fused():
             ops.call("m3d_bn_dgrad_f32", dy.data_ptr(), z.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 1, 0.2,
                      sums.data_ptr(), ns, M, N, w.data_ptr(), w.stride(0), K, dx.data_ptr(), K, dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                     0, 0, None, 0, torch.cuda.current_stream().cuda_stream)
+                     0, 0, None, 0, None, torch.cuda.current_stream().cuda_stream)
         t1, t2, t3 = timeit(red), timeit(fused), timeit(lambda: ops.linear_dgrad(dz, w))
         byt_r = 8 * M * N; byt_f = 4 * M * (3 * N + K)
         print(f"{name:9s} M={M:6d} N={N:4d} Kin={K:4d}  reduce {t1:6.1f}us ({byt_r/t1/1e3:5.0f} GB/s)  fused dz+dgrad {t2:6.1f}us "
