@@ -190,6 +190,17 @@ int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = i
                     int32_t C, void* stream);
 int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64_t ldo, int64_t m, int32_t C,
                          void* stream);
+
+/* CSR inverse of many-to-one row maps idx_j[n_j] -> [0, m_j) (the 1-NN tables of knn_interpolate(k = 1),
+ * pyg_randla_net.py:250): rows f with idx_j[f] == c are inv_j[ptr_j[c] .. ptr_j[c + 1]) (in no particular order; negative
+ * or out-of-range entries are left out).  njobs <= 8 maps in three launches; the job arrays are HOST arrays.  cnt_j: int32
+ * [m_j] workspace that must be ZERO on entry and is zero again afterwards; ptr_j: [m_j + 1]; inv_j: [n_j]. */
+int m3d_csr_invert_batch(int32_t njobs, const int32_t* const* idx, const int64_t* n, const int64_t* m,
+                         int32_t* const* cnt, int32_t* const* ptr, int32_t* const* inv, void* stream);
+/* out[c][0..C) (+)= sum over f in inv[ptr[c] .. ptr[c + 1]) of src[f][0..C): the transpose of m3d_gather_rows(idx) through
+ * the CSR inverse of idx — no atomics, no zero fill (accumulate != 0: added to what out holds).  C % 4 == 0. */
+int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const int32_t* inv, float* out, int64_t ldo,
+                        int64_t m, int32_t C, int32_t accumulate, void* stream);
 int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64_t n, void* stream);
 /* decimation_indices(): slot r of cloud b <- ptr[b] + P_b(r), P_b a keyed pseudo-random permutation of
  * [0, n_b); ptr_out is the decimated ptr (computed by the caller: max(1, n_b // factor) per cloud);

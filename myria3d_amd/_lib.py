@@ -45,6 +45,8 @@ SIGNATURES = {
                                 _p, _i32, _i32, _p, _i64, _p, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
     "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
+    "m3d_csr_invert_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p]),
+    "m3d_gather_sum_rows": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),
     "m3d_decimation_indices": (_i32, [_p, _p, _i32, _p, _u32, _p, _i64, _p]),
     "m3d_decimate_level": (_i32, [_p, _p, _i32, _p, _u32, _p, _p, _p, _p, _p, _p, _i64, _p]),

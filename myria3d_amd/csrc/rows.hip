@@ -81,6 +81,154 @@ extern "C" int m3d_scatter_add_rows(const float* src, const int32_t* idx, float*
   return M3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// The transpose of a many-to-one row gather WITHOUT atomics.  knn_interpolate(k = 1) (pyg_randla_net.py:250) reads
+// x_coarse[nn[f]] for every fine point f; its backward pass adds the fine rows back into their coarse row: ~4 fine rows per
+// coarse row, 6.5 M fp32 atomics for the [204 800, 32] gradient of level 1 (32 us; 81 us over the four FP modules).  The
+// map is position-only: its inverse (CSR lists, built on the geometry stream with the 1-NN tables) turns the scatter into
+// a gather-and-sum at streaming speed.
+// ------------------------------------------------------------------------------------------
+#define CSR_BATCH_MAX 8
+struct CsrBatch {
+  const int32_t* idx[CSR_BATCH_MAX]; int32_t* cnt[CSR_BATCH_MAX]; int32_t* ptr[CSR_BATCH_MAX]; int32_t* inv[CSR_BATCH_MAX];
+  int64_t n[CSR_BATCH_MAX], m[CSR_BATCH_MAX], start[CSR_BATCH_MAX + 1];  // start: first flat fine-row number of job j
+  int njobs;
+};
+__device__ __forceinline__ int csr_job(const CsrBatch& b, int64_t t) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < CSR_BATCH_MAX; ++i) j += (i < b.njobs && t >= b.start[i]) ? 1 : 0;
+  return j;
+}
+// pass 1: cnt[c] = number of fine rows mapped to c
+__global__ __launch_bounds__(256) void csr_count_kernel(CsrBatch b) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= b.start[b.njobs]) return;
+  const int j = csr_job(b, t);
+  const int32_t c = b.idx[j][t - b.start[j]];
+  if (c >= 0 && c < b.m[j]) atomicAdd(&b.cnt[j][c], 1);
+}
+// pass 2 (one workgroup per job): ptr = exclusive prefix sums of cnt, ptr[m] = total
+__global__ __launch_bounds__(1024) void csr_scan_kernel(CsrBatch b) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t m = b.m[j];
+  const int32_t* cnt = b.cnt[j];
+  int32_t* ptr = b.ptr[j];
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < m; base += 4096) {  // four consecutive targets per thread and trip
+    const int64_t c0 = base + 4 * (int64_t)tid;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = c0 + i < m ? cnt[c0 + i] : 0;
+    const int tot = (v[0] + v[1]) + (v[2] + v[3]);
+    int x = tot;  // inclusive scan of the thread totals inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    int run = off + x - tot;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (c0 + i < m) ptr[c0 + i] = run;
+      run += v[i];
+    }
+    __syncthreads();
+    if (tid == 1023) carry = off + x;
+    __syncthreads();
+  }
+  if (tid == 0) ptr[m] = carry;
+}
+// pass 3: inv[ptr[c] + k] = f for the k-th fine row of c (k counts cnt[c] down: cnt is zero again afterwards)
+__global__ __launch_bounds__(256) void csr_fill_kernel(CsrBatch b) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= b.start[b.njobs]) return;
+  const int j = csr_job(b, t);
+  const int64_t f = t - b.start[j];
+  const int32_t c = b.idx[j][f];
+  if (c >= 0 && c < b.m[j]) {
+    const int k = atomicSub(&b.cnt[j][c], 1) - 1;
+    b.inv[j][b.ptr[j][c] + k] = (int32_t)f;
+  }
+}
+
+extern "C" int m3d_csr_invert_batch(int32_t njobs, const int32_t* const* idx, const int64_t* n, const int64_t* m,
+                                    int32_t* const* cnt, int32_t* const* ptr, int32_t* const* inv, void* stream) {
+  if (njobs < 0 || njobs > CSR_BATCH_MAX) return M3D_ERR_INVALID;
+  if (njobs == 0) return M3D_OK;
+  if (!idx || !n || !m || !cnt || !ptr || !inv) return M3D_ERR_INVALID;
+  CsrBatch b;
+  b.njobs = njobs;
+  int64_t tot = 0;
+  for (int j = 0; j < CSR_BATCH_MAX; ++j) {
+    b.start[j] = tot;
+    if (j >= njobs) { b.idx[j] = nullptr; b.cnt[j] = b.ptr[j] = b.inv[j] = nullptr; b.n[j] = b.m[j] = 0; continue; }
+    if (n[j] < 0 || m[j] < 0 || n[j] > 0x7fffffff || m[j] >= 0x7fffffff || !ptr[j]) return M3D_ERR_INVALID;
+    if ((n[j] > 0 && (!idx[j] || !inv[j])) || (m[j] > 0 && !cnt[j])) return M3D_ERR_INVALID;
+    b.idx[j] = idx[j]; b.cnt[j] = cnt[j]; b.ptr[j] = ptr[j]; b.inv[j] = inv[j]; b.n[j] = n[j]; b.m[j] = m[j];
+    tot += n[j];
+  }
+  b.start[CSR_BATCH_MAX] = tot;
+  for (int j = njobs; j <= CSR_BATCH_MAX; ++j) b.start[j] = tot;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned gx = (unsigned)m3d_cdiv(tot > 0 ? tot : 1, 256);
+  if (tot > 0) hipLaunchKernelGGL(csr_count_kernel, dim3(gx), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3((unsigned)njobs), dim3(1024), 0, st, b);
+  if (tot > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3(gx), dim3(256), 0, st, b);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// out[c][:] (+)= sum of src[f][:] over f in inv[ptr[c] .. ptr[c + 1])   (C % 4 == 0, 16-byte aligned rows)
+__global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                              const int32_t* __restrict__ ptr,
+                                                              const int32_t* __restrict__ inv, float* __restrict__ out,
+                                                              int64_t ldo, int64_t m, int C4, int accumulate) {
+  const int64_t total = m * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t c = i / C4;
+    const int q = (int)(i % C4);
+    const int p0 = ptr[c], p1 = ptr[c + 1];
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int p = p0;
+    for (; p + 1 < p1; p += 2) {
+      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
+      const float4 b = *(const float4*)(src + (int64_t)inv[p + 1] * lds + 4 * q);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (p < p1) {
+      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    float4* d = (float4*)(out + c * ldo + 4 * q);
+    float4 o = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    if (accumulate) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+    *d = o;
+  }
+}
+
+extern "C" int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const int32_t* inv, float* out,
+                                   int64_t ldo, int64_t m, int32_t C, int32_t accumulate, void* stream) {
+  if (m < 0 || C < 0) return M3D_ERR_INVALID;
+  if (m == 0 || C == 0) return M3D_OK;
+  if (!src || !ptr || !inv || !out) return M3D_ERR_INVALID;
+  if ((C & 3) || (lds & 3) || (ldo & 3) || ((((uintptr_t)src) | ((uintptr_t)out)) & 15)) return M3D_ERR_UNSUPPORTED;
+  int64_t gx = m3d_cdiv(m * (int64_t)(C / 4), 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(gather_sum_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
+                     out, ldo, m, C / 4, accumulate);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
 // [n,3] (row stride `stride` floats) -> [n,4] with w = 0: 16-byte rows for single-load neighbour gathers
 __global__ __launch_bounds__(256) void pad_pos_kernel(const float* __restrict__ pos, int stride, float4* __restrict__ out,
                                                       int64_t n) {

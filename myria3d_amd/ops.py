@@ -447,6 +447,39 @@ def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int, out: Optional[Tensor]
     return out
 
 
+def csr_invert_batch(idxs, ms):
+    """CSR inverses of the many-to-one int32 row maps ``idxs[j]: [n_j] -> [0, ms[j])`` (``m3d_csr_invert_batch``, at most 8 per
+    call): a list of ``(ptr [m_j + 1], inv [n_j])`` int32 pairs for ``gather_sum_rows``."""
+    import ctypes
+
+    k = len(idxs)
+    assert 0 < k <= 8 and k == len(ms)
+    dev = idxs[0].device
+    idxs = [_chk(t.reshape(-1), torch.int32) for t in idxs]
+    cnt = torch.zeros(sum(int(m) for m in ms) + 1, dtype=torch.int32, device=dev)  # (zero again when the call has run)
+    cnts, off = [], 0
+    for m in ms:
+        cnts.append(cnt[off:off + int(m)])
+        off += int(m)
+    ptrs = [torch.empty(int(m) + 1, dtype=torch.int32, device=dev) for m in ms]
+    invs = [torch.empty(t.numel(), dtype=torch.int32, device=dev) for t in idxs]
+    vp = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+    call("m3d_csr_invert_batch", k, vp(idxs), (ctypes.c_int64 * k)(*[t.numel() for t in idxs]),
+         (ctypes.c_int64 * k)(*[int(m) for m in ms]), vp(cnts), vp(ptrs), vp(invs), _st())
+    return list(zip(ptrs, invs))
+
+
+def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Tensor, n_out: int, out: Optional[Tensor] = None) -> Tensor:
+    """``out[c] (+)= sum of src[f] over the rows f the CSR inverse ``(ptr, inv)`` lists for c``: what
+    ``scatter_add_rows(src, idx, n_out)`` computes, without atomics and without a zero fill."""
+    acc = out is not None
+    if out is None:
+        out = torch.empty((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
+    call("m3d_gather_sum_rows", _p(_chk(src)), src.stride(0), _p(ptr), _p(inv), _p(out), out.stride(0), n_out, src.shape[1],
+         int(acc), _st())
+    return out
+
+
 def pad_pos(pos: Tensor) -> Tensor:
     out = torch.empty((pos.shape[0], 4), dtype=torch.float32, device=pos.device)
     call("m3d_pad_pos", _p(pos), pos.stride(0), _p(out), pos.shape[0], _st())
@@ -695,13 +728,16 @@ class LinearFn(torch.autograd.Function):
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False, x0_slot=None, x1_slot=None,
-                drop=None):
+                drop=None, rows_inv=None):
         # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None;  bf16: matrix-core precision of the K > 64 GEMMs
         # x0_slot: GradSlot of x0, this layer being its LAST consumer in backward order (adds its input gradient to what
         # the others deposited and returns the sum); x1_slot: GradSlot of x1, this layer being the FIRST (deposits)
         # drop = (p, counter, seed): the layer's output goes through Dropout(p) (mlp_classif, pyg_randla_net.py:49-52) inside the
         # BatchNorm kernels — masked on the way out here, the incoming gradient masked on load in the backward pass
+        # rows_inv = (ptr, inv): CSR inverse of ``rows`` (csr_invert_batch) — the backward pass then sums the gathered rows'
+        # gradients per source row instead of scattering them with atomics
         ctx.slots = (x0_slot, x1_slot)
+        ctx.rows_inv = rows_inv if (rows is not None and x0.shape[1] % 4 == 0) else None
         ctx.drop = drop
         ctx.sinks = sinks
         ctx.bf16 = bool(bf16)
@@ -747,7 +783,10 @@ class SharedLayerTrainFn(torch.autograd.Function):
                                                    sinks=(sk[2], sk[3]) if sk else None, bf16=ctx.bf16, split=k0,
                                                    drop=ctx.drop)
             if ctx.needs_input_grad[0]:
-                dx0 = scatter_add_rows(s0, rows, x0.shape[0]) if rows is not None else s0
+                if rows is not None and ctx.rows_inv is not None:
+                    dx0 = gather_sum_rows(s0, ctx.rows_inv[0], ctx.rows_inv[1], x0.shape[0])
+                else:
+                    dx0 = scatter_add_rows(s0, rows, x0.shape[0]) if rows is not None else s0
             if ctx.needs_input_grad[1]:
                 dx1 = s1
             want_dx = False
@@ -766,7 +805,9 @@ class SharedLayerTrainFn(torch.autograd.Function):
                 dxc = linear_dgrad(dz, w, ctx.bf16)
             if ctx.needs_input_grad[0]:
                 dx0 = dxc[:, :k0]
-                if rows is not None:
+                if rows is not None and ctx.rows_inv is not None:
+                    dx0 = gather_sum_rows(dx0.contiguous(), ctx.rows_inv[0], ctx.rows_inv[1], x0.shape[0])
+                elif rows is not None:
                     dx0 = scatter_add_rows(dx0.contiguous(), rows, x0.shape[0])
                 elif k1:
                     dx0 = dx0.contiguous()
@@ -779,7 +820,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
             dx1 = None
         dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)

@@ -343,12 +343,13 @@ class HipRandLANet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
-                      rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None, drop=None) -> Tensor:
+                      rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None, drop=None,
+                      rows_inv=None) -> Tensor:
         lin, bn = mlp.lins[li], mlp.norms[li].module
         if train:
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
-                                                sk, self._bf16, x0_slot, x1_slot, drop)
+                                                sk, self._bf16, x0_slot, x1_slot, drop, rows_inv)
         if self._grad_eval:
             return ops.SharedLayerEvalFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
@@ -526,6 +527,12 @@ class HipRandLANet(nn.Module):
                 for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
                     g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True)[0])
             g.mark(9)
+            # CSR inverses of the four 1-NN tables (train): the backward pass of the decoder's x[nn] gathers sums rows per
+            # coarse point instead of scattering them with atomics (ops.gather_sum_rows).  A stage of its own: the forward
+            # pass needs the tables (stage 9) a millisecond before the backward pass needs the inverses
+            g.nn_inv.extend(ops.csr_invert_batch([t.view(-1) for t in g.nn], [plan.totals[l + 1] for l in range(4)])
+                            if train else [None] * 4)
+            g.mark(10)
         yield
 
     # ------------------------------------------------------------------------------------------
@@ -758,10 +765,13 @@ class HipRandLANet(nn.Module):
             # knn_interpolate(k=1) == x[nn] (weights cancel); fused as a row gather into the GEMM's A operand
             # (the skip tensor's other consumers run later in the backward pass: this layer deposits its gradient)
             h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train,
-                                   x1_slot=out_slot if lvl == 0 else in_slots[lvl])
+                                   x1_slot=out_slot if lvl == 0 else in_slots[lvl],
+                                   rows_inv=geo.nn_inv[lvl] if (train and geo.nn_inv) else None)
             if record is not None:
                 record[f"fp{lvl + 1}"] = h[index[lvl].inv.long()]
         h = self._shared_layer(self.mlp_classif, 0, h, train=train)
+        if train and 10 in geo.events:
+            geo.wait(10)  # the CSR inverses the decoder's backward pass reads
         p = self.mlp_classif.dropout[1]
         # Dropout(p) behind the layer (pyg_randla_net.py:49-52).  Flattened nets: a counter-based mask on the device step counter
         # the step prologue advances (seeded like the decimation: torch's global seed and the rank), applied INSIDE the
@@ -806,6 +816,7 @@ class _Geometry:
         self.src: List[Tensor] = []
         self.dec_ref: List[Tensor] = []
         self.nn: List[Tensor] = []
+        self.nn_inv: List[Optional[tuple]] = []  # train: CSR inverse (ptr, inv) of every 1-NN table
         self.events: Dict[int, object] = {}
         self._last_event = None
 
@@ -826,7 +837,7 @@ class _Geometry:
         """Every device buffer of this geometry, in a fixed order (``pos4`` / ``perm`` / ``inv`` are views of the
         index workspaces and come along with them)."""
         return [ix.ws for ix in self.index] + self.knn + [m for m in self.mom if m is not None] + self.src + \
-            self.dec_ref + self.nn
+            self.dec_ref + self.nn + [t for pair in self.nn_inv if pair is not None for t in pair]
 
     def rebound(self, buffers: List[Tensor], main) -> "_Geometry":
         """A geometry with the same structure whose buffers are ``buffers`` (same order as ``tensors()``); complete
@@ -843,6 +854,7 @@ class _Geometry:
         g.src = [next(it) for _ in self.src]
         g.dec_ref = [next(it) for _ in self.dec_ref]
         g.nn = [next(it) for _ in self.nn]
+        g.nn_inv = [(next(it), next(it)) if pair is not None else None for pair in self.nn_inv]
         return g
 
 

@@ -232,6 +232,37 @@ def test_gemm_forward(device, M, K, N):
 
 
 
+def test_csr_inverse_and_gather_sum_equal_the_atomic_scatter(device):
+    """``m3d_csr_invert_batch`` + ``m3d_gather_sum_rows`` (backward of the decoder's ``x[nn]`` gathers, pyg_randla_net.py:250):
+    the lists partition the mapped rows, and summing rows per target gives what the atomic ``m3d_scatter_add_rows`` gives —
+    targets nobody maps to get zeros (no zero fill needed), unmapped rows (negative ids) are left out, an existing
+    buffer can be added to."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(3)
+    sizes = [(204800, 51200, 32), (51200, 12800, 128), (3200, 800, 512), (1000, 7, 8), (5, 4000, 4)]
+    idxs = []
+    for n, m, _ in sizes:
+        ix = rs.randint(0, m, n).astype(np.int32)
+        ix[rs.rand(n) < 0.01] = -1
+        idxs.append(torch.from_numpy(ix).to(device))
+    pairs = ops.csr_invert_batch(idxs, [m for _, m, _ in sizes])
+    for (n, m, C), ix, (ptr, inv) in zip(sizes, idxs, pairs):
+        ptr_h, inv_h, ix_h = ptr.cpu().numpy(), inv.cpu().numpy(), ix.cpu().numpy()
+        cnt = np.bincount(ix_h[ix_h >= 0], minlength=m)
+        assert ptr_h[0] == 0 and np.array_equal(np.diff(ptr_h), cnt)
+        used = inv_h[:ptr_h[-1]]
+        assert np.array_equal(np.sort(used), np.nonzero(ix_h >= 0)[0])          # every mapped row exactly once
+        assert np.array_equal(ix_h[used], np.repeat(np.arange(m), cnt))          # ... in its target's list
+        src = torch.from_numpy(rs.uniform(-1, 1, (n, C)).astype(np.float32)).to(device)
+        ref = ops.scatter_add_rows(src, ix, m, out=torch.zeros(m, C, device=device))
+        got = ops.gather_sum_rows(src, ptr, inv, m)
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), (got - ref).abs().max().item()
+        base = torch.from_numpy(rs.uniform(-1, 1, (m, C)).astype(np.float32)).to(device)
+        got2 = ops.gather_sum_rows(src, ptr, inv, m, out=base.clone())
+        assert torch.allclose(got2, ref + base, rtol=1e-5, atol=1e-5)
+
+
 def test_dropout_counter_based_mask(device):
     """``m3d_dropout`` (mlp_classif's Dropout(0.5), pyg_randla_net.py:49-52): kept elements are scaled by 1 / (1 - p), the kept
     fraction is 1 - p, the mask is a function of (seed, device step counter, element) — the same call on dy reproduces the
