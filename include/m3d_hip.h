@@ -188,8 +188,11 @@ int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* scale, const 
 /* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
 int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,
                     int32_t C, void* stream);
+/* out[idx[i]][0..C) += src[i][0..C) (the transpose of m3d_gather_rows; negative ids are skipped).  flags bit 0: the ids are
+ * DISTINCT (the transpose of a subset selection, decimate(): pyg_randla_net.py:234-238): plain 16-byte read-modify-writes
+ * instead of float atomics (C % 4 == 0; otherwise the atomic kernel runs). */
 int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64_t ldo, int64_t m, int32_t C,
-                         void* stream);
+                         int32_t flags, void* stream);
 
 /* CSR inverse of many-to-one row maps idx_j[n_j] -> [0, m_j) (the 1-NN tables of knn_interpolate(k = 1),
  * pyg_randla_net.py:250): rows f with idx_j[f] == c are inv_j[ptr_j[c] .. ptr_j[c + 1]) (in no particular order; negative

@@ -44,7 +44,7 @@ SIGNATURES = {
     "m3d_bn_dgrad_f32": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i32, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p,
                                 _p, _i32, _i32, _p, _i64, _p, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
-    "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p]),
+    "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "m3d_csr_invert_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p]),
     "m3d_gather_sum_rows": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "m3d_pad_pos": (_i32, [_p, _i32, _p, _i64, _p]),

@@ -67,11 +67,39 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
   }
 }
 
+// the same for DISTINCT targets (the transpose of a subset selection: decimate(), pyg_randla_net.py:234-238): no two
+// rows meet, so a plain 16-byte read-modify-write does what 4 float atomics did
+__global__ __launch_bounds__(256) void scatter_add_distinct_rows_kernel(const float4* __restrict__ src,
+                                                                        const int32_t* __restrict__ idx,
+                                                                        float* __restrict__ out, int64_t ldo, int64_t m,
+                                                                        int C4) {
+  const int64_t total = m * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / C4;
+    const int q = (int)(i % C4);
+    const int64_t d = (int64_t)idx[r];
+    if (d < 0) continue;
+    float4* dst = (float4*)(out + d * ldo + 4 * q);
+    const float4 v = src[i];
+    float4 o = *dst;
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *dst = o;
+  }
+}
+
 extern "C" int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64_t ldo, int64_t m,
-                                    int32_t C, void* stream) {
+                                    int32_t C, int32_t flags, void* stream) {
   if (m < 0 || C < 0) return M3D_ERR_INVALID;
   if (m == 0 || C == 0) return M3D_OK;
   if (!src || !out || !idx) return M3D_ERR_INVALID;
+  if ((flags & 1) && !(C & 3) && !(ldo & 3) && !((((uintptr_t)src) | ((uintptr_t)out)) & 15)) {
+    int64_t g4 = m3d_cdiv(m * (int64_t)(C / 4), 256);
+    if (g4 > 8192) g4 = 8192;
+    hipLaunchKernelGGL(scatter_add_distinct_rows_kernel, dim3((unsigned)g4), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src, idx, out, ldo, m, C / 4);
+    M3D_CHECK_LAUNCH();
+    return M3D_OK;
+  }
   int64_t gx = m3d_cdiv(m * (int64_t)C, 256 * 2);
   if (gx > 8192) gx = 8192;
   if (gx < 1) gx = 1;

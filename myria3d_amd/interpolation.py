@@ -63,7 +63,7 @@ def scatter_sum(src: Tensor, index: Tensor, dim: int = 0, out: Optional[Tensor] 
             and out.shape[1] == src.shape[1]:
         # accumulate straight into the caller's buffer (the reference's `out=` use, interpolation.py:116)
         ops.call("m3d_scatter_add_rows", src.data_ptr(), idx.data_ptr(), out.data_ptr(), out.stride(0), src.shape[0],
-                 src.shape[1], torch.cuda.current_stream().cuda_stream)
+                 src.shape[1], 0, torch.cuda.current_stream().cuda_stream)
         return out
     n = dim_size if dim_size is not None else (out.shape[0] if out is not None else int(index.max().item()) + 1)
     res = ops.scatter_add_rows(src, idx, n)

@@ -439,11 +439,13 @@ class GradSlot:
         return b
 
 
-def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int, out: Optional[Tensor] = None) -> Tensor:
-    """``out[idx[i]] += src[i]`` (``out``: an existing ``[n_out, C]`` buffer to add into; default: zeros)."""
+def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int, out: Optional[Tensor] = None, distinct: bool = False) -> Tensor:
+    """``out[idx[i]] += src[i]`` (``out``: an existing ``[n_out, C]`` buffer to add into; default: zeros).  ``distinct``: the
+    caller guarantees that no id occurs twice (plain read-modify-writes instead of atomics)."""
     if out is None:
         out = arena.zeros((n_out, src.shape[1]), torch.float32, src.device)
-    call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], _st())
+    call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], int(distinct),
+         _st())
     return out
 
 
@@ -1010,23 +1012,25 @@ class GatherRowsFn(torch.autograd.Function):
     gather ``dy[inverse]`` (no atomics, no zero fill) instead of a scatter-add."""
 
     @staticmethod
-    def forward(ctx, x, idx, inverse=None, slot=None):
+    def forward(ctx, x, idx, inverse=None, slot=None, distinct=False):
         # slot: GradSlot of x, this gather being its LAST consumer in backward order: the rows are scatter-added into
         # the gradient another consumer deposited (no zero fill, no elementwise add)
+        # distinct: no row is gathered twice (a subset selection): the backward pass needs no atomics
         ctx.save_for_backward(idx, inverse)
         ctx.n = x.shape[0]
         ctx.slot = slot
+        ctx.distinct = bool(distinct)
         return gather_rows(x.contiguous(), idx)
 
     @staticmethod
     def backward(ctx, dy):
         idx, inverse = ctx.saved_tensors
         if inverse is not None:
-            return gather_rows(dy.contiguous(), inverse), None, None, None
+            return gather_rows(dy.contiguous(), inverse), None, None, None, None
         prev = ctx.slot.take() if ctx.slot is not None else None
         if prev is not None and not (prev.shape == (ctx.n, dy.shape[1]) and prev.is_contiguous()):
-            return scatter_add_rows(dy.contiguous(), idx, ctx.n).add_(prev), None, None, None
-        return scatter_add_rows(dy.contiguous(), idx, ctx.n, out=prev), None, None, None
+            return scatter_add_rows(dy.contiguous(), idx, ctx.n, distinct=ctx.distinct).add_(prev), None, None, None, None
+        return scatter_add_rows(dy.contiguous(), idx, ctx.n, out=prev, distinct=ctx.distinct), None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------

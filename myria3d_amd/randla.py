@@ -748,7 +748,10 @@ class HipRandLANet(nn.Module):
             self._advance_interleaved()
             self._advance_interleaved()  # (two position-only stages per level: table + moments, decimation + next grid)
             geo.wait(2 + 2 * lvl)  # decimation map into the next level
-            h = ops.GatherRowsFn.apply(h, geo.src[lvl], None, out_slot if lvl == 0 else None) if diff \
+            # (drawn indices are the head of a permutation of each cloud: distinct whenever a cloud keeps no more points
+            # than it has — the backward scatter then needs no atomics; injected indices may repeat rows)
+            distinct = decimation_idx is None and all(b <= a for a, b in zip(plan.sizes[lvl], plan.sizes[lvl + 1]))
+            h = ops.GatherRowsFn.apply(h, geo.src[lvl], None, out_slot if lvl == 0 else None, distinct) if diff \
                 else ops.gather_rows(h, geo.src[lvl])
             hin.append(h)
         self.last_decimation_idx = dec_ref

@@ -263,6 +263,23 @@ def test_csr_inverse_and_gather_sum_equal_the_atomic_scatter(device):
         assert torch.allclose(got2, ref + base, rtol=1e-5, atol=1e-5)
 
 
+def test_scatter_add_rows_distinct_targets(device):
+    """``m3d_scatter_add_rows`` with flags bit 0 (distinct ids: the transpose of decimate()'s subset selection,
+    pyg_randla_net.py:234-238) writes what the atomic kernel writes — into zeros and into an existing buffer."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(11)
+    for n, m, C in ((204800, 51200, 32), (12800, 3200, 256), (100, 100, 8), (1000, 3, 4)):
+        idx = torch.from_numpy(rs.permutation(n)[:m].astype(np.int32)).to(device)
+        src = torch.from_numpy(rs.uniform(-1, 1, (m, C)).astype(np.float32)).to(device)
+        base = torch.from_numpy(rs.uniform(-1, 1, (n, C)).astype(np.float32)).to(device)
+        ref = ops.scatter_add_rows(src, idx, n, out=base.clone())
+        got = ops.scatter_add_rows(src, idx, n, out=base.clone(), distinct=True)
+        assert torch.equal(got, ref)
+        assert torch.equal(ops.scatter_add_rows(src, idx, n, out=torch.zeros(n, C, device=device), distinct=True),
+                           ops.scatter_add_rows(src, idx, n, out=torch.zeros(n, C, device=device)))
+
+
 def test_dropout_counter_based_mask(device):
     """``m3d_dropout`` (mlp_classif's Dropout(0.5), pyg_randla_net.py:49-52): kept elements are scaled by 1 / (1 - p), the kept
     fraction is 1 - p, the mask is a function of (seed, device step counter, element) — the same call on dy reproduces the

@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box, round 4 call M: decoder backward through CSR inverses of the 1-NN tables (no atomics), 16-byte loads in the LFA
-# partial reduce — full parity suite, the step, the kernel timeline.
+# GPU box, round 4 call N (and M before it): decoder backward through CSR inverses of the 1-NN tables, distinct-target scatter for the
+# decimation gathers — full parity suite, the step, the kernel timeline.
 set -u
-TAG=${1:-r04m}
+TAG=${1:-r04n}
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 timeout -s KILL 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | grep -E "passed|failed|error|Error|assert|FAILED" | tail -12 > $OUT/pytest_gpu_$TAG.log; cat $OUT/pytest_gpu_$TAG.log
 step() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], 'ms; eval fwd', d['fwd_only']['ms_per_step'], 'roofline', d['roofline']['avg_launch_ms'], d['roofline']['frac'])"; }
