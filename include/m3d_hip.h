@@ -27,8 +27,10 @@ extern "C" {
 
 /* torch.nn.Dropout(p) fused into a SharedMLP layer's BatchNorm kernels (mlp_classif, pyg_randla_net.py:49-52): the mask
  * of m3d_dropout — a hash of (seed, counter[0], element) — applied to the layer's output in the forward pass and to the
- * incoming gradient in the backward pass.  A null pointer, a null counter or p == 0 mean "no dropout". */
-typedef struct { const int64_t* counter; uint64_t seed; float p; } M3DDropout;
+ * incoming gradient in the backward pass.  A null pointer, a null counter or p == 0 mean "no dropout".  rows (nullable,
+ * device int32 [M]): row r of the layer's tensors is row rows[r] of the caller's tensor (the net's cell-sorted order) — the
+ * mask is then a function of the CALLER's element, independent of that order. */
+typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; } M3DDropout;
 
 #define M3D_ABI_VERSION 14
 #define M3D_ADAM_STATE_WORDS 66

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
     }
     if (a.act) { u.x = lrelu(u.x, a.slope); u.y = lrelu(u.y, a.slope); u.z = lrelu(u.z, a.slope); u.w = lrelu(u.w, a.slope); }
     if (a.drop.thr16) {
-      const float4 m = drop_mul4(dkey, i, a.drop.thr16, a.drop.scale);
+      const float4 m = drop_mul4(dkey, drop_index(a.drop, i / N4, (int)(i % N4), N4), a.drop.thr16, a.drop.scale);
       u.x *= m.x; u.y *= m.y; u.z *= m.z; u.w *= m.w;
     }
     a.y[i] = u;
@@ -272,7 +272,8 @@ struct BnBwdArgs {
 __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, float4 zv, float4& z2v) {
   float4 g = ((const float4*)a.dy)[i];
   if (a.drop.thr16) {
-    const float4 m = drop_mul4(a.dkey, i, a.drop.thr16, a.drop.scale);
+    const int n4 = a.N / 4;
+    const float4 m = drop_mul4(a.dkey, drop_index(a.drop, i / n4, (int)(i % n4), n4), a.drop.thr16, a.drop.scale);
     g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
   }
   if (a.act) {

@@ -581,14 +581,16 @@ def stat_slots(N: int, device, M: int = 1 << 30) -> Tensor:
 
 
 def _drop_ref(drop):
-    """``drop = (p, counter, seed)`` or None -> a by-reference ``M3DDropout`` argument (None: a null pointer)."""
+    """``drop = (p, counter, seed[, rows])`` or None -> a by-reference ``M3DDropout`` argument (None: a null pointer).
+    ``rows``: int32 map from the tensors' rows to the caller's rows (the mask is a function of the caller's element)."""
     if drop is None:
         return None
     import ctypes
     from ._lib import M3DDropout
 
-    p, counter, seed = drop
-    return ctypes.byref(M3DDropout(counter.data_ptr(), int(seed), float(p)))
+    p, counter, seed = drop[:3]
+    rows = drop[3] if len(drop) > 3 else None
+    return ctypes.byref(M3DDropout(counter.data_ptr(), int(seed), float(p), _p(rows)))
 
 
 def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tensor, act: bool, stats2=None, bn2=None,
@@ -706,21 +708,24 @@ class LinearFn(torch.autograd.Function):
     accumulated straight into the flat gradient buffer and autograd gets None for them)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, sinks=None):
+    def forward(ctx, x, w, b, sinks=None, rows=None):
+        # rows: the layer reads x[rows] (a row gather fused into the GEMM's A operand — fc0 on the cell-sorted order of
+        # level 1 — and into the weight gradient's); only for inputs that need no gradient themselves
         x = x.contiguous()
-        ctx.save_for_backward(x, w)
+        assert rows is None or not x.requires_grad
+        ctx.save_for_backward(x, w, rows)
         ctx.sinks = sinks
         ctx.side = _grad_side if sinks is not None else None
-        return gemm(x, w, x.shape[0], w.shape[0], w.shape[1], bias=b)
+        return gemm(x, w, x.shape[0] if rows is None else rows.numel(), w.shape[0], w.shape[1], rows=rows, bias=b)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, rows = ctx.saved_tensors
         sk = ctx.sinks
         dy = dy.contiguous()
         dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dy, x, x.shape[1], out=sk[0] if sk else None, side=ctx.side)
-        return dx, dw, colsum(dy, out=sk[1] if sk else None), None
+        dw = linear_wgrad(dy, x, x.shape[1], rows=rows, out=sk[0] if sk else None, side=ctx.side)
+        return dx, dw, colsum(dy, out=sk[1] if sk else None), None, None
 
 
 # --------------------------------------------------------------------------------------------------

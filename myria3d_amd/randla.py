@@ -719,10 +719,16 @@ class HipRandLANet(nn.Module):
         hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
         geo.wait(0)
         diff = train or self._grad_eval  # the pass records an autograd graph
-        x = ops.GatherRowsFn.apply(x, index[0].perm, index[0].inv) if x.requires_grad else ops.gather_rows(x, index[0].perm)
+        # fc0 on the cell-sorted order of level 1: the input permutation is a row gather inside the GEMM's A operand (and inside
+        # the weight gradient's); an input that needs a gradient itself takes the differentiable gather in front
+        if x.requires_grad:
+            x = ops.GatherRowsFn.apply(x, index[0].perm, index[0].inv)
+            in_rows = None
+        else:
+            in_rows = index[0].perm
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
-                               self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None) if diff else \
-            ops.gemm(x, self.fc0.weight, x.shape[0], self.fc0.weight.shape[0], x.shape[1], bias=self.fc0.bias)
+                               self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None, in_rows) if diff else \
+            ops.gemm(x, self.fc0.weight, pos.shape[0], self.fc0.weight.shape[0], x.shape[1], rows=in_rows, bias=self.fc0.bias)
         # gradient meeting points (train): in_slots[l] = input of block l (hin[l]), out_slot = output of block 1
         use_slots = train and torch.is_grad_enabled() and self.share_input_gradients
         in_slots = [ops.GradSlot() if use_slots else None for _ in range(4)]
@@ -782,7 +788,7 @@ class HipRandLANet(nn.Module):
         fused_drop = (train and p > 0.0 and dropout_mask is None and self._flat is not None and torch.is_grad_enabled()
                       and ops._pow2(self.mlp_classif.lins[1].weight.shape[0]))
         h = self._shared_layer(self.mlp_classif, 1, h, train=train,
-                               drop=(p, self._nbt_flat[-1:], self._dropout_seed()) if fused_drop else None)
+                               drop=(p, self._nbt_flat[-1:], self._dropout_seed(), index[0].perm) if fused_drop else None)
         if train and p > 0.0 and not fused_drop:
             if dropout_mask is not None:  # given in the caller's row order
                 mask = ops.gather_rows(dropout_mask.to(h.dtype).contiguous(), index[0].perm)

@@ -47,6 +47,35 @@ def _nets(device, seed):
     return a.to(device), b.to(device)
 
 
+@pytest.mark.parametrize("sizes", [[12800, 12800], [700, 333, 50]])
+def test_fused_dropout_is_a_function_of_seed_step_and_caller_row(device, sizes):
+    """The classifier's dropout (fused into its layer's BatchNorm kernels on a flattened net) draws its mask from (seed, step
+    counter, the CALLER's row and column): two fresh nets with the same seed produce the same loss and gradients although the
+    cell-sorted order they work in breaks ties differently from run to run (atomics in the grid build), like the reference's
+    seeded ``torch.nn.Dropout``; another seed gives another mask."""
+    from myria3d_amd import cross_entropy
+    from oracle.randla_oracle import fixed_decimation_indices
+
+    x, pos, batch, ptr = rand_batch(sizes, 9, seed=4)
+    y = torch.from_numpy(np.random.RandomState(8).randint(0, 6, (sum(sizes),))).to(device)
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=9)
+    args = (x.to(device), pos.to(device), None, ptr.to(device))
+    res = []
+    for seed in (777, 777, 778):
+        net, _ = _nets(device, 23)
+        net.flatten_parameters()
+        net.train()
+        net._drop_seed = seed
+        loss = cross_entropy(net(*args, decimation_idx=dec), y, 65)
+        loss.backward()
+        if net.grad_side is not None:
+            net.grad_side.join()
+        res.append((loss.item(), net.flat_grads.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * max(1.0, abs(res[1][0]))
+    assert torch.allclose(res[0][1], res[1][1], rtol=2e-4, atol=1e-6 * res[1][1].abs().max().item())
+    assert abs(res[0][0] - res[2][0]) > 1e-5  # (a different mask)
+
+
 def test_flat_gradient_sinks_equal_autograd_gradients(device):
     """flatten_parameters(): parameter gradients written by the backward kernels into the flat buffer must equal
     the ones the same kernels hand to autograd; state_dict keys are unchanged; gradients accumulate over calls."""
