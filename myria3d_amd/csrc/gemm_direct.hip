@@ -886,12 +886,15 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 #ifndef WGRAD_DEPTH
 #define WGRAD_DEPTH 4
 #endif
+#ifndef WGRAD_DEPTH_BIG
+#define WGRAD_DEPTH_BIG 2  // 4-row steps in flight per trip of the waves with 8 or 16 accumulator tiles
+#endif
 template <int TN, int TK, bool BF = false>
 __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
   // big tiles (16 accumulator quads: the deep, few-row layers) keep one partial per WAVE and two steps in flight: their
   // register budget has no room for four, and their LDS reduction would take 48 KB
   constexpr bool WGR = TN * TK < 16;
-  constexpr int DEPTH = TN * TK < 8 ? WGRAD_DEPTH : 2;
+  constexpr int DEPTH = TN * TK < 8 ? WGRAD_DEPTH : WGRAD_DEPTH_BIG;
   __shared__ float red[WGR ? 3 : 1][WGR ? TN * TK * 256 : 1];  // accumulators of waves 1..3 (wave 0 keeps its own)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
