@@ -204,7 +204,7 @@ __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc
   const float4 zv = ld4(rz, f0);
   if (g.pro_drop.thr16) {  // (f0 / 16 = number of this float4 in the row-major [M, k0] output: lda0 == k0 is checked by the host)
     const int n4 = g.k0 >> 2;
-    const int64_t i4 = (int64_t)(f0 >> 4);
+    const int64_t i4 = f0 != OOB ? (int64_t)(f0 >> 4) : 0;  // (rows past the end: gy is 0 anyway, but rows[] must not be read there)
     const float4 m = drop_mul4(g.pro_dkey, drop_index(g.pro_drop, i4 / n4, (int)(i4 % n4), n4), g.pro_drop.thr16, g.pro_drop.scale);
     gy.x *= m.x; gy.y *= m.y; gy.z *= m.z; gy.w *= m.w;
   }

@@ -463,8 +463,14 @@ def csr_invert_batch(idxs, ms):
     for m in ms:
         cnts.append(cnt[off:off + int(m)])
         off += int(m)
-    ptrs = [torch.empty(int(m) + 1, dtype=torch.int32, device=dev) for m in ms]
-    invs = [torch.empty(t.numel(), dtype=torch.int32, device=dev) for t in idxs]
+    # one allocation for the eight index vectors (host time matters when the step is launched eagerly)
+    sizes = [int(m) + 1 for m in ms] + [t.numel() for t in idxs]
+    buf = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.int32, device=dev)
+    views, off = [], 0
+    for n in sizes:
+        views.append(buf[off:off + n])
+        off += (n + 3) // 4 * 4
+    ptrs, invs = views[:k], views[k:]
     vp = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
     call("m3d_csr_invert_batch", k, vp(idxs), (ctypes.c_int64 * k)(*[t.numel() for t in idxs]),
          (ctypes.c_int64 * k)(*[int(m) for m in ms]), vp(cnts), vp(ptrs), vp(invs), _st())

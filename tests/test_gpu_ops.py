@@ -343,6 +343,36 @@ def test_shared_layer_with_fused_dropout_equals_layer_then_dropout(device, M, K,
     assert (outs[1][0] == 0).float().mean().item() > 0.4  # the mask was applied
 
 
+@pytest.mark.parametrize("M", [1083, 20000])
+def test_fused_dropout_follows_the_callers_rows(device, M):
+    """``M3DDropout.rows``: a layer that works on a permuted row order (the net's cell-sorted order) with ``rows = perm`` drops the
+    same elements of the CALLER's tensor as the layer on the caller's order does — forward and backward; M is not a multiple of
+    the 16-row tiles (the dz-on-load prologue must not read ``rows`` for the rows past the end)."""
+    from myria3d_amd import ops
+
+    K, N = 64, 32
+    rs = np.random.RandomState(M)
+    t = lambda *shape: torch.from_numpy(rs.uniform(-1, 1, shape).astype(np.float32)).to(device)
+    x, w, g = t(M, K), t(N, K), t(M, N)
+    b, gamma, beta = torch.zeros(N, device=device), t(N) + 2, t(N)
+    perm = torch.from_numpy(rs.permutation(M).astype(np.int32)).to(device)
+    counter = torch.full((1,), 3, dtype=torch.int64, device=device)
+    res = []
+    for rows in (None, perm):
+        xin = (x if rows is None else x[rows.long()]).clone().requires_grad_(True)
+        wp = w.clone().requires_grad_(True)
+        bn = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+        drop = (0.5, counter, 99) if rows is None else (0.5, counter, 99, rows)
+        y = ops.SharedLayerTrainFn.apply(xin, None, wp, b, gamma, beta, bn, True, None, None, False, None, None, drop)
+        y.backward(g if rows is None else g[rows.long()])
+        res.append((y.detach(), xin.grad, wp.grad))
+    (y0, dx0, dw0), (y1, dx1, dw1) = res
+    pl = perm.long()
+    assert torch.equal(y1 != 0, (y0 != 0)[pl])
+    assert torch.allclose(y1, y0[pl], rtol=1e-4, atol=1e-5) and torch.allclose(dx1, dx0[pl], rtol=1e-3, atol=1e-5)
+    assert torch.allclose(dw1, dw0, rtol=1e-3, atol=1e-4 * dw0.abs().max().item())
+
+
 @pytest.mark.parametrize("M,K0,K1,N", [(3200, 256, 256, 512), (12800, 128, 128, 256), (801, 128, 256, 128), (3200, 512, 96, 64),
                                        (5000, 64, 32, 128), (300, 256, 256, 20)])
 def test_gemm_pair_equals_two_launches(device, M, K0, K1, N):
