@@ -127,7 +127,7 @@ class HipRandLANet(nn.Module):
         self._grad_eval = False  # eval-mode forward that records an autograd graph (set per call)
         self._use_sinks = False
         self._streams: Dict = {}
-        self._plan_ident = None  # (identity of the last ptr tensor read, weak reference to it, its plan)
+        self._plan_ident = None  # up to four (identity of a ptr tensor read lately, weak reference to it, its plan)
         # eval-mode derived tensors (folded BatchNorm scale/shift, folded encoder, packed attention weights) depend on
         # parameters / running statistics only: cached across forwards, dropped whenever those may have changed
         self._eval_cache: Dict = {}
@@ -323,9 +323,11 @@ class HipRandLANet(nn.Module):
         pyg_randla_net.py:219-229); cached by tile sizes."""
         # the SAME tensor asked twice (prefetch_geometry for the next batch, then its forward) is read from the device once:
         # a second .tolist() is a second host sync (0.45 ms of host time per step on the variable-layout path)
+        # (the last FOUR tensors are remembered: with a prefetch for the next batch in front of every forward, two alternate)
         ident = (ptr.data_ptr(), ptr._version, ptr.numel(), ptr.device)
-        if self._plan_ident is not None and self._plan_ident[0] == ident and self._plan_ident[1]() is ptr:
-            return self._plan_ident[2]
+        for ent in self._plan_ident or ():
+            if ent[0] == ident and ent[1]() is ptr:
+                return ent[2]
         key = tuple(ptr.tolist())
         plan = self._plans.get(key)
         if plan is None:
@@ -336,9 +338,9 @@ class HipRandLANet(nn.Module):
         import weakref
 
         try:
-            self._plan_ident = (ident, weakref.ref(ptr), plan)
+            self._plan_ident = [(ident, weakref.ref(ptr), plan)] + list(self._plan_ident or ())[:3]
         except TypeError:
-            self._plan_ident = None
+            pass
         return plan
 
     # ------------------------------------------------------------------------------------------
