@@ -158,26 +158,29 @@ struct BnStatsApplyArgs {
 // running statistics (one block does it)
 __device__ __forceinline__ void bn_stats_col(const BnStatsApplyArgs& a, const BnStatsArgs& b, int n, bool writer,
                                              float& sc, float& sh) {
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < a.nslots; ++p) {
-    s += b.slots[((size_t)p * 2 + 0) * a.N + n];
-    q += b.slots[((size_t)p * 2 + 1) * a.N + n];
-  }
-  const double mean = s / a.count;
-  double var = q / a.count - mean * mean;
+  // everything this column reads is requested up front (slot rows, affine parameters, the writer's running statistics)
+  // (branch-free: an absent operand reads scale[n] instead and drops it — a load under its own branch is waited for there)
+  const float gam0 = (b.gamma ? b.gamma : b.scale)[n], bet0 = (b.beta ? b.beta : b.scale)[n];
+  const float rm = (writer && b.running_mean ? b.running_mean : b.scale)[n];
+  const float rv = (writer && b.running_var ? b.running_var : b.scale)[n];
+  const float gam = b.gamma ? gam0 : 1.f, bet = b.beta ? bet0 : 0.f;
+  double sq[2];
+  slot_sums<2>(b.slots + n, a.nslots, 2 * (size_t)a.N, (size_t)a.N, sq);
+  const double mean = sq[0] / a.count;
+  double var = sq[1] / a.count - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)a.eps);
-  const double scd = (double)(b.gamma ? b.gamma[n] : 1.f) * invstd;
+  const double scd = (double)gam * invstd;
   sc = (float)scd;
-  sh = (float)((double)(b.beta ? b.beta[n] : 0.f) - mean * scd);
+  sh = (float)((double)bet - mean * scd);
   if (writer) {
     b.scale[n] = sc; b.shift[n] = sh;
     if (b.mean) b.mean[n] = (float)mean;
     if (b.invstd) b.invstd[n] = (float)invstd;
-    if (b.running_mean) b.running_mean[n] = (float)((1.0 - a.momentum) * (double)b.running_mean[n] + a.momentum * mean);
+    if (b.running_mean) b.running_mean[n] = (float)((1.0 - a.momentum) * (double)rm + a.momentum * mean);
     if (b.running_var) {
       const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
-      b.running_var[n] = (float)((1.0 - a.momentum) * (double)b.running_var[n] + a.momentum * unbiased);
+      b.running_var[n] = (float)((1.0 - a.momentum) * (double)rv + a.momentum * unbiased);
     }
   }
 }
@@ -413,18 +416,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   __shared__ float s_m1[BN_MAXN], s_m2[BN_MAXN], s_m3[BN_MAXN];
   if (a.nslots > 0) {
     for (int n = threadIdx.x; n < a.N; n += 256) {
-      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      for (int p = 0; p < a.nslots; ++p) {
-        s1 += a.sums[((size_t)p * 3 + 0) * a.N + n];
-        s2 += a.sums[((size_t)p * 3 + 1) * a.N + n];
-        if (a.z2) s3 += a.sums[((size_t)p * 3 + 2) * a.N + n];
+      // (the gradient sinks' old values are requested before the slot rows, not after them)
+      const bool old = blockIdx.x == 0 && a.acc_pg;  // branch-free: what is absent reads scale[n] and counts as 0
+      const bool h0 = old && a.dbeta, h1 = old && a.z2 && a.dbeta2, h2 = old && a.dgamma, h3 = old && a.z2 && a.dgamma2;
+      const float r0 = (h0 ? a.dbeta : a.scale)[n], r1 = (h1 ? a.dbeta2 : a.scale)[n];
+      const float r2 = (h2 ? a.dgamma : a.scale)[n], r3 = (h3 ? a.dgamma2 : a.scale)[n];
+      const float ob = h0 ? r0 : 0.f, ob2 = h1 ? r1 : 0.f, og = h2 ? r2 : 0.f, og2 = h3 ? r3 : 0.f;
+      double s1, s2, s3 = 0.0;
+      if (a.z2) {
+        double t[3];
+        slot_sums<3>(a.sums + n, a.nslots, 3 * (size_t)a.N, (size_t)a.N, t);
+        s1 = t[0]; s2 = t[1]; s3 = t[2];
+      } else {
+        double t[2];
+        slot_sums<2>(a.sums + n, a.nslots, 3 * (size_t)a.N, (size_t)a.N, t);
+        s1 = t[0]; s2 = t[1];
       }
       s_m1[n] = (float)(s1 * invM); s_m2[n] = (float)(s2 * invM); s_m3[n] = (float)(s3 * invM);
       if (blockIdx.x == 0) {
-        if (a.dbeta) a.dbeta[n] = (a.acc_pg ? a.dbeta[n] : 0.f) + (float)s1;
-        if (a.z2 && a.dbeta2) a.dbeta2[n] = (a.acc_pg ? a.dbeta2[n] : 0.f) + (float)s1;
-        if (a.dgamma) a.dgamma[n] = (a.acc_pg ? a.dgamma[n] : 0.f) + (float)s2;
-        if (a.z2 && a.dgamma2) a.dgamma2[n] = (a.acc_pg ? a.dgamma2[n] : 0.f) + (float)s3;
+        if (a.dbeta) a.dbeta[n] = ob + (float)s1;
+        if (a.z2 && a.dbeta2) a.dbeta2[n] = ob2 + (float)s1;
+        if (a.dgamma) a.dgamma[n] = og + (float)s2;
+        if (a.z2 && a.dgamma2) a.dgamma2[n] = og2 + (float)s3;
       }
     }
     __syncthreads();

@@ -177,16 +177,17 @@ __device__ __forceinline__ void pro_setup(const GemmArgs& g, float (&cf)[6][KP])
   for (int k = threadIdx.x; k < kmax; k += 256) {
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, m1 = 0.f, m2 = 0.f;
     if (k < K) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int p = 0; p < g.pro_slots; ++p) {
-        s1 += g.pro_sums[((size_t)p * 3 + 0) * K + k];
-        s2 += g.pro_sums[((size_t)p * 3 + 1) * K + k];
-      }
+      // every load of this column up front: its constants, the writer's old sink values, then all slot rows at once
       sc = g.pro_scale[k]; sh = g.pro_shift[k]; mu = g.pro_mean[k]; is = g.pro_invstd[k];
-      m1 = (float)(s1 * invM); m2 = (float)(s2 * invM);
+      const bool hb = writer && g.pro_acc && g.pro_dbeta, hg = writer && g.pro_acc && g.pro_dgamma;
+      const float rb = (hb ? g.pro_dbeta : g.pro_scale)[k], rg = (hg ? g.pro_dgamma : g.pro_scale)[k];  // (branch-free)
+      const float ob = hb ? rb : 0.f, og = hg ? rg : 0.f;
+      double t[2];
+      slot_sums<2>(g.pro_sums + k, g.pro_slots, 3 * (size_t)K, (size_t)K, t);
+      m1 = (float)(t[0] * invM); m2 = (float)(t[1] * invM);
       if (writer) {  // dbeta = s1, dgamma = s2 (what bn_bwd_apply_kernel's block 0 writes in the unfused path)
-        if (g.pro_dbeta) g.pro_dbeta[k] = (g.pro_acc ? g.pro_dbeta[k] : 0.f) + (float)s1;
-        if (g.pro_dgamma) g.pro_dgamma[k] = (g.pro_acc ? g.pro_dgamma[k] : 0.f) + (float)s2;
+        if (g.pro_dbeta) g.pro_dbeta[k] = ob + (float)t[0];
+        if (g.pro_dgamma) g.pro_dgamma[k] = og + (float)t[1];
       }
     }
     cf[0][k] = sc; cf[1][k] = sh; cf[2][k] = mu; cf[3][k] = is; cf[4][k] = m1; cf[5][k] = m2;

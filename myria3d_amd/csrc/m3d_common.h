@@ -145,6 +145,29 @@ __device__ __forceinline__ double xgroup_sum_d(double v) {
   return __hiloint2double(__float_as_int(ahi), __float_as_int(alo)) + __hiloint2double(__float_as_int(bhi), __float_as_int(blo));
 }
 __device__ __forceinline__ double wave_sum_d(double v) { return xgroup_sum_d(row16_sum_d(v)); }
+
+// acc[s] = sum over the slot rows p < nslots of base[p * row_stride + s * series_stride], in row order, with the loads of
+// eight rows of all S series in flight.  (A rolled `for p: acc += row[p]` waits for every row: 4-8 dependent L2 round
+// trips in front of every workgroup of a consumer — the ~8 us floor of the small layers' BatchNorm launches.)
+template <int S>
+__device__ __forceinline__ void slot_sums(const double* __restrict__ base, int nslots, size_t row_stride, size_t series_stride,
+                                          double (&acc)[S]) {
+#pragma unroll
+  for (int s = 0; s < S; ++s) acc[s] = 0.0;
+  for (int p0 = 0; p0 < nslots; p0 += 8) {
+    double v[8][S];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = p0 + u < nslots ? p0 + u : nslots - 1;  // clamped: an unconditional load, its value dropped below
+#pragma unroll
+      for (int s = 0; s < S; ++s) v[u][s] = base[(size_t)q * row_stride + (size_t)s * series_stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[s] += p0 + u < nslots ? v[u][s] : 0.0;
+  }
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -26,7 +26,48 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   __shared__ bool last;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   double ls = 0.0, cnt = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  // C <= 8 (this network: 6 / 7 classes): four rows per thread, their logits and targets all requested before the first is
+  // used, the target's logit picked from registers.  (The rolled loop below re-reads a row three times and reads row[t]
+  // behind target[i]: ~3 dependent round trips per row, 3-4 rows per thread, 17 us for 204 800 rows of 24 B.)
+  int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  if (C <= 8) {
+    for (; i < n; i += 4 * gstride) {
+      float v[4][8];
+      int64_t tg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = i + u * gstride < n ? i + u * gstride : n - 1;  // (clamped: branch-free loads)
+        tg[u] = target[r];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[u][c] = logits[r * ld + (c < C ? c : C - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + u * gstride >= n) break;
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mx = c < C ? fmaxf(mx, v[u][c]) : mx;
+        float s = 0.f, pick = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          s += c < C ? expf(v[u][c] - mx) : 0.f;
+          pick = tg[u] == c ? v[u][c] : pick;
+        }
+        const float l = mx + logf(s);
+        lse[i + u * gstride] = l;
+        if (tg[u] != ignore_index) {
+          if (tg[u] >= 0 && tg[u] < C) {
+            ls += (double)(l - pick);
+            cnt += 1.0;
+          } else {
+            ls += (double)__builtin_nanf("");  // (see below)
+          }
+        }
+      }
+    }
+  }
+  for (; i < n; i += gstride) {
     const float* row = logits + i * ld;
     float mx = -__builtin_inff();
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
@@ -111,7 +152,7 @@ extern "C" int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* t
   // flags bit 0: the ticket word acc[2] is already zero (a slice of the caller's pre-zeroed arena): no memset node
   if (!(flags & 1) && hipMemsetAsync(acc4, 0, 4 * sizeof(double), st) != hipSuccess) return M3D_ERR_LAUNCH;
   if (n > 0) {
-    int64_t gx = m3d_cdiv(n, 256);
+    int64_t gx = m3d_cdiv(n, C <= 8 ? 1024 : 256);  // (four rows per thread in the register path)
     if (gx > CE_MAX_BLOCKS) gx = CE_MAX_BLOCKS;  // (one partial pair per workgroup, summed by the last one's 256 threads)
     hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)gx), dim3(256), 0, st, logits, ld, target, n, C, ignore_index, lse,
                        acc4, loss);
