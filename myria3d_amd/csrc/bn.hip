@@ -185,46 +185,58 @@ __device__ __forceinline__ void bn_stats_col(const BnStatsApplyArgs& a, const Bn
   }
 }
 
+template <bool B2>
 __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a) {
-  // every block derives the N column constants ONCE (one thread per column, a few slot rows each, fp64) into LDS
+  // every block derives the N column constants ONCE (one thread per column, all slot rows at once, fp64) into LDS
   __shared__ float s_sc[BN_MAXN], s_sh[BN_MAXN], s_sc2[BN_MAXN], s_sh2[BN_MAXN];
   const bool writer = blockIdx.x == 0;
-  // the first rows of this thread are requested BEFORE the column pass: the pass is a dependent chain of its own (slot
-  // loads -> fp64 divide / sqrt -> LDS) and the small layers are nothing but latency (16 of the step's 23 launches: ~8 us)
+  // four float4 per thread and trip, all requested before the first is used (B2 is a template parameter: straight-line
+  // code); the first four BEFORE the column pass — the pass is a dependent chain of its own (slot loads -> fp64 divide /
+  // sqrt -> LDS) and the small layers are nothing but latency
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool has0 = i < a.total4;
-  float4 v0 = make_float4(0, 0, 0, 0), w0 = make_float4(0, 0, 0, 0);
-  if (has0) {
-    v0 = a.z[i];
-    if (a.b2.slots) w0 = a.z2[i];
-  }
+  float4 v[U], w[U];
+  auto load = [&](int64_t at) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = at + u * stride < a.total4 ? at + u * stride : a.total4 - 1;  // (clamped: branch-free loads)
+      v[u] = a.z[j];
+      if constexpr (B2) w[u] = a.z2[j];
+    }
+  };
+  load(i);
   for (int n = threadIdx.x; n < a.N; n += 256) {
     bn_stats_col(a, a.b1, n, writer, s_sc[n], s_sh[n]);
-    if (a.b2.slots) bn_stats_col(a, a.b2, n, writer, s_sc2[n], s_sh2[n]);
+    if constexpr (B2) bn_stats_col(a, a.b2, n, writer, s_sc2[n], s_sh2[n]);
   }
   __syncthreads();
   const int N4 = a.N / 4;
-  if (!has0) return;
+  if (i >= a.total4) return;
   const int c = (int)(i % N4) * 4;  // fixed for this thread: the grid stride is a multiple of N4 (checked by the host)
   const float4 sc = *(const float4*)&s_sc[c], sh = *(const float4*)&s_sh[c];
   float4 s2 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
-  if (a.b2.slots) { s2 = *(const float4*)&s_sc2[c]; h2 = *(const float4*)&s_sh2[c]; }
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  bool first = true;
+  if constexpr (B2) { s2 = *(const float4*)&s_sc2[c]; h2 = *(const float4*)&s_sh2[c]; }
   const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
-  for (; i < a.total4; i += stride, first = false) {
-    const float4 v = first ? v0 : a.z[i];
-    float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
-    if (a.b2.slots) {
-      const float4 w = first ? w0 : a.z2[i];
-      u.x += w.x * s2.x + h2.x; u.y += w.y * s2.y + h2.y; u.z += w.z * s2.z + h2.z; u.w += w.w * s2.w + h2.w;
+  while (true) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + u * stride;
+      if (j >= a.total4) break;
+      float4 o = make_float4(v[u].x * sc.x + sh.x, v[u].y * sc.y + sh.y, v[u].z * sc.z + sh.z, v[u].w * sc.w + sh.w);
+      if constexpr (B2) {
+        o.x += w[u].x * s2.x + h2.x; o.y += w[u].y * s2.y + h2.y; o.z += w[u].z * s2.z + h2.z; o.w += w[u].w * s2.w + h2.w;
+      }
+      if (a.act) { o.x = lrelu(o.x, a.slope); o.y = lrelu(o.y, a.slope); o.z = lrelu(o.z, a.slope); o.w = lrelu(o.w, a.slope); }
+      if (a.drop.thr16) {
+        const float4 m = drop_mul4(dkey, drop_index(a.drop, j / N4, (int)(j % N4), N4), a.drop.thr16, a.drop.scale);
+        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+      }
+      a.y[j] = o;
     }
-    if (a.act) { u.x = lrelu(u.x, a.slope); u.y = lrelu(u.y, a.slope); u.z = lrelu(u.z, a.slope); u.w = lrelu(u.w, a.slope); }
-    if (a.drop.thr16) {
-      const float4 m = drop_mul4(dkey, drop_index(a.drop, i / N4, (int)(i % N4), N4), a.drop.thr16, a.drop.scale);
-      u.x *= m.x; u.y *= m.y; u.z *= m.z; u.w *= m.w;
-    }
-    a.y[i] = u;
+    i += U * stride;
+    if (i >= a.total4) break;
+    load(i);
   }
 }
 
@@ -251,7 +263,8 @@ extern "C" int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t c
   if (gx > 1024) gx = 1024;
   if (gx < 1) gx = 1;
   // stride = gx * 256 must be a multiple of N4 (a power of two <= 256 divides 256)
-  hipLaunchKernelGGL(bn_stats_apply_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  if (slots2) hipLaunchKernelGGL(bn_stats_apply_kernel<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bn_stats_apply_kernel<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
@@ -293,11 +306,17 @@ __device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, 
 }
 
 // grid (row blocks, column passes): block (x, y) owns rows [x*rows_per_block, ...) and 256/rpp float4 column groups.
-// Per-thread fp32 partials over <= ~8 rows (all loads of the unrolled trip in flight), fp64 across threads (LDS),
-// one plain-stored partial row per block: part[x][3][N]  (summed by bn_bwd_finalize_kernel — no atomics).
+// Per-thread fp32 partials over 8-16 rows, fp64 across threads (LDS), one partial row per block (slot atomics, or
+// part[x][3][N] summed by bn_bwd_finalize_kernel).
+// The row loop is straight-line code (Z2 / DROP are template parameters, the column constants are loaded in front of it,
+// rows past the end re-read the first row and count as 0): the loads of eight rows — dy, z (, z2) — are in flight together.
+// With the operands' null checks and the activation's scale / shift loads inside the loop every row was two to three
+// DEPENDENT round trips (z, dy -> wait -> scale, shift -> wait -> ...), 16-32 of them per thread: the 9-27 us of the launches.
+template <bool Z2, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int rows_per_block, double* __restrict__ part) {
   __shared__ double red[256 * 12];
-  if (a.drop.thr16) a.dkey = drop_key(a.drop);
+  uint32_t dkey = 0u;
+  if constexpr (DROP) dkey = drop_key(a.drop);
   const int tid = threadIdx.x;
   const int N4 = a.N / 4;
   const int CG = N4 < 256 ? N4 : 256;  // column groups per block
@@ -311,22 +330,56 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int row
   for (int j = 0; j < 12; ++j) s[j] = 0.f;
   if (rl < rpp && c4 < N4) {
     const int c = c4 * 4;
+    const float4 zero4 = make_float4(0, 0, 0, 0);
     const float4 mu = *(const float4*)(a.mean + c), is = *(const float4*)(a.invstd + c);
-    float4 mu2 = make_float4(0, 0, 0, 0), is2 = make_float4(0, 0, 0, 0);
-    if (a.z2) { mu2 = *(const float4*)(a.mean2 + c); is2 = *(const float4*)(a.invstd2 + c); }
-#pragma unroll 4
-    for (int64_t r = r0 + rl; r < r1; r += rpp) {
-      const int64_t i = r * N4 + c4;
-      const float4 zv = ((const float4*)a.z)[i];
-      float4 z2v = make_float4(0, 0, 0, 0);
-      if (a.z2) z2v = ((const float4*)a.z2)[i];
-      const float4 g = bn_dact(a, i, c, zv, z2v);
-      s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-      s[4] += g.x * ((zv.x - mu.x) * is.x); s[5] += g.y * ((zv.y - mu.y) * is.y);
-      s[6] += g.z * ((zv.z - mu.z) * is.z); s[7] += g.w * ((zv.w - mu.w) * is.w);
-      if (a.z2) {
-        s[8] += g.x * ((z2v.x - mu2.x) * is2.x); s[9] += g.y * ((z2v.y - mu2.y) * is2.y);
-        s[10] += g.z * ((z2v.z - mu2.z) * is2.z); s[11] += g.w * ((z2v.w - mu2.w) * is2.w);
+    const float4 sc = *(const float4*)(a.scale + c), sh = *(const float4*)(a.shift + c);
+    float4 mu2 = zero4, is2 = zero4, sc2 = zero4, sh2 = zero4;
+    if constexpr (Z2) {
+      mu2 = *(const float4*)(a.mean2 + c); is2 = *(const float4*)(a.invstd2 + c);
+      sc2 = *(const float4*)(a.scale2 + c); sh2 = *(const float4*)(a.shift2 + c);
+    }
+    constexpr int U = 8;
+    for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * rpp) {
+      float4 zv[U], gv[U], z2v[U];
+      int64_t di[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t rr = r + (int64_t)u * rpp;
+        ok[u] = rr < r1;
+        const int64_t rc = ok[u] ? rr : r;
+        const int64_t i = rc * N4 + c4;
+        zv[u] = ((const float4*)a.z)[i];
+        gv[u] = ((const float4*)a.dy)[i];
+        z2v[u] = zero4;
+        if constexpr (Z2) z2v[u] = ((const float4*)a.z2)[i];
+        di[u] = 0;
+        if constexpr (DROP) di[u] = drop_index(a.drop, rc, c4, N4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float4 g = gv[u];
+        const float4 zz = zv[u], z2 = z2v[u];
+        if constexpr (DROP) {
+          const float4 m = drop_mul4(dkey, di[u], a.drop.thr16, a.drop.scale);
+          g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+        }
+        if (a.act) {
+          float4 v = make_float4(zz.x * sc.x + sh.x, zz.y * sc.y + sh.y, zz.z * sc.z + sh.z, zz.w * sc.w + sh.w);
+          if constexpr (Z2) {
+            v.x += z2.x * sc2.x + sh2.x; v.y += z2.y * sc2.y + sh2.y; v.z += z2.z * sc2.z + sh2.z; v.w += z2.w * sc2.w + sh2.w;
+          }
+          g.x *= v.x > 0.f ? 1.f : a.slope; g.y *= v.y > 0.f ? 1.f : a.slope;
+          g.z *= v.z > 0.f ? 1.f : a.slope; g.w *= v.w > 0.f ? 1.f : a.slope;
+        }
+        if (!ok[u]) g = zero4;
+        s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+        s[4] += g.x * ((zz.x - mu.x) * is.x); s[5] += g.y * ((zz.y - mu.y) * is.y);
+        s[6] += g.z * ((zz.z - mu.z) * is.z); s[7] += g.w * ((zz.w - mu.w) * is.w);
+        if constexpr (Z2) {
+          s[8] += g.x * ((z2.x - mu2.x) * is2.x); s[9] += g.y * ((z2.y - mu2.y) * is2.y);
+          s[10] += g.z * ((z2.z - mu2.z) * is2.z); s[11] += g.w * ((z2.w - mu2.w) * is2.w);
+        }
       }
     }
   }
@@ -401,6 +454,7 @@ __device__ __forceinline__ float4 bn_dz(const BnCol& k, float4 g, float4 zv) {
   return o;
 }
 
+template <bool Z2>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   if (a.drop.thr16) a.dkey = drop_key(a.drop);
   const int N4 = a.N / 4;
@@ -466,26 +520,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
                             (float)(a.sums[o + 3] * invM));
     }
   };
+  // four float4 per thread and trip: dy, z (, z2) of all four requested before the first is used (Z2 is a template
+  // parameter: straight-line code; elements past the end re-read the last one and are not stored)
+  constexpr int U = 4;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (fixed && i < total4) load_cols((int)(i % N4) * 4);
-  for (; i < total4; i += stride) {
-    if (!fixed) load_cols((int)(i % N4) * 4);
-    const float4 zv = ((const float4*)a.z)[i];
-    float4 g = ((const float4*)a.dy)[i];
-    float4 z2v = make_float4(0, 0, 0, 0);
-    if (a.z2) z2v = ((const float4*)a.z2)[i];
-    if (a.act) {
-      float4 u = make_float4(zv.x * k1.sc.x + k1.sh.x, zv.y * k1.sc.y + k1.sh.y, zv.z * k1.sc.z + k1.sh.z,
-                             zv.w * k1.sc.w + k1.sh.w);
-      if (a.z2) {
-        u.x += z2v.x * k2.sc.x + k2.sh.x; u.y += z2v.y * k2.sc.y + k2.sh.y;
-        u.z += z2v.z * k2.sc.z + k2.sh.z; u.w += z2v.w * k2.sc.w + k2.sh.w;
-      }
-      g.x *= u.x > 0.f ? 1.f : a.slope; g.y *= u.y > 0.f ? 1.f : a.slope;
-      g.z *= u.z > 0.f ? 1.f : a.slope; g.w *= u.w > 0.f ? 1.f : a.slope;
+  for (; i < total4; i += U * stride) {
+    float4 zq[U], gq[U], z2q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + u * stride < total4 ? i + u * stride : total4 - 1;
+      zq[u] = ((const float4*)a.z)[j];
+      gq[u] = ((const float4*)a.dy)[j];
+      z2q[u] = make_float4(0, 0, 0, 0);
+      if constexpr (Z2) z2q[u] = ((const float4*)a.z2)[j];
     }
-    ((float4*)a.dz)[i] = bn_dz(k1, g, zv);
-    if (a.z2) ((float4*)a.dz2)[i] = bn_dz(k2, g, z2v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + u * stride;
+      if (j >= total4) break;
+      if (!fixed) load_cols((int)(j % N4) * 4);
+      const float4 zv = zq[u], z2v = z2q[u];
+      float4 g = gq[u];
+      if (a.drop.thr16) {
+        const float4 m = drop_mul4(a.dkey, drop_index(a.drop, j / N4, (int)(j % N4), N4), a.drop.thr16, a.drop.scale);
+        g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
+      }
+      if (a.act) {
+        float4 v = make_float4(zv.x * k1.sc.x + k1.sh.x, zv.y * k1.sc.y + k1.sh.y, zv.z * k1.sc.z + k1.sh.z,
+                               zv.w * k1.sc.w + k1.sh.w);
+        if constexpr (Z2) {
+          v.x += z2v.x * k2.sc.x + k2.sh.x; v.y += z2v.y * k2.sc.y + k2.sh.y;
+          v.z += z2v.z * k2.sc.z + k2.sh.z; v.w += z2v.w * k2.sc.w + k2.sh.w;
+        }
+        g.x *= v.x > 0.f ? 1.f : a.slope; g.y *= v.y > 0.f ? 1.f : a.slope;
+        g.z *= v.z > 0.f ? 1.f : a.slope; g.w *= v.w > 0.f ? 1.f : a.slope;
+      }
+      ((float4*)a.dz)[j] = bn_dz(k1, g, zv);
+      if constexpr (Z2) ((float4*)a.dz2)[j] = bn_dz(k2, g, z2v);
+    }
   }
 }
 
@@ -545,8 +618,14 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   const BnBwdPlan pl = bn_bwd_plan(M, N);
   double* part = sums_ws + 3 * (size_t)N;  // sums_ws = [3][N] totals, then [blocks][3][N] partial rows
   const int N4 = N / 4;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)pl.blocks, (unsigned)pl.passes), dim3(256), 0, st, a,
-                     (int)pl.rows_per_block, part);
+  {
+    const dim3 rgrid((unsigned)pl.blocks, (unsigned)pl.passes);
+    const int rpb = (int)pl.rows_per_block;
+    if (z2 && a.drop.thr16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), rgrid, dim3(256), 0, st, a, rpb, part);
+    else if (z2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), rgrid, dim3(256), 0, st, a, rpb, part);
+    else if (a.drop.thr16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, true>), rgrid, dim3(256), 0, st, a, rpb, part);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), rgrid, dim3(256), 0, st, a, rpb, part);
+  }
   if (a.nslots <= 0)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)N, z2 ? 3 : 2), dim3(64), 0, st, a, (const double*)part,
                        (int)pl.blocks);
@@ -563,7 +642,8 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
     if (gy > 1024) gy = 1024;
     if (gy < 1) gy = 1;
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)gy), dim3(256), 0, st, a);
+  if (z2) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)gy), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)gy), dim3(256), 0, st, a);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

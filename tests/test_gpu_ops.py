@@ -309,7 +309,7 @@ def test_dropout_counter_based_mask(device):
         assert abs((other == keep).float().mean().item() - ((1 - p) ** 2 + p ** 2)) < 5e-3
 
 
-@pytest.mark.parametrize("M,K,N,k1", [(20000, 64, 32, 0), (4000, 256, 64, 0), (6000, 32, 32, 32)])
+@pytest.mark.parametrize("M,K,N,k1", [(20000, 64, 32, 0), (4000, 256, 64, 0), (6000, 32, 32, 32), (1000, 64, 32, 0)])
 def test_shared_layer_with_fused_dropout_equals_layer_then_dropout(device, M, K, N, k1):
     """Dropout fused into a SharedMLP layer's BatchNorm kernels (``SharedLayerTrainFn(..., drop=...)``: mask applied by
     ``m3d_bn_stats_apply`` on the way out, to the incoming gradient by the column-sum pass and the dz-on-load prologue) gives what the
