@@ -360,49 +360,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
-// the same for rows of float4 (N and ld multiples of 4, N <= 1024): thread = (column group, row lane), eight rows of 16 B in
-// flight per thread.  (The dword kernel keeps 2 MB in flight over the chip — 1 TB/s at ~2 us a round trip: 33 us for fc0's
-// 204 800 x 32 bias gradient, whose bytes stream in 4.)
-__global__ __launch_bounds__(256) void colsum4_kernel(const float4* __restrict__ x, int64_t ld4, int64_t M, int N4,
-                                                      float* __restrict__ out) {
-  __shared__ float4 red[256];
+// the same for rows of float4 (N and ld multiples of 4, N / 4 a power of two <= 256, the matrix inside one 2 GiB buffer
+// descriptor): 1 024 threads per workgroup = (column group, row lane), eight rows of 16 B in flight per thread, buffer loads
+// whose offset past the end reads as 0 (no tail loop).  (The dword kernel keeps 2 MB in flight over the chip: 33 us for fc0's
+// 204 800 x 32 bias gradient, whose bytes stream in 4; at most 256 workgroups, because each ends in one same-address atomic
+// per column, ~15 ns apiece — hence the 16 waves per workgroup.)
+__global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__ x, int64_t ld4, int64_t M, int N4,
+                                                       float* __restrict__ out) {
+  __shared__ float4 red[1024];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x80000000u, 0x00020000);
+  const unsigned oob = 0x80000000u;
   const int tid = threadIdx.x;
-  const int cols = N4 < 256 ? N4 : 256;
-  const int rpp = 256 / cols;
-  const int c = tid % cols, rl = tid / cols;
-  for (int cb = 0; cb < N4; cb += cols) {
-    const int n = cb + c;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rl < rpp && n < N4) {
-      const int64_t step = (int64_t)gridDim.x * rpp;
-      int64_t r = (int64_t)blockIdx.x * rpp + rl;
-      for (; r + 7 * step < M; r += 8 * step) {
-        float4 v[8];
+  const int rpp = 1024 / N4;
+  const int c = tid % N4, rl = tid / N4;
+  const int64_t step = (int64_t)gridDim.x * rpp;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t r = (int64_t)blockIdx.x * rpp + rl; r < M; r += 8 * step) {
+    f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = x[(r + u * step) * ld4 + n];
+    for (int u = 0; u < 8; ++u) {
+      const int64_t rr = r + u * step;
+      v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, rr < M ? (unsigned)((rr * ld4 + c) * 16) : oob, 0, 0);
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-      }
-      for (; r < M; r += step) {
-        const float4 v = x[r * ld4 + n];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
+    for (int u = 0; u < 8; ++u) { acc.x += v[u][0]; acc.y += v[u][1]; acc.z += v[u][2]; acc.w += v[u][3]; }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int h = 512; h >= N4; h >>= 1) {  // tree over the row lanes (1024 / N4 of them, a power of two)
+    if (tid < h) {
+      const float4 o = red[tid + h];
+      red[tid].x += o.x; red[tid].y += o.y; red[tid].z += o.z; red[tid].w += o.w;
     }
     __syncthreads();
-    red[tid] = acc;
-    __syncthreads();
-    for (int h = 128; h >= cols; h >>= 1) {  // tree over the row lanes (256 / cols of them, a power of two when cols is)
-      if (tid < h && tid + h < rpp * cols) {
-        const float4 o = red[tid + h];
-        red[tid].x += o.x; red[tid].y += o.y; red[tid].z += o.z; red[tid].w += o.w;
-      }
-      __syncthreads();
-    }
-    if (rl == 0 && n < N4) {
-      const float4 v = red[c];
-      atomicAdd(&out[4 * n + 0], v.x); atomicAdd(&out[4 * n + 1], v.y);
-      atomicAdd(&out[4 * n + 2], v.z); atomicAdd(&out[4 * n + 3], v.w);
-    }
+  }
+  if (tid < N4) {
+    const float4 v = red[tid];
+    atomicAdd(&out[4 * tid + 0], v.x); atomicAdd(&out[4 * tid + 1], v.y);
+    atomicAdd(&out[4 * tid + 2], v.z); atomicAdd(&out[4 * tid + 3], v.w);
   }
 }
 
@@ -411,12 +406,12 @@ extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, 
   if (M == 0 || N == 0) return M3D_OK;
   if (!x || !out) return M3D_ERR_INVALID;
   const int n4 = N / 4;
-  if (N % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (n4 & (n4 - 1)) == 0 && n4 <= 256) {
-    const int rpp4 = 256 / n4;
+  if (N % 4 == 0 && ld % 4 == 0 && (((uintptr_t)x) & 15) == 0 && (n4 & (n4 - 1)) == 0 && n4 <= 256 &&
+      M * ld * 4 <= (int64_t)0x80000000u - 64) {
+    const int rpp4 = 1024 / n4;
     int64_t g4 = m3d_cdiv(M, (int64_t)rpp4 * 8);
-    if (g4 > 256) g4 = 256;  // (one same-address atomic per column per workgroup, see below)
-    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)g4), dim3(256), 0, (hipStream_t)stream, (const float4*)x, ld / 4, M,
-                       n4, out);
+    if (g4 > 256) g4 = 256;
+    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)g4), dim3(1024), 0, (hipStream_t)stream, x, ld / 4, M, n4, out);
     M3D_CHECK_LAUNCH();
     return M3D_OK;
   }

@@ -840,14 +840,13 @@ struct WgradFrag {
 
 // operands of the 4-row step `s` (rows 4s .. 4s+3, this lane: row 4s + lg); buffer loads, no branches
 template <int TN, int TK>
+// `rr`: the row of x0 that row 4s + lg reads (the caller's prefetched rows[] entry, or the row itself)
 __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc_t rz, rsrc_t rx0, rsrc_t rx1, int64_t s,
-                                                        bool live, int nb, int kb, int lr, int lg, int K) {
+                                                        bool live, int64_t rr, int nb, int kb, int lr, int lg, int K) {
   WgradFrag<TN, TK> f;
   const int64_t m = 4 * s + lg;
   const bool ok = live && m < g.M;
   const int64_t mc = ok ? m : 0;
-  int64_t rr = mc;
-  if (g.rows) rr = (int64_t)g.rows[mc];
   const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
   const unsigned o0 = (ok && rr >= 0) ? (unsigned)(rr * g.ldx0 * 4) : OOB;
   const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
@@ -952,16 +951,41 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
       goto reduce_and_store;
     }
   }
+  {
+  // x0[rows] (fc0 on the cell-sorted order): the row numbers of a trip are requested one trip AHEAD, behind the operand
+  // loads of the trip before — read inside wgrad_load they were a dependent round trip in front of every 4-row step, and the
+  // wait for them drained the operand loads of the step before (the waves of that job ran one step at a time)
+  // (kept as the raw 32 bits until the next trip uses them: a sign extension right behind the load would wait for it)
+  auto x0_row = [&](int64_t st) -> int32_t {
+    const int64_t m = 4 * st + lg;
+    const int64_t mc = (st < s1 && m < g.M) ? m : 0;
+    return g.rows ? g.rows[mc] : (int32_t)mc;
+  };
+  int32_t rnext[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) rnext[d] = x0_row(s0 + d);
   for (int64_t s = s0; s < s1; s += DEPTH) {
     WgradFrag<TN, TK> f[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) f[d] = wgrad_load<TN, TK>(g, rz, rx0, rx1, s + d, s + d < s1, nb, kb, lr, lg, K);
+    for (int d = 0; d < DEPTH; ++d)
+      f[d] = wgrad_load<TN, TK>(g, rz, rx0, rx1, s + d, s + d < s1, rnext[d], nb, kb, lr, lg, K);
+    if (g.rows) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) rnext[d] = x0_row(s + DEPTH + d);
+    } else {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int64_t m = 4 * (s + DEPTH + d) + lg;
+        rnext[d] = (s + DEPTH + d < s1 && m < g.M) ? (int32_t)m : 0;
+      }
+    }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(f[d].a[a], f[d].b[b], acc[a][b]);
+  }
   }
 reduce_and_store:
   int64_t part = split;
