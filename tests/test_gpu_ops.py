@@ -479,6 +479,24 @@ def test_gemm_gather_concat_and_transposes(device):
     _close("colsum", ops.colsum(dzb.to(device)), dzb.double().sum(0), 1e-5, 5e-3)
 
 
+@pytest.mark.parametrize("M,N,ld", [(1083, 32, 32), (204800, 32, 32), (5000, 64, 96), (3001, 6, 6), (777, 1024, 1024),
+                                     (100, 2048, 2048), (1, 8, 8), (40000, 4, 4)])
+def test_colsum_row_shapes(device, M, N, ld):
+    """Bias gradients (``m3d_colsum_f32``): the float4 kernel (N / 4 a power of two <= 256, ld a multiple of 4 — also a column
+    slice of a wider matrix), the dword kernel for everything else (N = 6: fc_classif), row counts that end inside a trip of
+    eight rows, and ``out=`` as a gradient sink that is ADDED to."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M + N)
+    full = torch.from_numpy(rs.uniform(-1, 1, (M, ld)).astype(np.float32)).to(device)
+    x = full[:, :N]
+    ref = x.double().sum(0)
+    _close("colsum", ops.colsum(x), ref, 1e-5, 2e-4 * max(1.0, M ** 0.5))
+    sink = torch.full((N,), 3.0, device=device)
+    assert ops.colsum(x, out=sink) is None
+    _close("colsum.sink", sink, ref + 3.0, 1e-5, 2e-4 * max(1.0, M ** 0.5))
+
+
 # ----------------------------------------------------------------------------------------------- SharedMLP layer (train)
 def _cpu_layer(x, w, b, gamma, beta, act):
     lin = torch.nn.Linear(w.shape[1], w.shape[0])

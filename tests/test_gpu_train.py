@@ -9,7 +9,8 @@ from tests._util import fill_params_deterministic, rand_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,C,ignore", [(1000, 6, 65), (777, 7, 3), (5, 6, -100), (4096, 33, 0)])
+@pytest.mark.parametrize("n,C,ignore", [(1000, 6, 65), (777, 7, 3), (5, 6, -100), (4096, 33, 0), (300001, 6, 65), (70000, 8, 2),
+                                        (1, 1, -100)])
 def test_cross_entropy_matches_torch(device, n, C, ignore):
     from myria3d_amd import cross_entropy
 
