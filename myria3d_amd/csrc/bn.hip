@@ -285,26 +285,6 @@ struct BnBwdArgs {
   DropArgs drop; uint32_t dkey;  // thr16 != 0: the layer's output went through dropout: dy is masked first (dkey: set in-kernel)
 };
 
-__device__ __forceinline__ float4 bn_dact(const BnBwdArgs& a, int64_t i, int c, float4 zv, float4& z2v) {
-  float4 g = ((const float4*)a.dy)[i];
-  if (a.drop.thr16) {
-    const int n4 = a.N / 4;
-    const float4 m = drop_mul4(a.dkey, drop_index(a.drop, i / n4, (int)(i % n4), n4), a.drop.thr16, a.drop.scale);
-    g.x *= m.x; g.y *= m.y; g.z *= m.z; g.w *= m.w;
-  }
-  if (a.act) {
-    float4 sc = *(const float4*)(a.scale + c), sh = *(const float4*)(a.shift + c);
-    float4 u = make_float4(zv.x * sc.x + sh.x, zv.y * sc.y + sh.y, zv.z * sc.z + sh.z, zv.w * sc.w + sh.w);
-    if (a.z2) {
-      float4 s2 = *(const float4*)(a.scale2 + c), h2 = *(const float4*)(a.shift2 + c);
-      u.x += z2v.x * s2.x + h2.x; u.y += z2v.y * s2.y + h2.y; u.z += z2v.z * s2.z + h2.z; u.w += z2v.w * s2.w + h2.w;
-    }
-    g.x *= u.x > 0.f ? 1.f : a.slope; g.y *= u.y > 0.f ? 1.f : a.slope;
-    g.z *= u.z > 0.f ? 1.f : a.slope; g.w *= u.w > 0.f ? 1.f : a.slope;
-  }
-  return g;
-}
-
 // grid (row blocks, column passes): block (x, y) owns rows [x*rows_per_block, ...) and 256/rpp float4 column groups.
 // Per-thread fp32 partials over 8-16 rows, fp64 across threads (LDS), one partial row per block (slot atomics, or
 // part[x][3][N] summed by bn_bwd_finalize_kernel).
