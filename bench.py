@@ -467,11 +467,12 @@ def dropin_bench(args, dev):
 
     net.train()
     rs = np.random.RandomState(0)
-    var = []
+    var, var_sizes = [], []
     for i in range(8):
         sizes = [int(v) for v in rs.randint(N // 2, N + N // 2 + 1, size=B)]
         vx, vpos, vbatch, vptr, vy = synthetic_batch(sizes, first_tile_id=100 * i)
         var.append(tuple(t.to(dev) for t in (vx, vpos, vbatch, vptr, vy)))
+        var_sizes.append(sizes)
     turn = [0]
 
     def vstep():
@@ -507,12 +508,46 @@ def dropin_bench(args, dev):
         ostep()
     dto = timed(ostep, 16, 1) / 16
     net2.join_geometry()
+    # ... and when the loop hands over the tile sizes it already holds on the HOST (a loader collates on the CPU:
+    # ``batch.ptr.tolist()`` before the transfer costs nothing): the plan of every batch is built from
+    # them (a fresh ``make_plan`` per step, uploaded asynchronously) and nothing in the step reads the device — the host
+    # runs ahead of the GPU instead of waiting for the previous step at every ``ptr.tolist()``
+    from myria3d_amd import make_plan
+
+    host_ptr = [[0] + list(np.cumsum(sz_)) for sz_ in var_sizes]
+    live = {}
+
+    def hstep():
+        i, j = turn[0] % len(var), (turn[0] + 1) % len(var)
+        vx, vpos, vbatch, vptr, vy = var[i]
+        turn[0] += 1
+        live[j] = make_plan(host_ptr[j], 4, K, dev)
+        net2.prefetch_geometry(var[j][1], var[j][3], live[j], interleave=True)
+        cross_entropy(net2(vx, vpos, vbatch, vptr, plan=live.pop(i)), vy, ignore_index=65).backward()
+        opt2.step()
+
+    def hprime():
+        net2.join_geometry()
+        live.clear()
+        live[turn[0] % len(var)] = make_plan(host_ptr[turn[0] % len(var)], 4, K, dev)
+        net2.prefetch_geometry(var[turn[0] % len(var)][1], var[turn[0] % len(var)][3], live[turn[0] % len(var)])
+
+    hprime()
+    for _ in range(16):
+        hstep()
+    dth = timed(hstep, 16, 1) / 16
+    net2.join_geometry()
+    net2.prefetch_geometry(var[turn[0] % len(var)][1], var[turn[0] % len(var)][3])
     # ... and with the backward pass on the calling thread (one line at program start; one device per
     # process leaves the autograd engine's device thread nothing to overlap, and the hand-off costs ~10 us per node)
     torch.autograd.set_multithreading_enabled(False)
     for _ in range(8):
         ostep()
     dto_st = timed(ostep, 16, 1) / 16
+    hprime()
+    for _ in range(8):
+        hstep()
+    dth_st = timed(hstep, 16, 1) / 16
     net2.join_geometry()
     opt3 = torch.optim.Adam(net.parameters(), lr=0.003933709606504788)
 
@@ -534,6 +569,8 @@ def dropin_bench(args, dev):
                       "dropin_variable_layout_points_per_s": round(mean_pts / dtv, 1),
                       "optin_variable_layout_single_thread_autograd_ms_per_step": round(dto_st * 1e3, 4),
                       "dropin_variable_layout_single_thread_autograd_ms_per_step": round(dtv_st * 1e3, 4),
+                      "optin_host_sizes_variable_layout_ms_per_step": round(dth * 1e3, 4),
+                      "optin_host_sizes_variable_layout_single_thread_autograd_ms_per_step": round(dth_st * 1e3, 4),
                       "variable_layout": f"8 batches of {B} tiles, sizes uniform in [{N // 2}, {N + N // 2}] (mean "
                                          f"{mean_pts:.0f} points per batch), a different layout every step",
                       "fwd_only_ms": round(dtf * 1e3, 4), "unit": "points/s",
@@ -960,6 +997,8 @@ def _extra_legs(args, dev, res, B, N, K):
         res["optin_variable_layout_ms_per_step"] = di.get("optin_variable_layout_ms_per_step")
         res["optin_variable_layout_single_thread_autograd_ms_per_step"] = di.get("optin_variable_layout_single_thread_autograd_ms_per_step")
         res["dropin_variable_layout_single_thread_autograd_ms_per_step"] = di.get("dropin_variable_layout_single_thread_autograd_ms_per_step")
+        res["optin_host_sizes_variable_layout_ms_per_step"] = di.get("optin_host_sizes_variable_layout_ms_per_step")
+        res["optin_host_sizes_variable_layout_single_thread_autograd_ms_per_step"] = di.get("optin_host_sizes_variable_layout_single_thread_autograd_ms_per_step")
         res["dropin"] = di
 
     def collective():  # RCCL on this box: the N > 1 code path on a 1-rank group (collective + capture interplay)

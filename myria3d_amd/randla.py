@@ -74,21 +74,57 @@ class LevelPlan:
     ptrs: List[Tensor]  # device int64 [B+1] per level
     totals: List[int]
     num_edges: List[int] = field(default_factory=list)  # valid kNN edges per encoder level
+    staging: Optional[Tensor] = None  # pinned host copy of ``ptrs`` (source of the asynchronous upload)
+    ready: Optional[object] = None  # event behind that upload, None once it is known to have completed
 
 
 def make_plan(ptr_host: Sequence[int], decimation: int, num_neighbors: int, device, levels: int = 4) -> LevelPlan:
     sizes = [[int(ptr_host[i + 1]) - int(ptr_host[i]) for i in range(len(ptr_host) - 1)]]
     for _ in range(levels):
         sizes.append([max(1, n // decimation) for n in sizes[-1]])  # pyg_randla_net.py:215-217
-    ptrs, totals = [], []
+    flat, totals = [], []
     for s in sizes:
-        p = [0]
+        p = 0
+        flat.append(0)
         for n in s:
-            p.append(p[-1] + n)
-        ptrs.append(torch.tensor(p, dtype=torch.int64, device=device))
-        totals.append(p[-1])
+            p += n
+            flat.append(p)
+        totals.append(p)
+    # the per-level ``ptr`` vectors are ONE device tensor, uploaded by ONE copy.  On a GPU the copy leaves from pinned
+    # memory without waiting for the stream (``torch.tensor(list, device=cuda)`` is a blocking copy behind everything
+    # enqueued so far: five of them per layout, and a loop that builds its plans from host-side tile sizes —
+    # INTEGRATION.md section 3 — would stop at each one instead of running ahead of the device)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        staging = torch.empty(len(flat), dtype=torch.int64, pin_memory=True)
+        staging.copy_(torch.tensor(flat, dtype=torch.int64))
+        allp = staging.to(dev, non_blocking=True)
+    else:
+        staging = None
+        allp = torch.tensor(flat, dtype=torch.int64, device=dev)
+    nb = len(sizes[0]) + 1
+    ptrs = [allp[i * nb:(i + 1) * nb] for i in range(len(sizes))]
     num_edges = [sum(n * min(num_neighbors, n) for n in s) for s in sizes[:levels]]
-    return LevelPlan(sizes, ptrs, totals, num_edges)
+    plan = LevelPlan(sizes, ptrs, totals, num_edges)
+    plan.staging = staging  # (kept until the plan goes: the copy may still be in flight)
+    if staging is not None:
+        plan.ready = torch.cuda.Event()
+        plan.ready.record()  # consumers on OTHER streams wait for it (plan_ready): the blocking copy used to cover them
+    return plan
+
+
+def plan_ready(plan: LevelPlan) -> None:
+    """Order the current stream behind the upload of ``plan.ptrs`` (a no-op once the copy has completed, and inside a
+    stream capture — plans are built before a capture begins)."""
+    ev = plan.ready
+    if ev is None:
+        return
+    if ev.query():
+        plan.ready = None
+        return
+    main = torch.cuda.current_stream()
+    if ops.capture_id(main) == 0:
+        main.wait_event(ev)
 
 
 class HipRandLANet(nn.Module):
@@ -578,6 +614,7 @@ class HipRandLANet(nn.Module):
         ptr = ptr.to(torch.int64).contiguous()
         if plan is None:
             plan = self.plan_for(ptr)
+        plan_ready(plan)
         train = self.training if train is None else train
         key = (tuple(pos.shape), id(plan), bool(train))
         self._look_turn = (self._look_turn ^ 1) if slot is None else int(slot) & 1
@@ -590,6 +627,8 @@ class HipRandLANet(nn.Module):
                 and (old is None or old.consumer_fwd < self._fwd_count)
                 and ops.capture_id(main) == 0):
             side.wait_event(self._fwd_start)
+            if plan.ready is not None:
+                side.wait_event(plan.ready)  # (this branch does not wait for the main stream, which carries the plan's upload)
         else:
             side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -686,6 +725,7 @@ class HipRandLANet(nn.Module):
         the next level's permutation into a single row gather."""
         if plan is None:
             plan = self.plan_for(ptr)
+        plan_ready(plan)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
         if self.matmul_precision not in ("fp32", "bf16"):
             raise ValueError(f"matmul_precision must be 'fp32' or 'bf16', got {self.matmul_precision!r}")

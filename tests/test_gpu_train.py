@@ -173,6 +173,53 @@ def test_train_steps_follow_the_oracle(device):
     assert lg.item() < 3.0
 
 
+def test_plans_built_from_host_side_tile_sizes_give_the_same_steps(device):
+    """a loop that knows its tile sizes on the host builds every batch's plan with ``make_plan`` (one
+    asynchronous upload from pinned memory, no device read-back anywhere in the step) and hands the SAME object to
+    ``prefetch_geometry`` and ``forward``.  Four steps over four layouts, next batch's geometry interleaved: the same losses and parameters as the
+    loop that lets the net read ``ptr`` back from the device."""
+    from myria3d_amd import FusedAdam, HipRandLANet, cross_entropy, make_plan
+    from oracle.randla_oracle import RandLANetOracle
+
+    ref = RandLANetOracle(9, 6, return_logits=True)
+    fill_params_deterministic(ref, 9)
+    layouts = [[2600, 1900], [3100], [1500, 1700, 2100], [4000, 300]]
+    data = []
+    for i, sizes in enumerate(layouts):
+        x, pos, batch, ptr = rand_batch(sizes, seed=60 + i)
+        y = torch.from_numpy(np.random.RandomState(i).randint(0, 6, (sum(sizes),)))
+        data.append(tuple(t.to(device) for t in (x, pos, batch, ptr, y)))
+    runs = []
+    for host in (False, True):
+        torch.manual_seed(3)
+        net = HipRandLANet(9, 6, return_logits=True)
+        net.load_state_dict(ref.state_dict())
+        net = net.to(device).flatten_parameters().train()
+        opt = FusedAdam(net, lr=1e-3)
+        plans = [make_plan([0] + list(np.cumsum(s)), 4, 16, device) if host else None for s in layouts]
+        if host:
+            assert plans[0].staging is not None and plans[0].staging.is_pinned()
+            assert [p.tolist() for p in plans[2].ptrs][0] == [0, 1500, 3200, 5300]
+            assert plans[2].ptrs[1].tolist() == [0, 375, 800, 1325]  # pyg_randla_net.py:215-217: n // 4 per tile
+        net.prefetch_geometry(data[0][1], data[0][3], plans[0])
+        losses = []
+        for i, (x, pos, batch, ptr, y) in enumerate(data):
+            if i + 1 < len(data):
+                net.prefetch_geometry(data[i + 1][1], data[i + 1][3], plans[i + 1], interleave=True)
+            loss = cross_entropy(net(x, pos, batch, ptr, plan=plans[i]), y, ignore_index=65)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        net.join_geometry()
+        runs.append((losses, [p.detach().clone() for p in net.parameters()]))
+    print(f"[parity] losses (device read-back) {runs[0][0]} (host sizes) {runs[1][0]}")
+    # (not bit for bit: the grid build's and the LFA backward's atomics land in a different order from run to run)
+    assert np.allclose(runs[0][0], runs[1][0], rtol=2e-5)
+    worst = max((a_ - b_).abs().max().item() for a_, b_ in zip(runs[0][1], runs[1][1]))
+    print(f"[parity] largest parameter difference after 4 steps: {worst:.3e}")
+    assert worst < 4.5e-3  # (4 steps x lr 1e-3: Adam moves a weight by at most lr per step, whatever the gradient's size)
+
+
 def test_training_loop_over_changing_tile_layouts(device):
     """What a Lightning loop feeds the boundary (model.py:79): every batch has its own number of tiles and its own tile
     sizes (points_budget.yaml: 300 ... 40 000 nodes).  Four steps over four different layouts through the flat path — the
