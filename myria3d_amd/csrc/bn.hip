@@ -7,8 +7,12 @@
 //   m3d_bn_finalize   -> mean, invstd, folded (scale, shift), running-stat update
 //   m3d_bn_apply      -> y = act(z*scale + shift [+ z2*scale2 + shift2])     (the [+...] is the block's
 //                        residual: LeakyReLU(mlp2(x) + shortcut(x)), pyg_randla_net.py:186-187)
-//   m3d_bn_bwd_reduce / m3d_bn_bwd_apply -> gradient w.r.t. the raw Linear output(s), gamma, beta.
-// All HBM-bound elementwise / column-reduction kernels: float4 accesses, fp64 column accumulators.
+//   m3d_bn_stats_apply -> the two above in ONE launch from slot-mode statistics (what the training step uses), with the
+//                        classifier's dropout on the way out
+//   m3d_bn_bwd        -> column sums (bn_bwd_reduce_kernel) and, unless the input-gradient GEMM's prologue does it
+//                        (m3d_bn_dgrad_f32), the gradient w.r.t. the raw Linear output(s) (bn_bwd_apply_kernel); gamma, beta.
+// All HBM-bound elementwise / column-reduction kernels: float4 accesses, fp64 column accumulators, straight-line row
+// loops with 4-8 rows of every operand in flight (no load behind a branch inside a loop: DESIGN.md section 5).
 #include <stdlib.h>
 #include "m3d_common.h"
 #include "../../include/m3d_hip.h"

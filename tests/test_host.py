@@ -69,6 +69,16 @@ def test_level_plan_matches_reference_decimation_rule():
     assert [p.tolist() for p in plan.ptrs][1] == [0, 3200, 3212, 3213]
     assert plan.totals == [12851, 3213, 804, 202, 52]
     assert plan.num_edges[0] == 12800 * 16 + 50 * 16 + 1 and plan.num_edges[2] == 800 * 16 + 9 + 1
+    # all levels' ptr vectors are slices of ONE tensor (one upload); on the CPU there is no staging buffer and no event
+    assert [p.tolist() for p in plan.ptrs] == [[0, 12800, 12850, 12851], [0, 3200, 3212, 3213], [0, 800, 803, 804],
+                                               [0, 200, 201, 202], [0, 50, 51, 52]]
+    base = plan.ptrs[0].data_ptr()
+    assert [p.data_ptr() - base for p in plan.ptrs] == [32 * l for l in range(5)] and all(p.is_contiguous() for p in plan.ptrs)
+    assert plan.staging is None and plan.ready is None
+    from myria3d_amd.randla import plan_ready
+
+    plan_ready(plan)  # nothing to wait for: returns without touching a device
+    assert make_plan([0], 4, 16, "cpu").totals == [0, 0, 0, 0, 0]  # an empty batch still has its five (empty) levels
 
 
 def test_attention_weight_packing_is_the_mfma_b_fragment_order():
