@@ -119,12 +119,13 @@ def plan_ready(plan: LevelPlan) -> None:
     ev = plan.ready
     if ev is None:
         return
+    main = torch.cuda.current_stream()
+    if ops.capture_id(main) != 0:
+        return  # (no event query inside a capture; ``torch.cuda.graph`` synchronises the device before it begins)
     if ev.query():
         plan.ready = None
         return
-    main = torch.cuda.current_stream()
-    if ops.capture_id(main) == 0:
-        main.wait_event(ev)
+    main.wait_event(ev)
 
 
 class HipRandLANet(nn.Module):
