@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   }
 
   // ---- phase 3: softmax over each centre's neighbours + weighted sum, in the MFMA C layout
+  const float pinf = opaque_pinf();
 #pragma unroll
   for (int cc = 0; cc < MTW / KT; ++cc) {
     const int mt0 = wm * MTW + cc * KT;
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (vr[kt][r]) mx = fmaxf(mx, acc[cc * KT + kt][t][r]);
-      mx = xgroup_max(mx);
+          if (vr[kt][r]) mx = max_f(mx, acc[cc * KT + kt][t][r], pinf);
+      mx = xgroup_max(mx, pinf);
       float num = 0.f, den = 0.f;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     BWD_PRIO(4);
     if (LFA_BWD_DBG & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
+    const float pinf = opaque_pinf();
 #pragma unroll
     for (int cc = 0; cc < MTW / KT; ++cc) {
       const int mt0 = wm * MTW + cc * KT;
@@ -488,8 +489,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (vr[kt][r]) mx = fmaxf(mx, acc[cc * KT + kt][t][r]);
-        mx = xgroup_max(mx);
+            if (vr[kt][r]) mx = max_f(mx, acc[cc * KT + kt][t][r], pinf);
+        mx = xgroup_max(mx, pinf);
         float num = 0.f, den = 0.f;
         float fv[KT][4];
 #pragma unroll

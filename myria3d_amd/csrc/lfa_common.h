@@ -15,12 +15,21 @@ struct LfaArgs {
   float slope;
 };
 
+#ifndef LFA_FAST_SQRT
+#define LFA_FAST_SQRT 0
+#endif
 __device__ __forceinline__ void rel_pos(float4 pi, float4 pj, float (&r)[10]) {
   float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
   r[0] = pi.x; r[1] = pi.y; r[2] = pi.z;
   r[3] = pj.x; r[4] = pj.y; r[5] = pj.z;
   r[6] = dx; r[7] = dy; r[8] = dz;
+  // LFA_FAST_SQRT=1: v_sqrt_f32 (1 ulp) instead of the ~15-instruction correctly rounded sequence, once per edge in every
+  // LFA kernel (prepared at the end of round 4 with M3D_FAST_MAX; off until parity and time have been looked at on the GPU)
+#if LFA_FAST_SQRT
+  r[9] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+#else
   r[9] = sqrtf(dx * dx + dy * dy + dz * dz);
+#endif
 }
 
 // edge rows per forward workgroup (256 threads) per padded channel count; overridable for tuning sweeps

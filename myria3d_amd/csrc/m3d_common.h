@@ -112,10 +112,35 @@ __device__ __forceinline__ float xgroup_sum(float v) {
   xgroup_pair32(v, a, b); v = a + b;
   return v;
 }
-__device__ __forceinline__ float xgroup_max(float v) {
+// fmaxf() is three v_max_f32 whenever the compiler cannot prove that its operands are quiet (values out of a permlane
+// swap, an AGPR, LDS): both are canonicalised first.  M3D_FAST_MAX=1: v_med3_f32(a, b, +inf) — the median of the three IS
+// the maximum of the two, one instruction, the same value for every pair without a NaN.  The +inf comes from opaque_pinf(),
+// once per kernel: the optimiser folds med3(a, b, +inf) with a visible constant back into maxnum and its canonicalisations.
+// Prepared at the end of round 4 from the ISA of lfa_fwd_kernel<8,16> (36 of its 56 v_max_f32 are canonicalisations: 500 ->
+// 474 VALU instructions); off until it has had its A/B run on the GPU.
+#ifndef M3D_FAST_MAX
+#define M3D_FAST_MAX 0
+#endif
+__device__ __forceinline__ float opaque_pinf() {
+#if M3D_FAST_MAX
+  unsigned u;
+  asm("s_mov_b32 %0, 0x7f800000" : "=s"(u));
+  return __uint_as_float(u);
+#else
+  return __builtin_inff();
+#endif
+}
+__device__ __forceinline__ float max_f(float a, float b, float pinf) {
+#if M3D_FAST_MAX
+  return __builtin_amdgcn_fmed3f(a, b, pinf);
+#else
+  return fmaxf(a, b);
+#endif
+}
+__device__ __forceinline__ float xgroup_max(float v, float pinf) {
   float a, b;
-  xgroup_pair16(v, a, b); v = fmaxf(a, b);
-  xgroup_pair32(v, a, b); v = fmaxf(a, b);
+  xgroup_pair16(v, a, b); v = max_f(a, b, pinf);
+  xgroup_pair32(v, a, b); v = max_f(a, b, pinf);
   return v;
 }
 // fp64 sums across lanes without the LDS pipe: __shfl_xor on a double is two ds_bpermute_b32 per step; the two 32-bit halves
