@@ -108,8 +108,9 @@ def make_plan(ptr_host: Sequence[int], decimation: int, num_neighbors: int, devi
     plan = LevelPlan(sizes, ptrs, totals, num_edges)
     plan.staging = staging  # (kept until the plan goes: the copy may still be in flight)
     if staging is not None:
-        plan.ready = torch.cuda.Event()
-        plan.ready.record()  # consumers on OTHER streams wait for it (plan_ready): the blocking copy used to cover them
+        with torch.cuda.device(dev):  # (the copy went to ``dev``'s current stream, whichever device is current here)
+            plan.ready = torch.cuda.Event()
+            plan.ready.record()  # consumers on OTHER streams wait for it (plan_ready): the blocking copy used to cover them
     return plan
 
 
