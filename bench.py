@@ -223,20 +223,25 @@ def stage_rooflines(net, pos, plan):
         x, o = torch.randn(n, D, device=dev), torch.empty((n, ch), device=dev)
         ms = _time_launch(lambda: ops.call(
             "m3d_lfa_fwd", x.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
-            bf.data_ptr(), wp.data_ptr(), ops.LRELU_SLOPE, o.data_ptr(), st))
+            bf.data_ptr(), wp.data_ptr(), ops.LRELU_SLOPE, o.data_ptr(), ops.LFA_FULL, st))
         return ch, n, ms
 
     def time_lfa_bwd(lfa, lvl, geo):
+        """(ms of the kernel as the training step launches it — flags 1 | 2 | 4 | 8: dW_att accumulated, G pre-zeroed, the
+        partial-sum reduce deferred to the end of the backward pass, complete neighbourhoods: ONE kernel, what the
+        rocprofv3 kernel trace lists under its name —, ms of the self-contained call with its memsets + reduce)"""
         ch, n, D, wf, bf, wp, wpt = lfa_operands(lfa, lvl, geo)
         xin, dout = torch.randn(n, D, device=dev), torch.randn(n, ch, device=dev)
-        dx, dw = torch.zeros((n, D), device=dev), torch.empty((ch, ch), device=dev)
-        G = torch.empty(11 * D, dtype=torch.float64, device=dev)
+        dx, dw = torch.zeros((n, D), device=dev), torch.zeros((ch, ch), device=dev)
+        G = torch.zeros(11 * D, dtype=torch.float64, device=dev)
         ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
-        ms = _time_launch(lambda: ops.call(
-            "m3d_lfa_bwd", xin.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
-            bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(),
-            0, G.data_ptr(), ws.data_ptr(), st))
-        return ch, n, D, ms
+
+        def launch(flags):
+            return lambda: ops.call(
+                "m3d_lfa_bwd", xin.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
+                bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                flags, G.data_ptr(), ws.data_ptr(), st)
+        return ch, n, D, _time_launch(launch(1 | 2 | 4 | 8)), _time_launch(launch(8))
 
     def hbm_entry(kernel, nbytes, ms, prefix, grid=None):
         gbs = nbytes / (ms * 1e-3) / 1e9
@@ -250,7 +255,7 @@ def stage_rooflines(net, pos, plan):
         geo = net._geometry(pos, plan, None, True)
         net.overlap_geometry, net.batch_geometry = keep, keep_b
         # ---- dominant kernel: LFA backward at level 2, ch = 64
-        ch, n2, D, ms = time_lfa_bwd(net.block2.lfa2, 1, geo)
+        ch, n2, D, ms, ms_self = time_lfa_bwd(net.block2.lfa2, 1, geo)
         # ALGORITHMIC flops of this backward (backward = 2 x forward: dF = dA W and dW = dA^T F, plus the
         # encoder's two transposes) vs the flops the kernel EXECUTES (it recomputes the forward attention GEMM
         # A = F W^T instead of saving [E, ch] logits: a third GEMM)
@@ -258,14 +263,19 @@ def stage_rooflines(net, pos, plan):
         flop_exe = 3 * 2 * n2 * K * (ch * ch + 10 * D)
         tf = flop_alg / (ms * 1e-3) / 1e12
         tf_exe = flop_exe / (ms * 1e-3) / 1e12
-        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16> (block2.lfa2, ch={ch}, n={n2}, K={K}) + partial reduce",
+        out["dominant"] = {"kernel": f"lfa_bwd_kernel<64,16,PIPE,fp32,FULL> (block2.lfa2, ch={ch}, n={n2}, K={K}), launched as in the "
+                                     "step (partial-sum reduce deferred to the end of the backward pass)",
                            "bound": "mfma", "achieved": round(tf, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                            "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
                            "frac_algorithmic": round(tf / FP32_MFMA_PEAK_TF, 4),
                            "frac_executed": round(tf_exe / FP32_MFMA_PEAK_TF, 4),
                            **_traffic_fields("void lfa_bwd_kernel<64, 16, true"),
                            "algorithmic_flop_per_launch": flop_alg, "executed_flop_per_launch": flop_exe,
-                           "avg_launch_ms": round(ms, 4)}
+                           "avg_launch_ms": round(ms, 4),
+                           # rounds 1-4 timed the self-contained call (two memsets + this layer's partial-sum reduce behind
+                           # the kernel): kept beside it for continuity
+                           "self_contained_call_ms": round(ms_self, 4),
+                           "frac_self_contained_call": round(flop_alg / (ms_self * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
         # ---- kNN + LSE gather stage: the K-NN tables of all four levels, both LFA layers of level 1 fwd + bwd
         stage = []
         for lvl in range(4):
@@ -279,11 +289,11 @@ def stage_rooflines(net, pos, plan):
                                    KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], ((n + 63) // 64 * 64, (n + 255) // 256 * 256)))
         for lfa in (net.block1.lfa1, net.block1.lfa2):
             ch1, n1, ms_f = time_lfa_fwd(lfa, 0, geo)
-            stage.append(hbm_entry(f"lfa_fwd_kernel<{max(ch1, 16) if ch1 > 8 else 8},16> (level 1, ch={ch1}, n={n1}, K={K})",
-                                   n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1), ms_f, f"void lfa_fwd_kernel<{ch1}, 16"))
+            stage.append(hbm_entry(f"lfa_fwd_full_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
+                                   n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1), ms_f, f"void lfa_fwd_full_kernel<{ch1}, 16"))
         for lfa in (net.block1.lfa1, net.block1.lfa2):
-            ch1, n1, D1, ms_b = time_lfa_bwd(lfa, 0, geo)
-            stage.append(hbm_entry(f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K}) + partial reduce",
+            ch1, n1, D1, ms_b, _ = time_lfa_bwd(lfa, 0, geo)
+            stage.append(hbm_entry(f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
                                    n1 * (12 + 4 * D1 + 4 * ch1 + 4 * K) + 4 * n1 * D1, ms_b,
                                    f"void lfa_bwd_kernel<{ch1}, 16"))
         out["knn_lse"] = stage

@@ -32,7 +32,7 @@ extern "C" {
  * mask is then a function of the CALLER's element, independent of that order. */
 typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; } M3DDropout;
 
-#define M3D_ABI_VERSION 14
+#define M3D_ABI_VERSION 15
 #define M3D_ADAM_STATE_WORDS 66
 #define M3D_CE_ACC_DOUBLES 516
 int m3d_abi_version(void);
@@ -256,7 +256,7 @@ int m3d_lfa_prepare_batch(int32_t njobs, const double* const* mom65, const int64
  * att_w_packed_bf16: m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1) output `packed`. */
 int m3d_lfa_fwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                      const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16, float slope,
-                     float* out, void* stream);
+                     float* out, int32_t flags /* as m3d_lfa_fwd */, void* stream);
 /* W_att [CH, CH] fp32 -> bf16 operand fragments [CH/16][CH/32][64 lanes][8]:
  * packed: element i of lane l = W[16 nt + (l & 15)][32 ks + 8 (l >> 4) + i]; packed_t (optional): the same of W^T. */
 int m3d_lfa_pack_att_bf16(const float* w, int32_t CH, void* packed, void* packed_t, void* stream);
@@ -266,9 +266,14 @@ int m3d_lfa_pack_att_bf16(const float* w, int32_t CH, void* packed, void* packed
  *   packed[nt][s4][lane][i] = W[16*nt + (lane & 15)][4*(4*s4 + i) + (lane >> 4)]. */
 /* packs W_att (and, if packed_t != NULL, W_att^T) into that order: max(CH,16)^2 floats each */
 int m3d_lfa_pack_att(const float* w /* [CH, CH] row-major */, int32_t CH, float* packed, float* packed_t, void* stream);
+/* flags bit 0 (M3D_LFA_FULL): the caller PROMISES that every entry of idx is a valid row (no -1 padding: every cloud of the
+ * level has at least K points).  With K in {16, 32} the launch then takes the mask-free kernel (round 5; two centres per MFMA
+ * tile at CH = 8); without the promise, or for other K, the general kernel.  Same results up to fp32 rounding of the
+ * softmax exponent and the edge length (1 ulp). */
+#define M3D_LFA_FULL 1
 int m3d_lfa_fwd(const float* x /* [n, CH/2] */, const float* pos4, const int32_t* idx, int64_t n, int32_t K,
                 int32_t CH, const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
-                float slope, float* out, void* stream);
+                float slope, float* out, int32_t flags, void* stream);
 /* fused backward of m3d_lfa_fwd (recomputes the forward tile-by-tile; nothing of size [E,.] in HBM):
  *   dx[n, CH/2]  += d/dx           (atomically accumulated: zero it first)
  *   dw_att[CH,CH] = d/dW_att,  G[CH/2][11] (fp64) = sum_e dy_e [r_e | 1]  (input of m3d_lfa_enc_bwd_finalize)
@@ -277,7 +282,9 @@ size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH);
 int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                 const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
                 const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
-                int32_t flags /* bit 0: add into dw_att instead of overwriting; bit 1: G is already zero */, double* G,
+                int32_t flags /* bit 0: add into dw_att instead of overwriting; bit 1: G is already zero; bit 2: leave the
+                                 workgroup partials in ws (m3d_lfa_bwd_reduce_batch sums them later); bit 3: complete
+                                 neighbourhoods promised (as M3D_LFA_FULL of m3d_lfa_fwd: the mask-free kernel) */, double* G,
                 void* ws, void* stream);
 /* bf16 matrix-core variant (CH in {64, 128, 256}): the recomputed attention logits, dF and dW_att GEMMs take bf16
  * operands (fp32 accumulate); att_w*_packed_bf16 from m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1). */

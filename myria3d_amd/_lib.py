@@ -59,9 +59,9 @@ SIGNATURES = {
                                _p]),
     "m3d_lfa_prepare_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                      _p]),
-    "m3d_lfa_fwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
+    "m3d_lfa_fwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _i32, _p]),
     "m3d_lfa_pack_att_bf16": (_i32, [_p, _i32, _p, _p, _p]),
-    "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _p]),
+    "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _i32, _p]),
     "m3d_lfa_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
     "m3d_lfa_bwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
@@ -98,7 +98,7 @@ class M3DDropout(C.Structure):
     _fields_ = [("counter", C.c_void_p), ("seed", C.c_uint64), ("p", C.c_float), ("rows", C.c_void_p)]
 
 
-ABI_VERSION = 14  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 15  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

@@ -211,9 +211,231 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   }
 }
 
+// ---- the fast path (round 5): every neighbourhood is complete (K == KP and every id >= 0: the caller's promise,
+// flags bit 0) and every byte offset fits 32 bits.  Same arithmetic order per output as lfa_fwd_kernel except where noted;
+// built from the ISA of the general kernel (tools/isa_count.py: 484 / 523 VALU instructions per wavefront of 64 edges at
+// ch = 8 / 16, a kernel that is VALU-issue bound):
+//   * no validity masks (the general kernel pays four s_and_saveexec branches, a v_cndmask chain and zero fills per
+//     output register for the -1 padding of clouds with fewer than K points);
+//   * one dependent load chain per thread — id -> (x_j chunk, p_j) with p_i beside it — instead of ids through LDS, a
+//     barrier, then the gathers: the thread that owns edge row e loads ITS row's chunk of x_j, so the id stays in a
+//     register and the nbr[] table and its barrier are gone;
+//   * 32-bit byte offsets on scalar bases (global_load ... v_off, s[base]) instead of 64-bit pointer arithmetic;
+//   * softmax: exp2(fma(a, log2 e, -max * log2 e)) — one fma + v_exp_f32 per edge instead of sub, mul, exp —, one-instruction
+//     maxima (v_med3_f32 with +inf: max_f), raw v_sqrt_f32 for the edge length, LeakyReLU as max(v, slope * v)
+//     (0 <= slope <= 1: checked by the host);
+//   * ch = 8 (PACK2): TWO centres per 16-row MFMA tile.  The general kernel pads ch = 8 to a 16 x 16 x 16 product, i.e.
+//     3/4 of the tile's flops and half of the softmax lanes are padding.  Here packed row p * KP + k holds neighbour k of
+//     centre 2p in columns 0-7 and of centre 2p + 1 in columns 8-15, the B operand is diag(W^T, W^T) (assembled from the
+//     standard fragments: lane (n, g) of the lower block reads what lane (n - 8, g) holds), and output column c of a tile
+//     is channel c % 8 of centre 2p + c / 8: half the MFMAs, half the softmax passes, every lane busy, no zero fill.
+template <int CH, int KP, bool BF>
+__global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
+  constexpr bool PACK2 = CH == 8;
+  constexpr int CHP = CH < 16 ? 16 : CH;
+  constexpr int D = CH / 2;
+  constexpr int ROWS = LfaCfg<CHP>::ROWS;  // edge rows per workgroup
+  constexpr int TC = ROWS / KP;            // centres per workgroup
+  constexpr int KT = KP / 16;
+  constexpr int STR = CHP + 2;
+  constexpr int PROWS = PACK2 ? ROWS / 2 : ROWS;  // rows of the LDS tile
+  constexpr int MT = PROWS / 16, NT = CHP / 16;
+  constexpr int WN = NT < 4 ? NT : 4, WM = 4 / WN;
+  constexpr int NTW = NT / WN, MTW = MT / WM;
+  constexpr int S4 = CHP / 16;
+  constexpr int NG = 256 / ROWS;  // threads per edge row
+  constexpr int DG = D / NG;      // x_j floats and encoder channels per thread
+  constexpr int G4 = DG / 4;
+  static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
+  static_assert(DG % 4 == 0 && G4 >= 1, "a thread gathers whole float4s");
+  static_assert(!PACK2 || (TC % 2 == 0), "pairs of centres");
+  __shared__ float F[PROWS * STR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const unsigned n = (unsigned)a.n;
+  const unsigned c0 = (unsigned)xcd_major(blockIdx.x, gridDim.x) * TC;
+  const int e = tid % ROWS;
+  const int g = __builtin_amdgcn_readfirstlane(tid / ROWS);
+
+  // ---- phase 1: one load chain per thread
+  unsigned eo = c0 * KP + e;
+  const unsigned elast = n * KP - 1;
+  eo = eo < elast ? eo : elast;  // rows past the last centre repeat its last edge (computed, never stored)
+  unsigned ci = c0 + e / KP;
+  ci = ci < n ? ci : n - 1;
+  const unsigned j = (unsigned)a.idx[eo];
+  const float4 pi = *(const float4*)((const char*)a.pos4 + ci * 16u);
+  const float4 pj = *(const float4*)((const char*)a.pos4 + j * 16u);
+  float4 xg[G4];
+#pragma unroll
+  for (int u = 0; u < G4; ++u)
+    xg[u] = *(const float4*)((const char*)a.x + (j * (unsigned)(D * 4) + (unsigned)((g * DG + u * 4) * 4)));
+  // B fragments of the first k-step group: independent of everything above, in flight during phase 1
+  const int wn = wid % WN, wm = wid / WN;
+  float4 b0[NTW];
+  if constexpr (!BF) {
+    if constexpr (PACK2) {
+      const float4 t = a.wp[lr < 8 ? lane : lane - 8];
+      b0[0] = lr < 8 ? make_float4(t.x, t.y, 0.f, 0.f) : make_float4(0.f, 0.f, t.x, t.y);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) b0[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
+    }
+  }
+  // row of the LDS tile and column base of this thread's edge
+  int prow, cbase;
+  if constexpr (PACK2) {
+    const int cl = e / KP, k = e % KP;
+    prow = (cl >> 1) * KP + k;
+    cbase = (cl & 1) * 8;
+  } else {
+    prow = e;
+    cbase = 0;
+  }
+  float* frow = &F[prow * STR + cbase];
+#pragma unroll
+  for (int u = 0; u < G4; ++u) {
+    float* d = frow + g * DG + u * 4;
+    *(float2*)d = make_float2(xg[u].x, xg[u].y);
+    *(float2*)(d + 2) = make_float2(xg[u].z, xg[u].w);
+  }
+  {
+    float r[10];
+    const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+    r[0] = pi.x; r[1] = pi.y; r[2] = pi.z; r[3] = pj.x; r[4] = pj.y; r[5] = pj.z; r[6] = dx; r[7] = dy; r[8] = dz;
+    r[9] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+#pragma unroll
+    for (int cc = 0; cc < DG; ++cc) {
+      const int c = g * DG + cc;
+      const float* w = a.wf + c * 10;
+      float v = a.bf[c];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+      frow[D + c] = fmaxf(v, v * a.slope);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: A = F * W_att^T on MFMA
+  f32x4 acc[MTW][NTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (BF) {
+    static_assert(!BF || CHP % 32 == 0, "bf16 tiles are 32 deep");
+    constexpr int KS = CHP / 32;
+    const uint4* wpb = (const uint4*)a.wp;
+    const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg * 8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Bf16Frag b[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+      }
+    }
+  } else {
+    const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg];
+#pragma unroll 1
+    for (int s4 = 0; s4 < S4; ++s4) {
+      float4 b[NTW];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) b[t] = b0[t];
+      if (s4 + 1 < S4) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b0[t] = a.wp[((size_t)(wn * NTW + t) * S4 + s4 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float av[MTW];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) av[m] = fa[m * 16 * STR + (s4 * 4 + i) * 4];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const float bv = i == 0 ? b[t].x : (i == 1 ? b[t].y : (i == 2 ? b[t].z : b[t].w));
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) acc[m][t] = mfma16(av[m], bv, acc[m][t]);
+        }
+      }
+    }
+  }
+
+  // ---- phase 3: softmax over each centre's KP neighbours + weighted sum, in the MFMA C layout (no masks)
+  const float pinf = fast_pinf();
+  constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+  for (int cc = 0; cc < MTW / KT; ++cc) {
+    const int mt0 = wm * MTW + cc * KT;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (wn * NTW + t) * 16 + lr;
+      float mx = acc[cc * KT][t][0];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt + r > 0) mx = fast_max(mx, acc[cc * KT + kt][t][r], pinf);
+      {
+        float p, q;
+        xgroup_pair16(mx, p, q); mx = fast_max(p, q, pinf);
+        xgroup_pair32(mx, p, q); mx = fast_max(p, q, pinf);
+      }
+      const float ml = mx * LOG2E;
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[cc * KT + kt][t][r], LOG2E, -ml));
+          const float f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
+          num = __builtin_fmaf(p, f, num);
+          den += p;
+        }
+      num = xgroup_sum(num);
+      den = xgroup_sum(den);
+      // output row: PACK2 — tile mt0 / KT is centre pair (c0 / 2 + that), its 16 columns are 2 x 8 channels = 16 consecutive
+      // floats of out; otherwise centre c0 + mt0 / KT, column col
+      unsigned orow, ocol;
+      bool ok;
+      if constexpr (PACK2) {
+        const unsigned cen = c0 + 2u * (unsigned)(mt0 / KT) + (unsigned)(lr >> 3);
+        ok = cen < n;
+        orow = c0 + 2u * (unsigned)(mt0 / KT);
+        ocol = (unsigned)lr;
+      } else {
+        orow = c0 + (unsigned)(mt0 / KT);
+        ok = orow < n && col < CH;
+        ocol = (unsigned)col;
+      }
+      if (lg == 0 && ok)
+        *(float*)((char*)a.out + (orow * (unsigned)(CH * 4) + ocol * 4u)) = num * __builtin_amdgcn_rcpf(den + 1e-16f);
+    }
+  }
+}
+
+// fast path: the caller promises complete neighbourhoods (flags bit 0), K fills its MFMA tiles exactly, every byte offset
+// fits 32 bits and LeakyReLU can be written max(v, slope v)
+static inline bool lfa_full_ok(const LfaArgs& a, int flags) {
+  const int64_t lim = (int64_t)1 << 31;
+  return (flags & 1) && (a.K == 16 || a.K == 32) && a.n * a.K < lim && a.n * (int64_t)a.CH * 4 < lim && a.n * 16 < lim &&
+         a.slope >= 0.f && a.slope <= 1.f;
+}
+
 template <int CH, bool BF = false>
-static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st) {
+static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st, int flags) {
   constexpr int ROWS = LfaCfg<(CH < 16 ? 16 : CH)>::ROWS;
+  if (lfa_full_ok(a, flags)) {
+    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
+    return M3D_OK;
+  }
   if (a.K <= 16) {
     hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
   } else {
@@ -225,7 +447,7 @@ static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st) {
 
 extern "C" int m3d_lfa_fwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                            const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
-                           float slope, float* out, void* stream) {
+                           float slope, float* out, int32_t flags, void* stream) {
   if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
   if (n == 0) return M3D_OK;
   if (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed || !out) return M3D_ERR_INVALID;
@@ -237,18 +459,18 @@ extern "C" int m3d_lfa_fwd(const float* x, const float* pos4, const int32_t* idx
   a.wp = (const float4*)att_w_packed; a.out = out; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
   hipStream_t st = (hipStream_t)stream;
   switch (CH) {
-    case 8: return launch_lfa_fwd<8>(a, st);
-    case 16: return launch_lfa_fwd<16>(a, st);
-    case 32: return launch_lfa_fwd<32>(a, st);
-    case 64: return launch_lfa_fwd<64>(a, st);
-    case 128: return launch_lfa_fwd<128>(a, st);
-    default: return launch_lfa_fwd<256>(a, st);
+    case 8: return launch_lfa_fwd<8>(a, st, flags);
+    case 16: return launch_lfa_fwd<16>(a, st, flags);
+    case 32: return launch_lfa_fwd<32>(a, st, flags);
+    case 64: return launch_lfa_fwd<64>(a, st, flags);
+    case 128: return launch_lfa_fwd<128>(a, st, flags);
+    default: return launch_lfa_fwd<256>(a, st, flags);
   }
 }
 
 extern "C" int m3d_lfa_fwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                                 const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16,
-                                float slope, float* out, void* stream) {
+                                float slope, float* out, int32_t flags, void* stream) {
   if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
   if (n == 0) return M3D_OK;
   if (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed_bf16 || !out) return M3D_ERR_INVALID;
@@ -260,10 +482,10 @@ extern "C" int m3d_lfa_fwd_bf16(const float* x, const float* pos4, const int32_t
   a.wp = (const float4*)att_w_packed_bf16; a.out = out; a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
   hipStream_t st = (hipStream_t)stream;
   switch (CH) {
-    case 32: return launch_lfa_fwd<32, true>(a, st);
-    case 64: return launch_lfa_fwd<64, true>(a, st);
-    case 128: return launch_lfa_fwd<128, true>(a, st);
-    default: return launch_lfa_fwd<256, true>(a, st);
+    case 32: return launch_lfa_fwd<32, true>(a, st, flags);
+    case 64: return launch_lfa_fwd<64, true>(a, st, flags);
+    case 128: return launch_lfa_fwd<128, true>(a, st, flags);
+    default: return launch_lfa_fwd<256, true>(a, st, flags);
   }
 }
 

@@ -40,6 +40,10 @@ struct LfaBwdArgs {
 #ifndef LFA_BWD_DBG
 #define LFA_BWD_DBG 0
 #endif
+// A/B builds only: 1 = ignore the FULL promise (flags bit 3) and launch the general kernels
+#ifndef LFA_BWD_DBG_NOFULL
+#define LFA_BWD_DBG_NOFULL 0
+#endif
 // tile geometry of the backward kernel per padded channel count: edge rows per workgroup iteration, waves per
 // workgroup, cap on resident (persistent) workgroups.  Overridable at compile time for tuning sweeps.
 // 1: double-buffer the weight fragments of GEMM-1 / GEMM-2 in the non-pipelined kernel (ch >= 128): untuned A/B knob
@@ -143,7 +147,13 @@ template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = 
 // BF (ch >= 64): the three attention GEMMs (recomputed logits, dF, dW_att) take bf16 operands on
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation — fragments are rounded when they are built from the fp32 LDS tiles
 // (a.wp / a.wpt then hold the bf16 fragments of m3d_lfa_pack_att_bf16); everything else is unchanged fp32.
-template <int CH, int KP, bool PIPE, bool BF = false>
+// FULL (round 5; flags bit 3 of m3d_lfa_bwd): the caller promises complete neighbourhoods (K == KP, every id >= 0) and the
+// host has checked that every byte offset fits 32 bits — the validity masks of every phase (zero fills of masked rows, the
+// s_and_saveexec branches around each output register, the v_cndmask chains of the maxima), the 64-bit pointer arithmetic
+// and the three-instruction maxima / IEEE square root / sub-mul-exp of the general kernel are compiled out: read off the
+// ISA (tools/isa_count.py), the kernels are VALU-issue bound beside their MFMAs.  Centres past n (last group) are
+// computed from clamped rows with dout = 0: every contribution they make is an exact zero.
+template <int CH, int KP, bool PIPE, bool BF = false, bool FULL = false>
 __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
@@ -213,7 +223,14 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   float4 xg[GPT], ppi, ppj;
   float dgp[NCW][NTW], dgc[NCW][NTW];
   int jn = -1;
+  const unsigned n32 = (unsigned)a.n, elast = n32 * KP - 1u;
   auto load_idx = [&](int64_t g) -> int {
+    if constexpr (FULL) {
+      // (groups past the end re-read the last edge: an unconditional load, its row never used)
+      unsigned eo = (unsigned)g * ROWS + (unsigned)(tid < ROWS ? tid : 0);
+      eo = eo < elast ? eo : elast;
+      return a.idx[eo];
+    }
     int j = -1;
     if (tid < ROWS && g < gend) {
       const int ci = tid / KP, k = tid % KP;
@@ -224,6 +241,33 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   };
   auto prefetch = [&](int64_t g, const int* nb) {
     const int64_t c0 = g * TC;
+    if constexpr (FULL) {
+      const unsigned c32 = (unsigned)c0;
+#pragma unroll
+      for (int u = 0; u < GPT; ++u) {
+        const int f = tid + u * NTHR;
+        const int e = (f / D4) % ROWS, c4 = f % D4;
+        xg[u] = *(const float4*)((const char*)a.x + ((unsigned)nb[e] * (unsigned)(D * 4) + (unsigned)(c4 * 16)));
+      }
+      {
+        const int e = tid % ROWS;
+        unsigned i = c32 + (unsigned)(e / KP);
+        i = i < n32 ? i : n32 - 1u;
+        ppi = *(const float4*)((const char*)a.pos4 + i * 16u);
+        ppj = *(const float4*)((const char*)a.pos4 + (unsigned)nb[e] * 16u);
+      }
+#pragma unroll
+      for (int cc = 0; cc < NCW; ++cc) {
+        unsigned i = c32 + (unsigned)((wm * MTW + cc * KT) / KT);
+        i = i < n32 ? i : n32 - 1u;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const int col = (wn * NTW + t) * 16 + lr;
+          dgp[cc][t] = *(const float*)((const char*)a.dout + (i * (unsigned)(CH * 4) + (unsigned)((col < CH ? col : CH - 1) * 4)));
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < GPT; ++u) {
       const int f = tid + u * NTHR;
@@ -269,7 +313,9 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           if (f < ROWS * D4) {
             const int e = f / D4, c4 = f % D4;
             float4 v = xg[u];
-            if (nbr[e] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!FULL) {
+              if (nbr[e] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             float* d = &F[e * STR + c4 * 4];
             *(float2*)d = make_float2(v.x, v.y);
             *(float2*)(d + 2) = make_float2(v.z, v.w);
@@ -286,9 +332,10 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         const int e = tid % ROWS;
         const int grp_c = __builtin_amdgcn_readfirstlane(tid / ROWS);
         constexpr int DG = D / NG;
-        const int j = nbr[e];
+        const int j = FULL ? 0 : nbr[e];
         float r[10];
-        rel_pos(ppi, ppj, r);
+        if constexpr (FULL) rel_pos_fast(ppi, ppj, r);
+        else rel_pos(ppi, ppj, r);
         if (j < 0) {
 #pragma unroll
           for (int q = 0; q < 10; ++q) r[q] = 0.f;
@@ -306,7 +353,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           float v = a.bf[c];
 #pragma unroll
           for (int q = 0; q < 10; ++q) v += w[q] * r[q];
-          F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+          if constexpr (FULL) F[e * STR + D + c] = fmaxf(v, v * a.slope);  // (0 <= slope <= 1: checked by the host)
+          else F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
         }
       }
 #pragma unroll
@@ -318,11 +366,16 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     } else {
       // ---- phase 1a: neighbour ids
       for (int e = tid; e < ROWS; e += NTHR) {
-        int ci = e / KP, k = e % KP;
-        int64_t i = c0 + ci;
-        int j = -1;
-        if (i < a.n && k < K) j = a.idx[i * K + k];
-        nbr[e] = j;
+        if constexpr (FULL) {
+          unsigned eo = (unsigned)c0 * KP + (unsigned)e;
+          nbr[e] = a.idx[eo < elast ? eo : elast];
+        } else {
+          int ci = e / KP, k = e % KP;
+          int64_t i = c0 + ci;
+          int j = -1;
+          if (i < a.n && k < K) j = a.idx[i * K + k];
+          nbr[e] = j;
+        }
       }
       __syncthreads();
       // ---- phase 1b: gather x_j
@@ -332,7 +385,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           int e = f / D4, c4 = f % D4;
           int j = nbr[e];
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
+          if constexpr (FULL) v = *(const float4*)((const char*)a.x + ((unsigned)j * (unsigned)(D * 4) + (unsigned)(c4 * 16)));
+          else if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
           float* d = &F[e * STR + c4 * 4];
           *(float2*)d = make_float2(v.x, v.y);
           *(float2*)(d + 2) = make_float2(v.z, v.w);
@@ -353,7 +407,11 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         float r[10];
 #pragma unroll
         for (int q = 0; q < 10; ++q) r[q] = 0.f;
-        if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
+        if constexpr (FULL) {
+          unsigned i32 = (unsigned)c0 + (unsigned)(e / KP);
+          i32 = i32 < n32 ? i32 : n32 - 1u;
+          rel_pos_fast(*(const float4*)((const char*)a.pos4 + i32 * 16u), *(const float4*)((const char*)a.pos4 + (unsigned)j * 16u), r);
+        } else if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
         if (grp_c == 0) {
           float* rt = &RT[e * RSTR];
 #pragma unroll
@@ -367,7 +425,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           float v = a.bf[c];
 #pragma unroll
           for (int q = 0; q < 10; ++q) v += w[q] * r[q];
-          F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
+          if constexpr (FULL) F[e * STR + D + c] = fmaxf(v, v * a.slope);
+          else F[e * STR + D + c] = j >= 0 ? lrelu(v, a.slope) : 0.f;
         }
       }
       __syncthreads();
@@ -471,7 +530,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     BWD_PRIO(4);
     if (LFA_BWD_DBG & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
-    const float pinf = opaque_pinf();
+    const float pinf = FULL ? fast_pinf() : opaque_pinf();
 #pragma unroll
     for (int cc = 0; cc < MTW / KT; ++cc) {
       const int mt0 = wm * MTW + cc * KT;
@@ -480,29 +539,48 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vr[kt][r] = nbr[(mt0 + kt) * 16 + lg * 4 + r] >= 0;
+        for (int r = 0; r < 4; ++r) vr[kt][r] = FULL ? true : nbr[(mt0 + kt) * 16 + lg * 4 + r] >= 0;
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         const int col = (wn * NTW + t) * 16 + lr;
         float mx = -__builtin_inff();
+        if constexpr (FULL) {
+          mx = acc[cc * KT][t][0];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+          for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (vr[kt][r]) mx = max_f(mx, acc[cc * KT + kt][t][r], pinf);
-        mx = xgroup_max(mx, pinf);
+            for (int r = 0; r < 4; ++r)
+              if (kt + r > 0) mx = fast_max(mx, acc[cc * KT + kt][t][r], pinf);
+          float p_, q_;
+          xgroup_pair16(mx, p_, q_); mx = fast_max(p_, q_, pinf);
+          xgroup_pair32(mx, p_, q_); mx = fast_max(p_, q_, pinf);
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (vr[kt][r]) mx = max_f(mx, acc[cc * KT + kt][t][r], pinf);
+          mx = xgroup_max(mx, pinf);
+        }
         float num = 0.f, den = 0.f;
         float fv[KT][4];
+        const float ml = mx * 1.4426950408889634f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float p = 0.f, f = 0.f;
-            if (vr[kt][r]) {
-              p = __expf(acc[cc * KT + kt][t][r] - mx);
+            if constexpr (FULL) {
+              p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[cc * KT + kt][t][r], 1.4426950408889634f, -ml));
               f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
+              num = __builtin_fmaf(p, f, num);
+            } else {
+              if (vr[kt][r]) {
+                p = __expf(acc[cc * KT + kt][t][r] - mx);
+                f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
+              }
+              num += p * f;
             }
-            num += p * f;
             den += p;
             acc[cc * KT + kt][t][r] = p;
             fv[kt][r] = f;
@@ -514,6 +592,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         float g = 0.f;
         if (i < a.n && col < CH) {
           if constexpr (PIPE) g = dgc[cc][t];
+          else if constexpr (FULL) g = *(const float*)((const char*)a.dout + ((unsigned)i * (unsigned)(CH * 4) + (unsigned)(col * 4)));
           else g = a.dout[i * CH + col];
         }
 #pragma unroll
@@ -674,7 +753,9 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
               DA[row * STR + col] = v;  // D < 16: only D of 16 lanes hold dx columns -> repacked below
             } else {
               const int j = nbr[row];
-              if (j >= 0 && !(LFA_BWD_DBG & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
+              if constexpr (FULL) {
+                if (!(LFA_BWD_DBG & 1)) atomicAdd((float*)((char*)a.dx + ((unsigned)j * (unsigned)(D * 4) + (unsigned)(col * 4))), v);
+              } else if (j >= 0 && !(LFA_BWD_DBG & 1)) atomicAdd(a.dx + (int64_t)j * D + col, v);
             }
           } else if (col < CH) {
             const float lse = F[row * STR + col];
@@ -689,7 +770,9 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       for (int f = tid; f < ROWS * D; f += NTHR) {
         const int row = f / D, col = f % D;
         const int j = nbr[row];
-        if (j >= 0 && !(LFA_BWD_DBG & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
+        if constexpr (FULL) {
+          if (!(LFA_BWD_DBG & 1)) atomicAdd((float*)((char*)a.dx + ((unsigned)j * (unsigned)(D * 4) + (unsigned)(col * 4))), DA[row * STR + col]);
+        } else if (j >= 0 && !(LFA_BWD_DBG & 1)) atomicAdd(a.dx + (int64_t)j * D + col, DA[row * STR + col]);
       }
     }
     if (LFA_BWD_DBG & 32) continue;  // timing experiment: phases 1-6
@@ -843,7 +926,7 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
 }
 
 template <int CH>
-static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16) {
+static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
   // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*; BWD_PIPE_* at compile time)
   constexpr bool pipe = CH <= 64 && !LFA_BWD_DBG &&
@@ -851,13 +934,19 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
   if constexpr (CH >= 64) {
     if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
       constexpr bool P = CH == 64;
-      if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      if (full) {
+        if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+        else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
       else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
       return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
     }
   }
   if (bf16) return M3D_ERR_UNSUPPORTED;
-  if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  if (full) {
+    if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe, false, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+    else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe, false, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
   else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
@@ -883,13 +972,18 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   a.g_part = a.dw_part + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
   a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
   int rc;
+  // flags bit 3 (M3D_LFA_BWD_FULL): complete neighbourhoods promised; taken when K fills its MFMA tiles, every byte offset
+  // fits 32 bits and LeakyReLU can be written max(v, slope v)
+  const int64_t lim = (int64_t)1 << 31;
+  const bool full = (flags & 8) && (K == 16 || K == 32) && n > 0 && n * K < lim && n * (int64_t)CH * 4 < lim && n * 16 < lim &&
+                    slope >= 0.f && slope <= 1.f && !LFA_BWD_DBG_NOFULL;
   switch (CH) {
-    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16); break;
-    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16); break;
-    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16); break;
-    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16); break;
-    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16); break;
-    default: rc = launch_lfa_bwd<256>(a, p, st, bf16); break;
+    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full); break;
+    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full); break;
+    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16, full); break;
+    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16, full); break;
+    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16, full); break;
+    default: rc = launch_lfa_bwd<256>(a, p, st, bf16, full); break;
   }
   if (rc != M3D_OK) return rc;
   if (flags & 4) return M3D_OK;  // the caller sums the partials later (m3d_lfa_bwd_reduce_batch): ws must live until then

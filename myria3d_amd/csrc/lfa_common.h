@@ -32,6 +32,15 @@ __device__ __forceinline__ void rel_pos(float4 pi, float4 pj, float (&r)[10]) {
 #endif
 }
 
+// the same with the raw v_sqrt_f32 (1 ulp) for the edge length: the round-5 fast kernels
+__device__ __forceinline__ void rel_pos_fast(float4 pi, float4 pj, float (&r)[10]) {
+  const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+  r[0] = pi.x; r[1] = pi.y; r[2] = pi.z;
+  r[3] = pj.x; r[4] = pj.y; r[5] = pj.z;
+  r[6] = dx; r[7] = dy; r[8] = dz;
+  r[9] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
 // edge rows per forward workgroup (256 threads) per padded channel count; overridable for tuning sweeps
 #ifndef FWD_ROWS_16
 #define FWD_ROWS_16 256

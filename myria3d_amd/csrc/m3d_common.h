@@ -36,6 +36,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // that L2 instead of bouncing the line between the chiplets.
 #ifndef M3D_XCD_ORDER
 #define M3D_XCD_ORDER 1
+#endif
 
 // ---- counter-based dropout mask (torch.nn.Dropout of mlp_classif, pyg_randla_net.py:49-52; see m3d_dropout in rows.hip) ----
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -74,7 +75,6 @@ static inline DropArgs drop_args(const M3DDropout* d) {
   }
   return a;
 }
-#endif
 __device__ __forceinline__ int64_t xcd_major(int64_t b, int64_t nblk) {
   if (!M3D_XCD_ORDER) return b;
   const int64_t q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, i8 = b >> 3;
@@ -137,6 +137,14 @@ __device__ __forceinline__ float max_f(float a, float b, float pinf) {
   return fmaxf(a, b);
 #endif
 }
+// the one-instruction maximum, unconditionally (round-5 fast kernels): fast_pinf() once per kernel, then
+// fast_max(a, b, pinf) = v_med3_f32(a, b, +inf) = max(a, b) for every pair without a NaN
+__device__ __forceinline__ float fast_pinf() {
+  unsigned u;
+  asm("s_mov_b32 %0, 0x7f800000" : "=s"(u));
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ float fast_max(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
 __device__ __forceinline__ float xgroup_max(float v, float pinf) {
   float a, b;
   xgroup_pair16(v, a, b); v = max_f(a, b, pinf);

@@ -1185,10 +1185,17 @@ def lfa_prepare_batch(jobs) -> list:
     return outs
 
 
+LFA_FULL = 1  # M3D_LFA_FULL (include/m3d_hip.h): every entry of the neighbour table is a valid row
+USE_LFA_FULL = os.environ.get("M3D_LFA_FULL", "1") != "0"  # A/B switch: 0 = the general (masked) kernels everywhere
+
+
 def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_att: Tensor,
-                wp: Optional[Tensor] = None, bf16: bool = False) -> Tensor:
-    """``bf16``: ``wp`` holds the bf16 operand fragments and the attention GEMM runs on bf16 matrix cores."""
+                wp: Optional[Tensor] = None, bf16: bool = False, full: bool = False) -> Tensor:
+    """``bf16``: ``wp`` holds the bf16 operand fragments and the attention GEMM runs on bf16 matrix cores.
+    ``full``: the caller knows that ``idx`` has no -1 padding (every cloud of the level has at least K points:
+    ``plan.num_edges[level] == n * K``) — the launch takes the mask-free kernel (``M3D_LFA_FULL``)."""
     n, K = idx.shape
+    fl = LFA_FULL if (full and USE_LFA_FULL) else 0
     ch = w_att.shape[0]
     if K > 32:  # the fused kernels tile one centre's neighbours onto <= 2 MFMA row tiles
         return lfa_forward_unfused(x, pos4, idx, wf, bf, w_att)
@@ -1196,11 +1203,11 @@ def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_
     if bf16:
         assert wp is not None and wp.dtype == torch.int16
         call("m3d_lfa_fwd_bf16", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out),
-             _st())
+             fl, _st())
         return out
     if wp is None:
         wp, _ = pack_attention_weights(w_att, False)  # named local: stays alive until the launch is enqueued
-    call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), _st())
+    call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), fl, _st())
     return out
 
 
@@ -1238,7 +1245,9 @@ class LFATrainFn(torch.autograd.Function):
         else:
             wf, bf, mean, invstd = lfa_enc_fold(enc_lin, enc_bn, mom, num_edges)
             wp = wpt = None
-        out = lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16)
+        # complete neighbourhoods (every cloud has >= K points: what the plan's edge count says) take the mask-free kernels
+        ctx.full = bool(num_edges == idx.shape[0] * K) and USE_LFA_FULL
+        out = lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16, full=ctx.full)
         ctx.packed = (wp, wpt)
         ctx.bf16 = bf16
         ctx.save_for_backward(x, pos4, idx, mom, wf, bf, mean, invstd, enc_w, enc_b, enc_gamma, w_att)
@@ -1263,7 +1272,7 @@ class LFATrainFn(torch.autograd.Function):
             defer = sk is not None and ctx.side is not None and DEFER_WGRAD
             call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
                  _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2 |
-                 (4 if defer else 0), _p(G), _p(ws), _st())
+                 (4 if defer else 0) | (8 if ctx.full else 0), _p(G), _p(ws), _st())
             if defer:
                 # dW_att, G and the encoder parameter gradients are leaves: summed / finished with every other LFA
                 # layer's at the end of the backward pass (GradSideStream.flush) instead of two launches in the chain

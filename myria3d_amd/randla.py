@@ -420,7 +420,8 @@ class HipRandLANet(nn.Module):
             else:
                 wf, bf, wp = self._cached(("lfa", id(p), False), lambda: ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)[:2]
                                           + (None,), (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
-            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16)
+            agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16,
+                                  full=bool(num_edges == idx.shape[0] * idx.shape[1]))
         return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,

@@ -76,6 +76,6 @@ def test_invalid_arguments_return_error_codes_not_crashes():
     assert h.m3d_knn_query(None, None, 10, 1, None, 3, None, None, 10, 16, 0, None, None, None) == -1
     assert h.m3d_gemm_f32(None, 0, 0, None, 4, None, 0, 0, None, 0, 0, 8, 8, None, None, None, 0, 0.2, None, 0,
                           None, 0, 0, 1, None) == -1
-    assert h.m3d_lfa_fwd(None, None, None, 10, 16, 8, None, None, None, 0.2, None, None) == -1
+    assert h.m3d_lfa_fwd(None, None, None, 10, 16, 8, None, None, None, 0.2, None, 0, None) == -1
     with pytest.raises(_lib.M3DError):
         _lib.call("m3d_bn_apply", None, None, None, None, None, None, 1, 0.2, None, 10, 8, None)

@@ -727,6 +727,40 @@ def test_lfa_eval_forward(device, ch, k):
     _close(f"lfa_unfused(ch={ch},k={k})", got_u, ref, 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize("ch", [8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("k", [16, 32])
+@pytest.mark.parametrize("sizes", [[151, 41, 77], [16 * 40 + 32]])
+def test_lfa_forward_full_neighbourhood_kernel(device, ch, k, sizes):
+    """Round 5: the mask-free forward kernel (``M3D_LFA_FULL``: complete neighbourhoods promised; two centres per MFMA
+    tile at ch = 8, 32-bit offsets, exp2-fma softmax) against the oracle AND against the general kernel on the same
+    inputs.  An odd point count (the last centre pair of the ch = 8 tiles is half empty, the last workgroup partly
+    empty) and one that is a multiple of every tile."""
+    from myria3d_amd import ops
+
+    x, pos, ptr, lfa, idx, ei = _lfa_setup(ch, sizes, k, seed=ch + k + len(sizes))
+    assert min(sizes) >= k and int(idx.min()) >= 0
+    lfa.eval()
+    with torch.no_grad():
+        ref = lfa.aggregate(ei, x, pos)
+    enc_lin, enc_bn = lfa.mlp_encoder.lins[0].to(device), lfa.mlp_encoder.norms[0].module.to(device)
+    w_att = lfa.mlp_attention.lins[0].weight.to(device)
+    wf, bf, _, _ = ops.lfa_enc_fold(enc_lin, enc_bn, None, 0)
+    pos4 = ops.pad_pos(pos.to(device))
+    idx32 = idx.to(torch.int32).to(device)
+    got = ops.lfa_forward(x.to(device), pos4, idx32, wf, bf, w_att, full=True)
+    gen = ops.lfa_forward(x.to(device), pos4, idx32, wf, bf, w_att, full=False)
+    _close(f"lfa_fwd_full(ch={ch},k={k})", got, ref, 2e-5, 2e-5)
+    _close(f"lfa_fwd_full vs general (ch={ch},k={k})", got, gen, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("ch,k", [(8, 16), (16, 16), (32, 16), (64, 16), (128, 16), (256, 16), (8, 32), (16, 32), (64, 32),
+                                  (256, 32)])
+def test_lfa_train_full_neighbourhoods(device, ch, k):
+    """Round 5: forward + fused backward on the mask-free kernels (every cloud has >= K points, so ``LFATrainFn`` passes
+    ``M3D_LFA_FULL`` / flags bit 3) against the fp64 oracle, at a point count that leaves the last group partly empty."""
+    _lfa_train_parity(device, ch, k, [203, 41, 91], seed=ch + 1, fused=True)
+
+
 def _relclose(name, got, ref, rel):
     """Reduced quantities (sums over all edges): relative L2 error of the whole tensor."""
     got, ref = got.detach().cpu().double(), ref.detach().cpu().double()

@@ -4,7 +4,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myria3d_amd import ops
 dev = torch.device("cuda:0")
-what = set(sys.argv[1:]) or {"gemm", "wgrad", "knn", "lfa", "bn"}
+FULL = "nofull" not in sys.argv  # lfa: complete neighbourhoods promised (the mask-free kernels of round 5); "nofull": the general ones
+what = (set(sys.argv[1:]) - {"nofull"}) or {"gemm", "wgrad", "knn", "lfa", "bn"}
 
 def timeit(fn, reps=10, inner=10):
     """median over `reps` replays of a hipGraph holding `inner` back-to-back calls (no host launch overhead)"""
@@ -120,7 +121,7 @@ if "knn" in what or "lfa" in what:
                 D = ch // 2
                 xin = torch.randn(n, D, device=dev); wf = torch.randn(D, 10, device=dev) * 0.3; bf = torch.randn(D, device=dev) * 0.1
                 watt = torch.randn(ch, ch, device=dev) / ch ** 0.5
-                tfw = timeit(lambda: ops.lfa_forward(xin, p4[l], idxs[l], wf, bf, watt))
+                tfw = timeit(lambda: ops.lfa_forward(xin, p4[l], idxs[l], wf, bf, watt, full=FULL))
                 dout = torch.randn(n, ch, device=dev)
                 def bwd():
                     dx = torch.zeros((n, D), device=dev); G = torch.empty(11 * D, dtype=torch.float64, device=dev)
@@ -128,7 +129,7 @@ if "knn" in what or "lfa" in what:
                     ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n, 16, ch), dtype=torch.uint8, device=dev)
                     wp, wpt = ops.pack_attention_weight(watt), ops.pack_attention_weight(watt.t())
                     ops.call("m3d_lfa_bwd", xin.data_ptr(), p4[l].data_ptr(), idxs[l].data_ptr(), n, 16, ch, wf.data_ptr(), bf.data_ptr(),
-                             wp.data_ptr(), wpt.data_ptr(), 0.2, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(), 0, G.data_ptr(), ws.data_ptr(),
+                             wp.data_ptr(), wpt.data_ptr(), 0.2, dout.data_ptr(), dx.data_ptr(), dw.data_ptr(), 8 if FULL else 0, G.data_ptr(), ws.data_ptr(),
                              torch.cuda.current_stream().cuda_stream)
                 tbw = timeit(bwd)
                 alg = n * (16 + 4 * D + 64 + 4 * ch)
