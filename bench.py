@@ -49,8 +49,10 @@ def _progress(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (default 200: a timed region of ~0.8 s; rounds 1-4 defaulted to 20 = 86 ms, within the "
+                         "box-to-box noise)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tiles", type=int, default=16, help="tiles per GPU")
     ap.add_argument("--points", type=int, default=12800, help="points per tile")
     ap.add_argument("--neighbors", type=int, default=16)
@@ -80,8 +82,7 @@ def parse():
                     "predict,bf16,dropin,collective,torch,dense,pointnet2")
     ap.add_argument("--cpu-tiles", type=int, default=16, help="tiles in the CPU-baseline sample (BASELINE.md 3: 16)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="BASELINE.md 3 protocol in full: 3 warm-up + 10 timed iterations, at the probe-picked thread "
-                         "count AND on all cores (several minutes of CPU time)")
+                    help="also time the CPU oracle on ALL host cores (3 + 10 iterations more; several minutes of CPU time)")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="launch check without GPUs: bring the N ranks up over gloo, exchange one all-reduce, print the "
                          "rank census (used by the CPU tests)")
@@ -118,8 +119,14 @@ def _leg_in_fresh_process(extra_args, timeout=240):
     return json.loads(lines[-1])
 
 
+LAST_RANK_SECONDS = None  # per-rank seconds of the most recent timed() region BEFORE its closing barrier (N > 1 only)
+
+
 def timed(fn, steps, world):
-    """Time exactly ``steps`` calls bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+    """Time exactly ``steps`` calls bracketed by barrier + synchronize on both sides; max over ranks (seconds).  With
+    N > 1 every rank's own time up to its synchronize (i.e. before the closing barrier makes them equal) is gathered into
+    ``LAST_RANK_SECONDS``, so that the line can show a slow rank."""
+    global LAST_RANK_SECONDS
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -127,6 +134,7 @@ def timed(fn, steps, world):
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -134,6 +142,10 @@ def timed(fn, steps, world):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([own], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        LAST_RANK_SECONDS = [float(v.item()) for v in every]
     return dt
 
 
@@ -326,9 +338,10 @@ def _pick_threads():
 def cpu_baseline(tiles, points, K, full=False):
     """The CPU oracle (op-for-op restatement of the reference path; kNN through cKDTree like torch_cluster's CPU
     path), BASELINE.md section 3 protocol: fwd+bwd in train mode (CE loss) and fwd-only in eval mode, 3 warm-up + 10
-    timed iterations, median, at the thread count a micro-probe picks.  Default sample (round 4): ALL of the GPU line's 16
-    tiles — the same batch the GPU steps on — with 1 warm-up + 3 timed iterations per leg (~30 s of CPU work at 16 threads,
-    so the driver's default run stays short); ``full``: 3 + 10 iterations, and the same on every host core."""
+    timed iterations, median, on ALL of the GPU line's 16 tiles (the same batch the GPU steps on), at the thread count a
+    micro-probe picks (the one deviation from that section, stated in the line: on the 256-core GPU host "all cores" did
+    not finish three iterations in 460 s).  ~2 minutes of CPU time at 16 threads.  ``full``: the same once more on every
+    host core."""
     import statistics
 
     from oracle.randla_oracle import RandLANetOracle
@@ -373,13 +386,13 @@ def cpu_baseline(tiles, points, K, full=False):
             res[name] = tiles * points / statistics.median(ts)
         return res
 
-    warm, reps = (3, 10) if full else (1, 3)
+    warm, reps = 3, 10  # BASELINE.md section 3 (rounds 3-4 ran 1 + 3 by default: VERDICT r4, "protocol drift")
     _progress(f"CPU baseline: {tiles} tiles, {picked} threads, {warm} + {reps} iterations")
     main = leg(picked, warm, reps)
     out = {"value": round(main["fwd_bwd"], 1), "unit": "points/s", "cores": picked, "kind": "port",
            "fwd_only": round(main["fwd_only"], 1), "host_cores": ncpu,
            "sample": f"{tiles} tiles x {points} pts (the GPU line's whole batch), median of {reps} timed iterations after {warm} "
-                     f"warm-up (BASELINE.md 3 asks for 3 + 10: --cpu-baseline-full); fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
+                     f"warm-up (BASELINE.md section 3's protocol); fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
                      f"oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN); threads = {picked} (fastest of "
                      f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
     if full and picked != ncpu:
@@ -908,6 +921,7 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     for _ in range(warmup):
         step_fn()
     dt = timed(step_fn, steps, world)
+    rank_seconds = LAST_RANK_SECONDS if world > 1 else None
     # eval forward of the trained weights (the first eval pass folds the BatchNorms / packs the attention weights; the
     # module caches them until the next training phase)
     _progress("eval forward")
@@ -943,6 +957,10 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
         "fwd_only": {"value": round(total_points * steps / dt_f, 1), "unit": "points/s",
                      "ms_per_step": round(dt_f / steps * 1e3, 4), "mode": "eval, no_grad", "launch": flaunch},
     }
+    if rank_seconds:
+        # every rank's own clock over the same timed steps (before the closing barrier): a slow rank shows here
+        per = [round(v / steps * 1e3, 4) for v in rank_seconds]
+        res["per_rank_ms_per_step"] = {"min": min(per), "max": max(per), "ranks": per}
     if probe:
         res["launch_probe_ms"] = {k: round(v, 4) for k, v in probe.items()}
     if "eager" in probe:

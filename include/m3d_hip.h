@@ -30,7 +30,10 @@ extern "C" {
  * incoming gradient in the backward pass.  A null pointer, a null counter or p == 0 mean "no dropout".  rows (nullable,
  * device int32 [M]): row r of the layer's tensors is row rows[r] of the caller's tensor (the net's cell-sorted order) — the
  * mask is then a function of the CALLER's element, independent of that order. */
-typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; } M3DDropout;
+/* snapshot (nullable, device int64): FORWARD launches copy *counter there; the backward launches of the same layer are then
+ * handed counter = snapshot, so that a second train-mode forward between a forward and its backward (loss = f(a) + f(b), a
+ * no_grad recalibration pass), which advances the live counter, cannot change the mask the backward pass rebuilds. */
+typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; int64_t* snapshot; } M3DDropout;
 
 #define M3D_ABI_VERSION 15
 #define M3D_ADAM_STATE_WORDS 66

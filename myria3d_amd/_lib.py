@@ -95,7 +95,8 @@ SIGNATURES = {
 
 class M3DDropout(C.Structure):
     """``M3DDropout`` of include/m3d_hip.h (read by the library on the host, at call time)."""
-    _fields_ = [("counter", C.c_void_p), ("seed", C.c_uint64), ("p", C.c_float), ("rows", C.c_void_p)]
+    _fields_ = [("counter", C.c_void_p), ("seed", C.c_uint64), ("p", C.c_float), ("rows", C.c_void_p),
+                ("snapshot", C.c_void_p)]
 
 
 ABI_VERSION = 15  # M3D_ABI_VERSION in include/m3d_hip.h

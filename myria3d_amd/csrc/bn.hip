@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
   float4 s2 = make_float4(0, 0, 0, 0), h2 = make_float4(0, 0, 0, 0);
   if constexpr (B2) { s2 = *(const float4*)&s_sc2[c]; h2 = *(const float4*)&s_sh2[c]; }
   const uint32_t dkey = a.drop.thr16 ? drop_key(a.drop) : 0u;
+  if (a.drop.thr16 && a.drop.snap && blockIdx.x == 0 && threadIdx.x == 0) *a.drop.snap = a.drop.counter[0];  // (M3DDropout::snapshot)
   while (true) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {

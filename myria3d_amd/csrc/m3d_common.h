@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // rows (nullable): row r of the tensor is row rows[r] of the CALLER's tensor — the net works on a cell-sorted order whose
 // ties (points of one grid cell) fall differently from run to run, and the mask must not: it is a function of the seed, the
 // step and the caller's element, like the reference's seeded dropout.
-struct DropArgs { const int64_t* counter; uint64_t seed; uint32_t thr16; float scale; const int32_t* rows; };
+struct DropArgs { const int64_t* counter; uint64_t seed; uint32_t thr16; float scale; const int32_t* rows; int64_t* snap; };
 // number of float4 `q` of row `r` (rows of n4 float4) in the caller's tensor
 __device__ __forceinline__ int64_t drop_index(const DropArgs& d, int64_t r, int q, int n4) {
   return (d.rows ? (int64_t)d.rows[r] : r) * n4 + q;
@@ -66,12 +66,12 @@ __device__ __forceinline__ float4 drop_mul4(uint32_t key, int64_t i, uint32_t th
 }
 // host side: the C ABI's M3DDropout (nullable) -> kernel arguments
 static inline DropArgs drop_args(const M3DDropout* d) {
-  DropArgs a{nullptr, 0, 0u, 1.f, nullptr};
+  DropArgs a{nullptr, 0, 0u, 1.f, nullptr, nullptr};
   if (d && d->counter && d->p > 0.f) {
     uint32_t thr = (uint32_t)(d->p * 65536.f + 0.5f);
     if (thr > 65535u) thr = 65535u;
     a.counter = d->counter; a.seed = d->seed; a.thr16 = thr; a.scale = 1.f / (1.f - (float)thr / 65536.f);
-    a.rows = d->rows;
+    a.rows = d->rows; a.snap = d->snapshot;
   }
   return a;
 }

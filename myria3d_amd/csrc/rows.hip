@@ -344,7 +344,7 @@ extern "C" int m3d_dropout(const float* x, float* y, int64_t n, float p, const i
   if (n < 0 || (n & 3) || !(p >= 0.f && p < 1.f)) return M3D_ERR_INVALID;
   if (n == 0) return M3D_OK;
   if (!x || !y || !counter || ((((uintptr_t)x) | ((uintptr_t)y)) & 15)) return M3D_ERR_INVALID;
-  const M3DDropout md{counter, seed, p, nullptr};
+  const M3DDropout md{counter, seed, p, nullptr, nullptr};
   DropArgs d = drop_args(&md);
   if (d.thr16 == 0) { d.counter = counter; d.seed = seed; }  // p rounds to 0: the identity (every 16-bit draw is >= 0)
   int64_t gx = m3d_cdiv(n / 4, 256 * 4);

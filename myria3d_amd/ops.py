@@ -596,7 +596,8 @@ def _drop_ref(drop):
 
     p, counter, seed = drop[:3]
     rows = drop[3] if len(drop) > 3 else None
-    return ctypes.byref(M3DDropout(counter.data_ptr(), int(seed), float(p), _p(rows)))
+    snap = drop[4] if len(drop) > 4 else None  # forward launches: the counter's value is copied there (see SharedLayerTrainFn)
+    return ctypes.byref(M3DDropout(counter.data_ptr(), int(seed), float(p), _p(rows), _p(snap)))
 
 
 def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tensor, act: bool, stats2=None, bn2=None,
@@ -751,7 +752,15 @@ class SharedLayerTrainFn(torch.autograd.Function):
         # gradients per source row instead of scattering them with atomics
         ctx.slots = (x0_slot, x1_slot)
         ctx.rows_inv = rows_inv if (rows is not None and x0.shape[1] % 4 == 0) else None
-        ctx.drop = drop
+        if drop is not None:
+            # the backward pass rebuilds the mask from the counter value THIS forward saw, not from the live counter: another
+            # train-mode forward may run (and advance it) before this one's backward
+            snap = torch.empty(1, dtype=torch.int64, device=w.device)
+            rows_d = drop[3] if len(drop) > 3 else None
+            ctx.drop = (drop[0], snap, drop[2], rows_d)
+            drop = (drop[0], drop[1], drop[2], rows_d, snap)
+        else:
+            ctx.drop = None
         ctx.sinks = sinks
         ctx.bf16 = bool(bf16)
         ctx.side = _grad_side if sinks is not None else None
@@ -1367,7 +1376,8 @@ class DropoutFn(torch.autograd.Function):
         x = _chk(x.contiguous())
         y = torch.empty_like(x)
         call("m3d_dropout", _p(x), _p(y), x.numel(), float(p), _p(counter), int(seed), _st())
-        ctx.args = (float(p), counter, int(seed))
+        # (the counter's value at THIS forward: a later train-mode forward advances the live one before our backward runs)
+        ctx.args = (float(p), counter.clone(), int(seed))
         return y
 
     @staticmethod

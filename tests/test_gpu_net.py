@@ -1,7 +1,8 @@
 """GPU parity of the whole hot path: ``HipRandLANet`` (HIP kernels through the C ABI) vs the CPU oracle.
 
 Tolerances (fp32 both sides, different summation orders through ~45 GEMMs / 35 BatchNorms):
-  eval logits      |d| <= 2e-4 + 2e-4*|ref|      and identical argmax on >= 99.9 % of points
+  eval logits      |d| <= 1e-4 + 1e-4*|ref|      and identical argmax on >= 99.99 % of the points whose top-2 logits are not
+                   tied inside that tolerance (SURVEY 8c's numbers, asserted since round 5; recorded intermediates 2e-4)
   train logits     |d| <= 2e-3 + 2e-3*|ref|
   parameter grads  relative L2 error <= 5e-3 per tensor (vs an fp64 oracle run)
 """
@@ -31,9 +32,29 @@ def _pair(device, num_features=9, num_classes=6, k=16, seed=0, return_logits=Tru
 def _report(name, got, ref, rtol, atol):
     got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
     err = (got - ref).abs()
-    print(f"[parity] {name}: max_abs_err={err.max().item():.3e} ref_absmax={ref.abs().max().item():.3e}")
+    used = (err / (atol + rtol * ref.abs())).max().item()  # 1.0 = at the bound
+    print(f"[parity] {name}: max_abs_err={err.max().item():.3e} ref_absmax={ref.abs().max().item():.3e} "
+          f"fraction of the tolerance used = {used:.3f}")
     bad = err > atol + rtol * ref.abs()
     assert not bool(bad.any()), f"{name}: {int(bad.sum())} / {bad.numel()} outside tol, max err {err.max().item():.3e}"
+
+
+# SURVEY section 8c's own numbers for the eval forward (asserted since round 5 on the FINAL logits of every eval test; the
+# recorded intermediates keep 2e-4: they hold raw BatchNorm inputs of magnitude 10 - 100)
+EVAL_RTOL, EVAL_ATOL, EVAL_ARGMAX = 1e-4, 1e-4, 0.9999
+
+
+def _argmax_agreement(name, got, ref, floor=EVAL_ARGMAX):
+    """Share of points with the same argmax, counted over the points whose top-2 reference logits are further apart than
+    the logit tolerance (a tie inside the tolerance can legitimately fall either way)."""
+    got, ref = got.detach().cpu(), ref.detach().cpu().float()
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * (EVAL_ATOL + EVAL_RTOL * top2[:, 0].abs())
+    agree_all = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    agree = (got.argmax(1)[clear] == ref.argmax(1)[clear]).float().mean().item() if bool(clear.any()) else 1.0
+    print(f"[parity] {name}: argmax agreement {agree_all:.6f} over all points, {agree:.6f} over the {int(clear.sum())} "
+          f"points without a tie inside the tolerance")
+    assert agree_all >= 0.999 and agree >= floor, (name, agree_all, agree)
 
 
 @pytest.mark.parametrize("sizes", [[300, 211], [50, 50], [1250, 1000], [5, 1, 40]])
@@ -53,9 +74,8 @@ def test_eval_logits_match_oracle(device, sizes):
             assert torch.equal(rec_g[key].cpu().long(), rec_r[key]), key
         elif key in rec_r:
             _report(key, rec_g[key], rec_r[key], 2e-4, 2e-4)
-    _report("logits", out_g, out_r, 2e-4, 2e-4)
-    agree = (out_g.cpu().argmax(1) == out_r.argmax(1)).float().mean().item()
-    assert agree >= 0.999, agree
+    _report("logits", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
+    _argmax_agreement("logits", out_g, out_r)
 
 
 def test_eval_lidar_tiles_and_log_softmax(device):
@@ -68,7 +88,7 @@ def test_eval_lidar_tiles_and_log_softmax(device):
     with torch.no_grad():
         out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
         out_g = net(x.to(device), pos.to(device), batch.to(device), ptr.to(device), decimation_idx=dec)
-    _report("log_probas", out_g, out_r, 2e-4, 2e-4)
+    _report("log_probas", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
     assert torch.allclose(out_g.exp().sum(1).cpu(), torch.ones(5000), atol=1e-4)
 
 
@@ -84,7 +104,7 @@ def test_dense_neighbourhood_k32_matches_oracle(device):
     with torch.no_grad():
         out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
         out_g = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec)
-    _report("k32.eval_logits", out_g, out_r, 2e-4, 2e-4)
+    _report("k32.eval_logits", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
     ref.train(), net.train()
     mask = torch.ones(sum(sizes), 32)
     out_r = ref(x, pos, batch, ptr, decimation_idx=dec, dropout_mask=mask)
@@ -110,7 +130,7 @@ def test_golden_fixture(device):
     with torch.no_grad():
         out = net(torch.from_numpy(g["x"]).to(device), torch.from_numpy(g["pos"]).to(device), None,
                   torch.from_numpy(g["ptr"]).to(device), decimation_idx=dec)
-    _report("golden.eval_logits", out, torch.from_numpy(g["logits_eval"]), 2e-4, 2e-4)
+    _report("golden.eval_logits", out, torch.from_numpy(g["logits_eval"]), EVAL_RTOL, EVAL_ATOL)
     rec = {}
     net.train()
     out_t = net(torch.from_numpy(g["x"]).to(device), torch.from_numpy(g["pos"]).to(device), None,
@@ -145,7 +165,7 @@ def _reference_fixture_case(device, g, pre):
     x, pos, ptr = t("x").to(device), t("pos").to(device), t("ptr").to(device)
     with torch.no_grad():
         out = net(x, pos, None, ptr, decimation_idx=dec)
-    _report(f"reference_fixture[{pre}].eval_logits", out, t("logits_eval"), 2e-4, 2e-4)
+    _report(f"reference_fixture[{pre}].eval_logits", out, t("logits_eval"), EVAL_RTOL, EVAL_ATOL)
     assert (out.cpu().argmax(1) == t("logits_eval").argmax(1)).float().mean().item() >= 0.999
     net.train()
     out_t = net(x, pos, None, ptr, decimation_idx=dec)
@@ -262,8 +282,31 @@ def test_baseline_tiles_train_and_eval_match_oracle(device):
     with torch.no_grad():
         out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
         out_g = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec)
-    _report("baseline_tiles.eval_logits", out_g, out_r, 2e-4, 2e-4)
-    assert (out_g.cpu().argmax(1) == out_r.argmax(1)).float().mean().item() >= 0.999
+    _report("baseline_tiles.eval_logits", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
+    _argmax_agreement("baseline_tiles.eval_logits", out_g, out_r)
+
+
+def test_config2_full_batch_eval_logits_match_oracle(device):
+    """BASELINE config 2's WHOLE batch — 16 tiles x 12 800 synthetic Lidar-HD-shaped points, K = 16, the launch shapes the
+    bench times (204 800 / 51 200 / 12 800 / 3 200 / 800 rows) — eval logits against the CPU oracle on the same decimation
+    indices, at SURVEY 8c's tolerance (round 4 had numbers at 2 tiles and properties only at 16)."""
+    from oracle.randla_oracle import RandLANetOracle, fixed_decimation_indices, synthetic_batch
+    from myria3d_amd import HipRandLANet
+
+    x, pos, batch, ptr, _ = synthetic_batch([12800] * 16)
+    ref = RandLANetOracle(9, 6, num_neighbors=16, return_logits=True, knn="kdtree")
+    fill_params_deterministic(ref, 16)
+    net = HipRandLANet(9, 6, num_neighbors=16, return_logits=True)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(device).eval()
+    ref.eval()
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=12)
+    with torch.no_grad():
+        out_g = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec)
+        out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
+    assert out_g.shape == (16 * 12800, 6)
+    _report("config2_full_batch.eval_logits", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
+    _argmax_agreement("config2_full_batch.eval_logits", out_g, out_r)
 
 
 def test_flattened_path_every_gradient_vs_fp64_oracle(device):
@@ -290,7 +333,7 @@ def test_reference_size_cases_numeric(device, num_nodes):
         out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
         out_g = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec)
     assert out_g.shape == torch.Size([sum(num_nodes), 6])
-    _report("reference_sizes.eval_logits", out_g, out_r, 2e-4, 2e-4)
+    _report("reference_sizes.eval_logits", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
 
 
 def test_dense_tile_40000_points_k32_eval_matches_oracle(device):
@@ -304,7 +347,7 @@ def test_dense_tile_40000_points_k32_eval_matches_oracle(device):
     with torch.no_grad():
         out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
         out_g = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec)
-    _report("dense_tile.eval_logits", out_g, out_r, 2e-4, 2e-4)
+    _report("dense_tile.eval_logits", out_g, out_r, EVAL_RTOL, EVAL_ATOL)
     assert (out_g.cpu().argmax(1) == out_r.argmax(1)).float().mean().item() >= 0.999
 
 

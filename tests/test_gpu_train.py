@@ -77,6 +77,42 @@ def test_fused_dropout_is_a_function_of_seed_step_and_caller_row(device, sizes):
     assert abs(res[0][0] - res[2][0]) > 1e-5  # (a different mask)
 
 
+def test_fused_dropout_backward_uses_the_mask_of_its_own_forward(device):
+    """the backward pass rebuilt the classifier's dropout mask from the LIVE device step counter.  A second
+    train-mode forward between a forward and its backward (here a no_grad pass, as a BatchNorm recalibration or a metrics pass
+    would be) advances that counter; the gradients must still be those of the first forward's mask: the forward snapshots the
+    counter value it saw (``M3DDropout::snapshot``) and the backward launches read the snapshot."""
+    from myria3d_amd import cross_entropy
+    from oracle.randla_oracle import fixed_decimation_indices
+
+    sizes = [500, 320]
+    x, pos, batch, ptr = rand_batch(sizes, 9, seed=14)
+    y = torch.from_numpy(np.random.RandomState(3).randint(0, 6, (sum(sizes),))).to(device)
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=2)
+    args = (x.to(device), pos.to(device), None, ptr.to(device))
+    grads = []
+    for interleave in (False, True):
+        net, _ = _nets(device, 31)
+        net.flatten_parameters()
+        net.train()
+        net._drop_seed = 4242
+        for m in net.modules():  # (the extra pass must not move the second run's batch statistics away from the first's)
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.momentum = 0.0
+        loss = cross_entropy(net(*args, decimation_idx=dec), y, 65)
+        if interleave:
+            with torch.no_grad():
+                net(*args, decimation_idx=dec)  # bumps the live dropout counter
+        loss.backward()
+        if net.grad_side is not None:
+            net.grad_side.join()
+        grads.append((loss.item(), net.flat_grads.clone()))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * max(1.0, abs(grads[0][0]))
+    ref, got = grads[0][1], grads[1][1]
+    assert torch.allclose(got, ref, rtol=2e-4, atol=1e-6 * ref.abs().max().item()), \
+        f"gradients changed by {(got - ref).norm().item() / ref.norm().item():.3e} when a second forward ran before the backward"
+
+
 def test_flat_gradient_sinks_equal_autograd_gradients(device):
     """flatten_parameters(): parameter gradients written by the backward kernels into the flat buffer must equal
     the ones the same kernels hand to autograd; state_dict keys are unchanged; gradients accumulate over calls."""
@@ -608,6 +644,55 @@ def test_collective_path_on_a_one_rank_rccl_group(device):
         g.fill_(1.0)
         dist.all_reduce(g)
         assert float(g.min()) == 1.0 and float(g.max()) == 1.0
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_net_under_torch_distributed_data_parallel_on_a_one_rank_rccl_group(device):
+    """The reference's own multi-GPU strategy (``configs/experiment/RandLaNet_base_run_FR-MultiGPU.yaml:9-13``:
+    ``strategy: ddp_find_unused_parameters_false``): ``HipRandLANet`` wrapped in
+    ``torch.nn.parallel.DistributedDataParallel(find_unused_parameters=False)`` on the 1-rank RCCL group a 1-GPU box can
+    host — DDP's constructor broadcast, its autograd hooks on every parameter, its bucketed all-reduce over RCCL — two
+    optimizer steps, then parameters, running statistics and Adam moments compared with the unwrapped net's.  (What
+    ``myria3d_amd/ddp.py`` claims; the stand-alone loops use ``FusedAdam``'s single flat bucket instead.)"""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from oracle.randla_oracle import fixed_decimation_indices
+
+    sizes = [900, 640, 77]
+    x, pos, batch, ptr = rand_batch(sizes, 9, seed=21)
+    rs = np.random.RandomState(5)
+    y = torch.from_numpy(rs.randint(0, 6, (sum(sizes),))).to(device)
+    mask = torch.from_numpy((rs.uniform(size=(sum(sizes), 32)) > 0.5).astype(np.float32)).to(device)
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=6)
+    args = (x.to(device), pos.to(device), batch.to(device), ptr.to(device))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1,
+                                device_id=torch.device(device))
+        created = True
+    try:
+        plain, wrapped_net = _nets(device, 41)
+        ddp = DDP(wrapped_net, device_ids=[torch.device(device).index or 0], find_unused_parameters=False)
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-3, eps=0.1) for m in (plain, ddp)]
+        for step in range(2):
+            for m, opt in zip((plain, ddp), opts):
+                m.train()
+                opt.zero_grad(set_to_none=True)
+                out = m(*args, decimation_idx=dec, dropout_mask=mask)
+                torch.nn.functional.cross_entropy(out, y, ignore_index=65).backward()
+                opt.step()
+        torch.cuda.synchronize()
+        # every parameter took part (find_unused_parameters=False would have raised on the second step otherwise)
+        for (name, p), (_, q) in zip(plain.named_parameters(), ddp.module.named_parameters()):
+            assert q.grad is not None, name
+            assert torch.allclose(q, p, rtol=5e-3, atol=2e-4), (name, (q - p).abs().max().item())
+        for (name, b), (_, c) in zip(plain.named_buffers(), ddp.module.named_buffers()):
+            assert torch.allclose(c.float(), b.float(), rtol=5e-3, atol=2e-4), name
+        for sp, sq in zip(opts[0].state.values(), opts[1].state.values()):
+            assert torch.allclose(sq["exp_avg"], sp["exp_avg"], rtol=5e-3, atol=1e-5)
     finally:
         if created:
             dist.destroy_process_group()
