@@ -929,7 +929,7 @@ template <int CH>
 static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
   // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*; BWD_PIPE_* at compile time)
-  constexpr bool pipe = CH <= 64 && !LFA_BWD_DBG &&
+  constexpr bool pipe = CH <= 64 && !(LFA_BWD_DBG & ~1) &&  // (bit 0, no dx atomics, keeps the pipelined kernel: no `continue` in it)
                         (CH == 8 ? BWD_PIPE_8 : (CH == 16 ? BWD_PIPE_16 : (CH == 32 ? BWD_PIPE_32 : BWD_PIPE_64)));
   if constexpr (CH >= 64) {
     if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
