@@ -261,13 +261,44 @@ def stage_rooflines(net, pos, plan):
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
                 **_traffic_fields(prefix, grid), "avg_launch_ms": round(ms, 4)}
 
+    # ---- the dominant kernel INSIDE training steps: HIP events around block2.lfa2's backward launch (the launch stream) over
+    # eagerly launched fwd + CE + bwd steps on the bench's batch — the same kernel, operands and neighbourhood of launches as
+    # in the timed region (whose hipGraph replay cannot carry events around one node)
+    in_step = None
+    try:
+        from myria3d_amd import cross_entropy
+
+        n2_, was_training = plan.totals[1], net.training
+        xs = torch.randn(pos.shape[0], net.fc0.weight.shape[1], device=dev)
+        ys = torch.randint(0, net.fc_classif.weight.shape[0], (pos.shape[0],), device=dev)
+        ops.LFA_BWD_TIMER = {"key": (n2_, 64), "events": []}
+        net.train()
+        for _ in range(12):
+            cross_entropy(net(xs, pos, None, plan.ptrs[0], plan=plan), ys, 65).backward()
+            if net.grad_side is not None:
+                net.grad_side.join()
+        torch.cuda.synchronize()
+        evs = ops.LFA_BWD_TIMER["events"][4:]  # (the first steps settle the allocator / arena)
+        if evs:
+            in_step = {"ms": sum(a.elapsed_time(b) for a, b in evs) / len(evs), "launches": len(evs),
+                       "flags": ops.LFA_BWD_TIMER.get("flags")}
+        if net.flat_grads is not None:
+            net.flat_grads.zero_()
+        net.train(was_training)
+    except Exception as e:  # the isolated launch below still gives the entry
+        in_step = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        ops.LFA_BWD_TIMER = None
     with torch.no_grad():
         net.overlap_geometry, keep = False, net.overlap_geometry
         net.batch_geometry, keep_b = False, net.batch_geometry  # per-level launches: the kernels the captured step runs
         geo = net._geometry(pos, plan, None, True)
         net.overlap_geometry, net.batch_geometry = keep, keep_b
         # ---- dominant kernel: LFA backward at level 2, ch = 64
-        ch, n2, D, ms, ms_self = time_lfa_bwd(net.block2.lfa2, 1, geo)
+        ch, n2, D, ms_iso, ms_self = time_lfa_bwd(net.block2.lfa2, 1, geo)
+        # primary figure: the launches inside training steps; the isolated launch on random operands stays beside it (it runs
+        # 5-8 % slower: random activations / gradients draw more power than a net's — DVFS, MI355X_MICROARCH.md)
+        ms = in_step["ms"] if (in_step and "ms" in in_step) else ms_iso
         # ALGORITHMIC flops of this backward (backward = 2 x forward: dF = dA W and dW = dA^T F, plus the
         # encoder's two transposes) vs the flops the kernel EXECUTES (it recomputes the forward attention GEMM
         # A = F W^T instead of saving [E, ch] logits: a third GEMM)
@@ -284,6 +315,11 @@ def stage_rooflines(net, pos, plan):
                            **_traffic_fields("void lfa_bwd_kernel<64, 16, true"),
                            "algorithmic_flop_per_launch": flop_alg, "executed_flop_per_launch": flop_exe,
                            "avg_launch_ms": round(ms, 4),
+                           "timed": ("HIP events around the layer's launch inside eagerly launched training steps (fwd + CE + bwd on "
+                                     "the bench's batch), launch stream" if (in_step and "ms" in in_step) else
+                                     "HIP events around an isolated launch on random operands"),
+                           "in_step": in_step, "isolated_launch_ms": round(ms_iso, 4),
+                           "frac_isolated_launch": round(flop_alg / (ms_iso * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4),
                            # rounds 1-4 timed the self-contained call (two memsets + this layer's partial-sum reduce behind
                            # the kernel): kept beside it for continuity
                            "self_contained_call_ms": round(ms_self, 4),

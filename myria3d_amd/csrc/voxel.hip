@@ -558,11 +558,19 @@ __device__ __forceinline__ void ts_range(double v, const TileSelArgs& a, int& lo
 
 template <bool WRITE>
 __global__ __launch_bounds__(64) void tile_select_kernel(TileSelArgs a) {
-  __shared__ int cnt[TS_MAX_SAMPLES];
   __shared__ int memb[TS_MAX_MEMB][64];  // per lane: the samples of its point, ascending
+  // dynamic LDS sized by the number of samples (400 for a 1 km tile of 50 m samples: 5 KB, seven workgroups per CU beside memb;
+  // sized for TS_MAX_SAMPLES it would be 96 KB and one wavefront per CU): mask[S] (write pass: lanes of the current 64 points
+  // per sample), then cnt[S]
+  extern __shared__ unsigned long long ts_dyn[];
   const int lane = threadIdx.x, wg = blockIdx.x;
   const int S = a.nc * a.nc;
-  for (int s = lane; s < S; s += 64) cnt[s] = WRITE ? a.hist[(size_t)s * a.nwg + wg] : 0;
+  unsigned long long* mask = ts_dyn;
+  int* cnt = (int*)(ts_dyn + (WRITE ? S : 0));
+  for (int s = lane; s < S; s += 64) {
+    cnt[s] = WRITE ? a.hist[(size_t)s * a.nwg + wg] : 0;
+    if (WRITE) mask[s] = 0ull;
+  }
   __syncthreads();
   const float xmin = a.minxy[0], ymin = a.minxy[1];
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -587,23 +595,29 @@ __global__ __launch_bounds__(64) void tile_select_kernel(TileSelArgs a) {
         }
       }
     }
-    // every sample that has members among these 64 points, in ascending sample order; inside a sample the members
-    // are ranked by lane = by point index, so each sample's list stays ascending whatever route a point took to it
-    int k = 0;
-    for (;;) {
-      const int cur = k < nm ? memb[k][lane] : 0x7fffffff;
-      int s0 = cur;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s0 = min(s0, __shfl_xor(s0, o, 64));
-      if (s0 == 0x7fffffff) break;
-      const bool mine = cur == s0;
-      const unsigned long long mask = __ballot(mine);
-      const int c0 = cnt[s0];
-      if (WRITE && mine) a.out_idx[c0 + __popcll(mask & lt)] = (int32_t)p;
-      __syncthreads();  // (one wavefront: orders the LDS read above before the update below)
-      if (lane == 0) cnt[s0] = c0 + __popcll(mask);
+    // Round 5: rank by per-sample lane masks instead of walking the distinct samples of the 64 points one after the other
+    // (6 cross-lane steps, a ballot and 2 barriers per DISTINCT sample: a cloud whose points arrive in no spatial order — the
+    // bench's synthetic one — has ~60 of them per 64 points, 13.8 ms for 10 M points; a scan-ordered LAS has a few).
+    //   count pass: an LDS counter per membership, nothing else;
+    //   write pass: every lane ORs its bit into mask[s] for EACH of its samples, then its slot in sample s is
+    //   cnt[s] + (set bits below its own): ascending by point index inside every sample, whatever route a point took to it (a
+    //   lane is in a sample at most once); the lowest lane of a mask advances the counter and clears the mask.
+    if (!WRITE) {
+      for (int k = 0; k < nm; ++k) atomicAdd(&cnt[memb[k][lane]], 1);
+    } else {
+      for (int k = 0; k < nm; ++k) atomicOr(&mask[memb[k][lane]], 1ull << lane);
       __syncthreads();
-      k += mine ? 1 : 0;
+      for (int k = 0; k < nm; ++k) {
+        const int s0 = memb[k][lane];
+        a.out_idx[cnt[s0] + __popcll(mask[s0] & lt)] = (int32_t)p;
+      }
+      __syncthreads();
+      for (int k = 0; k < nm; ++k) {
+        const int s0 = memb[k][lane];
+        const unsigned long long m = mask[s0];
+        if ((m & lt) == 0ull) { cnt[s0] += __popcll(m); mask[s0] = 0ull; }  // (one leader per sample: no race)
+      }
+      __syncthreads();
     }
   }
   if (!WRITE) {
@@ -658,13 +672,13 @@ extern "C" int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, 
     if (nparts > 1023) nparts = 1023;
     hipLaunchKernelGGL(tile_sel_min_kernel, dim3(nparts), dim3(256), 0, st, pos, pos_stride, n, part);
     hipLaunchKernelGGL(tile_sel_min_final, dim3(1), dim3(64), 0, st, (const float*)part, nparts, part + 2048 - 2);
-    hipLaunchKernelGGL((tile_select_kernel<false>), dim3((unsigned)nwg), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tile_select_kernel<false>), dim3((unsigned)nwg), dim3(64), (size_t)S * 4 + 16, st, a);
     // exclusive scan in sample-major order: hist[s][wg] -> first output slot of (sample s, chunk wg); total at the end
     hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, hist, S * nwg, hist + S * nwg);
     hipLaunchKernelGGL(tile_sel_ptr_kernel, dim3((unsigned)m3d_cdiv(S + 1, 256)), dim3(256), 0, st, (const int32_t*)hist,
                        (int)S, (int)nwg, sample_ptr, (const int*)a.err);
   } else {
-    hipLaunchKernelGGL((tile_select_kernel<true>), dim3((unsigned)nwg), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tile_select_kernel<true>), dim3((unsigned)nwg), dim3(64), (size_t)S * 12 + 16, st, a);
   }
   M3D_CHECK_LAUNCH();
   return M3D_OK;

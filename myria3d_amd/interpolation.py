@@ -27,17 +27,20 @@ def _ptr_from_batch(batch: Optional[Tensor], n: int, device) -> Tensor:
 
 
 def knn_interpolate(x: Tensor, pos_x: Tensor, pos_y: Tensor, batch_x: Optional[Tensor] = None,
-                    batch_y: Optional[Tensor] = None, k: int = 3, num_workers: int = 1) -> Tensor:
+                    batch_y: Optional[Tensor] = None, k: int = 3, num_workers: int = 1,
+                    ptr_x: Optional[Tensor] = None, ptr_y: Optional[Tensor] = None) -> Tensor:
     """Same signature and semantics as PyG's ``knn_interpolate`` (``batch_*`` must be sorted, as PyG requires).
-    ``num_workers`` is accepted and ignored (it only steers torch_cluster's CPU path)."""
+    ``num_workers`` is accepted and ignored (it only steers torch_cluster's CPU path).  Extension: ``ptr_x`` / ``ptr_y``
+    (device int64 ``[B + 1]`` CSR offsets, what ``Batch.ptr`` holds) instead of the batch vectors — converting a batch vector
+    costs a ``bincount`` and a device read-back per call."""
     if not x.is_cuda:
         raise RuntimeError("myria3d_amd.knn_interpolate runs on the HIP device only (no CPU fallback)")
     dev = x.device
     with torch.no_grad():
         pos_x = pos_x.to(dev, torch.float32).contiguous()
         pos_y = pos_y.to(dev, torch.float32).contiguous()
-        ptr_x = _ptr_from_batch(batch_x, pos_x.shape[0], dev)
-        ptr_y = _ptr_from_batch(batch_y, pos_y.shape[0], dev)
+        ptr_x = ptr_x.to(dev, torch.int64) if ptr_x is not None else _ptr_from_batch(batch_x, pos_x.shape[0], dev)
+        ptr_y = ptr_y.to(dev, torch.int64) if ptr_y is not None else _ptr_from_batch(batch_y, pos_y.shape[0], dev)
         if ptr_y.numel() < ptr_x.numel():  # trailing clouds without queries
             ptr_y = torch.cat([ptr_y, ptr_y[-1:].expand(ptr_x.numel() - ptr_y.numel())])
         elif ptr_x.numel() < ptr_y.numel():

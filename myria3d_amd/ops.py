@@ -1194,6 +1194,7 @@ def lfa_prepare_batch(jobs) -> list:
     return outs
 
 
+LFA_BWD_TIMER = None  # bench.py sets {"key": (n, ch), "events": []}: LFATrainFn.backward then brackets that layer's launch with HIP events
 LFA_FULL = 1  # M3D_LFA_FULL (include/m3d_hip.h): every entry of the neighbour table is a valid row
 USE_LFA_FULL = os.environ.get("M3D_LFA_FULL", "1") != "0"  # A/B switch: 0 = the general (masked) kernels everywhere
 
@@ -1279,9 +1280,18 @@ class LFATrainFn(torch.autograd.Function):
             ws = torch.empty(lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
             wp, wpt = ctx.packed  # packed in the forward pass (one launch for both orientations)
             defer = sk is not None and ctx.side is not None and DEFER_WGRAD
+            tm = LFA_BWD_TIMER  # (bench.py: HIP events around ONE layer's launch inside real training steps)
+            ev = None
+            if tm is not None and tm["key"] == (n, ch):
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
                  _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2 |
                  (4 if defer else 0) | (8 if ctx.full else 0), _p(G), _p(ws), _st())
+            if ev is not None:
+                ev[1].record()
+                tm["events"].append(ev)
+                tm["flags"] = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0)
             if defer:
                 # dW_att, G and the encoder parameter gradients are leaves: summed / finished with every other LFA
                 # layer's at the end of the backward pass (GradSideStream.flush) instead of two launches in the chain

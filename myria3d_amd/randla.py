@@ -381,6 +381,26 @@ class HipRandLANet(nn.Module):
             pass
         return plan
 
+    def plan_from_host_sizes(self, ptr_host: Sequence[int]) -> LevelPlan:
+        """The level plan of a batch from its CSR offsets held on the HOST (a loader has them before the transfer;
+        ``grid_sampling(..., return_host_ptr=True)`` returns them): ``forward(..., plan=...)`` and ``prefetch_geometry`` then
+        read nothing back from the device.  Cached by tile sizes like ``plan_for``."""
+        key = tuple(int(v) for v in ptr_host)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 64:
+                self._plans.clear()
+            plan = make_plan(key, self.decimation, self.num_neighbors, next(self.parameters()).device)
+            self._plans[key] = plan
+        return plan
+
+    def invalidate_plan_cache(self) -> None:
+        """Forget every remembered ``ptr`` tensor / level plan.  ``plan_for`` recognises a ``ptr`` tensor it has seen by
+        identity + autograd version counter; a write that bypasses the counter (a raw kernel, a hipGraph replay into a static
+        ``ptr`` buffer) is invisible to it — call this after such a write, or hand ``forward`` an explicit ``plan``."""
+        self._plan_ident = []
+        self._plans.clear()
+
     # ------------------------------------------------------------------------------------------
     def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
                       rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None, drop=None,

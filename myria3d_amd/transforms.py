@@ -48,9 +48,12 @@ def _f32(t: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------------------
 # functional layer
 # --------------------------------------------------------------------------------------------------
-def grid_sampling(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tensor, size: float
-                  ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Tensor]:
-    """GridSampling(size) of every tile of a batch: ``(pos', x', y', ptr')``, rows in ascending voxel id per tile."""
+def grid_sampling(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tensor, size: float,
+                  return_host_ptr: bool = False):
+    """GridSampling(size) of every tile of a batch: ``(pos', x', y', ptr')``, rows in ascending voxel id per tile.
+    ``return_host_ptr``: a fifth result, ``ptr'`` as a host list — the ONE device read of this call (the voxel count sizes the
+    outputs) then also carries the per-tile counts, and callers that need them on the host (``node_budget``, the net's level
+    plan) need not read the device again."""
     _need_device(pos, "grid_sampling")
     dev = pos.device
     pos = _f32(pos)
@@ -69,21 +72,25 @@ def grid_sampling(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Te
     ops.call("m3d_grid_sampling", pos.data_ptr(), 3, dp(xin), F if xin is not None else 0, F, dp(yin), ptr.data_ptr(), B,
              n, float(size), ws.data_ptr(), out_pos.data_ptr(), dp(out_x), dp(out_y), out_ptr.data_ptr(), _st())
     ops.call("m3d_grid_sampling_status", ws.data_ptr(), n, B, status.data_ptr(), _st())
-    m = int(out_ptr[-1].item()) if B > 0 else 0  # the only host sync: the number of voxels sizes the outputs
-    if int(status.item()) != 0:
+    # the only host sync (ONE copy: the per-tile voxel offsets and the status word): the number of voxels sizes the outputs
+    host = torch.cat([out_ptr, status.to(torch.int64)]).tolist()
+    m = int(host[B]) if B > 0 else 0
+    if int(host[-1]) != 0:
         raise ValueError("GridSampling: a tile's voxel grid has >= 2**40 cells (size too small for its extent)")
-    return (out_pos[:m], None if out_x is None else out_x[:m], None if out_y is None else out_y[:m], out_ptr)
+    res = (out_pos[:m], None if out_x is None else out_x[:m], None if out_y is None else out_y[:m], out_ptr)
+    return res + (host[:B + 1],) if return_host_ptr else res
 
 
 def node_budget(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tensor, minimum: int = 0,
-                maximum: Optional[int] = None, seed: int = 0):
+                maximum: Optional[int] = None, seed: int = 0, ptr_host: Optional[Sequence[int]] = None):
     """MinimumNumNodes(minimum) then MaximumNumNodes(maximum) for every tile of a batch: tiles with fewer points are
     filled with further random permutations of themselves, tiles with more keep the head of one random permutation
     (the reference's scheme; the pseudo-random permutations are keyed by ``seed`` and the tile number).
-    Returns ``(pos', x', y', ptr', idx)`` with ``idx`` the kept rows (int32, into the input)."""
+    Returns ``(pos', x', y', ptr', idx)`` with ``idx`` the kept rows (int32, into the input).  ``ptr_host``: ``ptr`` as a host
+    list when the caller has it (``grid_sampling(..., return_host_ptr=True)``): no device read-back here then."""
     _need_device(pos, "node_budget")
     dev = pos.device
-    ptr_c = ptr.cpu().to(torch.int64)
+    ptr_c = torch.tensor(list(ptr_host), dtype=torch.int64) if ptr_host is not None else ptr.cpu().to(torch.int64)
     counts = ptr_c[1:] - ptr_c[:-1]
     out = counts.clone()
     if minimum:
