@@ -30,6 +30,7 @@ struct VoxWs {
   int32_t* bsum;     // [nsc + 1]
   int32_t* seg;      // [n + 1] first sorted position of voxel v
   int32_t* misc;     // [4]     0: number of voxels, 1: error flag
+  int32_t* scan;     // block sums of the multi-workgroup prefix sums (exscan_launch)
 };
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -47,6 +48,7 @@ static VoxWs vox_carve(void* ws, int64_t n, int B) {
   w.bsum = (int32_t*)p; p += al256((size_t)(nsc + 1) * sizeof(int32_t));
   w.seg = (int32_t*)p; p += al256((size_t)(n + 1) * sizeof(int32_t));
   w.misc = (int32_t*)p; p += 256;
+  w.scan = (int32_t*)p;
   return w;
 }
 
@@ -55,7 +57,8 @@ extern "C" size_t m3d_grid_sampling_workspace_bytes(int64_t n, int32_t num_cloud
   const int64_t nblk = m3d_cdiv(n, RS_TILE), nsc = m3d_cdiv(n, SC_TILE);
   return al256((size_t)num_clouds * 16) + al256((size_t)num_clouds * 32) + 2 * al256((size_t)n * 8) +
          2 * al256((size_t)n * 4) + al256((size_t)256 * nblk * 4) + al256((size_t)n * 4) +
-         al256((size_t)(nsc + 1) * 4) + al256((size_t)(n + 1) * 4) + 256 + 256;
+         al256((size_t)(nsc + 1) * 4) + al256((size_t)(n + 1) * 4) + 256 + 256 +
+         al256((size_t)((256 * nblk > nsc ? 256 * nblk : nsc) / 4096 + 2) * 4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -165,6 +168,87 @@ __global__ __launch_bounds__(1024) void exscan_kernel(int32_t* __restrict__ a, i
     run += v;
   }
   if (total && tid == 1023) *total = woff + incl;
+}
+
+// ---- the same over many workgroups (round 5).  exscan_kernel walks its array with ONE workgroup whose threads each sum a
+// contiguous chunk (stride-`chunk` accesses across the lanes): 0.37 ms for the 156 k radix histogram entries of a 1.25 M-point
+// batch, seven times per GridSampling call, and 3.9 ms for the 1.95 M (sample, chunk) counters of m3d_tile_select on a
+// 10 M-point cloud — 24.7 of the 65 ms of the predict chain (profiles/r05g_predict_trace_summary.log).  Three phases over
+// SCAN_BLK-element blocks with coalesced 16-byte accesses: block sums, their scan (one workgroup: a few hundred entries), then
+// the per-block scan with its offset.  `scratch`: cdiv(len, SCAN_BLK) + 1 ints.
+#define SCAN_BLK 4096  // elements per 256-thread workgroup: 16 per thread
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const int32_t* __restrict__ a, int64_t len, int32_t* __restrict__ bsum) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLK + (int64_t)tid * 16;
+  int s = 0;
+  if (base + 16 <= len) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 v = *(const int4*)(a + base + 4 * q);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int64_t i = base; i < len && i < base + 16; ++i) s += a[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) wsum[wid] = s;
+  __syncthreads();
+  if (tid == 0) bsum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(int32_t* __restrict__ a, int64_t len, const int32_t* __restrict__ boff) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLK + (int64_t)tid * 16;
+  int v[16];
+  const bool whole = base + 16 <= len;
+  if (whole) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 t = *(const int4*)(a + base + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = base + i < len ? a[base + i] : 0;
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += v[i];
+  int incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  int run = boff[blockIdx.x] + incl - s;
+  for (int i = 0; i < wid; ++i) run += wsum[i];
+  int o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[i] = run; run += v[i]; }
+  if (whole) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(int4*)(a + base + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (base + i < len) a[base + i] = o[i];
+  }
+}
+static inline size_t scan_scratch_bytes(int64_t len) { return al256((size_t)(m3d_cdiv(len > 0 ? len : 1, SCAN_BLK) + 1) * 4); }
+// exclusive prefix sum of a[0..len) in place (a 16-byte aligned); *total (optional) receives the sum
+static void exscan_launch(int32_t* a, int64_t len, int32_t* total, int32_t* scratch, hipStream_t st) {
+  if (len <= 2 * SCAN_BLK || !scratch) {
+    hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, a, len, total);
+    return;
+  }
+  const int64_t nb = m3d_cdiv(len, SCAN_BLK);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int32_t*)a, len, scratch);
+  hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, scratch, nb, total);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, len, (const int32_t*)scratch);
 }
 
 __global__ __launch_bounds__(64) void rs_scatter_kernel(const u64* __restrict__ kin, const int32_t* __restrict__ vin,
@@ -354,14 +438,14 @@ extern "C" int m3d_grid_sampling(const float* pos, int32_t pos_stride, const flo
   int cur = 0;
   for (int p = 0; p < passes; ++p) {
     hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(64), 0, st, w.keys[cur], n, p * 8, w.hist, nblk);
-    hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, w.hist, (int64_t)256 * nblk, (int32_t*)nullptr);
+    exscan_launch(w.hist, (int64_t)256 * nblk, nullptr, w.scan, st);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(64), 0, st, w.keys[cur], w.vals[cur], w.keys[cur ^ 1],
                        w.vals[cur ^ 1], n, p * 8, w.hist, nblk);
     cur ^= 1;
   }
   const int nsc = (int)m3d_cdiv(n, SC_TILE);
   hipLaunchKernelGGL(vox_flagsum_kernel, dim3(nsc), dim3(256), 0, st, w.keys[cur], n, w.bsum);
-  hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, w.bsum, (int64_t)nsc, (int32_t*)nullptr);
+  exscan_launch(w.bsum, (int64_t)nsc, nullptr, w.scan, st);
   hipLaunchKernelGGL(vox_assign_kernel, dim3(nsc), dim3(256), 0, st, w.keys[cur], n, w.bsum, w.vid, w.seg, w.misc);
   hipLaunchKernelGGL(vox_ptr_kernel, dim3((unsigned)m3d_cdiv(num_clouds + 1, 256)), dim3(256), 0, st, ptr, num_clouds,
                      n, w.vid, w.misc, out_ptr);
@@ -640,7 +724,7 @@ extern "C" size_t m3d_tile_select_workspace_bytes(int64_t n, int32_t centers_per
   if (n < 0 || centers_per_axis < 1) return 0;
   const int64_t nwg = m3d_cdiv(n > 0 ? n : 1, TS_CHUNK);
   const int64_t S = (int64_t)centers_per_axis * centers_per_axis;
-  return al256((size_t)(S * nwg + 1) * 4) + al256(2 * 1024 * 4) + 512;
+  return al256((size_t)(S * nwg + 1) * 4) + al256(2 * 1024 * 4) + 512 + al256((size_t)((S * nwg) / 4096 + 2) * 4);
 }
 
 // pass 0 (count_only != 0): fills the histogram, scans it, writes sample_ptr[S + 1] (int64) — the caller reads
@@ -674,7 +758,7 @@ extern "C" int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, 
     hipLaunchKernelGGL(tile_sel_min_final, dim3(1), dim3(64), 0, st, (const float*)part, nparts, part + 2048 - 2);
     hipLaunchKernelGGL((tile_select_kernel<false>), dim3((unsigned)nwg), dim3(64), (size_t)S * 4 + 16, st, a);
     // exclusive scan in sample-major order: hist[s][wg] -> first output slot of (sample s, chunk wg); total at the end
-    hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, st, hist, S * nwg, hist + S * nwg);
+    exscan_launch(hist, S * nwg, hist + S * nwg, (int32_t*)(p + al256(2 * 1024 * 4) + 512), st);
     hipLaunchKernelGGL(tile_sel_ptr_kernel, dim3((unsigned)m3d_cdiv(S + 1, 256)), dim3(256), 0, st, (const int32_t*)hist,
                        (int)S, (int)nwg, sample_ptr, (const int*)a.err);
   } else {

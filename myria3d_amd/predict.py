@@ -118,9 +118,6 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
             logits = net(cur["xn"], cur["pn"], None, cur["ptr"], plan=cur["plan"])
         else:
             logits = net(cur["xn"], cur["pn"], None, cur["ptr"])
-        if b + 1 < len(batches):  # the next batch's preparation: enqueued now, behind nothing the main stream still has to do
-            with torch.cuda.stream(side):
-                nxt = prepare(b + 1)
         full = knn_interpolate(logits, cur["p"], cur["pos_copy"], ptr_x=cur["ptr"], ptr_y=cur["ptr_full"], k=interpolation_k)
         if acc is None:
             acc = torch.zeros((n_full, full.shape[1]), dtype=torch.float32, device=dev)
@@ -129,6 +126,11 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
         scatter_sum(full, cur["rows"], out=acc, dim=0)
         if world_size > 1:
             kept_rows.append(cur["rows"])
+        if b + 1 < len(batches):
+            # the next batch's preparation, enqueued on the side stream once ALL of this batch's main-stream work is queued: the
+            # host then blocks on the side stream's read-back while the main stream has ~6 ms of kernels in front of it
+            with torch.cuda.stream(side):
+                nxt = prepare(b + 1)
     main.wait_stream(side)
     if acc is None:  # no non-empty sample (an empty cloud)
         C = int(num_classes) if num_classes else 0

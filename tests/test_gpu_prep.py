@@ -30,7 +30,9 @@ def _batch(rs, sizes, **kw):
     return torch.cat(P), torch.cat(X), torch.cat(Y), ptr
 
 
-@pytest.mark.parametrize("sizes,size", [([30000, 12000], 0.25), ([5000], 1.0), ([1, 700, 2], 0.25), ([4000, 4000, 4000], 5.0)])
+# ([90000, 45000]: 256 x 66 radix-histogram entries per pass — the multi-workgroup prefix sum of round 5, exscan_launch)
+@pytest.mark.parametrize("sizes,size", [([30000, 12000], 0.25), ([5000], 1.0), ([1, 700, 2], 0.25), ([4000, 4000, 4000], 5.0),
+                                        ([90000, 45000], 0.25)])
 def test_grid_sampling_matches_pyg_semantics(device, sizes, size):
     from myria3d_amd import transforms as T
     from oracle import prep_oracle as O
