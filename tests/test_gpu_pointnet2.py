@@ -224,6 +224,54 @@ def test_forward_contract(device):
         HipPointNet2(3, 7, subsampling="voxel")
 
 
+def test_prefetched_geometry_gives_the_same_step(device):
+    """Round 5: ``HipPointNet2.prefetch_geometry`` computes the position-only tables of the NEXT batch (farthest-point sampling,
+    grids, grouping and 1-NN tables) on a side stream; the forward that picks them up must give exactly what the forward
+    that computes them inline gives — logits, loss gradients, the sampled index lists — and a prefetch for ANOTHER batch, or
+    a ``pos`` written since, must be dropped."""
+    from myria3d_amd.pointnet2 import HipPointNet2
+
+    xa, pa, ba, ptra = rand_batch([900, 640, 77], seed=3)
+    xb, pb, bb, ptrb = rand_batch([500, 1200], seed=4)
+    A = tuple(t.to(device) for t in (xa, pa, ba, ptra))
+    B = tuple(t.to(device) for t in (xb, pb, bb, ptrb))
+    torch.manual_seed(0)
+    net = HipPointNet2(9, 6, num_neighbors=16, return_logits=True).to(device).train()
+    ya = torch.from_numpy(np.random.RandomState(2).randint(0, 6, (A[0].shape[0],))).to(device)
+
+    def run(prefetch):
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.momentum = 0.0
+        net.zero_grad(set_to_none=True)
+        if prefetch:
+            net.prefetch_geometry(A[1], A[3])
+            assert net._look is not None
+        out = net(*A, dropout_mask=torch.ones(A[0].shape[0], 32, device=device))
+        assert net._look is None
+        torch.nn.functional.cross_entropy(out, ya).backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), [s.clone() for s in net.last_sample_idx], [p.grad.clone() for p in net.parameters()]
+
+    o0, s0, g0 = run(False)
+    o1, s1, g1 = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(s0, s1)), "same sampled points"
+    assert torch.equal(o0, o1), "same logits, bit for bit (the same kernels on the same tables)"
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(1.0, a.abs().max().item()))
+    # a prefetch for another batch is not used; neither is one whose positions were written afterwards
+    net.prefetch_geometry(B[1], B[3])
+    with torch.no_grad():
+        o2 = net(*A, dropout_mask=torch.ones(A[0].shape[0], 32, device=device))
+    assert torch.equal(o2, o0) and net._look is None
+    pa2 = A[1].clone()
+    net.prefetch_geometry(pa2, A[3])
+    pa2.mul_(1.0)  # (bumps the version counter)
+    with torch.no_grad():
+        net(A[0], pa2, A[2], A[3], dropout_mask=torch.ones(A[0].shape[0], 32, device=device))
+    assert net._look is None
+
+
 @pytest.mark.parametrize("sizes,k", [([300, 211], 16), ([64, 700, 20], 32)])
 def test_train_forward_backward_match_fp64_oracle(device, sizes, k):
     x, pos, batch, ptr = rand_batch(sizes, seed=sizes[0])
