@@ -113,7 +113,7 @@ class HipPointNet2(nn.Module):
         self.last_sample_idx: List[Tensor] = []
         # position-only work of the NEXT batch (prefetch_geometry): (pos tensor, its version, ptr key, train flag, tables, event)
         self._look = None
-        self._side = None
+        self._side = self._side_q = None
 
     # ------------------------------------------------------------------------------------------
     def plan_for(self, ptr: Tensor) -> SAPlan:
@@ -152,7 +152,8 @@ class HipPointNet2(nn.Module):
         return ops.decimation_indices(plan.ptrs[lvl], plan.ptrs[lvl + 1], m, seed, lvl)
 
     # ------------------------------------------------------------------------------------------
-    def _geometry(self, pos: Tensor, plan: SAPlan, train: bool, sample_idx: Optional[List[Tensor]] = None) -> dict:
+    def _geometry(self, pos: Tensor, plan: SAPlan, train: bool, sample_idx: Optional[List[Tensor]] = None,
+                  query_stream: Optional["torch.cuda.Stream"] = None) -> dict:
         """Everything that depends on positions only, for all levels: padded positions, kNN grids, the sampled centres
         (farthest-point or random), the grouping tables and the decoder's 1-NN tables.  Farthest-point sampling is a serial
         chain on ONE compute unit per cloud (33.5 ms for 16 x 40 000 points on 16 of the 256 CUs): ``prefetch_geometry`` runs
@@ -162,6 +163,18 @@ class HipPointNet2(nn.Module):
         pos4 = [ops.pad_pos(pos.to(torch.float32).contiguous())]
         index = [ops.KnnIndex(pos4[0], plan.ptrs[0])]
         sels, nbrs = [], []
+        cur = torch.cuda.current_stream()
+
+        def on_query_stream(fn):
+            # ``query_stream`` (prefetch only): the grouping / 1-NN queries leave the sampler's stream — the chain sampler ->
+            # centres -> next level's sampler is the critical path (one CU per cloud), the queries fill the other 240 CUs beside it
+            if query_stream is None:
+                return fn()
+            query_stream.wait_stream(cur)
+            with torch.cuda.stream(query_stream):
+                out = fn()
+            return out
+
         for lvl in range(3):
             m = plan.totals[lvl + 1]
             if sample_idx is not None:
@@ -172,11 +185,13 @@ class HipPointNet2(nn.Module):
                 sel = self._sample(lvl, pos4[lvl], plan, train, index[lvl])
             sels.append(sel)
             ctr = ops.gather_rows(pos4[lvl], sel)
-            nbr, _ = index[lvl].query(K, pos_qry=ctr, ptr_qry=plan.ptrs[lvl + 1])
-            nbrs.append(nbr)
+            nbrs.append(on_query_stream(lambda: index[lvl].query(K, pos_qry=ctr, ptr_qry=plan.ptrs[lvl + 1])[0]))
             pos4.append(ctr)
             index.append(ops.KnnIndex(ctr, plan.ptrs[lvl + 1]))
-        nn = {lvl: index[lvl + 1].query(1, pos_qry=pos4[lvl], ptr_qry=plan.ptrs[lvl])[0] for lvl in (2, 1, 0)}
+        nn = on_query_stream(lambda: {lvl: index[lvl + 1].query(1, pos_qry=pos4[lvl], ptr_qry=plan.ptrs[lvl])[0]
+                                      for lvl in (2, 1, 0)})
+        if query_stream is not None:
+            cur.wait_stream(query_stream)
         return {"pos4": pos4, "index": index, "sel": sels, "nbr": nbrs, "nn": nn}
 
     def prefetch_geometry(self, pos: Tensor, ptr: Tensor) -> None:
@@ -191,11 +206,12 @@ class HipPointNet2(nn.Module):
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=pos.device)
+            self._side_q = torch.cuda.Stream(device=pos.device)
         side = self._side
         side.wait_stream(main)  # (pos may just have been written on the main stream)
         train = self.training
         with torch.cuda.stream(side), torch.no_grad():
-            geo = self._geometry(pos, plan, train)
+            geo = self._geometry(pos, plan, train, query_stream=self._side_q)
             ev = torch.cuda.Event()
             ev.record(side)
         self._look = (pos, pos._version, tuple(plan.totals), train, geo, ev)
