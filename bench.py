@@ -661,18 +661,18 @@ def pointnet2_bench(args, dev):
 
     def step_pipelined():
         # the next step's position-only work (farthest-point sampling: a serial chain on 16 of the 256 CUs, kNN grids, grouping
-        # and 1-NN tables) is enqueued on the side stream as soon as this step's forward has been launched, and runs under its
-        # forward / backward / optimizer (HipPointNet2.prefetch_geometry, round 5)
+        # and 1-NN tables) is enqueued on the side streams in front of this step's forward and runs under the whole step
+        # (HipPointNet2.prefetch_geometry, round 5)
         opt.zero_grad()
-        out = net(x, pos, batch, ptr)
-        net.prefetch_geometry(pos, ptr)
-        crit(out, y).backward()
+        net.prefetch_geometry(pos, ptr, wait_main=False)  # the NEXT step's tables (the batch is resident): queued behind this step's
+        crit(net(x, pos, batch, ptr), y).backward()      # (this forward takes the tables queued one step ago)
         opt.step()
 
     steps = max(2, min(args.steps, 10))
     for _ in range(3):
         step()
     dt_serial = timed(step, steps, 1) / steps
+    net.prefetch_geometry(pos, ptr)
     for _ in range(3):
         step_pipelined()
     dt = timed(step_pipelined, steps, 1) / steps

@@ -194,12 +194,14 @@ class HipPointNet2(nn.Module):
             cur.wait_stream(query_stream)
         return {"pos4": pos4, "index": index, "sel": sels, "nbr": nbrs, "nn": nn}
 
-    def prefetch_geometry(self, pos: Tensor, ptr: Tensor) -> None:
-        """Enqueue the position-only work of the batch ``(pos, ptr)`` on a side stream now; the next ``forward`` on the SAME
+    def prefetch_geometry(self, pos: Tensor, ptr: Tensor, wait_main: bool = True) -> None:
+        """Enqueue the position-only work of the batch ``(pos, ptr)`` on a side stream now; a later ``forward`` on the SAME
         ``pos`` tensor (unchanged since: identity + version counter) and tile layout picks the tables up instead of
-        computing them.  Call it right after the current step's ``forward`` returned: the sampler then runs under that
-        step's backward pass.  Sampling is deterministic (farthest-point from point 0 of every cloud; with
-        ``random_start`` / ``subsampling="random"`` the draw simply happens here instead of inside the forward)."""
+        computing them (first in, first out: up to two batches may be waiting).  Call it for the NEXT batch in front of the
+        current step's ``forward``: the sampler then runs under that whole step.  ``wait_main=False``: ``pos`` is known to be
+        complete (a resident / already transferred batch) — the side stream then does not wait for what the calling stream
+        still has queued (the previous step's backward and optimizer).  Sampling is deterministic (farthest-point from point
+        0 of every cloud; with ``random_start`` / ``subsampling="random"`` the draw happens here instead of in the forward)."""
         if not pos.is_cuda:
             raise RuntimeError("HipPointNet2 runs on an MI355X only (no CPU fallback by design)")
         plan = self.plan_for(ptr)
@@ -208,21 +210,29 @@ class HipPointNet2(nn.Module):
             self._side = torch.cuda.Stream(device=pos.device)
             self._side_q = torch.cuda.Stream(device=pos.device)
         side = self._side
-        side.wait_stream(main)  # (pos may just have been written on the main stream)
+        if wait_main:
+            side.wait_stream(main)  # (pos may just have been written on the calling stream)
         train = self.training
         with torch.cuda.stream(side), torch.no_grad():
             geo = self._geometry(pos, plan, train, query_stream=self._side_q)
             ev = torch.cuda.Event()
             ev.record(side)
-        self._look = (pos, pos._version, tuple(plan.totals), train, geo, ev)
+        self._look = ((self._look or []) + [(pos, pos._version, tuple(plan.totals), train, geo, ev)])[-2:]
 
     def _take_lookahead(self, pos: Tensor, plan: SAPlan, train: bool) -> Optional[dict]:
-        look, self._look = self._look, None
-        if look is None:
+        queue = self._look or []
+        hit = None
+        for i, ent in enumerate(queue):  # oldest first
+            if ent[0] is pos and ent[1] == pos._version and ent[2] == tuple(plan.totals) and ent[3] == train:
+                hit = i
+                break
+        if hit is None:
+            # prefetched for another batch / mode, or ``pos`` was written since: a stale entry for THIS tensor is dropped, entries
+            # for other tensors (the batch after this one) stay
+            self._look = [e for e in queue if e[0] is not pos] or None
             return None
-        lpos, ver, totals, ltrain, geo, ev = look
-        if lpos is not pos or ver != pos._version or totals != tuple(plan.totals) or ltrain != train:
-            return None  # prefetched for another batch / mode, or ``pos`` was written since: dropped
+        lpos, ver, totals, ltrain, geo, ev = queue[hit]
+        self._look = (queue[:hit] + queue[hit + 1:]) or None
         main = torch.cuda.current_stream()
         main.wait_event(ev)
         for t in geo["pos4"] + geo["sel"] + geo["nbr"] + list(geo["nn"].values()):  # allocated on the side stream, read on this one

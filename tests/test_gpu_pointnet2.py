@@ -259,11 +259,23 @@ def test_prefetched_geometry_gives_the_same_step(device):
     assert torch.equal(o0, o1), "same logits, bit for bit (the same kernels on the same tables)"
     for a, b in zip(g0, g1):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(1.0, a.abs().max().item()))
-    # a prefetch for another batch is not used; neither is one whose positions were written afterwards
+    # a prefetch for another batch is not used by this one (and stays queued for its own forward); one whose positions were
+    # written afterwards is dropped
     net.prefetch_geometry(B[1], B[3])
     with torch.no_grad():
         o2 = net(*A, dropout_mask=torch.ones(A[0].shape[0], 32, device=device))
-    assert torch.equal(o2, o0) and net._look is None
+    assert torch.equal(o2, o0) and net._look is not None and net._look[0][0] is B[1]
+    with torch.no_grad():
+        net(*B)
+    assert net._look is None
+    # two batches queued, consumed first in, first out
+    net.prefetch_geometry(A[1], A[3])
+    net.prefetch_geometry(B[1], B[3], wait_main=False)
+    with torch.no_grad():
+        o3 = net(*A, dropout_mask=torch.ones(A[0].shape[0], 32, device=device))
+        assert torch.equal(o3, o0) and len(net._look) == 1
+        net(*B)
+    assert net._look is None
     pa2 = A[1].clone()
     net.prefetch_geometry(pa2, A[3])
     pa2.mul_(1.0)  # (bumps the version counter)
