@@ -229,50 +229,70 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
 //     centre 2p in columns 0-7 and of centre 2p + 1 in columns 8-15, the B operand is diag(W^T, W^T) (assembled from the
 //     standard fragments: lane (n, g) of the lower block reads what lane (n - 8, g) holds), and output column c of a tile
 //     is channel c % 8 of centre 2p + c / 8: half the MFMAs, half the softmax passes, every lane busy, no zero fill.
+//   * IN-LANE NEIGHBOURHOODS (second half of round 5, from the SQ counters: the kernels issue VALU instructions for 100 % of
+//     their SIMDs' issue slots, a third of them the softmax's cross-lane maxima / sums).  The MFMA C layout gives lane
+//     (lr, lg) rows 4 lg + r of a 16-row tile.  A wave owns 4 row tiles; edge (unit u of the wave, neighbour k) is stored in
+//     LDS row 64 w + 16 (k / 4) + 4 u + (k % 4) instead of 64 w + 16 u + k — i.e. tile k / 4 holds neighbours 4 (k / 4) .. + 3
+//     of all four units of the wave.  Lane (lr, lg) then holds ALL 16 neighbours of unit lg for column lr in its 4 tiles x 4
+//     registers: maximum, exponentials and both sums are plain register arithmetic, no permlane swaps, and all four lane
+//     groups store an output row (before: only group 0).  K = 32: a unit is half a neighbourhood, ONE row swap joins the
+//     halves.  Same MFMA instructions and weight fragments as before — only the row permutation of the LDS tile changed.
+// rows of the LDS tile per workgroup in this kernel: 64 per wave-row (WM) — ch = 8 takes 512 edges (256 packed rows)
+template <int CHP> struct LfaFullCfg { static constexpr int ROWS = LfaCfg<CHP>::ROWS; };
+template <> struct LfaFullCfg<16> { static constexpr int ROWS = 256; };
+template <int CH> struct LfaFullRows { static constexpr int ROWS = CH == 8 ? 512 : LfaFullCfg<(CH < 16 ? 16 : CH)>::ROWS; };
+
 template <int CH, int KP, bool BF>
 __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
   constexpr bool PACK2 = CH == 8;
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;
-  constexpr int ROWS = LfaCfg<CHP>::ROWS;  // edge rows per workgroup
-  constexpr int TC = ROWS / KP;            // centres per workgroup
-  constexpr int KT = KP / 16;
+  constexpr int ROWS = LfaFullRows<CH>::ROWS;  // edge rows per workgroup
+  constexpr int TC = ROWS / KP;                // centres per workgroup
   constexpr int STR = CHP + 2;
   constexpr int PROWS = PACK2 ? ROWS / 2 : ROWS;  // rows of the LDS tile
   constexpr int MT = PROWS / 16, NT = CHP / 16;
   constexpr int WN = NT < 4 ? NT : 4, WM = 4 / WN;
   constexpr int NTW = NT / WN, MTW = MT / WM;
   constexpr int S4 = CHP / 16;
-  constexpr int NG = 256 / ROWS;  // threads per edge row
-  constexpr int DG = D / NG;      // x_j floats and encoder channels per thread
+  constexpr int EPT = ROWS >= 256 ? ROWS / 256 : 1;  // edges per thread
+  constexpr int NG = ROWS >= 256 ? 1 : 256 / ROWS;   // threads per edge row
+  constexpr int DG = D / NG;                         // x_j floats and encoder channels per thread
   constexpr int G4 = DG / 4;
-  static_assert(MTW % KT == 0, "centre tiles must stay inside one wave");
+  static_assert(MTW == 4, "a wave owns four row tiles: the 16 neighbours of a unit sit in one lane");
   static_assert(DG % 4 == 0 && G4 >= 1, "a thread gathers whole float4s");
-  static_assert(!PACK2 || (TC % 2 == 0), "pairs of centres");
+  static_assert(KP == 16 || KP == 32, "whole MFMA tiles per neighbourhood");
   __shared__ float F[PROWS * STR];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const unsigned n = (unsigned)a.n;
   const unsigned c0 = (unsigned)xcd_major(blockIdx.x, gridDim.x) * TC;
-  const int e = tid % ROWS;
-  const int g = __builtin_amdgcn_readfirstlane(tid / ROWS);
-
-  // ---- phase 1: one load chain per thread
-  unsigned eo = c0 * KP + e;
-  const unsigned elast = n * KP - 1;
-  eo = eo < elast ? eo : elast;  // rows past the last centre repeat its last edge (computed, never stored)
-  unsigned ci = c0 + e / KP;
-  ci = ci < n ? ci : n - 1;
-  const unsigned j = (unsigned)a.idx[eo];
-  const float4 pi = *(const float4*)((const char*)a.pos4 + ci * 16u);
-  const float4 pj = *(const float4*)((const char*)a.pos4 + j * 16u);
-  float4 xg[G4];
-#pragma unroll
-  for (int u = 0; u < G4; ++u)
-    xg[u] = *(const float4*)((const char*)a.x + (j * (unsigned)(D * 4) + (unsigned)((g * DG + u * 4) * 4)));
-  // B fragments of the first k-step group: independent of everything above, in flight during phase 1
+  const int g = __builtin_amdgcn_readfirstlane(NG > 1 ? tid / ROWS : 0);
   const int wn = wid % WN, wm = wid / WN;
+  const unsigned elast = n * KP - 1;
+
+  // ---- phase 1: one load chain per thread and edge: id -> (x_j chunk, p_j), p_i beside it
+  unsigned jj[EPT];
+  float4 pi[EPT], pj[EPT], xg[EPT][G4];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = (NG > 1 ? tid % ROWS : tid) + q * 256;
+    unsigned eo = c0 * KP + e;
+    eo = eo < elast ? eo : elast;  // rows past the last centre repeat its last edge (computed, never stored)
+    jj[q] = (unsigned)a.idx[eo];
+    unsigned ci = c0 + e / KP;
+    ci = ci < n ? ci : n - 1;
+    pi[q] = *(const float4*)((const char*)a.pos4 + ci * 16u);
+  }
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    pj[q] = *(const float4*)((const char*)a.pos4 + jj[q] * 16u);
+#pragma unroll
+    for (int u = 0; u < G4; ++u)
+      xg[q][u] = *(const float4*)((const char*)a.x + (jj[q] * (unsigned)(D * 4) + (unsigned)((g * DG + u * 4) * 4)));
+  }
+  // B fragments of the first k-step group: independent of everything above, in flight during phase 1
   float4 b0[NTW];
   if constexpr (!BF) {
     if constexpr (PACK2) {
@@ -283,35 +303,29 @@ __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
       for (int t = 0; t < NTW; ++t) b0[t] = a.wp[((size_t)(wn * NTW + t) * S4) * 64 + lane];
     }
   }
-  // row of the LDS tile and column base of this thread's edge
-  int prow, cbase;
-  if constexpr (PACK2) {
-    const int cl = e / KP, k = e % KP;
-    prow = (cl >> 1) * KP + k;
-    cbase = (cl & 1) * 8;
-  } else {
-    prow = e;
-    cbase = 0;
-  }
-  float* frow = &F[prow * STR + cbase];
 #pragma unroll
-  for (int u = 0; u < G4; ++u) {
-    float* d = frow + g * DG + u * 4;
-    *(float2*)d = make_float2(xg[u].x, xg[u].y);
-    *(float2*)(d + 2) = make_float2(xg[u].z, xg[u].w);
-  }
-  {
+  for (int q = 0; q < EPT; ++q) {
+    const int e = (NG > 1 ? tid % ROWS : tid) + q * 256;
+    // LDS row of edge (local centre cl, neighbour k): unit = centre (pair of centres: PACK2; half a neighbourhood: KP = 32)
+    const int cl = e / KP, k = e % KP;
+    const int unit = ((PACK2 ? cl >> 1 : cl) * (KP / 16)) + (k >> 4), kk = k & 15;
+    const int prow = (unit >> 2) * 64 + (kk >> 2) * 16 + (unit & 3) * 4 + (kk & 3);
+    float* frow = &F[prow * STR + (PACK2 ? (cl & 1) * 8 : 0)];
+#pragma unroll
+    for (int u = 0; u < G4; ++u) {
+      float* d = frow + g * DG + u * 4;
+      *(float2*)d = make_float2(xg[q][u].x, xg[q][u].y);
+      *(float2*)(d + 2) = make_float2(xg[q][u].z, xg[q][u].w);
+    }
     float r[10];
-    const float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-    r[0] = pi.x; r[1] = pi.y; r[2] = pi.z; r[3] = pj.x; r[4] = pj.y; r[5] = pj.z; r[6] = dx; r[7] = dy; r[8] = dz;
-    r[9] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+    rel_pos_fast(pi[q], pj[q], r);
 #pragma unroll
     for (int cc = 0; cc < DG; ++cc) {
       const int c = g * DG + cc;
       const float* w = a.wf + c * 10;
       float v = a.bf[c];
 #pragma unroll
-      for (int q = 0; q < 10; ++q) v += w[q] * r[q];
+      for (int qq = 0; qq < 10; ++qq) v += w[qq] * r[qq];
       frow[D + c] = fmaxf(v, v * a.slope);
     }
   }
@@ -366,56 +380,57 @@ __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
     }
   }
 
-  // ---- phase 3: softmax over each centre's KP neighbours + weighted sum, in the MFMA C layout (no masks)
+  // ---- phase 3: softmax over the neighbours + weighted sum: lane (lr, lg) holds the 16 neighbours of unit 4 wm + lg (tile
+  // m, register r = neighbour 4 m + r) for column 16 (wn NTW + t) + lr
   const float pinf = fast_pinf();
   constexpr float LOG2E = 1.4426950408889634f;
+  const int unit = wm * 4 + lg;  // unit of this lane inside the workgroup
+  const float* fcol = &F[(wm * 64 + lg * 4) * STR];
 #pragma unroll
-  for (int cc = 0; cc < MTW / KT; ++cc) {
-    const int mt0 = wm * MTW + cc * KT;
+  for (int t = 0; t < NTW; ++t) {
+    const int col = (wn * NTW + t) * 16 + lr;
+    float mx = acc[0][t][0];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = (wn * NTW + t) * 16 + lr;
-      float mx = acc[cc * KT][t][0];
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kt + r > 0) mx = fast_max(mx, acc[cc * KT + kt][t][r], pinf);
-      {
-        float p, q;
-        xgroup_pair16(mx, p, q); mx = fast_max(p, q, pinf);
-        xgroup_pair32(mx, p, q); mx = fast_max(p, q, pinf);
-      }
-      const float ml = mx * LOG2E;
-      float num = 0.f, den = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[cc * KT + kt][t][r], LOG2E, -ml));
-          const float f = F[((mt0 + kt) * 16 + lg * 4 + r) * STR + col];
-          num = __builtin_fmaf(p, f, num);
-          den += p;
-        }
-      num = xgroup_sum(num);
-      den = xgroup_sum(den);
-      // output row: PACK2 — tile mt0 / KT is centre pair (c0 / 2 + that), its 16 columns are 2 x 8 channels = 16 consecutive
-      // floats of out; otherwise centre c0 + mt0 / KT, column col
-      unsigned orow, ocol;
-      bool ok;
-      if constexpr (PACK2) {
-        const unsigned cen = c0 + 2u * (unsigned)(mt0 / KT) + (unsigned)(lr >> 3);
-        ok = cen < n;
-        orow = c0 + 2u * (unsigned)(mt0 / KT);
-        ocol = (unsigned)lr;
-      } else {
-        orow = c0 + (unsigned)(mt0 / KT);
-        ok = orow < n && col < CH;
-        ocol = (unsigned)col;
-      }
-      if (lg == 0 && ok)
-        *(float*)((char*)a.out + (orow * (unsigned)(CH * 4) + ocol * 4u)) = num * __builtin_amdgcn_rcpf(den + 1e-16f);
+      for (int r = 0; r < 4; ++r)
+        if (m + r > 0) mx = fast_max(mx, acc[m][t][r], pinf);
+    if constexpr (KP == 32) {  // the other half of the neighbourhood sits in lane group lg ^ 1
+      float p, q;
+      xgroup_pair16(mx, p, q);
+      mx = fast_max(p, q, pinf);
     }
+    const float ml = mx * LOG2E;
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][t][r], LOG2E, -ml));
+        const float f = fcol[(m * 16 + r) * STR + col];
+        num = __builtin_fmaf(p, f, num);
+        den += p;
+      }
+    if constexpr (KP == 32) {
+      float p, q;
+      xgroup_pair16(num, p, q); num = p + q;
+      xgroup_pair16(den, p, q); den = p + q;
+    }
+    // output row of this lane.  PACK2: unit = centre pair, its tile's 16 columns are 2 x 8 channels = 16 consecutive floats of out
+    unsigned orow, ocol;
+    bool ok;
+    if constexpr (PACK2) {
+      const unsigned pair = (unsigned)(KP == 32 ? unit >> 1 : unit);
+      orow = c0 + 2u * pair;
+      ok = orow + (unsigned)(lr >> 3) < n;
+      ocol = (unsigned)lr;
+    } else {
+      orow = c0 + (unsigned)(KP == 32 ? unit >> 1 : unit);
+      ok = orow < n && col < CH;
+      ocol = (unsigned)col;
+    }
+    if (KP == 32 && (lg & 1)) ok = false;  // (both halves hold the result: the even group stores it)
+    if (ok) *(float*)((char*)a.out + (orow * (unsigned)(CH * 4) + ocol * 4u)) = num * __builtin_amdgcn_rcpf(den + 1e-16f);
   }
 }
 
@@ -431,8 +446,9 @@ template <int CH, bool BF = false>
 static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st, int flags) {
   constexpr int ROWS = LfaCfg<(CH < 16 ? 16 : CH)>::ROWS;
   if (lfa_full_ok(a, flags)) {
-    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
+    constexpr int FROWS = LfaFullRows<CH>::ROWS;
+    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, FROWS / 16)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF>), dim3((unsigned)m3d_cdiv(a.n, FROWS / 32)), dim3(256), 0, st, a);
     if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
     return M3D_OK;
   }
