@@ -186,6 +186,17 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   constexpr int D4 = D >> 2;
   constexpr int GPT = (ROWS * D4 + NTHR - 1) / NTHR;  // prefetched x_j segments (float4) per thread
   constexpr int NCW = MTW / KT;                       // centres per wave in the softmax phase
+  // IN-LANE NEIGHBOURHOODS (round 5, as in lfa_fwd_full_kernel): a wave owns four row tiles and LDS row
+  // 64 w + 16 m + 4 u + r holds neighbour 4 m + r of the wave's centre u, so that lane (lr, lg) of the MFMA C layout has all 16
+  // logits of centre lg for its column in its 4 tiles x 4 registers — the softmax backward needs no cross-lane maxima / sums.
+  // Everything indexed by LDS row (ids, F, RT, DA, the dx scatter) stays as it is; only "which edge is row rho" changes.
+  constexpr bool INL = FULL && KP == 16 && MTW == 4 && ROWS == 64 * WM;
+  auto row_edge = [](int rho) -> int {    // natural edge number (centre * KP + neighbour) of LDS row rho
+    return INL ? (((rho >> 6) * 4 + ((rho >> 2) & 3)) * 16 + ((rho >> 4) & 3) * 4 + (rho & 3)) : rho;
+  };
+  auto row_centre = [](int rho) -> int {  // group-local centre of LDS row rho
+    return INL ? ((rho >> 6) * 4 + ((rho >> 2) & 3)) : rho / KP;
+  };
   static_assert(!PIPE || ROWS <= NTHR, "one neighbour id per thread");
   static_assert(!PIPE || S4 * NTW <= 8, "B fragments of one GEMM are held in registers");
 
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   auto load_idx = [&](int64_t g) -> int {
     if constexpr (FULL) {
       // (groups past the end re-read the last edge: an unconditional load, its row never used)
-      unsigned eo = (unsigned)g * ROWS + (unsigned)(tid < ROWS ? tid : 0);
+      unsigned eo = (unsigned)g * ROWS + (unsigned)row_edge(tid < ROWS ? tid : 0);
       eo = eo < elast ? eo : elast;
       return a.idx[eo];
     }
@@ -251,14 +262,15 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       }
       {
         const int e = tid % ROWS;
-        unsigned i = c32 + (unsigned)(e / KP);
+        unsigned i = c32 + (unsigned)row_centre(e);
         i = i < n32 ? i : n32 - 1u;
         ppi = *(const float4*)((const char*)a.pos4 + i * 16u);
         ppj = *(const float4*)((const char*)a.pos4 + (unsigned)nb[e] * 16u);
       }
 #pragma unroll
-      for (int cc = 0; cc < NCW; ++cc) {
-        unsigned i = c32 + (unsigned)((wm * MTW + cc * KT) / KT);
+      for (int cc = 0; cc < (INL ? 1 : NCW); ++cc) {
+        // (INL: ONE centre per lane — centre 4 wm + lg of the group — instead of the wave's NCW centres in every lane)
+        unsigned i = c32 + (unsigned)(INL ? wm * 4 + lg : (wm * MTW + cc * KT) / KT);
         i = i < n32 ? i : n32 - 1u;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       // ---- phase 1a: neighbour ids
       for (int e = tid; e < ROWS; e += NTHR) {
         if constexpr (FULL) {
-          unsigned eo = (unsigned)c0 * KP + (unsigned)e;
+          unsigned eo = (unsigned)c0 * KP + (unsigned)row_edge(e);
           nbr[e] = a.idx[eo < elast ? eo : elast];
         } else {
           int ci = e / KP, k = e % KP;
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 #pragma unroll
         for (int q = 0; q < 10; ++q) r[q] = 0.f;
         if constexpr (FULL) {
-          unsigned i32 = (unsigned)c0 + (unsigned)(e / KP);
+          unsigned i32 = (unsigned)c0 + (unsigned)row_centre(e);
           i32 = i32 < n32 ? i32 : n32 - 1u;
           rel_pos_fast(*(const float4*)((const char*)a.pos4 + i32 * 16u), *(const float4*)((const char*)a.pos4 + (unsigned)j * 16u), r);
         } else if (j >= 0) rel_pos(a.pos4[i], a.pos4[j], r);
@@ -531,6 +543,51 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     if (LFA_BWD_DBG & 4) continue;   // timing experiment: phases 1-2
     // ---- phase 3': softmax, dA -> LDS, acc <- dout * s
     const float pinf = FULL ? fast_pinf() : opaque_pinf();
+    if constexpr (INL) {
+      // lane (lr, lg): centre 4 wm + lg of the group, column 16 (wn NTW + t) + lr, neighbour 4 m + r in acc[m][t][r]
+      const int64_t ic = c0 + wm * 4 + lg;
+      const int rbase = (wm * 64 + lg * 4) * STR;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wn * NTW + t) * 16 + lr;
+        float mx = acc[0][t][0];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (m + r > 0) mx = fast_max(mx, acc[m][t][r], pinf);
+        const float ml = mx * 1.4426950408889634f;
+        float num = 0.f, den = 0.f;
+        float fv[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][t][r], 1.4426950408889634f, -ml));
+            const float f = F[rbase + (m * 16 + r) * STR + col];
+            num = __builtin_fmaf(p, f, num);
+            den += p;
+            acc[m][t][r] = p;
+            fv[m][r] = f;
+          }
+        const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);
+        const float o = num * inv;
+        float g = 0.f;
+        if (ic < a.n && col < CH) {
+          if constexpr (PIPE) g = dgc[0][t];
+          else g = *(const float*)((const char*)a.dout + ((unsigned)ic * (unsigned)(CH * 4) + (unsigned)(col * 4)));
+        }
+        const float gi = g * inv;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gs = acc[m][t][r] * gi;  // dout * softmax weight
+            DA[rbase + (m * 16 + r) * STR + col] = gs * (fv[m][r] - o);
+            acc[m][t][r] = gs;
+          }
+      }
+    } else
 #pragma unroll
     for (int cc = 0; cc < MTW / KT; ++cc) {
       const int mt0 = wm * MTW + cc * KT;
