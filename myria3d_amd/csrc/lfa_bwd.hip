@@ -41,6 +41,13 @@ struct LfaBwdArgs {
 #define LFA_BWD_DBG 0
 #endif
 // A/B builds only: 1 = ignore the FULL promise (flags bit 3) and launch the general kernels
+// A/B builds only: 0 = the complete-neighbourhood kernels keep the cross-lane softmax (no in-lane row permutation)
+#ifndef LFA_BWD_INL
+#define LFA_BWD_INL 1
+#endif
+#ifndef LFA_BWD_INL_MINCH
+#define LFA_BWD_INL_MINCH 128
+#endif
 #ifndef LFA_BWD_DBG_NOFULL
 #define LFA_BWD_DBG_NOFULL 0
 #endif
@@ -190,7 +197,10 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   // 64 w + 16 m + 4 u + r holds neighbour 4 m + r of the wave's centre u, so that lane (lr, lg) of the MFMA C layout has all 16
   // logits of centre lg for its column in its 4 tiles x 4 registers — the softmax backward needs no cross-lane maxima / sums.
   // Everything indexed by LDS row (ids, F, RT, DA, the dx scatter) stays as it is; only "which edge is row rho" changes.
-  constexpr bool INL = FULL && KP == 16 && MTW == 4 && ROWS == 64 * WM;
+  // (ch = 64 keeps the cross-lane softmax: same-box A/B, profiles/r05n_*: isolated launches 233 vs 237 us in favour of the
+  // in-lane layout, but INSIDE training steps 234 vs 223 us against it, three runs out of three; ch = 128 / 256: 227 vs 232 and
+  // 270 vs 280 us)
+  constexpr bool INL = LFA_BWD_INL && FULL && KP == 16 && MTW == 4 && ROWS == 64 * WM && CH >= LFA_BWD_INL_MINCH;
   auto row_edge = [](int rho) -> int {    // natural edge number (centre * KP + neighbour) of LDS row rho
     return INL ? (((rho >> 6) * 4 + ((rho >> 2) & 3)) * 16 + ((rho >> 4) & 3) * 4 + (rho & 3)) : rho;
   };
