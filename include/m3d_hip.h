@@ -105,6 +105,25 @@ int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_
                  int64_t M, int32_t N, const float* bias, const float* scale, const float* shift, int32_t act,
                  float slope, double* stat_part, int32_t stat_parts, float* c, int64_t ldc, int32_t accumulate,
                  int32_t splitk, void* stream);
+/* The SharedMLP layer BEHIND another one, fused with that layer's train-mode BatchNorm + LeakyReLU (pyg_randla_net.py:97-109):
+ *   y = lrelu((z - mean) * invstd * gamma + beta)   (z [M, k0]: the raw Linear output of the layer in front; statistics from ITS
+ *                                                     slot table `slots` [nslots][2][k0], as m3d_bn_stats_apply derives them)
+ *   C[M, N] = y B[N, k0]^T + bias,  column sums / sums of squares of C into the pre-zeroed slot table stat_part [stat_slots][2][N]
+ * One launch instead of m3d_bn_stats_apply + m3d_gemm_f32, one pass over the activation less.  The launch also writes what the
+ * backward pass of the layer in front needs (scale / shift / mean / invstd [k0]), updates its running statistics, and stores
+ * y (nullable) for this layer's weight-gradient GEMM.  k0 <= 64 and k0 % 4 == 0 (the row-stream kernel: the 204 800 / 51 200-row
+ * layers); M3D_ERR_UNSUPPORTED otherwise (callers then use the two launches). */
+typedef struct {
+  const double* slots; int32_t nslots; int64_t count;
+  const float* gamma; const float* beta; float eps; float momentum;
+  float* running_mean; float* running_var;               /* nullable: updated in place */
+  float* scale; float* shift; float* mean; float* invstd; /* [k0] outputs */
+  int32_t act; float slope;
+  float* y;                                               /* [M, k0] output (nullable) */
+} M3DBnOnLoad;
+int m3d_gemm_bn_on_load_f32(const M3DBnOnLoad* pro, const float* z, int32_t k0, const float* b, int64_t ldb, int64_t M,
+                            int32_t N, const float* bias, double* stat_part, int32_t stat_slots, float* c, int64_t ldc,
+                            void* stream);
 /* two products with ONE output shape, C_i[M, N] (+)= A_i[M, k_i] B_i^T (+ bias_i), i = 0, 1, as one launch when the
  * fragment-direct k-loop kernel takes both (k_i > 64, 16-byte aligned rows, same tile plan), as two m3d_gemm_f32 launches
  * otherwise: the mlp2 / shortcut Linears of a DilatedResidualBlock (pyg_randla_net.py:172-188) and their input

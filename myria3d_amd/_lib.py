@@ -59,6 +59,7 @@ SIGNATURES = {
                                _p]),
     "m3d_lfa_prepare_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                      _p]),
+    "m3d_gemm_bn_on_load_f32": (_i32, [_p, _p, _i32, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _i64, _p]),
     "m3d_lfa_fwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _i32, _p]),
     "m3d_lfa_pack_att_bf16": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_fwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _f32, _p, _i32, _p]),
@@ -97,6 +98,14 @@ class M3DDropout(C.Structure):
     """``M3DDropout`` of include/m3d_hip.h (read by the library on the host, at call time)."""
     _fields_ = [("counter", C.c_void_p), ("seed", C.c_uint64), ("p", C.c_float), ("rows", C.c_void_p),
                 ("snapshot", C.c_void_p)]
+
+
+class M3DBnOnLoad(C.Structure):
+    """``M3DBnOnLoad`` of include/m3d_hip.h (read by the library on the host, at call time)."""
+    _fields_ = [("slots", C.c_void_p), ("nslots", C.c_int32), ("count", C.c_int64), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("eps", C.c_float), ("momentum", C.c_float), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("y", C.c_void_p)]
 
 
 ABI_VERSION = 15  # M3D_ABI_VERSION in include/m3d_hip.h

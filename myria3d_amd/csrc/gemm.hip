@@ -255,6 +255,31 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   return M3D_OK;
 }
 
+// SharedMLP layer whose INPUT is the raw output z of the SharedMLP layer in front (its train-mode BatchNorm + LeakyReLU not
+// applied yet): C[M, N] = lrelu(z * scale + shift) B^T + bias with slot-mode statistics of C, scale / shift derived in the
+// launch from the front layer's slot statistics (pyg_randla_net.py:97-109: torch runs BatchNorm1d, LeakyReLU and the next
+// Linear as three kernels and three passes).  K <= 64 (the row-stream kernel: levels 1-2), 16-byte rows, un-gathered A.
+extern "C" int m3d_gemm_bn_on_load_f32(const M3DBnOnLoad* pro, const float* z, int32_t k0, const float* b, int64_t ldb,
+                                       int64_t M, int32_t N, const float* bias, double* stat_part, int32_t stat_slots,
+                                       float* c, int64_t ldc, void* stream) {
+  if (!pro || M < 0 || N < 0 || k0 < 1 || stat_slots < 1) return M3D_ERR_INVALID;
+  if (M == 0 || N == 0) return M3D_OK;
+  if (!z || !b || !c || !stat_part || !pro->slots || !pro->scale || !pro->shift || pro->nslots < 1 || pro->count < 1)
+    return M3D_ERR_INVALID;
+  if (k0 > 64 || (k0 & 3)) return M3D_ERR_UNSUPPORTED;
+  GemmArgs g{};
+  g.a0 = z; g.lda0 = k0; g.k0 = k0; g.b = b; g.ldb = ldb; g.M = M; g.N = N; g.bias = bias;
+  g.stat_part = stat_part; g.stat_sum = stat_part; g.stat_sumsq = stat_part + N; g.stat_slots = stat_slots;
+  g.c = c; g.ldc = ldc; g.splitk = 1; g.kchunk = m3d_align((int64_t)k0, BK);
+  g.fpro = 1; g.fpro_slots = pro->slots; g.fpro_nslots = pro->nslots; g.fpro_count = (double)pro->count;
+  g.fpro_gamma = pro->gamma; g.fpro_beta = pro->beta; g.fpro_eps = pro->eps; g.fpro_momentum = pro->momentum;
+  g.fpro_rmean = pro->running_mean; g.fpro_rvar = pro->running_var; g.fpro_scale = pro->scale; g.fpro_shift = pro->shift;
+  g.fpro_mean = pro->mean; g.fpro_invstd = pro->invstd; g.fpro_act = pro->act & 1; g.fpro_slope = pro->slope;
+  g.fpro_y = pro->y;
+  const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
+  return rc == 1 ? M3D_ERR_UNSUPPORTED : rc;  // (never the LDS-tiled fallback: it knows no prologue)
+}
+
 // Two independent products C_i[M, N] (+)= A_i[M, K_i] B_i^T with one output shape as ONE launch when the fragment-direct
 // k-loop kernel covers both (K_i > 64, 16-byte aligned rows, same tile plan); otherwise two ordinary launches.  The mlp2 /
 // shortcut Linears of a DilatedResidualBlock (/root/reference/myria3d/models/modules/pyg_randla_net.py:172-188) and their

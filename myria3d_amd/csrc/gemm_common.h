@@ -36,6 +36,17 @@ struct GemmArgs {
   // c[m][.] (ldc), columns [c_split, N) to c1[m][. - c_split] (ldc1) — two contiguous matrices instead of one that has to
   // be sliced and copied.  c_split = 0: plain output.  Direct kernels, plain epilogue only.
   int c_split; float* c1; int64_t ldc1;
+  // forward A-prologue (m3d_gemm_bn_on_load_f32, round 5; row-stream kernels, statistics epilogue): A0 holds the RAW output z
+  // [M, k0] of the SharedMLP layer in front, whose train-mode BatchNorm + LeakyReLU has not been applied: this launch
+  // derives that layer's scale / shift from its slot statistics (every workgroup, as m3d_bn_stats_apply's do; workgroup (0, 0)
+  // also stores scale / shift / mean / invstd for the backward pass and updates the running statistics), its MFMAs see
+  // y = lrelu(z * scale + shift), and column slice 0 stores y (the weight-gradient GEMM of THIS layer reads it) — the
+  // m3d_bn_stats_apply launch between the two GEMMs and one pass over the activation are gone.
+  int fpro;
+  const double* fpro_slots; int fpro_nslots; double fpro_count;
+  const float* fpro_gamma; const float* fpro_beta; float fpro_eps, fpro_momentum;
+  float* fpro_rmean; float* fpro_rvar; float* fpro_scale; float* fpro_shift; float* fpro_mean; float* fpro_invstd;
+  int fpro_act; float fpro_slope; float* fpro_y;
 };
 
 // gemm_direct.hip: returns M3D_OK when it handled the problem, 1 when the shape is not covered (caller falls back)

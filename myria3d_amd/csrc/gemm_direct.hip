@@ -225,6 +225,59 @@ __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc
   return o;
 }
 
+// ------------------------------------------------------------------------------------------
+// forward A-prologue (GemmArgs::fpro_*): scale / shift of the layer in front from its slot statistics -> LDS [2][64]
+// (zeros past k0), same arithmetic as bn_stats_col (bn.hip): fp64 mean / biased variance / invstd, running statistics with
+// the unbiased variance
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fpro_setup(const GemmArgs& g, float (&cf)[2][64]) {
+  const int K = g.k0;
+  const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+  for (int k = threadIdx.x; k < 64; k += 256) {
+    float sc = 0.f, sh = 0.f;
+    if (k < K) {
+      const float gam0 = (g.fpro_gamma ? g.fpro_gamma : g.fpro_scale)[k], bet0 = (g.fpro_beta ? g.fpro_beta : g.fpro_scale)[k];
+      const float rm = (writer && g.fpro_rmean ? g.fpro_rmean : g.fpro_scale)[k];
+      const float rv = (writer && g.fpro_rvar ? g.fpro_rvar : g.fpro_scale)[k];
+      const float gam = g.fpro_gamma ? gam0 : 1.f, bet = g.fpro_beta ? bet0 : 0.f;
+      double sq[2];
+      slot_sums<2>(g.fpro_slots + k, g.fpro_nslots, 2 * (size_t)K, (size_t)K, sq);
+      const double mean = sq[0] / g.fpro_count;
+      double var = sq[1] / g.fpro_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)g.fpro_eps);
+      const double scd = (double)gam * invstd;
+      sc = (float)scd;
+      sh = (float)((double)bet - mean * scd);
+      if (writer) {
+        g.fpro_scale[k] = sc; g.fpro_shift[k] = sh;
+        if (g.fpro_mean) g.fpro_mean[k] = (float)mean;
+        if (g.fpro_invstd) g.fpro_invstd[k] = (float)invstd;
+        if (g.fpro_rmean) g.fpro_rmean[k] = (float)((1.0 - g.fpro_momentum) * (double)rm + g.fpro_momentum * mean);
+        if (g.fpro_rvar) {
+          const double unbiased = g.fpro_count > 1.0 ? var * g.fpro_count / (g.fpro_count - 1.0) : var;
+          g.fpro_rvar[k] = (float)((1.0 - g.fpro_momentum) * (double)rv + g.fpro_momentum * unbiased);
+        }
+      }
+    }
+    cf[0][k] = sc; cf[1][k] = sh;
+  }
+  __syncthreads();
+}
+// y[m][k .. k+3] = lrelu(z * scale + shift) of the (never gathered) row; `store`: also write it to fpro_y (same layout as z)
+__device__ __forceinline__ float4 a_frag_fpro(const GemmArgs& g, rsrc_t ra0, const ARow& r, int k, const float (&cf)[2][64],
+                                              bool store) {
+  const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
+  const float4 z = ld4(ra0, f0);
+  const float4 sc = *(const float4*)&cf[0][k], sh = *(const float4*)&cf[1][k];
+  float4 y = make_float4(z.x * sc.x + sh.x, z.y * sc.y + sh.y, z.z * sc.z + sh.z, z.w * sc.w + sh.w);
+  if (g.fpro_act) { y.x = lrelu(y.x, g.fpro_slope); y.y = lrelu(y.y, g.fpro_slope); y.z = lrelu(y.z, g.fpro_slope); y.w = lrelu(y.w, g.fpro_slope); }
+  const bool live = f0 != OOB;  // (rows / columns that do not exist must stay 0: lrelu(shift) is not)
+  y.x = live ? y.x : 0.f; y.y = live ? y.y : 0.f; y.z = live ? y.z : 0.f; y.w = live ? y.w : 0.f;
+  if (store && live) *(float4*)((char*)g.fpro_y + f0) = y;
+  return y;
+}
+
 // accumulate, pre-loaded (GemmArgs::acc_pre): the lane's four old output values of row m, columns n0..n0+3 (the C/D
 // fragment layout of the transposed product) as the initial accumulator; zeros where the tile has no output
 __device__ __forceinline__ f32x4 c_prev(const GemmArgs& g, rsrc_t rc, rsrc_t rc1, int64_t m, int n0) {
@@ -369,9 +422,10 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
 // K <= 16*KQ <= 64, column slice 16*NT <= 64: weights in registers, rows streamed.
 // grid: (row workgroups, column slices); 4 waves per workgroup take interleaved 16-row tiles.
 // ------------------------------------------------------------------------------------------
-template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM, bool PRO = false>
+template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM, bool PRO = false, bool FPRO = false>
 __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
   if constexpr (PRO) g.pro_dkey = pro_key(g);
+  __shared__ float fcf[FPRO ? 2 : 1][FPRO ? 64 : 4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * NT;
@@ -389,6 +443,7 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
   // (after the weight / bias loads were issued: the column pass is a dependent chain of its own — slot loads, fp64, LDS,
   // barrier — and the small layers are nothing but latency)
   if constexpr (PRO) pro_setup<64>(g, (float (&)[6][64])cf);
+  if constexpr (FPRO) fpro_setup(g, (float (&)[2][64])fcf);
   double ssum[NT][4], ssq[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -404,6 +459,7 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
       if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
+      else if constexpr (FPRO) a[q] = a_frag_fpro(g, ra0, row, 16 * q + 4 * lg, (const float (&)[2][64])fcf, blockIdx.y == 0 && g.fpro_y);
       else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
     }
     f32x4 acc[NT];
@@ -578,7 +634,10 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_pair_kernel(Gemm
 template <int NT, int KQ, int MODE>
 static void launch_rs(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
   switch (variant) {
-    case 0: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
+    case 0:
+      if (MODE == 1 && g.fpro) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 1, true, false, false, false, true>), grid, dim3(256), 0, st, g, cvec);
+      else hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec);
+      break;
     case 1: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
     case 2:
       if (g.pro_z) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec);
@@ -725,6 +784,10 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
     return M3D_ERR_UNSUPPORTED;
   const RowPlan rp = plan_rows(g.M, g.N, K, mode);
   if (rp.slices > 65535) return 1;
+  // the forward BatchNorm prologue: row-stream kernel, vector loads of ONE un-gathered operand, statistics epilogue
+  if (g.fpro && (!rp.rowstream || variant != 0 || mode != 1 || g.a0_rows || g.lda0 != g.k0 || K > 64 || !g.fpro_slots ||
+                 !g.fpro_scale || !g.fpro_shift || (g.fpro_y && !al16(g.fpro_y))))
+    return M3D_ERR_UNSUPPORTED;
   dim3 grid((unsigned)rp.wgs, (unsigned)rp.slices);
   GemmArgs gk = g;
   gk.ksplit = rp.ksplit;

@@ -601,7 +601,7 @@ def _drop_ref(drop):
 
 
 def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tensor, act: bool, stats2=None, bn2=None,
-                   z2=None, drop=None):
+                   z2=None, drop=None, out=None):
     """``bn_finalize`` + ``bn_apply`` in one launch (``m3d_bn_stats_apply``) from slot-mode statistics.  Returns
     ``(y, (scale, shift, mean, invstd)[, (scale2, shift2, mean2, invstd2)])``."""
     if count < 2:
@@ -609,10 +609,14 @@ def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tenso
     n = bn.num_features
     dev = z.device
     # (one allocation for the 4 (+4) per-column vectors: widths are multiples of 4, so every row stays 16-byte aligned)
-    pv = torch.empty((8 if bn2 is not None else 4, n), dtype=torch.float32, device=dev).unbind(0)
-    p1 = pv[:4]
-    p2 = pv[4:] if bn2 is not None else (None,) * 4
-    y = torch.empty_like(z)
+    if out is not None:  # (y, (scale, shift, mean, invstd)) allocated by the caller: PendingBN.materialize
+        y, p1 = out
+        p2 = (None,) * 4
+    else:
+        pv = torch.empty((8 if bn2 is not None else 4, n), dtype=torch.float32, device=dev).unbind(0)
+        p1 = pv[:4]
+        p2 = pv[4:] if bn2 is not None else (None,) * 4
+        y = torch.empty_like(z)
     call("m3d_bn_stats_apply", _p(stats), stats.shape[0], count, _p(bn.weight), _p(bn.bias), float(bn.eps),
          float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p1[3]),
          _p(_chk(z)), _p(stats2), _p(bn2.weight if bn2 is not None else None),
@@ -623,6 +627,89 @@ def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tenso
         if b is not None and not getattr(b, "_m3d_flat_counter", False):  # flattened nets bump all counters at once
             b.num_batches_tracked += 1
     return (y, p1, p2) if bn2 is not None else (y, p1)
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm apply-on-load (round 5): a SharedMLP layer whose only consumer is the next SharedMLP layer's GEMM (levels 1-2:
+# the row-stream kernel) does not launch m3d_bn_stats_apply; the consumer's GEMM derives scale / shift from the slot
+# statistics, applies BatchNorm + LeakyReLU to its A fragments as they are loaded and stores the activation on the way
+# (m3d_gemm_bn_on_load_f32).  The producer hands over ``y`` — allocated, NOT yet written — tagged with a PendingBN.
+# --------------------------------------------------------------------------------------------------
+BN_ON_LOAD = os.environ.get("M3D_BN_ON_LOAD", "1") != "0"  # A/B switch
+
+
+class PendingBN:
+    """The not-yet-applied BatchNorm (+ LeakyReLU) of a SharedMLP layer: raw output ``z``, slot statistics, the module, and
+    the buffers the apply would have written (``y`` and the four per-column vectors the backward pass reads)."""
+
+    __slots__ = ("z", "stats", "count", "bn", "act", "y", "vecs", "done")
+
+    def __init__(self, z, stats, count, bn, act, y, vecs):
+        self.z, self.stats, self.count, self.bn, self.act, self.y, self.vecs, self.done = z, stats, count, bn, act, y, vecs, False
+
+    def materialize(self) -> Tensor:
+        """The unfused launch after all (a consumer the fused GEMM does not cover)."""
+        if not self.done:
+            bn_stats_apply(self.stats, self.count, self.bn, self.z, self.act, out=(self.y, self.vecs))
+            self.done = True
+        return self.y
+
+
+_pending: List[PendingBN] = []  # created during the current forward and not consumed yet (checked at its end)
+_last_pending: Optional[PendingBN] = None
+
+
+def take_pending(t: Optional[Tensor]) -> Optional[PendingBN]:
+    """The PendingBN whose (unwritten) activation buffer ``t`` is, or None."""
+    if t is None or not _pending:
+        return None
+    for p in _pending:
+        if p.y is t or (p.y.data_ptr() == t.data_ptr() and p.y.shape == t.shape):
+            return p
+    return None
+
+
+def _settle(p: PendingBN) -> None:
+    p.materialize()
+    if p in _pending:
+        _pending.remove(p)
+
+
+def settle_pending() -> None:
+    """End of a forward: an activation nobody consumed through a fused GEMM is written by the plain launch."""
+    while _pending:
+        _pending.pop().materialize()
+
+
+def gemm_bn_on_load(pend: PendingBN, w: Tensor, M: int, N: int, bias: Optional[Tensor], stats: Tensor) -> Optional[Tensor]:
+    """``C = lrelu(BN(pend.z)) W^T + bias`` with slot-mode statistics into ``stats``; also writes ``pend.y`` and
+    ``pend.vecs`` and updates the running statistics.  None when the shape is not covered (nothing was launched)."""
+    import ctypes
+    from ._lib import M3DBnOnLoad
+
+    bn = pend.bn
+    k0 = pend.z.shape[1]
+    if pend.count < 2:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [{pend.count}, {k0}]")
+    if k0 > 64 or k0 % 4 or not pend.z.is_contiguous() or w.shape[1] != k0:
+        return None
+    out = torch.empty((M, N), dtype=torch.float32, device=w.device)
+    sc, sh, mu, isd = pend.vecs
+    pro = M3DBnOnLoad(_p(pend.stats), pend.stats.shape[0], pend.count, _p(bn.weight), _p(bn.bias), float(bn.eps),
+                      float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(sc), _p(sh), _p(mu), _p(isd),
+                      int(pend.act), LRELU_SLOPE, _p(pend.y))
+    rc = lib().m3d_gemm_bn_on_load_f32(ctypes.byref(pro), _p(pend.z), k0, _p(w), w.stride(0), M, N, _p(bias), _p(stats),
+                                       stats.shape[0], _p(out), out.stride(0), _st())
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError(f"m3d_gemm_bn_on_load_f32 failed with status {rc}")
+    if not getattr(bn, "_m3d_flat_counter", False):
+        bn.num_batches_tracked += 1
+    pend.done = True
+    if pend in _pending:
+        _pending.remove(pend)
+    return out
 
 
 def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Tensor] = None,
@@ -742,7 +829,7 @@ class LinearFn(torch.autograd.Function):
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False, x0_slot=None, x1_slot=None,
-                drop=None, rows_inv=None):
+                drop=None, rows_inv=None, defer_apply=False):
         # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None;  bf16: matrix-core precision of the K > 64 GEMMs
         # x0_slot: GradSlot of x0, this layer being its LAST consumer in backward order (adds its input gradient to what
         # the others deposited and returns the sum); x1_slot: GradSlot of x1, this layer being the FIRST (deposits)
@@ -768,13 +855,38 @@ class SharedLayerTrainFn(torch.autograd.Function):
         N = w.shape[0]
         k0 = x0.shape[1]
         k1 = x1.shape[1] if x1 is not None else 0
+        # x0 may be the (unwritten) activation buffer of the layer in front (PendingBN): this GEMM then applies that layer's
+        # BatchNorm + LeakyReLU as it loads its A fragments and stores the activation (defer_apply of the layer in front)
+        pend = take_pending(x0) if (x1 is None and rows is None) else None
+        if pend is None and x0 is not None and take_pending(x0) is not None:
+            take_pending(x0).materialize()  # (a gathered / concatenated read: the plain launch first)
+            _pending.remove(take_pending(x0))
+        global _last_pending
         if _pow2(N):  # slot-mode statistics: GEMM + ONE fused finalize/apply launch
             stats = stat_slots(N, w.device, M)
-            z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, stat_slots=True, bf16=bf16)
-            y, (scale, shift, mean, invstd) = bn_stats_apply(stats, M, bn, z, act, drop=drop)
+            z = gemm_bn_on_load(pend, w, M, N, b, stats) if pend is not None else None
+            if z is None:
+                if pend is not None:
+                    pend.materialize()
+                    _pending.remove(pend)
+                z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, stat_slots=True, bf16=bf16)
+            if defer_apply and drop is None and BN_ON_LOAD:
+                # the consumer's GEMM applies this layer's BatchNorm (the caller knows it is a SharedMLP layer on the same rows)
+                pv = torch.empty((4, N), dtype=torch.float32, device=w.device).unbind(0)
+                y = torch.empty_like(z)
+                scale, shift, mean, invstd = pv
+                if M < 2:
+                    raise ValueError(f"Expected more than 1 value per channel when training, got input size [{M}, {N}]")
+                _last_pending = PendingBN(z, stats, M, bn, act, y, pv)
+                _pending.append(_last_pending)
+            else:
+                y, (scale, shift, mean, invstd) = bn_stats_apply(stats, M, bn, z, act, drop=drop)
         else:
             if drop is not None:
                 raise ValueError("fused dropout needs a power-of-two layer width")
+            if pend is not None:
+                pend.materialize()
+                _pending.remove(pend)
             stats = stat_buffer(M, N, k0 + k1, w.device)
             z = gemm(x0, w, M, N, k0, rows=rows, a1=x1, k1=k1, bias=b, stats=stats, bf16=bf16)
             scale, shift, mean, invstd = bn_finalize(stats, M, bn)
@@ -842,7 +954,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
             dx1 = None
         dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
@@ -861,12 +973,22 @@ class ResidualTailTrainFn(torch.autograd.Function):
             st2, sts = stat_slots(N, w2.device, M), stat_slots(N, w2.device, M)
             if PAIR_GEMMS and min(x2.shape[1], xs.shape[1]) > 64 and st2.shape == sts.shape:
                 # deep levels: both Linears in one launch (each alone is a few hundred workgroups)
+                if take_pending(x2) is not None:
+                    _settle(take_pending(x2))
                 z2, zs = gemm_pair((x2.contiguous(), xs.contiguous()), (w2, ws), M, N, bias=(b2, bs), stats=(st2, sts), bf16=bf16)
             else:
-                z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, stat_slots=True, bf16=bf16)
+                pend = take_pending(x2)
+                z2 = gemm_bn_on_load(pend, w2, M, N, b2, st2) if pend is not None else None
+                if z2 is None:
+                    if pend is not None:
+                        pend.materialize()
+                        _pending.remove(pend)
+                    z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, stat_slots=True, bf16=bf16)
                 zs = gemm(xs, ws, M, N, xs.shape[1], bias=bs, stats=sts, stat_slots=True, bf16=bf16)
             y, (sc2, sh2, mu2, is2), (scs, shs, mus, iss) = bn_stats_apply(st2, M, bn2, z2, True, sts, bns, zs)
         else:
+            if take_pending(x2) is not None:
+                _settle(take_pending(x2))
             st2 = stat_buffer(M, N, x2.shape[1], w2.device)
             sts = stat_buffer(M, N, xs.shape[1], w2.device)
             z2 = gemm(x2, w2, M, N, x2.shape[1], bias=b2, stats=st2, bf16=bf16)

@@ -404,12 +404,14 @@ class HipRandLANet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
                       rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None, drop=None,
-                      rows_inv=None) -> Tensor:
+                      rows_inv=None, defer: bool = False) -> Tensor:
+        """``defer`` (train mode): the layer's ONLY consumer is the next SharedMLP layer on the same rows — its BatchNorm +
+        LeakyReLU are applied by that layer's GEMM as it loads its input (``ops.PendingBN``, round 5), no launch here."""
         lin, bn = mlp.lins[li], mlp.norms[li].module
         if train:
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
-                                                sk, self._bf16, x0_slot, x1_slot, drop, rows_inv)
+                                                sk, self._bf16, x0_slot, x1_slot, drop, rows_inv, defer)
         if self._grad_eval:
             return ops.SharedLayerEvalFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
@@ -419,7 +421,7 @@ class HipRandLANet(nn.Module):
                         bf16=self._bf16)
 
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
-             train: bool, prepared=None) -> Tensor:
+             train: bool, prepared=None, defer_post: bool = False) -> Tensor:
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
         bf16 = self._bf16 and ops.lfa_bf16_ok(w_att.shape[0], idx.shape[1])
@@ -442,7 +444,7 @@ class HipRandLANet(nn.Module):
                                           + (None,), (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
             agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16,
                                   full=bool(num_edges == idx.shape[0] * idx.shape[1]))
-        return self._shared_layer(p.mlp_post_attention, 0, agg, train=train)
+        return self._shared_layer(p.mlp_post_attention, 0, agg, train=train, defer=defer_post)
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
                mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str,
@@ -459,7 +461,11 @@ class HipRandLANet(nn.Module):
         h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train, prepared[0])
         if rec is not None:
             rec[name + ".lfa1"] = h[index.inv.long()]
-        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1])
+        # lfa2's SharedMLP feeds mlp2 only: on levels 1-2 (<= 64 channels: the row-stream GEMM) mlp2's GEMM applies its
+        # BatchNorm on load instead of a launch of its own
+        defer2 = bool(train and rec is None and ops.BN_ON_LOAD and blk.mlp2.lins[0].weight.shape[1] <= 64
+                      and blk.mlp2.lins[0].weight.shape[1] % 4 == 0 and torch.is_grad_enabled())
+        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1], defer_post=defer2)
         l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
         ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
         if train:
@@ -838,12 +844,17 @@ class HipRandLANet(nn.Module):
             skip = feats[0] if lvl == 0 else hin[lvl]  # b1_out, resp. the decimated output of block lvl
             # knn_interpolate(k=1) == x[nn] (weights cancel); fused as a row gather into the GEMM's A operand
             # (the skip tensor's other consumers run later in the backward pass: this layer deposits its gradient)
+            # (fp1 -> mlp_classif[0] -> mlp_classif[1]: a chain of SharedMLP layers on the level-1 rows — each next GEMM applies
+            # the BatchNorm of the layer in front on load)
+            chain = bool(train and record is None and ops.BN_ON_LOAD and torch.is_grad_enabled())
             h = self._shared_layer(fp.nn, 0, h, x1=skip, rows=nn_idx.view(-1), train=train,
                                    x1_slot=out_slot if lvl == 0 else in_slots[lvl],
-                                   rows_inv=geo.nn_inv[lvl] if (train and geo.nn_inv) else None)
+                                   rows_inv=geo.nn_inv[lvl] if (train and geo.nn_inv) else None,
+                                   defer=chain and lvl == 0)
             if record is not None:
                 record[f"fp{lvl + 1}"] = h[index[lvl].inv.long()]
-        h = self._shared_layer(self.mlp_classif, 0, h, train=train)
+        h = self._shared_layer(self.mlp_classif, 0, h, train=train,
+                               defer=bool(train and record is None and ops.BN_ON_LOAD and torch.is_grad_enabled()))
         if train and 10 in geo.events:
             geo.wait(10)  # the CSR inverses the decoder's backward pass reads
         p = self.mlp_classif.dropout[1]
@@ -873,6 +884,7 @@ class HipRandLANet(nn.Module):
             logits = ops.gemm(h, self.fc_classif.weight, h.shape[0], self.fc_classif.weight.shape[0], h.shape[1],
                               bias=self.fc_classif.bias)
             logits = ops.gather_rows(logits, index[0].inv)
+        ops.settle_pending()  # (nothing is left pending on the paths above: a guard)
         if self.return_logits:
             return logits
         return logits.log_softmax(dim=-1)

@@ -695,6 +695,61 @@ def test_decimation_draws_look_uniform(device):
     assert 800.0 < chi2 < 1250.0  # mean 999, sd 44.7
 
 
+@pytest.mark.parametrize("M,K,N,act", [(20000, 16, 32, True), (5003, 64, 128, True), (1083, 32, 64, False), (204800, 64, 32, True),
+                                        (777, 8, 16, True)])
+def test_gemm_with_batchnorm_applied_on_load(device, M, K, N, act):
+    """Round 5: ``m3d_gemm_bn_on_load_f32`` (the SharedMLP layer behind another one: BatchNorm + LeakyReLU of the layer in
+    front applied to the A fragments as they are loaded) against the two launches it replaces, ``m3d_bn_stats_apply`` +
+    ``m3d_gemm_f32`` — product, its slot statistics, the stored activation, the four per-column vectors of the backward pass
+    and the running statistics."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M % 97 + K)
+    z = torch.from_numpy((rs.normal(0.3, 1.5, (M, K)) * rs.uniform(0.2, 3.0, (1, K))).astype(np.float32)).to(device)
+    w = torch.from_numpy(rs.normal(0, K ** -0.5, (N, K)).astype(np.float32)).to(device)
+    b = torch.from_numpy(rs.normal(0, 0.1, (N,)).astype(np.float32)).to(device)
+
+    def bn_module():
+        bn = torch.nn.BatchNorm1d(K, eps=1e-6, momentum=0.01).to(device)
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(rs.uniform(0.5, 1.5, K).astype(np.float32)))
+            bn.bias.copy_(torch.from_numpy(rs.normal(0, 0.2, K).astype(np.float32)))
+            bn.running_mean.fill_(0.25)
+            bn.running_var.fill_(2.0)
+        return bn
+
+    state = rs.get_state()
+    bn_a = bn_module()
+    rs.set_state(state)
+    bn_b = bn_module()
+    ops.arena.stop()
+    # the statistics of the layer in front: column sums / sums of squares of z in slot mode (here: from torch, in slot 0)
+    slots = torch.zeros((ops.bn_slots(M), 2, K), dtype=torch.float64, device=device)
+    slots[0, 0] = z.double().sum(0)
+    slots[0, 1] = (z.double() ** 2).sum(0)
+    # reference: the two launches
+    y_ref, vec_ref = ops.bn_stats_apply(slots, M, bn_a, z, act)
+    st_ref = torch.zeros((ops.bn_slots(M), 2, N), dtype=torch.float64, device=device)
+    c_ref = ops.gemm(y_ref, w, M, N, K, bias=b, stats=st_ref, stat_slots=True)
+    # fused
+    pv = torch.empty((4, K), dtype=torch.float32, device=device).unbind(0)
+    pend = ops.PendingBN(z, slots, M, bn_b, act, torch.empty_like(z), pv)
+    st = torch.zeros_like(st_ref)
+    c = ops.gemm_bn_on_load(pend, w, M, N, b, st)
+    if K % 4 or K > 64:
+        assert c is None
+        return
+    assert c is not None and pend.done
+    _close("bn_on_load.C", c, c_ref, 1e-5, 1e-5)
+    assert torch.equal(pend.y, y_ref), "the stored activation: the same arithmetic as m3d_bn_stats_apply"
+    for name, a_, b_ in zip(("scale", "shift", "mean", "invstd"), pend.vecs, vec_ref):
+        assert torch.equal(a_, b_), name
+    assert torch.equal(bn_b.running_mean, bn_a.running_mean) and torch.equal(bn_b.running_var, bn_a.running_var)
+    assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked) == 1
+    tot, tot_ref = st.sum(0), st_ref.sum(0)
+    assert torch.allclose(tot, tot_ref, rtol=1e-9, atol=1e-6 * float(tot_ref.abs().max()))
+
+
 # ----------------------------------------------------------------------------------------------- LFA
 def _lfa_setup(ch, sizes, k, seed):
     from oracle.randla_oracle import LocalFeatureAggregation, dense_to_edge_index, knn_exact
