@@ -201,6 +201,46 @@ def _pmc_traffic(prefix, grid=None):
     return int(2 * r + w)
 
 
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def _pmc_sq(prefix, grid=None):
+    """``{counter: mean per launch}`` of a kernel from the NEWEST committed SQ pass (profiles/*pmc_sq_roofline_kernels.csv,
+    tools/gpu_pmc.sh over tools/pmc_target.py), or None."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq_roofline_kernels.csv")))
+    if not files:
+        return None
+    rows = [r for r in csv.DictReader(open(files[-1])) if r["kernel"].startswith(prefix)]
+    if grid is not None:
+        grids = grid if isinstance(grid, (tuple, list)) else (grid,)
+        rows = [r for r in rows if any(r["kernel"].rstrip().endswith(f"grid={g}") for g in grids)] or rows
+    if not rows:
+        return None
+    r = max(rows, key=lambda r: float(r.get("SQ_INSTS_VALU", 0) or 0))
+    return {k: float(v) for k, v in r.items() if k not in ("kernel",) and v not in ("", None)} | {"file": os.path.basename(files[-1])}
+
+
+def _valu_fields(prefix, units, ms, min_lane_ops_per_unit, unit_name, grid=None):
+    """The roofline that actually binds the kNN / level-1 LSE kernels: VALU issue.  ``valu_issue_frac`` = the
+    wave-level VALU instructions the newest SQ pass counted for this kernel x 4 cycles / (1 024 SIMDs x launch time x 2.4 GHz):
+    how busy the VALU issue ports are; ``valu_algorithmic_frac`` = the stated MINIMUM of lane operations per unit (an FMA = 1)
+    x units / 64 lanes against the same peak: how far the kernel is from the least VALU work the arithmetic needs."""
+    sq = _pmc_sq(prefix, grid)
+    out = {"valu_peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS, f"min_lane_ops_per_{unit_name}": min_lane_ops_per_unit,
+           "valu_algorithmic_frac": round(min_lane_ops_per_unit * units / 64.0 / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)}
+    if sq and sq.get("SQ_INSTS_VALU"):
+        out["valu_insts_per_launch"] = sq["SQ_INSTS_VALU"]
+        out[f"valu_insts_per_64_{unit_name}s"] = round(sq["SQ_INSTS_VALU"] / (units / 64.0), 1)
+        out["valu_issue_frac"] = round(sq["SQ_INSTS_VALU"] / (ms * 1e-3) / VALU_PEAK_WAVE_INSTS, 4)
+        out["sq_pass"] = sq["file"]
+    else:
+        out["valu_insts_per_launch"] = None
+    return {"valu": out}
+
+
 def _traffic_fields(prefix, grid=None):
     try:
         return {"traffic": _pmc_traffic(prefix, grid)}
@@ -333,17 +373,32 @@ def stage_rooflines(net, pos, plan):
             ms_knn = _time_launch(lambda: ops.call(
                 "m3d_knn_query", ix.ws.data_ptr(), ix.ptr.data_ptr(), n, ix.num_clouds, None, 0, ix.ws.data_ptr(),
                 ix.ptr.data_ptr(), n, K, 1, idx.data_ptr(), None, st))
-            stage.append(hbm_entry(f"knn_query (self-kNN, level {lvl + 1}, n={n}, K={K})", n * (12 + 4 * K), ms_knn,
-                                   KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], ((n + 63) // 64 * 64, (n + 255) // 256 * 256)))
+            ent = hbm_entry(f"knn_query (self-kNN, level {lvl + 1}, n={n}, K={K})", n * (12 + 4 * K), ms_knn,
+                            KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], ((n + 63) // 64 * 64, (n + 255) // 256 * 256))
+            # least VALU work of an exact K-NN query on a grid: ~2 K candidates inspected (a disc holding K points sits in a
+            # square of ~2 K), 8 lane operations per distance + 2 per comparison, K log2 K compare-exchanges to keep the list
+            ent.update(_valu_fields(KNN_KERNEL_PREFIX[0 if lvl == 0 else 1], n, ms_knn, 2 * K * 10 + K * 4 * 2, "query",
+                                    ((n + 63) // 64 * 64, (n + 255) // 256 * 256)))
+            ent["binding_roofline"] = "valu"
+            stage.append(ent)
         for lfa in (net.block1.lfa1, net.block1.lfa2):
             ch1, n1, ms_f = time_lfa_fwd(lfa, 0, geo)
-            stage.append(hbm_entry(f"lfa_fwd_full_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
-                                   n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1), ms_f, f"void lfa_fwd_full_kernel<{ch1}, 16"))
+            ent = hbm_entry(f"lfa_fwd_full_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
+                            n1 * (12 + 4 * ch1 // 2 + 4 * K + 4 * ch1), ms_f, f"void lfa_fwd_full_kernel<{ch1}, 16")
+            # least VALU work per edge: relative position (9), encoder ch/2 x (10 FMA + 1 activation), softmax-weighted sum
+            # ch x (scale, exp, 2 accumulations); the attention product itself runs on the matrix instruction
+            ent.update(_valu_fields(f"void lfa_fwd_full_kernel<{ch1}, 16", n1 * K, ms_f, 9 + (ch1 // 2) * 11 + ch1 * 4, "edge"))
+            ent["binding_roofline"] = "valu"
+            stage.append(ent)
         for lfa in (net.block1.lfa1, net.block1.lfa2):
             ch1, n1, D1, ms_b, _ = time_lfa_bwd(lfa, 0, geo)
-            stage.append(hbm_entry(f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
-                                   n1 * (12 + 4 * D1 + 4 * ch1 + 4 * K) + 4 * n1 * D1, ms_b,
-                                   f"void lfa_bwd_kernel<{ch1}, 16"))
+            ent = hbm_entry(f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
+                            n1 * (12 + 4 * D1 + 4 * ch1 + 4 * K) + 4 * n1 * D1, ms_b, f"void lfa_bwd_kernel<{ch1}, 16")
+            # forward recompute (as above) + softmax backward ch x 6 + activation derivative / scatter ch x 2 per edge
+            ent.update(_valu_fields(f"void lfa_bwd_kernel<{ch1}, 16", n1 * K, ms_b,
+                                    9 + (ch1 // 2) * 11 + ch1 * 4 + ch1 * 8, "edge"))
+            ent["binding_roofline"] = "valu + dx atomics (profiles/r05b_*: 36-42 us of the launch)"
+            stage.append(ent)
         out["knn_lse"] = stage
     return out
 
