@@ -310,6 +310,10 @@ int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n
                 void* ws, void* stream);
 /* bf16 matrix-core variant (CH in {64, 128, 256}): the recomputed attention logits, dF and dW_att GEMMs take bf16
  * operands (fp32 accumulate); att_w*_packed_bf16 from m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1). */
+/* flags bit 4 (with bit 3): SPLIT-bf16 operands ("bf16x3": every operand x = hi + lo, hi = bf16(x), lo = bf16(x - hi); the
+ * products run as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation: ~2^-16 relative operand error
+ * instead of 2^-8).  att_w*_packed_bf16 then hold the CH*CH hi values followed by the CH*CH lo values
+ * (m3d_lfa_prepare(bf16 = 2)).  The same for m3d_lfa_fwd_bf16: flags bit 1. */
 int m3d_lfa_bwd_bf16(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                      const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed_bf16,
                      const void* att_wt_packed_bf16, float slope, const float* dout, float* dx, float* dw_att,

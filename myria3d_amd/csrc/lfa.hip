@@ -242,7 +242,8 @@ template <int CHP> struct LfaFullCfg { static constexpr int ROWS = LfaCfg<CHP>::
 template <> struct LfaFullCfg<16> { static constexpr int ROWS = 256; };
 template <int CH> struct LfaFullRows { static constexpr int ROWS = CH == 8 ? 512 : LfaFullCfg<(CH < 16 ? 16 : CH)>::ROWS; };
 
-template <int CH, int KP, bool BF>
+// BF: 0 = f32-input MFMA, 1 = bf16 operands (one product), 2 = split-bf16 (hi + lo operands, three products: m3d_common.h)
+template <int CH, int KP, int BF>
 __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
   constexpr bool PACK2 = CH == 8;
   constexpr int CHP = CH < 16 ? 16 : CH;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
   }
   // B fragments of the first k-step group: independent of everything above, in flight during phase 1
   float4 b0[NTW];
-  if constexpr (!BF) {
+  if constexpr (BF == 0) {
     if constexpr (PACK2) {
       const float4 t = a.wp[lr < 8 ? lane : lane - 8];
       b0[0] = lr < 8 ? make_float4(t.x, t.y, 0.f, 0.f) : make_float4(0.f, 0.f, t.x, t.y);
@@ -337,21 +338,35 @@ __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if constexpr (BF) {
-    static_assert(!BF || CHP % 32 == 0, "bf16 tiles are 32 deep");
+  if constexpr (BF != 0) {
+    static_assert(BF == 0 || CHP % 32 == 0, "bf16 tiles are 32 deep");
     constexpr int KS = CHP / 32;
     const uint4* wpb = (const uint4*)a.wp;
+    const uint4* wpl = wpb + (size_t)CH * CH / 8;  // (BF == 2) the lo fragments behind the hi ones
     const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg * 8];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      Bf16Frag b[NTW];
+      Bf16Frag b[NTW], bl[NTW];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+      for (int t = 0; t < NTW; ++t) {
+        b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+        if constexpr (BF == 2) bl[t].q = wpl[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+      }
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
-        const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+        if constexpr (BF == 2) {
+          const Bf16Split av = lds_row_to_bf16_split(fa + m * 16 * STR + ks * 32);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+          for (int t = 0; t < NTW; ++t) {
+            acc[m][t] = mfma_bf16(av.lo, b[t].v, acc[m][t]);
+            acc[m][t] = mfma_bf16(av.hi, bl[t].v, acc[m][t]);
+            acc[m][t] = mfma_bf16(av.hi, b[t].v, acc[m][t]);
+          }
+        } else {
+          const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+        }
       }
     }
   } else {
@@ -447,11 +462,20 @@ static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st, int flags) {
   constexpr int ROWS = LfaCfg<(CH < 16 ? 16 : CH)>::ROWS;
   if (lfa_full_ok(a, flags)) {
     constexpr int FROWS = LfaFullRows<CH>::ROWS;
-    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, FROWS / 16)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF>), dim3((unsigned)m3d_cdiv(a.n, FROWS / 32)), dim3(256), 0, st, a);
+    const dim3 g16((unsigned)m3d_cdiv(a.n, FROWS / 16)), g32((unsigned)m3d_cdiv(a.n, FROWS / 32));
+    if constexpr (BF) {
+      if (flags & 2) {  // split-bf16 operands: att_w_packed holds the hi fragments, then the lo fragments
+        if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, 2>), g16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, 2>), g32, dim3(256), 0, st, a);
+        return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+      }
+    }
+    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF ? 1 : 0>), g16, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF ? 1 : 0>), g32, dim3(256), 0, st, a);
     if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
     return M3D_OK;
   }
+  if (BF && (flags & 2)) return M3D_ERR_UNSUPPORTED;  // the split-bf16 product exists in the complete-neighbourhood kernels only
   if (a.K <= 16) {
     hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
   } else {
@@ -766,8 +790,15 @@ __device__ __forceinline__ void lfa_prepare_body(const double* __restrict__ mom,
       const int KS = CH / 32;
       const int i = t & 7, ln = (t >> 3) & 63, ks = (t >> 9) % KS, nt = (t >> 9) / KS;
       const int r = 16 * nt + (ln & 15), c = 32 * ks + 8 * (ln >> 4) + i;
-      ((unsigned short*)packed)[t] = (unsigned short)(pack_bf16(w_att[r * CH + c], 0.f) & 0xffffu);
-      if (packed_t) ((unsigned short*)packed_t)[t] = (unsigned short)(pack_bf16(w_att[c * CH + r], 0.f) & 0xffffu);
+      const float v = w_att[r * CH + c], vt = w_att[c * CH + r];
+      const unsigned h = pack_bf16(v, 0.f) & 0xffffu, ht = pack_bf16(vt, 0.f) & 0xffffu;
+      ((unsigned short*)packed)[t] = (unsigned short)h;
+      if (packed_t) ((unsigned short*)packed_t)[t] = (unsigned short)ht;
+      if (bf16 == 2) {  // split-bf16: the lo fragments (bf16 of the rounding remainder) behind the CH * CH hi values
+        ((unsigned short*)packed)[CH * CH + t] = (unsigned short)(pack_bf16(v - __uint_as_float(h << 16), 0.f) & 0xffffu);
+        if (packed_t)
+          ((unsigned short*)packed_t)[CH * CH + t] = (unsigned short)(pack_bf16(vt - __uint_as_float(ht << 16), 0.f) & 0xffffu);
+      }
     } else {
       if (t >= CHP * CHP) return;
       const int S4 = CHP / 16;

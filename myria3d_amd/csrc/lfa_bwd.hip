@@ -160,7 +160,9 @@ template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = 
 // and the three-instruction maxima / IEEE square root / sub-mul-exp of the general kernel are compiled out: read off the
 // ISA (tools/isa_count.py), the kernels are VALU-issue bound beside their MFMAs.  Centres past n (last group) are
 // computed from clamped rows with dout = 0: every contribution they make is an exact zero.
-template <int CH, int KP, bool PIPE, bool BF = false, bool FULL = false>
+// X3 (with BF and FULL): split-bf16 operands — every bf16 product becomes hi*hi + hi*lo + lo*hi (m3d_common.h); a.wp / a.wpt hold
+// the hi fragments followed by the lo fragments (m3d_lfa_prepare(bf16 = 2)).
+template <int CH, int KP, bool PIPE, bool BF = false, bool FULL = false, bool X3 = false>
 __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
@@ -465,17 +467,31 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     if constexpr (BF) {
       constexpr int KS = CHP / 32;
       const uint4* wpb = (const uint4*)a.wp;
+      const uint4* wpl = wpb + (size_t)CH * CH / 8;
       const float* fa = &F[((wm * MTW) * 16 + lr) * STR + lg * 8];
 #pragma unroll(KS <= 2 ? KS : 1)
       for (int ks = 0; ks < KS; ++ks) {
-        Bf16Frag b[NTW];
+        Bf16Frag b[NTW], bl[NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+        for (int t = 0; t < NTW; ++t) {
+          b[t].q = wpb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+          if constexpr (X3) bl[t].q = wpl[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+        }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-          const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+          if constexpr (X3) {
+            const Bf16Split av = lds_row_to_bf16_split(fa + m * 16 * STR + ks * 32);
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+            for (int t = 0; t < NTW; ++t) {
+              acc[m][t] = mfma_bf16(av.lo, b[t].v, acc[m][t]);
+              acc[m][t] = mfma_bf16(av.hi, bl[t].v, acc[m][t]);
+              acc[m][t] = mfma_bf16(av.hi, b[t].v, acc[m][t]);
+            }
+          } else {
+            const bf16x8 av = lds_row_to_bf16(fa + m * 16 * STR + ks * 32);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+          }
         }
       }
     } else     if constexpr (PIPE) {
@@ -680,17 +696,31 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
     if constexpr (BF) {
       constexpr int KS = CHP / 32;
       const uint4* wptb = (const uint4*)a.wpt;
+      const uint4* wptl = wptb + (size_t)CH * CH / 8;
       const float* da = &DA[((wm * MTW) * 16 + lr) * STR + lg * 8];
 #pragma unroll(KS <= 2 ? KS : 1)
       for (int ks = 0; ks < KS; ++ks) {
-        Bf16Frag b[NTW];
+        Bf16Frag b[NTW], bl[NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) b[t].q = wptb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+        for (int t = 0; t < NTW; ++t) {
+          b[t].q = wptb[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+          if constexpr (X3) bl[t].q = wptl[((size_t)(wn * NTW + t) * KS + ks) * 64 + lane];
+        }
 #pragma unroll
         for (int m = 0; m < MTW; ++m) {
-          const bf16x8 av = lds_row_to_bf16(da + m * 16 * STR + ks * 32);
+          if constexpr (X3) {
+            const Bf16Split av = lds_row_to_bf16_split(da + m * 16 * STR + ks * 32);
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+            for (int t = 0; t < NTW; ++t) {
+              acc[m][t] = mfma_bf16(av.lo, b[t].v, acc[m][t]);
+              acc[m][t] = mfma_bf16(av.hi, bl[t].v, acc[m][t]);
+              acc[m][t] = mfma_bf16(av.hi, b[t].v, acc[m][t]);
+            }
+          } else {
+            const bf16x8 av = lds_row_to_bf16(da + m * 16 * STR + ks * 32);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[m][t] = mfma_bf16(av, b[t].v, acc[m][t]);
+          }
         }
         if constexpr (PIPE) {
           if (ks == 0 && grp + gs < gend) {  // next group's loads (see the fp32 branch below)
@@ -773,6 +803,26 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       for (int sr = 0; sr < ROWS / 32; ++sr) {
         const int eo = (32 * sr + 8 * lg) * STR + lr;
         constexpr int KB = KTW3 < 4 ? KTW3 : 4;  // F fragments in flight (a [16, 8] bf16 fragment is 4 VGPRs)
+        if constexpr (X3) {
+          constexpr int KB3 = KTW3 < 2 ? KTW3 : 2;
+          Bf16Split av[CTW3];
+#pragma unroll
+          for (int c = 0; c < CTW3; ++c) av[c] = lds_col_to_bf16_split(&DA[eo + (ct0 + c) * 16], STR);
+#pragma unroll
+          for (int k0 = 0; k0 < KTW3; k0 += KB3) {
+            Bf16Split bv[KB3];
+#pragma unroll
+            for (int k = 0; k < KB3; ++k) bv[k] = lds_col_to_bf16_split(&F[eo + (kt0 + k0 + k) * 16], STR);
+#pragma unroll
+            for (int c = 0; c < CTW3; ++c)
+#pragma unroll
+              for (int k = 0; k < KB3; ++k) {
+                acc3[c][k0 + k] = mfma_bf16(av[c].lo, bv[k].hi, acc3[c][k0 + k]);
+                acc3[c][k0 + k] = mfma_bf16(av[c].hi, bv[k].lo, acc3[c][k0 + k]);
+                acc3[c][k0 + k] = mfma_bf16(av[c].hi, bv[k].hi, acc3[c][k0 + k]);
+              }
+          }
+        } else {
         bf16x8 av[CTW3];
 #pragma unroll
         for (int c = 0; c < CTW3; ++c) av[c] = lds_col_to_bf16(&DA[eo + (ct0 + c) * 16], STR);
@@ -785,6 +835,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           for (int c = 0; c < CTW3; ++c)
 #pragma unroll
             for (int k = 0; k < KB; ++k) acc3[c][k0 + k] = mfma_bf16(av[c], bv[k], acc3[c][k0 + k]);
+        }
         }
       }
     } else {
@@ -993,7 +1044,7 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
 }
 
 template <int CH>
-static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full) {
+static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full, bool x3) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
   // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*; BWD_PIPE_* at compile time)
   constexpr bool pipe = CH <= 64 && !(LFA_BWD_DBG & ~1) &&  // (bit 0, no dx atomics, keeps the pipelined kernel: no `continue` in it)
@@ -1001,7 +1052,12 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
   if constexpr (CH >= 64) {
     if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
       constexpr bool P = CH == 64;
-      if (full) {
+      if (full && x3) {
+        if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+        else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      } else if (x3) {
+        return M3D_ERR_UNSUPPORTED;  // (the split-bf16 product exists in the complete-neighbourhood kernels only)
+      } else if (full) {
         if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
         else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
       } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
@@ -1044,13 +1100,14 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   const int64_t lim = (int64_t)1 << 31;
   const bool full = (flags & 8) && (K == 16 || K == 32) && n > 0 && n * K < lim && n * (int64_t)CH * 4 < lim && n * 16 < lim &&
                     slope >= 0.f && slope <= 1.f && !LFA_BWD_DBG_NOFULL;
+  const bool x3 = bf16 && (flags & 16);  // flags bit 4: split-bf16 operands (att_w*_packed hold hi then lo fragments)
   switch (CH) {
-    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full); break;
-    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full); break;
-    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16, full); break;
-    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16, full); break;
-    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16, full); break;
-    default: rc = launch_lfa_bwd<256>(a, p, st, bf16, full); break;
+    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full, x3); break;
+    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full, x3); break;
+    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16, full, x3); break;
+    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16, full, x3); break;
+    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16, full, x3); break;
+    default: rc = launch_lfa_bwd<256>(a, p, st, bf16, full, x3); break;
   }
   if (rc != M3D_OK) return rc;
   if (flags & 4) return M3D_OK;  // the caller sums the partials later (m3d_lfa_bwd_reduce_batch): ws must live until then

@@ -237,6 +237,28 @@ __device__ __forceinline__ bf16x8 lds_col_to_bf16(const float* p, int str) {
   for (int i = 0; i < 4; ++i) f.u[i] = pack_bf16(p[(2 * i) * str], p[(2 * i + 1) * str]);
   return f.v;
 }
+// ---- split-bf16 ("bf16x3") operands: x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits in two bf16 values.
+// a * b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 matrix cores (fp32 accumulate): the fp32 contract's attention GEMMs at
+// ~2^-16 relative operand error instead of bf16's 2^-8, off the vector pipe the f32-input MFMAs share with the VALU phases.
+struct Bf16Split { bf16x8 hi, lo; };
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+  lo = pack_bf16(a - ah, b - bh);
+}
+__device__ __forceinline__ Bf16Split lds_row_to_bf16_split(const float* p) {
+  const float2 a = *(const float2*)p, b = *(const float2*)(p + 2), c = *(const float2*)(p + 4), d = *(const float2*)(p + 6);
+  Bf16Frag h, l;
+  split_pair(a.x, a.y, h.u[0], l.u[0]); split_pair(b.x, b.y, h.u[1], l.u[1]);
+  split_pair(c.x, c.y, h.u[2], l.u[2]); split_pair(d.x, d.y, h.u[3], l.u[3]);
+  return Bf16Split{h.v, l.v};
+}
+__device__ __forceinline__ Bf16Split lds_col_to_bf16_split(const float* p, int str) {
+  Bf16Frag h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split_pair(p[(2 * i) * str], p[(2 * i + 1) * str], h.u[i], l.u[i]);
+  return Bf16Split{h.v, l.v};
+}
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }

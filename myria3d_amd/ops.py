@@ -1268,8 +1268,8 @@ def lfa_prepare(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int, w_att: T
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [{num_edges}, {D}]")
     wf = torch.empty((D, 10), dtype=torch.float32, device=dev)
     bf, mean, invstd = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
-    if bf16:
-        wp = torch.empty(ch * ch, dtype=torch.int16, device=dev)
+    if bf16:  # (2 = split-bf16: the hi fragments, then the lo fragments)
+        wp = torch.empty(ch * ch * (2 if int(bf16) == 2 else 1), dtype=torch.int16, device=dev)
     else:
         wp = torch.empty(max(ch, 16) ** 2, dtype=torch.float32, device=dev)
     wpt = torch.empty_like(wp) if want_t else None
@@ -1295,7 +1295,7 @@ def lfa_prepare_batch(jobs) -> list:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size [{num_edges}, {D}]")
         wf = torch.empty((D, 10), dtype=torch.float32, device=dev)
         vec = torch.empty((3, D), dtype=torch.float32, device=dev)
-        wp = torch.empty(ch * ch, dtype=torch.int16, device=dev) if bf16 else \
+        wp = torch.empty(ch * ch * (2 if int(bf16) == 2 else 1), dtype=torch.int16, device=dev) if bf16 else \
             torch.empty(max(ch, 16) ** 2, dtype=torch.float32, device=dev)
         outs.append((wf, vec[0], vec[1], vec[2], wp, torch.empty_like(wp)))
     vp = lambda vals: (ctypes.c_void_p * m)(*vals)
@@ -1308,7 +1308,7 @@ def lfa_prepare_batch(jobs) -> list:
          vp([o[1].data_ptr() for o in outs]), vp([o[2].data_ptr() for o in outs]), vp([o[3].data_ptr() for o in outs]),
          (ctypes.c_int32 * m)(*[j[0].weight.shape[0] for j in jobs]), vp([_chk(j[4]).data_ptr() for j in jobs]),
          (ctypes.c_int32 * m)(*[j[4].shape[0] for j in jobs]), vp([o[4].data_ptr() for o in outs]),
-         vp([o[5].data_ptr() for o in outs]), (ctypes.c_int32 * m)(*[int(bool(j[5])) for j in jobs]), _st())
+         vp([o[5].data_ptr() for o in outs]), (ctypes.c_int32 * m)(*[int(j[5]) for j in jobs]), _st())
     for enc_lin, enc_bn, *_ in jobs:
         assert float(enc_bn.eps) == float(bn0.eps) and float(enc_bn.momentum) == float(bn0.momentum)
         if not getattr(enc_bn, "_m3d_flat_counter", False):
@@ -1335,7 +1335,7 @@ def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_
     if bf16:
         assert wp is not None and wp.dtype == torch.int16
         call("m3d_lfa_fwd_bf16", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out),
-             fl, _st())
+             fl | (2 if int(bf16) == 2 else 0), _st())
         return out
     if wp is None:
         wp, _ = pack_attention_weights(w_att, False)  # named local: stays alive until the launch is enqueued
@@ -1369,7 +1369,10 @@ class LFATrainFn(torch.autograd.Function):
         ctx.side = _grad_side if sinks is not None else None
         x = x.contiguous()
         K = idx.shape[1]
-        bf16 = bool(bf16) and lfa_bf16_ok(w_att.shape[0], K)
+        bf16 = int(bf16) if lfa_bf16_ok(w_att.shape[0], K) else 0  # 0 fp32, 1 bf16 operands, 2 split-bf16 (three products)
+        if bf16 == 2 and not (num_edges == idx.shape[0] * K and USE_LFA_FULL and K in (16, 32)):
+            assert prepared is None, "split-bf16 needs complete neighbourhoods: the caller packs fp32 weights otherwise"
+            bf16 = 0  # (the split product exists in the complete-neighbourhood kernels only)
         if prepared is not None:
             wf, bf, mean, invstd, wp, wpt = prepared
         elif K <= 32:  # encoder fold + both weight packings: one launch
@@ -1409,7 +1412,7 @@ class LFATrainFn(torch.autograd.Function):
                 ev[0].record()
             call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
                  _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2 |
-                 (4 if defer else 0) | (8 if ctx.full else 0), _p(G), _p(ws), _st())
+                 (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0), _p(G), _p(ws), _st())
             if ev is not None:
                 ev[1].record()
                 tm["events"].append(ev)

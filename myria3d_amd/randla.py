@@ -420,11 +420,19 @@ class HipRandLANet(nn.Module):
                         k1=0 if x1 is None else x1.shape[1], bias=lin.bias, scale=scale, shift=shift, act=mlp.act,
                         bf16=self._bf16)
 
+    def _lfa_mode(self, ch: int, K: int, full: bool) -> int:
+        """Matrix-core mode of an LFA layer's attention GEMMs: 0 = f32-input MFMA, 1 = bf16 operands, 2 = split-bf16."""
+        if not ops.lfa_bf16_ok(ch, K):
+            return 0
+        if self._bf16:
+            return 1
+        return 2 if (getattr(self, "_bf16x3", False) and full and ops.USE_LFA_FULL and K in (16, 32)) else 0
+
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
              train: bool, prepared=None, defer_post: bool = False) -> Tensor:
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
-        bf16 = self._bf16 and ops.lfa_bf16_ok(w_att.shape[0], idx.shape[1])
+        bf16 = self._lfa_mode(w_att.shape[0], idx.shape[1], num_edges == idx.shape[0] * idx.shape[1])
         if train:
             sk = self._sinks(enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, w_att) if self._use_sinks \
                 else None
@@ -756,8 +764,11 @@ class HipRandLANet(nn.Module):
             plan = self.plan_for(ptr)
         plan_ready(plan)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
-        if self.matmul_precision not in ("fp32", "bf16"):
-            raise ValueError(f"matmul_precision must be 'fp32' or 'bf16', got {self.matmul_precision!r}")
+        if self.matmul_precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError(f"matmul_precision must be 'fp32', 'bf16' or 'bf16x3', got {self.matmul_precision!r}")
+        # "bf16x3": the attention GEMMs of the LFA layers with >= 64 channels as split-bf16 products (hi + lo operands, three
+        # matrix-core products, fp32 accumulate: ~fp32 accuracy off the vector pipe); everything else stays fp32
+        self._bf16x3 = self.matmul_precision == "bf16x3"
         self._bf16 = self.matmul_precision == "bf16" or (
             torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
         bump = self._nbt_flat if (train and self._flat is not None) else None  # BatchNorm step counters (one int64 vector)
@@ -813,7 +824,8 @@ class HipRandLANet(nn.Module):
                 for lfa in (blk.lfa1, blk.lfa2):
                     w_att = lfa.mlp_attention.lins[0].weight
                     jobs.append((lfa.mlp_encoder.lins[0], lfa.mlp_encoder.norms[0].module, geo.mom[lvl], plan.num_edges[lvl],
-                                 w_att, self._bf16 and ops.lfa_bf16_ok(w_att.shape[0], self.num_neighbors)))
+                                 w_att, self._lfa_mode(w_att.shape[0], self.num_neighbors,
+                                                       plan.num_edges[lvl] == plan.totals[lvl] * self.num_neighbors)))
             outs = ops.lfa_prepare_batch(jobs)
             prepared = [(outs[2 * l], outs[2 * l + 1]) for l in range(4)]
         for lvl, blk in enumerate(blocks):

@@ -195,12 +195,13 @@ def _reference_fixture_case(device, g, pre):
             assert torch.allclose(bufs[k[len(pre) + 4:]].cpu(), torch.from_numpy(g[k]), rtol=1e-3, atol=1e-5), k
 
 
-def _train_parity(device, x, pos, batch, ptr, y, seed, k=16, grad_tol=5e-3, flat=False):
+def _train_parity(device, x, pos, batch, ptr, y, seed, k=16, grad_tol=5e-3, flat=False, precision="fp32"):
     """One train-mode forward + cross-entropy + backward of HipRandLANet against the fp64 oracle on the same weights,
     decimation indices and dropout mask: logits, loss, every parameter gradient, the running statistics."""
     from oracle.randla_oracle import fixed_decimation_indices
 
     ref, net = _pair(device, seed=seed, k=k)
+    net.matmul_precision = precision
     ref = ref.double()
     dec = fixed_decimation_indices(ptr.tolist(), 4, seed=3)
     n = x.shape[0]
@@ -571,6 +572,30 @@ def test_seeded_decimation_is_reproducible(device):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][0], outs[0][1])          # the stream advances from call to call
     assert not torch.equal(decs[0][0], decs[2][0])          # another seed, another draw
+
+
+def test_split_bf16_mode_meets_the_fp32_tolerances(device):
+    """``matmul_precision = "bf16x3"`` (round 5 experiment): the attention GEMMs of the LFA layers with >= 64 channels as
+    split-bf16 products on the matrix cores, everything else fp32 — the net must meet the tolerances of the fp32 contract:
+    eval logits 1e-4 + 1e-4 |ref| at 2 x 12 800 points, and (train mode, fp64 oracle) train logits 2e-3, loss, EVERY
+    parameter gradient 5e-3 relative L2, running statistics."""
+    from oracle.randla_oracle import fixed_decimation_indices, synthetic_batch
+
+    ref, net = _pair(device, seed=7)
+    x, pos, batch, ptr, y = synthetic_batch([12800, 12800])
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=3)
+    args = (x.to(device), pos.to(device), None, ptr.to(device))
+    ref.eval(), net.eval()
+    with torch.no_grad():
+        out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
+        out32 = net(*args, decimation_idx=dec)
+        net.matmul_precision = "bf16x3"
+        out3 = net(*args, decimation_idx=dec)
+    assert not torch.equal(out32, out3), "the split-bf16 kernels really ran"
+    _report("bf16x3.eval_logits", out3, out_r, EVAL_RTOL, EVAL_ATOL)
+    _argmax_agreement("bf16x3.eval_logits", out3, out_r)
+    print(f"[parity] bf16x3 vs fp32 kernels: max |d logit| = {(out3 - out32).abs().max().item():.3e}")
+    _train_parity(device, x, pos, batch, ptr, y, seed=7, precision="bf16x3")
 
 
 def test_bf16_mode_within_the_stated_tolerance(device):

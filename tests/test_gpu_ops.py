@@ -816,6 +816,17 @@ def test_lfa_train_full_neighbourhoods(device, ch, k):
     _lfa_train_parity(device, ch, k, [203, 41, 91], seed=ch + 1, fused=True)
 
 
+@pytest.mark.parametrize("ch,k,n", [(64, 16, 335), (128, 16, 335), (256, 16, 335), (64, 32, 400), (256, 32, 400), (64, 16, 17000),
+                                    (128, 16, 8500)])
+def test_lfa_split_bf16_products_meet_the_fp32_tolerances(device, ch, k, n):
+    """Round 5 experiment: the three attention GEMMs of the LFA kernels as SPLIT-bf16 products — operands
+    x = hi + lo (two bf16 values, 16 mantissa bits), hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32 accumulate — against
+    the fp64 oracle at the UNCHANGED tolerances of the fp32 kernels (forward 1e-4, dx 1e-3, parameter gradients 1e-3 / 2e-3),
+    small sizes and sizes that keep every persistent workgroup in its loop."""
+    third = n // 3
+    _lfa_train_parity(device, ch, k, [third, third + 1, n - 2 * third - 1], seed=ch + 2, fused=True, big=n > 1000, mode=2)
+
+
 def _relclose(name, got, ref, rel):
     """Reduced quantities (sums over all edges): relative L2 error of the whole tensor."""
     got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
@@ -825,7 +836,7 @@ def _relclose(name, got, ref, rel):
     assert err <= rel * den + 1e-7, f"{name}: relative L2 error {err / max(den, 1e-30):.3e} > {rel}"
 
 
-def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False):
+def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False, mode=0):
     """m3d_lfa_fwd + m3d_lfa_bwd (train mode: encoder BatchNorm on batch statistics) vs the fp64 oracle
     (LocalFeatureAggregation.aggregate + autograd).  ``big``: kNN table through cKDTree (any valid table serves an
     op-level check), reduced gradients compared by relative L2 norm."""
@@ -857,7 +868,7 @@ def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False):
     mom = ops.lfa_moments(pos4, idx32)
     xg = x.to(device).requires_grad_(True)
     out = ops.LFATrainFn.apply(xg, pos4, idx32, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                               enc_bn.bias, enc_lin, enc_bn, w_att)
+                               enc_bn.bias, enc_lin, enc_bn, w_att, None, mode)
     out.backward(gy.float().to(device))
     sc = max(1.0, gy.abs().max().item())
     checks = [
