@@ -926,9 +926,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   }
 }
 
-#ifndef LFA_RED_WIDE
-#define LFA_RED_WIDE 0  // prepared at the end of round 4 (tools/isa_audit.py: 2 of the kernel's 3 loop blocks wait for ONE load); off until its A/B run
-#endif
+// (round 4 prepared eight partials in flight in both loops of this reduce — -DLFA_RED_WIDE=1; its A/B in round 5 moved nothing,
+// profiles/r05a_step_lfa_full_ab.log; removed)
 // sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64).  blockIdx.x owns 256 consecutive
 // elements, blockIdx.y a contiguous chunk of the partials; chunks are combined with one atomic per element per
 // chunk into the (pre-zeroed) outputs, so the pass runs at HBM speed instead of one block walking every partial.
@@ -944,15 +943,6 @@ __device__ __forceinline__ void lfa_bwd_reduce_body(const float* __restrict__ dw
     const int p0 = y * per, p1 = min(parts3, p0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int p = p0;
-#if LFA_RED_WIDE
-    for (; p + 7 < p1; p += 8) {  // eight partials in flight; the same four running sums in the same order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = dw_part[(size_t)(p + u) * nw + t];
-      s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
-      s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
-    }
-#endif
     for (; p + 3 < p1; p += 4) {
       s0 += dw_part[(size_t)p * nw + t];
       s1 += dw_part[(size_t)(p + 1) * nw + t];
@@ -968,21 +958,7 @@ __device__ __forceinline__ void lfa_bwd_reduce_body(const float* __restrict__ dw
       const int per = (parts4 + ny - 1) / ny;
       const int p0 = y * per, p1 = min(parts4, p0 + per);
       double s = 0.0;
-#if LFA_RED_WIDE
-      int p = p0;
-      // the G sums were ONE load per trip: at ch = 256 (512 workgroup partials over 7 chunks) 73 dependent round trips per
-      // thread — the critical path of the whole batched launch (72 us for 185 MB that stream in 25)
-      for (; p + 7 < p1; p += 8) {
-        float v[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) v[w] = g_part[(size_t)(p + w) * DP * 16 + u];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += (double)v[w];
-      }
-      for (; p < p1; ++p) s += (double)g_part[(size_t)p * DP * 16 + u];
-#else
       for (int p = p0; p < p1; ++p) s += (double)g_part[(size_t)p * DP * 16 + u];
-#endif
       const int c = u / 16, q = u % 16;
       if (c < D && q < 11 && p1 > p0) atomicAdd(&G[c * 11 + q], s);
     }

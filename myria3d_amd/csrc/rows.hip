@@ -215,9 +215,8 @@ extern "C" int m3d_csr_invert_batch(int32_t njobs, const int32_t* const* idx, co
 }
 
 // out[c][:] (+)= sum of src[f][:] over f in inv[ptr[c] .. ptr[c + 1])   (C % 4 == 0, 16-byte aligned rows)
-#ifndef ROWS_GATHER_BATCH
-#define ROWS_GATHER_BATCH 0  // prepared at the end of round 4 (tools/isa_audit.py flags 6 of the kernel's 7 loop blocks); off until its A/B run
-#endif
+// (round 4 prepared a variant with eight contributors' ids, then rows, per trip — -DROWS_GATHER_BATCH=1; its A/B in round 5,
+// profiles/r05a_step_lfa_full_ab.log, moved nothing: 4.130 vs 4.118 / 4.135 ms per step; removed)
 __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __restrict__ src, int64_t lds,
                                                               const int32_t* __restrict__ ptr,
                                                               const int32_t* __restrict__ inv, float* __restrict__ out,
@@ -229,24 +228,6 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __res
     const int p0 = ptr[c], p1 = ptr[c + 1];
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int p = p0;
-#if ROWS_GATHER_BATCH
-    // eight contributors per trip: their ids together, then their rows together (ids past the end repeat the last one and
-    // count as 0) — the pair loop below is two dependent round trips per PAIR (ids -> rows), five or six per output row at the
-    // four contributors a 1-NN inverse has on average.  Same sums in the same order (even ones into s0, odd ones into s1).
-    for (; p < p1; p += 8) {
-      int id[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) id[u] = inv[p + u < p1 ? p + u : p1 - 1];
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(src + (int64_t)id[u] * lds + 4 * q);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        float4& s = (u & 1) ? s1 : s0;
-        if (p + u < p1) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-      }
-    }
-#endif
     for (; p + 1 < p1; p += 2) {
       const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
       const float4 b = *(const float4*)(src + (int64_t)inv[p + 1] * lds + 4 * q);
