@@ -370,3 +370,51 @@ def test_zero_arena_learns_its_size_across_an_eval_pass():
     assert c.data_ptr() < base or c.data_ptr() >= base + ar.buf.numel()
     ar.begin(dev)
     assert ar.buf.numel() >= 512 + 4096
+
+
+def test_node_budget_offsets_on_the_host_follow_the_device_rule():
+    """``predict._budget_offsets`` (round 5: the predict chain keeps the CSR offsets of a batch on the host so that the net's
+    level plan needs no device read-back) = the count rule of ``transforms.node_budget`` / the reference's
+    ``MinimumNumNodes`` + ``MaximumNumNodes`` (transforms.py:48-87): tiles with 0 points stay empty, tiles below the minimum
+    are filled up to it, tiles above the maximum are cut."""
+    import torch
+
+    from myria3d_amd.predict import _budget_offsets
+
+    counts = [0, 1, 299, 300, 301, 39999, 40000, 40001, 123456]
+    ptr = [0]
+    for c in counts:
+        ptr.append(ptr[-1] + c)
+    for minimum, maximum in ((300, 40000), (0, 40000), (300, None), (0, None)):
+        t = torch.tensor(counts)
+        out = t.clone()
+        if minimum:
+            out = torch.where((t > 0) & (t < minimum), torch.full_like(out, minimum), out)
+        if maximum is not None:
+            out = out.clamp(max=maximum)
+        want = [0] + out.cumsum(0).tolist()
+        assert _budget_offsets(ptr, minimum, maximum) == want, (minimum, maximum)
+
+
+def test_pending_batchnorm_bookkeeping():
+    """``ops.PendingBN`` (BatchNorm apply-on-load, round 5): the producer hands over an allocated, unwritten activation buffer;
+    the consumer recognises it by identity or by storage, and a forward that ends with one left over would settle it (here only
+    the bookkeeping, on host tensors: the launches need the GPU)."""
+    import torch
+
+    from myria3d_amd import ops
+
+    assert ops.take_pending(None) is None and ops.take_pending(torch.zeros(3)) is None
+    z, y = torch.zeros(5, 4), torch.empty(5, 4)
+    p = ops.PendingBN(z, torch.zeros(1, 2, 4, dtype=torch.float64), 5, torch.nn.BatchNorm1d(4), True, y,
+                      tuple(torch.empty(4) for _ in range(4)))
+    ops._pending.append(p)
+    try:
+        assert ops.take_pending(y) is p
+        assert ops.take_pending(y.view(5, 4)) is p          # another tensor object over the same storage and shape
+        assert ops.take_pending(torch.empty(5, 4)) is None  # somebody else's buffer
+        assert ops.take_pending(z) is None                  # the raw output is not the activation
+        p.done = True                                       # (as a fused consumer leaves it)
+        assert p.materialize() is y                         # no launch once it is done
+    finally:
+        ops._pending.clear()

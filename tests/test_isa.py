@@ -24,3 +24,37 @@ def test_batchnorm_column_sums_keep_their_row_loads_in_flight():
     assert len(reduce_rows) == 4, [r[3] for r in rows]  # <Z2, DROP> = four instantiations, each with loop blocks
     for flagged, blocks, fewest, name in reduce_rows:
         assert flagged == 0, (name, flagged, blocks, fewest)
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc (cross-compiles without a GPU)")
+def test_complete_neighbourhood_lfa_forward_kernels_keep_their_instruction_diet():
+    """Round 5: the level-1 LFA forward kernels are VALU-issue bound (SQ counters: 75 % of the SIMDs' issue slots), so their
+    instruction count IS their time.  Read off the ISA (tools/isa_count.py: the kernels are straight-line per wave):
+    the complete-neighbourhood kernels hold <= 300 static VALU instructions per wavefront at ch = 8 (128 edges: two centres per
+    MFMA tile) and <= 260 at ch = 16 (64 edges) — round 4's kernel: 484 / 523 per 64 edges —, their K = 16 instantiations carry
+    NO cross-lane swap (in-lane neighbourhoods) and no exec-mask branch for the -1 padding (at most the bounds checks)."""
+    import re
+    import subprocess
+    import tempfile
+
+    src = os.path.join(ROOT, "myria3d_amd", "csrc", "lfa.hip")
+    with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-w", "--cuda-device-only", "-S",
+                        src, "-o", tmp.name], check=True, cwd=os.path.dirname(src))
+        text = open(tmp.name).read()
+    kernels = {}
+    for m in re.finditer(r"^(_Z19lfa_fwd_full_kernelILi(\d+)ELi(\d+)ELi0EEv7LfaArgs):.*?\.Lfunc_end", text, re.S | re.M):
+        body = [ln.strip().split()[0] for ln in m.group(0).split("\n")[1:] if ln.strip() and not ln.strip().startswith((";", "."))
+                and not ln.strip().endswith(":")]
+        kernels[(int(m.group(2)), int(m.group(3)))] = body
+    assert (8, 16) in kernels and (16, 16) in kernels and (64, 16) in kernels, sorted(kernels)
+    valu = lambda ops: sum(1 for o in ops if o.startswith("v_") and not o.startswith(("v_mfma", "v_accvgpr")))
+    assert valu(kernels[(8, 16)]) <= 300, valu(kernels[(8, 16)])
+    assert valu(kernels[(16, 16)]) <= 260, valu(kernels[(16, 16)])
+    assert valu(kernels[(64, 16)]) <= 270, valu(kernels[(64, 16)])
+    for key in ((8, 16), (16, 16), (64, 16)):
+        ops = kernels[key]
+        assert not any(o.startswith("v_permlane") for o in ops), (key, "cross-lane swaps in a K = 16 kernel")
+        assert sum(1 for o in ops if o.startswith("s_and_saveexec")) <= 4, (key, "exec-mask branches")
+    # K = 32: exactly the three joins of the two half neighbourhoods (maximum, numerator, denominator) per column tile
+    assert sum(1 for o in kernels[(16, 32)] if o.startswith("v_permlane16_swap")) == 3
