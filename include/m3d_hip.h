@@ -35,7 +35,7 @@ extern "C" {
  * no_grad recalibration pass), which advances the live counter, cannot change the mask the backward pass rebuilds. */
 typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; int64_t* snapshot; } M3DDropout;
 
-#define M3D_ABI_VERSION 15
+#define M3D_ABI_VERSION 16
 #define M3D_ADAM_STATE_WORDS 66
 #define M3D_CE_ACC_DOUBLES 516
 int m3d_abi_version(void);
@@ -225,9 +225,15 @@ int m3d_scatter_add_rows(const float* src, const int32_t* idx, float* out, int64
 int m3d_csr_invert_batch(int32_t njobs, const int32_t* const* idx, const int64_t* n, const int64_t* m,
                          int32_t* const* cnt, int32_t* const* ptr, int32_t* const* inv, void* stream);
 /* out[c][0..C) (+)= sum over f in inv[ptr[c] .. ptr[c + 1]) of src[f][0..C): the transpose of m3d_gather_rows(idx) through
- * the CSR inverse of idx — no atomics, no zero fill (accumulate != 0: added to what out holds).  C % 4 == 0. */
+ * the CSR inverse of idx — no atomics, no zero fill (accumulate bit 0: added to what out holds; bit 1: the lists are long
+ * (~16 rows, m3d_knn_reverse): four lanes share a list).  C % 4 == 0. */
 int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const int32_t* inv, float* out, int64_t ldo,
                         int64_t m, int32_t C, int32_t accumulate, void* stream);
+/* Reverse neighbour lists of a K-NN table idx [n, K] (entries outside [0, n) are left out): edge e = i * K + k with
+ * idx[i][k] == j is one of inv[ptr[j] .. ptr[j + 1]) (in no particular order); ptr: [n + 1], inv: [n * K].  With
+ * m3d_gather_sum_rows(accumulate | 2) this is the scatter-free backward of every gather x[idx] (m3d_lfa_bwd flags bit 5). */
+size_t m3d_knn_reverse_workspace_bytes(int64_t n, int32_t K);
+int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv, void* ws, void* stream);
 int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64_t n, void* stream);
 /* decimation_indices(): slot r of cloud b <- ptr[b] + P_b(r), P_b a keyed pseudo-random permutation of
  * [0, n_b); ptr_out is the decimated ptr (computed by the caller: max(1, n_b // factor) per cloud);
@@ -306,8 +312,14 @@ int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n
                 const float* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
                 int32_t flags /* bit 0: add into dw_att instead of overwriting; bit 1: G is already zero; bit 2: leave the
                                  workgroup partials in ws (m3d_lfa_bwd_reduce_batch sums them later); bit 3: complete
-                                 neighbourhoods promised (as M3D_LFA_FULL of m3d_lfa_fwd: the mask-free kernel) */, double* G,
+                                 neighbourhoods promised (as M3D_LFA_FULL of m3d_lfa_fwd: the mask-free kernel); bit 5
+                                 (with bit 3, where m3d_lfa_bwd_edge_rows_ok says 1): `dx` is an [n * K, D] EDGE-row buffer
+                                 — row i * K + k = the gradient that edge (centre i, neighbour k) sends to x[idx[i][k]] —
+                                 plainly stored: no atomics; the caller sums the rows of every point's reverse neighbour
+                                 list (m3d_csr_invert_batch of idx + m3d_gather_sum_rows) */, double* G,
                 void* ws, void* stream);
+/* 1: flags bit 5 of m3d_lfa_bwd is honoured for this layer (CH in {8, 16}, K = 16, 32-bit offsets); 0: M3D_ERR_UNSUPPORTED */
+int m3d_lfa_bwd_edge_rows_ok(int64_t n, int32_t K, int32_t CH, float slope);
 /* bf16 matrix-core variant (CH in {64, 128, 256}): the recomputed attention logits, dF and dW_att GEMMs take bf16
  * operands (fp32 accumulate); att_w*_packed_bf16 from m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1). */
 /* flags bit 4 (with bit 3): SPLIT-bf16 operands ("bf16x3": every operand x = hi + lo, hi = bf16(x), lo = bf16(x - hi); the

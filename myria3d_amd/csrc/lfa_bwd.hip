@@ -28,6 +28,7 @@ struct LfaBwdArgs {
   const float4* wpt;  // packed W_att^T  (GEMM-2 B fragments)
   const float* dout;  // [n, CH]
   float* dx;          // [n, D], atomically accumulated
+  float* dxe;         // (flags bit 5) [n * K, D]: the x-part of dF per EDGE, plainly stored; the caller sums it per neighbour
   float* dw_part;     // [parts][CHP*CHP]
   float* g_part;      // [parts][GP*16],  GP = max(16, D)
   int64_t n;
@@ -926,6 +927,372 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ch <= 16, K = 16, complete neighbourhoods: WAVE-AUTONOMOUS backward (round 5).
+// lfa_bwd_kernel at ch = 8 / 16 is four waves around one 128-edge tile with five workgroup barriers per tile and 18 MFMAs
+// per wave between them: the SQ counters show the level-1 launches parked on memory / barriers for half of their wave-cycles
+// at 30-35 % VALU issue (profiles/r05mid_pmc_sq*.csv) — 158 / 215 us for the work the forward kernels do in 21 / 35.
+// Here a WAVE owns 64 LDS rows (64 edges; 128 at ch = 8, two centres per packed row as in lfa_fwd_full_kernel) from the gather
+// to the atomics, in the in-lane neighbourhood layout (row 16 (k / 4) + 4 u + k % 4 = neighbour k of the wave's unit u), so
+//   * there is no workgroup barrier in the loop: LDS traffic of one wave is processed in order, the phases are separated by
+//     compiler fences only, and the four waves of a workgroup drift apart;
+//   * the thread that owns an edge loads id -> (x_j, p_j) one trip ahead into registers (as PIPE does);
+//   * the softmax backward is register arithmetic (lane (lr, lg) holds the 16 logits of unit lg for column lr);
+//   * the encoder sums G = dy^T [r | 1] leave the matrix pipe (16 MFMAs of a tile that is 1/3 - 1/6 useful, plus an LDS tile of
+//     r): the centre position and the 1 are constant per unit, so their columns come from the in-lane neighbour sums of dy in
+//     the C layout (4 accumulators per lane); the thread that owns an edge accumulates dy * (p_j - p_i) and dy * |p_j - p_i|
+//     (4 D accumulators per lane), and the p_j columns are the sum of the two (no cancellation: small added to large).
+//     One cross-lane reduction per wave at the end of the kernel.
+// Same partial-sum layout and workspace as lfa_bwd_kernel (four partials per workgroup); workgroups past `nwork` only write
+// zero partials (the resident count is bounded by registers / LDS, the workspace by bwd_plan).
+#ifndef LFA_BWD_SMALL
+#define LFA_BWD_SMALL 1
+#endif
+#ifndef BWD_SMALL_CAP_8
+#define BWD_SMALL_CAP_8 768
+#endif
+#ifndef BWD_SMALL_CAP_16
+#define BWD_SMALL_CAP_16 768
+#endif
+#ifndef BWD_SMALL_MINW
+#define BWD_SMALL_MINW 3
+#endif
+__device__ __forceinline__ float row16_sum_f(float v) {  // every lane of a 16-lane row ends with the row's sum (DPP)
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
+}
+// LDS written by some lanes of a wave, read by others of the SAME wave: the LDS pipe keeps a wave's instructions in order, so
+// only the compiler has to be kept from moving accesses across this point
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// EDGE (flags bit 5 of m3d_lfa_bwd): no atomics at all — the x-part of dF is stored per edge ([n K, D], plain 16 / 32-byte row
+// stores) and the caller sums the rows of every point's REVERSE neighbour list (m3d_gather_sum_rows over the CSR inverse of
+// the neighbour table, built with the position-only work).  Measured (profiles/r05p_*): with the atomics this kernel takes
+// 193 / 199 us at level 1, without them 83 / 113 — the L2 needs ~30 ps per 16 / 32-byte row atomic whatever the kernel does.
+template <int CH, bool EDGE>
+__global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaBwdArgs a, int nwork) {
+  constexpr bool PACK2 = CH == 8;
+  constexpr int D = CH / 2, D4 = D / 4, STR = 18;
+  constexpr int EPT = PACK2 ? 2 : 1;  // edges per lane and trip
+  constexpr int EW = 64 * EPT;        // edges per wave and trip
+  constexpr int UC = EW / 16;         // centres per wave and trip
+  static_assert(CH == 8 || CH == 16, "one 16-column MFMA tile");
+  __shared__ __attribute__((aligned(16))) float Fs[4 * 64 * STR];
+  __shared__ __attribute__((aligned(16))) float DAs[4 * 64 * STR];
+  __shared__ __attribute__((aligned(16))) int NBs[4 * EW];
+  __shared__ float4 PCs[4 * UC];  // positions of the trip's centres
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  float* const F = Fs + wid * 64 * STR;
+  float* const DA = DAs + wid * 64 * STR;
+  int* const NB = NBs + wid * EW;
+  float4* const PC = PCs + wid * UC;
+  float* const dwp = a.dw_part + ((size_t)blockIdx.x * 4 + wid) * 256;
+  float* const gp = a.g_part + ((size_t)blockIdx.x * 4 + wid) * 256;
+  if ((int)blockIdx.x >= nwork) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dwp[lane + 64 * i] = 0.f; gp[lane + 64 * i] = 0.f; }
+    return;
+  }
+  const unsigned n32 = (unsigned)a.n, elast = n32 * 16u - 1u;
+  const int64_t ngroups = (a.n + 4 * UC - 1) / (4 * UC);
+  int64_t g0, gs, gend;
+  xcd_range(blockIdx.x, nwork, ngroups, g0, gs, gend);
+
+  // where this lane's edges live: edge el = lane + 64 q of the trip = neighbour el % 16 of local centre el / 16
+  int prow[EPT], hoff[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int el = lane + 64 * q, cl = el >> 4, k = el & 15;
+    const int unit = PACK2 ? cl >> 1 : cl;
+    prow[q] = (k >> 2) * 16 + unit * 4 + (k & 3);
+    hoff[q] = PACK2 ? (cl & 1) * 8 : 0;
+  }
+  // the two weight fragments are loop invariants (ch = 8: diag(W, W), see lfa_fwd_full_kernel)
+  float4 bw, bwt;
+  if constexpr (PACK2) {
+    const float4 t = a.wp[lr < 8 ? lane : lane - 8], u = a.wpt[lr < 8 ? lane : lane - 8];
+    bw = lr < 8 ? make_float4(t.x, t.y, 0.f, 0.f) : make_float4(0.f, 0.f, t.x, t.y);
+    bwt = lr < 8 ? make_float4(u.x, u.y, 0.f, 0.f) : make_float4(0.f, 0.f, u.x, u.y);
+  } else {
+    bw = a.wp[lane];
+    bwt = a.wpt[lane];
+  }
+  // folded encoder weights: read through the CONSTANT address space (nothing writes them during the kernel), so the loads inside
+  // the loop stay scalar (s_load into SGPRs) although dx atomics precede them — as plain global loads they become 44 / 88
+  // uniform vector loads per trip held in VGPRs
+  typedef const float __attribute__((address_space(4))) * cptr_t;
+  const cptr_t wfc = (cptr_t)(unsigned long long)a.wf, bfc = (cptr_t)(unsigned long long)a.bf;
+  // column roles in the C layout: lane (lr, lg) holds column lr of the 16 rows of unit lg
+  const int cc = PACK2 ? (lr & 7) : lr;  // channel inside its centre's CH columns
+  const bool is_dx = cc < D;             // x-part column (scattered to dx) or encoder column (dy)
+
+  f32x4 acc3 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float accd[D][4];  // this lane's edges: sum dy[c] * (dx, dy, dz, length)
+#pragma unroll
+  for (int c = 0; c < D; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accd[c][t] = 0.f;
+  float accp[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's (unit, encoder column): sum dy * (p_i, 1)
+
+  unsigned jc[EPT], jn[EPT];  // ids of the trip whose rows are in flight / of the trip after it (two trips ahead of the compute)
+  float4 pi[EPT], pj[EPT], xg[EPT][D4];
+  float dgn = 0.f;
+  auto ld_ids = [&](int64_t g) {
+    const unsigned c0w = ((unsigned)g * 4u + (unsigned)wid) * UC;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      unsigned eo = c0w * 16u + (unsigned)(lane + 64 * q);
+      eo = eo < elast ? eo : elast;
+      jn[q] = (unsigned)a.idx[eo];
+    }
+  };
+  auto ld_rows = [&](int64_t g) {  // everything of trip g that hangs on its ids (jc), plus dout
+    const unsigned c0w = ((unsigned)g * 4u + (unsigned)wid) * UC;
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      unsigned ci = c0w + (unsigned)((lane + 64 * q) >> 4);
+      ci = ci < n32 ? ci : n32 - 1u;
+      pi[q] = *(const float4*)((const char*)a.pos4 + ci * 16u);
+      pj[q] = *(const float4*)((const char*)a.pos4 + jc[q] * 16u);
+#pragma unroll
+      for (int u = 0; u < D4; ++u) xg[q][u] = *(const float4*)((const char*)a.x + (jc[q] * (unsigned)(D * 4) + (unsigned)(u * 16)));
+    }
+    unsigned cu = PACK2 ? c0w + 2u * (unsigned)lg + (unsigned)(lr >> 3) : c0w + (unsigned)lg;
+    const bool ok = cu < n32;  // (centres past n: clamped rows with dout = 0 — every contribution an exact zero)
+    cu = ok ? cu : n32 - 1u;
+    const float v = *(const float*)((const char*)a.dout + (cu * (unsigned)(CH * 4) + (unsigned)(cc * 4)));
+    dgn = ok ? v : 0.f;
+  };
+  if (g0 < gend) {
+    ld_ids(g0);
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) jc[q] = jn[q];
+    ld_rows(g0);
+    ld_ids(g0 + gs);
+  }
+  for (int64_t grp = g0; grp < gend; grp += gs) {
+    // ---- phase 1: x_j, folded encoder -> F; ids -> NB
+    float rd[EPT][4];
+    const float dg = dgn;
+    // ch = 16: 88 weights + the kernel's other scalars exceed the SGPR file once the loads are hoisted out of the loop (78
+    // v_readlane / v_writelane spills in the ISA): an offset the optimiser cannot see through keeps the s_loads inside the trip
+    int wz = 0;
+    if constexpr (CH == 16) asm volatile("s_mov_b32 %0, 0" : "=s"(wz));
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      float r[10];
+      rel_pos_fast(pi[q], pj[q], r);
+      float* frow = F + prow[q] * STR + hoff[q];
+#pragma unroll
+      for (int u = 0; u < D4; ++u) {
+        *(float2*)(frow + u * 4) = make_float2(xg[q][u].x, xg[q][u].y);
+        *(float2*)(frow + u * 4 + 2) = make_float2(xg[q][u].z, xg[q][u].w);
+      }
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        float v = bfc[wz + c];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) v += wfc[wz + c * 10 + t] * r[t];
+        frow[D + c] = fmaxf(v, v * a.slope);
+      }
+      NB[(PACK2 ? (hoff[q] >> 3) * 64 : 0) + prow[q]] = (int)jc[q];
+      rd[q][0] = r[6]; rd[q][1] = r[7]; rd[q][2] = r[8]; rd[q][3] = r[9];
+      if ((lane & 15) == 0) PC[(lane + 64 * q) >> 4] = pi[q];
+    }
+    // next trip's loads fly during the phases below (past the end of this workgroup's range: loaded, never used)
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) jc[q] = jn[q];
+    ld_rows(grp + gs);
+    ld_ids(grp + 2 * gs);
+    wave_lds_fence();
+
+    // ---- phase 2: A = F W_att^T
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float* fa = F + lr * STR + lg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float bv = i == 0 ? bw.x : (i == 1 ? bw.y : (i == 2 ? bw.z : bw.w));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = mfma16(fa[m * 16 * STR + i * 4], bv, acc[m]);
+      }
+    }
+    // ---- phase 3': softmax over the unit's 16 neighbours, dA -> DA, acc <- dout * s
+    {
+      const float pinf = fast_pinf();
+      const float* fcol = F + lg * 4 * STR + lr;
+      float* dcol = DA + lg * 4 * STR + lr;
+      float mx = acc[0][0];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m + r > 0) mx = fast_max(mx, acc[m][r], pinf);
+      const float ml = mx * 1.4426950408889634f;
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[m][r], 1.4426950408889634f, -ml));
+          const float f = fcol[(m * 16 + r) * STR];
+          num = __builtin_fmaf(p, f, num);
+          den += p;
+          acc[m][r] = p;
+        }
+      const float inv = __builtin_amdgcn_rcpf(den + 1e-16f);
+      const float o = num * inv, gi = dg * inv;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gsw = acc[m][r] * gi;  // dout * softmax weight
+          dcol[(m * 16 + r) * STR] = gsw * (fcol[(m * 16 + r) * STR] - o);  // (F re-read: 16 registers less across the phase)
+          acc[m][r] = gsw;
+        }
+    }
+    wave_lds_fence();
+    // ---- phase 4: dF = dout * s + DA W_att
+    {
+      const float* da = DA + lr * STR + lg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float bv = i == 0 ? bwt.x : (i == 1 ? bwt.y : (i == 2 ? bwt.z : bwt.w));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = mfma16(da[m * 16 * STR + i * 4], bv, acc[m]);
+      }
+    }
+    // ---- phase 5: dW_att += DA^T F over the wave's 64 rows (ch = 8: the 16 x 16 product of the PACKED tiles, whose two
+    // diagonal 8 x 8 blocks are added at the end of the kernel)
+    {
+      const float* da = DA + lg * STR + lr;
+      const float* fb = F + lg * STR + lr;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc3 = mfma16(da[4 * s * STR], fb[4 * s * STR], acc3);
+    }
+    // ---- phase 6: x-part columns -> dx atomics; encoder columns -> dy = dF * LeakyReLU'(lse) -> DA, neighbour sums of dy
+    {
+      const int* nb = NB + (PACK2 ? (lr >> 3) * 64 : 0) + lg * 4;
+      if (is_dx && EDGE) {
+        const unsigned ci = ((unsigned)grp * 4u + (unsigned)wid) * UC + (unsigned)(PACK2 ? 2 * lg + (lr >> 3) : lg);
+        if (ci < n32) {
+          float* erow = (float*)((char*)a.dxe + (ci * (unsigned)(16 * D * 4) + (unsigned)(cc * 4)));
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) erow[(4 * m + r) * D] = acc[m][r];
+        }
+      } else if (is_dx) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int4 j4 = *(const int4*)(nb + m * 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned j = (unsigned)(r == 0 ? j4.x : (r == 1 ? j4.y : (r == 2 ? j4.z : j4.w)));
+            if (!(LFA_BWD_DBG & 1)) atomicAdd((float*)((char*)a.dx + (j * (unsigned)(D * 4) + (unsigned)(cc * 4))), acc[m][r]);
+          }
+        }
+      } else {
+        const float* fcol = F + lg * 4 * STR + lr;
+        float* dcol = DA + lg * 4 * STR + lr;
+        float sdy = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float lse = fcol[(m * 16 + r) * STR];
+            const float dy = acc[m][r] * (lse > 0.f ? 1.f : a.slope);
+            dcol[(m * 16 + r) * STR] = dy;
+            sdy += dy;
+          }
+        const float4 pu = PC[PACK2 ? 2 * lg + (lr >> 3) : lg];
+        accp[0] = __builtin_fmaf(sdy, pu.x, accp[0]);
+        accp[1] = __builtin_fmaf(sdy, pu.y, accp[1]);
+        accp[2] = __builtin_fmaf(sdy, pu.z, accp[2]);
+        accp[3] += sdy;
+      }
+    }
+    wave_lds_fence();
+    // ---- phase 7: this lane's edges: dy * (p_j - p_i, |p_j - p_i|)
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const float* dyr = DA + prow[q] * STR + hoff[q] + D;
+#pragma unroll
+      for (int c2 = 0; c2 < D; c2 += 2) {
+        const float2 dy = *(const float2*)(dyr + c2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          accd[c2][t] = __builtin_fmaf(dy.x, rd[q][t], accd[c2][t]);
+          accd[c2 + 1][t] = __builtin_fmaf(dy.y, rd[q][t], accd[c2 + 1][t]);
+        }
+      }
+    }
+    wave_lds_fence();
+  }
+
+  // ---- this wave's partials
+  {
+    if constexpr (PACK2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) F[(lg * 4 + r) * STR + lr] = acc3[r];
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = lg * 4 + r;
+        dwp[c * 16 + lr] = (c < 8 && lr < 8) ? F[c * STR + lr] + F[(c + 8) * STR + lr + 8] : 0.f;
+      }
+      wave_lds_fence();
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dwp[(lg * 4 + r) * 16 + lr] = acc3[r];
+    }
+    // G[c][0..2] = sum dy p_i, [3..5] = sum dy p_j = [6..8] + [0..2], [6..8] = sum dy (p_j - p_i), [9] = sum dy |p_j - p_i|, [10] = sum dy
+    float* PL = F;            // [D][4]
+    float* DL = F + D * 4;    // [D][4]
+    float ps[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ps[t] = xgroup_sum(accp[t]);  // over the four units of the wave
+    if constexpr (PACK2) {
+      // columns 4 + c and 12 + c hold the two centres of a pair: lane lr and lane lr ^ 8
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ps[t] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ps[t]), 0x128, 0xF, 0xF, false));  // row_ror:8
+    }
+    if (lg == 0 && !is_dx && lr < 8 + (PACK2 ? 0 : 8)) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) PL[(cc - D) * 4 + t] = ps[t];
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v = xgroup_sum(row16_sum_f(accd[c][t]));
+        if (lane == 0) DL[c * 4 + t] = v;
+      }
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = lane + 64 * i, c = e >> 4, t = e & 15;
+      float v = 0.f;
+      if (c < D && t < 11) {
+        if (t < 3) v = PL[c * 4 + t];
+        else if (t < 6) v = PL[c * 4 + t - 3] + DL[c * 4 + t - 3];
+        else if (t < 10) v = DL[c * 4 + t - 6];
+        else v = PL[c * 4 + 3];
+      }
+      gp[e] = v;
+    }
+  }
+}
+
 // (round 4 prepared eight partials in flight in both loops of this reduce — -DLFA_RED_WIDE=1; its A/B in round 5 moved nothing,
 // profiles/r05a_step_lfa_full_ab.log; removed)
 // sums the workgroup partials: dw_att[CH, CH] (fp32) and G[D, 11] (fp64).  blockIdx.x owns 256 consecutive
@@ -1042,12 +1409,31 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
     }
   }
   if (bf16) return M3D_ERR_UNSUPPORTED;
+  if constexpr (CH <= 16) {
+    if (full && a.K == 16 && LFA_BWD_SMALL) {
+      constexpr int UC4 = CH == 8 ? 32 : 16;  // centres per workgroup trip
+      const int64_t ng = (a.n + UC4 - 1) / UC4;
+      int nwork = p.grid < (CH == 8 ? BWD_SMALL_CAP_8 : BWD_SMALL_CAP_16) ? p.grid : (CH == 8 ? BWD_SMALL_CAP_8 : BWD_SMALL_CAP_16);
+      if (ng < nwork) nwork = (int)ng;
+      if (a.dxe) hipLaunchKernelGGL((lfa_bwd_small_kernel<CH, true>), dim3(p.grid), dim3(256), 0, st, a, nwork);
+      else hipLaunchKernelGGL((lfa_bwd_small_kernel<CH, false>), dim3(p.grid), dim3(256), 0, st, a, nwork);
+      return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+    }
+  }
+  if (a.dxe) return M3D_ERR_UNSUPPORTED;  // (edge rows exist in the wave-autonomous kernels only: m3d_lfa_bwd_edge_rows_ok)
   if (full) {
     if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe, false, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
     else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe, false, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
   } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
   else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+}
+
+// 1: m3d_lfa_bwd(flags | 8 | 32) is honoured for this layer shape (the wave-autonomous kernels: ch <= 16, K = 16)
+extern "C" int m3d_lfa_bwd_edge_rows_ok(int64_t n, int32_t K, int32_t CH, float slope) {
+  const int64_t lim = (int64_t)1 << 31;
+  return LFA_BWD_SMALL && !LFA_BWD_DBG_NOFULL && (CH == 8 || CH == 16) && K == 16 && n > 0 && n * K * (int64_t)(CH / 2) * 4 < lim &&
+         n * (int64_t)CH * 4 < lim && slope >= 0.f && slope <= 1.f;
 }
 
 static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
@@ -1067,6 +1453,7 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   LfaBwdArgs a;
   a.x = x; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded;
   a.wp = (const float4*)att_w_packed; a.wpt = (const float4*)att_wt_packed; a.dout = dout; a.dx = dx;
+  a.dxe = nullptr;
   a.dw_part = (float*)ws;
   a.g_part = a.dw_part + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
   a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
@@ -1077,6 +1464,11 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   const bool full = (flags & 8) && (K == 16 || K == 32) && n > 0 && n * K < lim && n * (int64_t)CH * 4 < lim && n * 16 < lim &&
                     slope >= 0.f && slope <= 1.f && !LFA_BWD_DBG_NOFULL;
   const bool x3 = bf16 && (flags & 16);  // flags bit 4: split-bf16 operands (att_w*_packed hold hi then lo fragments)
+  if (flags & 32) {  // flags bit 5: `dx` is the [n K, D] edge-row buffer (stored, not accumulated)
+    if (!full || bf16 || !m3d_lfa_bwd_edge_rows_ok(n, K, CH, slope)) return M3D_ERR_UNSUPPORTED;
+    a.dxe = dx;
+    a.dx = nullptr;
+  }
   switch (CH) {
     case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full, x3); break;
     case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full, x3); break;

@@ -245,16 +245,179 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __res
   }
 }
 
+__global__ void gather_sum_rows4_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ ptr,
+                                        const int32_t* __restrict__ inv, float* __restrict__ out, int64_t ldo, int64_t m, int C4,
+                                        int accumulate);
 extern "C" int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const int32_t* inv, float* out,
                                    int64_t ldo, int64_t m, int32_t C, int32_t accumulate, void* stream) {
   if (m < 0 || C < 0) return M3D_ERR_INVALID;
   if (m == 0 || C == 0) return M3D_OK;
   if (!src || !ptr || !inv || !out) return M3D_ERR_INVALID;
   if ((C & 3) || (lds & 3) || (ldo & 3) || ((((uintptr_t)src) | ((uintptr_t)out)) & 15)) return M3D_ERR_UNSUPPORTED;
+  if (accumulate & 2) {  // long lists: four lanes per (target, chunk)
+    int64_t gx4 = m3d_cdiv(m * (int64_t)(C / 4), 64);
+    if (gx4 > 32768) gx4 = 32768;
+    hipLaunchKernelGGL(gather_sum_rows4_kernel, dim3((unsigned)gx4), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
+                       out, ldo, m, C / 4, accumulate & 1);
+    M3D_CHECK_LAUNCH();
+    return M3D_OK;
+  }
   int64_t gx = m3d_cdiv(m * (int64_t)(C / 4), 256);
   if (gx > 8192) gx = 8192;
   hipLaunchKernelGGL(gather_sum_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
-                     out, ldo, m, C / 4, accumulate);
+                     out, ldo, m, C / 4, accumulate & 1);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 4 <= n) *(int4*)(p + i) = make_int4(0, 0, 0, 0);
+  else for (int64_t k = i; k < n; ++k) p[k] = 0;
+}
+// ---- long lists (flags bit 1 of m3d_gather_sum_rows; the reverse neighbour lists of a K-NN table: ~K rows per point): FOUR
+// lanes share a (target, float4 chunk) — lane l sums contributors p0 + l, p0 + l + 4, ... — and meet through two quad DPP adds:
+// the dependent id -> row load chain of a target is a quarter as long (16 contributors: 64 -> ~20 us for 204 800 targets).
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+  return v;
+}
+__global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __restrict__ src, int64_t lds,
+                                                               const int32_t* __restrict__ ptr,
+                                                               const int32_t* __restrict__ inv, float* __restrict__ out,
+                                                               int64_t ldo, int64_t m, int C4, int accumulate) {
+  const int64_t total = m * C4;
+  const int l = threadIdx.x & 3;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; i < total; i += (int64_t)gridDim.x * 64) {  // (uniform per quad)
+    const int64_t c = i / C4;
+    const int q = (int)(i % C4);
+    const int p0 = ptr[c], p1 = ptr[c + 1];
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int p = p0 + l;
+    for (; p + 4 < p1; p += 8) {
+      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
+      const float4 b = *(const float4*)(src + (int64_t)inv[p + 4] * lds + 4 * q);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (p < p1) {
+      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    float4 o = make_float4(quad_sum(s0.x + s1.x), quad_sum(s0.y + s1.y), quad_sum(s0.z + s1.z), quad_sum(s0.w + s1.w));
+    if (l == 0) {
+      float4* d = (float4*)(out + c * ldo + 4 * q);
+      if (accumulate) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *d = o;
+    }
+  }
+}
+
+// ---- reverse neighbour lists of a K-NN table (round 5: the LFA backward kernels of the 8 / 16-channel layers store their input
+// gradient per edge; point j's list = the edges (i, k) with idx[i][k] == j).  The generic m3d_csr_invert_batch would do it in
+// count (atomics) + one-workgroup scan + fill (atomics with return): 57 + 168 + 126 us for 204 800 x 16 (profiles/r05q_*).
+// Here: ONE pass of atomics that also keeps each edge's rank in its list, a three-launch scan over 4096-element blocks, and a
+// fill without atomics.
+#define REV_BLK 4096
+__global__ __launch_bounds__(256) void rev_rank_kernel(const int32_t* __restrict__ idx, int64_t ne, int32_t n, int32_t* __restrict__ cnt,
+                                                       int32_t* __restrict__ rank) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= ne) return;
+  const int32_t c = idx[e];
+  rank[e] = (c >= 0 && c < n) ? atomicAdd(&cnt[c], 1) : -1;
+}
+__global__ __launch_bounds__(256) void rev_block_sums_kernel(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ bsum) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * REV_BLK + (int64_t)tid * 16;
+  int s = 0;
+  for (int i = 0; i < 16; ++i) s += base + i < n ? cnt[base + i] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) wsum[wid] = s;
+  __syncthreads();
+  if (tid == 0) bsum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(1024) void rev_scan_blocks_kernel(int32_t* __restrict__ bsum, int nb) {  // exclusive, in place
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int v = base + tid < nb ? bsum[base + tid] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    if (base + tid < nb) bsum[base + tid] = off + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = off + x;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void rev_ptr_kernel(const int32_t* __restrict__ cnt, int64_t n, const int32_t* __restrict__ boff,
+                                                      int32_t* __restrict__ ptr) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * REV_BLK + (int64_t)tid * 16;
+  int v[16], s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { v[i] = base + i < n ? cnt[base + i] : 0; s += v[i]; }
+  int incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  int run = boff[blockIdx.x] + incl - s;
+  for (int i = 0; i < wid; ++i) run += wsum[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (base + i < n) ptr[base + i] = run;
+    run += v[i];
+    if (base + i == n - 1) ptr[n] = run;
+  }
+}
+__global__ __launch_bounds__(256) void rev_fill_kernel(const int32_t* __restrict__ idx, int64_t ne, const int32_t* __restrict__ rank,
+                                                       const int32_t* __restrict__ ptr, int32_t* __restrict__ inv) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= ne) return;
+  const int r = rank[e];
+  if (r >= 0) inv[ptr[idx[e]] + r] = (int32_t)e;
+}
+static inline size_t rev_al(size_t b) { return (b + 255) & ~(size_t)255; }
+extern "C" size_t m3d_knn_reverse_workspace_bytes(int64_t n, int32_t K) {
+  if (n < 0 || K < 1) return 0;
+  return rev_al((size_t)n * K * 4) + rev_al((size_t)n * 4) + rev_al((size_t)(m3d_cdiv(n, REV_BLK) + 1) * 4) + 256;
+}
+extern "C" int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv, void* ws, void* stream) {
+  if (n < 0 || K < 1 || n * (int64_t)K > 0x7fffffff) return M3D_ERR_INVALID;
+  if (!ptr) return M3D_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return hipMemsetAsync(ptr, 0, 4, st) == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+  if (!idx || !inv || !ws) return M3D_ERR_INVALID;
+  const int64_t ne = n * K;
+  int32_t* rank = (int32_t*)ws;
+  int32_t* cnt = (int32_t*)((char*)ws + rev_al((size_t)ne * 4));
+  int32_t* bsum = (int32_t*)((char*)cnt + rev_al((size_t)n * 4));
+  const int nb = (int)m3d_cdiv(n, REV_BLK);
+  hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)m3d_cdiv(n, 1024)), dim3(256), 0, st, cnt, n);
+  hipLaunchKernelGGL(rev_rank_kernel, dim3((unsigned)m3d_cdiv(ne, 256)), dim3(256), 0, st, idx, ne, (int32_t)n, cnt, rank);
+  hipLaunchKernelGGL(rev_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int32_t*)cnt, n, bsum);
+  hipLaunchKernelGGL(rev_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, bsum, nb);
+  hipLaunchKernelGGL(rev_ptr_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int32_t*)cnt, n, (const int32_t*)bsum, ptr);
+  hipLaunchKernelGGL(rev_fill_kernel, dim3((unsigned)m3d_cdiv(ne, 256)), dim3(256), 0, st, idx, ne, (const int32_t*)rank,
+                     (const int32_t*)ptr, inv);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

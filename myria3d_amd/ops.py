@@ -477,15 +477,29 @@ def csr_invert_batch(idxs, ms):
     return list(zip(ptrs, invs))
 
 
-def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Tensor, n_out: int, out: Optional[Tensor] = None) -> Tensor:
+def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Tensor, n_out: int, out: Optional[Tensor] = None,
+                    long_lists: bool = False) -> Tensor:
     """``out[c] (+)= sum of src[f] over the rows f the CSR inverse ``(ptr, inv)`` lists for c``: what
-    ``scatter_add_rows(src, idx, n_out)`` computes, without atomics and without a zero fill."""
+    ``scatter_add_rows(src, idx, n_out)`` computes, without atomics and without a zero fill.  ``long_lists``: ~16 rows per
+    list (``knn_reverse``): four lanes share a list."""
     acc = out is not None
     if out is None:
         out = torch.empty((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
     call("m3d_gather_sum_rows", _p(_chk(src)), src.stride(0), _p(ptr), _p(inv), _p(out), out.stride(0), n_out, src.shape[1],
-         int(acc), _st())
+         int(acc) | (2 if long_lists else 0), _st())
     return out
+
+
+def knn_reverse(idx: Tensor):
+    """Reverse neighbour lists ``(ptr [n + 1], inv [n K])`` of a K-NN table (``m3d_knn_reverse``): edge ``i * K + k`` is in the
+    list of point ``idx[i][k]``."""
+    n, K = idx.shape
+    idx = _chk(idx, torch.int32)
+    buf = torch.empty((n + 1 + 3) // 4 * 4 + n * K, dtype=torch.int32, device=idx.device)
+    ptr, inv = buf[:n + 1], buf[(n + 1 + 3) // 4 * 4:]
+    ws = torch.empty(lib().m3d_knn_reverse_workspace_bytes(n, K), dtype=torch.uint8, device=idx.device)
+    call("m3d_knn_reverse", _p(idx), n, K, _p(ptr), _p(inv), _p(ws), _st())
+    return ptr, inv
 
 
 def pad_pos(pos: Tensor) -> Tensor:
@@ -1316,6 +1330,7 @@ def lfa_prepare_batch(jobs) -> list:
     return outs
 
 
+USE_LFA_EDGE_ROWS = os.environ.get("M3D_LFA_EDGE_ROWS", "1") != "0"  # A/B switch: 0 = dx by float atomics everywhere
 LFA_BWD_TIMER = None  # bench.py sets {"key": (n, ch), "events": []}: LFATrainFn.backward then brackets that layer's launch with HIP events
 LFA_FULL = 1  # M3D_LFA_FULL (include/m3d_hip.h): every entry of the neighbour table is a valid row
 USE_LFA_FULL = os.environ.get("M3D_LFA_FULL", "1") != "0"  # A/B switch: 0 = the general (masked) kernels everywhere
@@ -1362,9 +1377,13 @@ class LFATrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att,
-                sinks=None, bf16=False, prepared=None):
+                sinks=None, bf16=False, prepared=None, rev=None):
         # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
         # prepared = this layer's (wf, bf, mean, invstd, wp, wpt) from lfa_prepare_batch (one launch for all layers)
+        # rev = (ptr, inv): CSR inverse of idx (csr_invert_batch(idx.view(-1), n)) — where the kernel can store its input
+        #       gradient per edge (m3d_lfa_bwd_edge_rows_ok), the backward pass sums every point's reverse neighbour list
+        #       instead of 16 / 32-byte float atomics (round 5: ~30 ps each at the L2, half of the level-1 launches)
+        ctx.rev = rev
         ctx.sinks = sinks
         ctx.side = _grad_side if sinks is not None else None
         x = x.contiguous()
@@ -1398,7 +1417,9 @@ class LFATrainFn(torch.autograd.Function):
         dev = x.device
         sk = ctx.sinks
         dout = dout.contiguous()
-        dx = arena.zeros((n, D), torch.float32, dev)
+        edge_rows = bool(ctx.rev is not None and ctx.full and not ctx.bf16 and USE_LFA_EDGE_ROWS and K <= 32 and
+                         not LFATrainFn.force_unfused_backward and lib().m3d_lfa_bwd_edge_rows_ok(n, K, ch, LRELU_SLOPE))
+        dx = torch.empty((n * K, D), dtype=torch.float32, device=dev) if edge_rows else arena.zeros((n, D), torch.float32, dev)
         if K <= 32 and not LFATrainFn.force_unfused_backward:
             G = arena.zeros((11 * D,), torch.float64, dev)  # (pre-zeroed: flag bit 1 below skips the memset)
             dw_att = sk[4] if sk else torch.empty((ch, ch), dtype=torch.float32, device=dev)
@@ -1412,7 +1433,10 @@ class LFATrainFn(torch.autograd.Function):
                 ev[0].record()
             call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
                  _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2 |
-                 (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0), _p(G), _p(ws), _st())
+                 (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0) | (32 if edge_rows else 0),
+                 _p(G), _p(ws), _st())
+            if edge_rows:
+                dx = gather_sum_rows(dx, ctx.rev[0], ctx.rev[1], n, long_lists=True)
             if ev is not None:
                 ev[1].record()
                 tm["events"].append(ev)
@@ -1422,7 +1446,7 @@ class LFATrainFn(torch.autograd.Function):
                 # layer's at the end of the backward pass (GradSideStream.flush) instead of two launches in the chain
                 ctx.side.defer_lfa((n, K, ch, ws, dw_att, G, mom, ctx.num_edges, enc_w, enc_b, enc_gamma, mean, invstd,
                                     sk[0], sk[1], sk[2], sk[3]))
-                return (dx,) + (None,) * 14
+                return (dx,) + (None,) * 15
         else:
             G = torch.empty(11 * D, dtype=torch.float64, device=dev)
             dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
@@ -1436,8 +1460,8 @@ class LFATrainFn(torch.autograd.Function):
         call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
              _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, int(sk is not None), _st())
         if sk:
-            return (dx,) + (None,) * 14
-        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None, None
+            return (dx,) + (None,) * 15
+        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None, None, None
 
 
 def _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G):

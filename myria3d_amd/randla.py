@@ -429,7 +429,7 @@ class HipRandLANet(nn.Module):
         return 2 if (getattr(self, "_bf16x3", False) and full and ops.USE_LFA_FULL and K in (16, 32)) else 0
 
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
-             train: bool, prepared=None, defer_post: bool = False) -> Tensor:
+             train: bool, prepared=None, defer_post: bool = False, rev=None) -> Tensor:
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
         bf16 = self._lfa_mode(w_att.shape[0], idx.shape[1], num_edges == idx.shape[0] * idx.shape[1])
@@ -437,7 +437,7 @@ class HipRandLANet(nn.Module):
             sk = self._sinks(enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, w_att) if self._use_sinks \
                 else None
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16, prepared)
+                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16, prepared, rev)
         elif self._grad_eval:
             agg = ops.LFAEvalFn.apply(x, pos4, idx, enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, enc_lin, enc_bn,
                                       w_att)
@@ -456,7 +456,7 @@ class HipRandLANet(nn.Module):
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
                mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str,
-               wait_graph=None, x_slot=None, prepared=(None, None)) -> Tensor:
+               wait_graph=None, x_slot=None, prepared=(None, None), rev=None) -> Tensor:
         # idx: knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
         # x_slot (train): the block input has several consumers (mlp1, the shortcut, and on the decimated levels the FP
         # module's skip): their input gradients meet in one buffer, mlp1 — last in backward order — returns the sum
@@ -466,14 +466,14 @@ class HipRandLANet(nn.Module):
         if rec is not None:
             rec[name + ".knn_idx"] = _knn_to_reference_order(idx, index)
             rec[name + ".mlp1"] = h[index.inv.long()]
-        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train, prepared[0])
+        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train, prepared[0], rev=rev)
         if rec is not None:
             rec[name + ".lfa1"] = h[index.inv.long()]
         # lfa2's SharedMLP feeds mlp2 only: on levels 1-2 (<= 64 channels: the row-stream GEMM) mlp2's GEMM applies its
         # BatchNorm on load instead of a launch of its own
         defer2 = bool(train and rec is None and ops.BN_ON_LOAD and blk.mlp2.lins[0].weight.shape[1] <= 64
                       and blk.mlp2.lins[0].weight.shape[1] % 4 == 0 and torch.is_grad_enabled())
-        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1], defer_post=defer2)
+        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1], defer_post=defer2, rev=rev)
         l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
         ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
         if train:
@@ -538,6 +538,23 @@ class HipRandLANet(nn.Module):
             pass
         return g
 
+    def _reverse_neighbours(self, plan: LevelPlan, lvl: int, idx: Tensor, train: bool):
+        """(ptr, inv): CSR inverse of a level's K-NN table — point j's list holds the edges (i, k) with idx[i][k] == j — for the
+        levels whose LFA backward kernels store their input gradient per EDGE instead of adding it with float atomics
+        (``m3d_lfa_bwd`` flags bit 5: the 8 / 16-channel layers of block 1 with complete neighbourhoods; round 5: the atomics
+        were half of those launches).  Position-only, enqueued behind the table on the geometry stream (off the step's
+        critical path; the backward pass is ordered behind it through the stages the forward pass waits for).  None: the
+        level's layers scatter with atomics."""
+        K = self.num_neighbors
+        n = plan.totals[lvl]
+        if not (train and ops.USE_LFA_FULL and ops.USE_LFA_EDGE_ROWS and plan.num_edges[lvl] == n * K):
+            return None
+        blk = (self.block1, self.block2, self.block3, self.block4)[lvl]
+        chs = [lfa.mlp_attention.lins[0].weight.shape[0] for lfa in (blk.lfa1, blk.lfa2)]
+        if not any(ops.lib().m3d_lfa_bwd_edge_rows_ok(n, K, ch, ops.LRELU_SLOPE) for ch in chs):
+            return None
+        return ops.knn_reverse(idx)
+
     def _geometry_stages(self, g: "_Geometry", pos: Tensor, plan: LevelPlan, decimation_idx, train: bool):
         """The position-only work as a generator: each ``next()`` enqueues one stage on ``g.side`` (10 stages: grid of
         level 1; then per level its kNN table + encoder moments, and its decimation + the next level's grid; last the
@@ -562,6 +579,7 @@ class HipRandLANet(nn.Module):
                     g.knn.append(idx)
                     g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
                     g.mark(1 + 2 * lvl)
+                    g.knn_inv.append(self._reverse_neighbours(plan, lvl, idx, train))
                 yield
             with torch.cuda.stream(side):
                 ix = g.index[lvl]
@@ -594,6 +612,7 @@ class HipRandLANet(nn.Module):
                 g.mom.extend(ops.lfa_moments_batch(g.pos4[:4], g.knn) if train else [None] * 4)
                 for lvl in range(4):
                     g.mark(1 + 2 * lvl, new=(lvl == 0))
+                g.knn_inv.extend(self._reverse_neighbours(plan, lvl, g.knn[lvl], train) for lvl in range(4))
             yield
         with torch.cuda.stream(side):
             if batched:
@@ -832,7 +851,8 @@ class HipRandLANet(nn.Module):
             h = self._block(blk, h, pos4[lvl], index[lvl], geo.knn[lvl], geo.mom[lvl], plan.num_edges[lvl], train,
                             record, f"block{lvl + 1}",
                             wait_graph=lambda s=1 + 2 * lvl: geo.wait(s),  # kNN table (+ encoder moments) of this level
-                            x_slot=in_slots[lvl], prepared=prepared[lvl])
+                            x_slot=in_slots[lvl], prepared=prepared[lvl],
+                            rev=geo.knn_inv[lvl] if (train and lvl < len(geo.knn_inv)) else None)
             feats.append(h)
             self._advance_interleaved()
             self._advance_interleaved()  # (two position-only stages per level: table + moments, decimation + next grid)
@@ -915,6 +935,7 @@ class _Geometry:
         self.dec_ref: List[Tensor] = []
         self.nn: List[Tensor] = []
         self.nn_inv: List[Optional[tuple]] = []  # train: CSR inverse (ptr, inv) of every 1-NN table
+        self.knn_inv: List[Optional[tuple]] = []  # train: CSR inverse of a level's K-NN table where its LFA layers use it
         self.events: Dict[int, object] = {}
         self._last_event = None
 
@@ -935,7 +956,8 @@ class _Geometry:
         """Every device buffer of this geometry, in a fixed order (``pos4`` / ``perm`` / ``inv`` are views of the
         index workspaces and come along with them)."""
         return [ix.ws for ix in self.index] + self.knn + [m for m in self.mom if m is not None] + self.src + \
-            self.dec_ref + self.nn + [t for pair in self.nn_inv if pair is not None for t in pair]
+            self.dec_ref + self.nn + [t for pair in self.nn_inv if pair is not None for t in pair] + \
+            [t for pair in self.knn_inv if pair is not None for t in pair]
 
     def rebound(self, buffers: List[Tensor], main) -> "_Geometry":
         """A geometry with the same structure whose buffers are ``buffers`` (same order as ``tensors()``); complete
@@ -953,6 +975,7 @@ class _Geometry:
         g.dec_ref = [next(it) for _ in self.dec_ref]
         g.nn = [next(it) for _ in self.nn]
         g.nn_inv = [(next(it), next(it)) if pair is not None else None for pair in self.nn_inv]
+        g.knn_inv = [(next(it), next(it)) if pair is not None else None for pair in self.knn_inv]
         return g
 
 

@@ -263,6 +263,35 @@ def test_csr_inverse_and_gather_sum_equal_the_atomic_scatter(device):
         assert torch.allclose(got2, ref + base, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,K,C", [(204800, 16, 8), (204800, 16, 4), (5000, 16, 8), (4097, 16, 4), (300, 16, 8), (70000, 32, 16), (1, 1, 4)])
+def test_knn_reverse_lists_and_the_four_lane_gather(device, n, K, C):
+    """Round 5: ``m3d_knn_reverse`` (one pass of atomics that keeps every edge's rank, multi-workgroup scan, atomic-free fill)
+    + ``m3d_gather_sum_rows(long lists)``: every edge exactly once in the list of the point it names, padding (-1) left out,
+    points nobody names get empty lists / zero rows, and the sums equal the atomic scatter's."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(n % 1000 + K)
+    # a K-NN-like table: neighbours a few hundred rows around the centre, some rows never named, some padding
+    ix = (np.arange(n)[:, None] + rs.randint(-300, 300, (n, K))) % max(n - n // 50, 1)
+    ix[rs.rand(n, K) < 0.002] = -1
+    ix = ix.astype(np.int32)
+    idx = torch.from_numpy(ix).to(device)
+    ptr, inv = ops.knn_reverse(idx)
+    ptr_h, inv_h, flat = ptr.cpu().numpy(), inv.cpu().numpy(), ix.reshape(-1)
+    cnt = np.bincount(flat[flat >= 0], minlength=n)
+    assert ptr_h[0] == 0 and np.array_equal(np.diff(ptr_h), cnt)
+    used = inv_h[:ptr_h[-1]]
+    assert np.array_equal(np.sort(used), np.nonzero(flat >= 0)[0])
+    assert np.array_equal(flat[used], np.repeat(np.arange(n), cnt))
+    src = torch.from_numpy(rs.uniform(-1, 1, (n * K, C)).astype(np.float32)).to(device)
+    ref = ops.scatter_add_rows(src, idx.view(-1), n, out=torch.zeros(n, C, device=device))
+    got = ops.gather_sum_rows(src, ptr, inv, n, long_lists=True)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5), (got - ref).abs().max().item()
+    assert torch.allclose(ops.gather_sum_rows(src, ptr, inv, n), ref, rtol=1e-5, atol=2e-5)
+    base = torch.from_numpy(rs.uniform(-1, 1, (n, C)).astype(np.float32)).to(device)
+    assert torch.allclose(ops.gather_sum_rows(src, ptr, inv, n, out=base.clone(), long_lists=True), ref + base, rtol=1e-5, atol=2e-5)
+
+
 def test_scatter_add_rows_distinct_targets(device):
     """``m3d_scatter_add_rows`` with flags bit 0 (distinct ids: the transpose of decimate()'s subset selection,
     pyg_randla_net.py:234-238) writes what the atomic kernel writes — into zeros and into an existing buffer."""
@@ -836,7 +865,7 @@ def _relclose(name, got, ref, rel):
     assert err <= rel * den + 1e-7, f"{name}: relative L2 error {err / max(den, 1e-30):.3e} > {rel}"
 
 
-def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False, mode=0):
+def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False, mode=0, edge_rows=False):
     """m3d_lfa_fwd + m3d_lfa_bwd (train mode: encoder BatchNorm on batch statistics) vs the fp64 oracle
     (LocalFeatureAggregation.aggregate + autograd).  ``big``: kNN table through cKDTree (any valid table serves an
     op-level check), reduced gradients compared by relative L2 norm."""
@@ -867,8 +896,12 @@ def _lfa_train_parity(device, ch, k, sizes, seed, fused=True, big=False, mode=0)
     num_edges = sum(n * min(k, n) for n in sizes)
     mom = ops.lfa_moments(pos4, idx32)
     xg = x.to(device).requires_grad_(True)
+    rev = None
+    if edge_rows:  # the input gradient stored per edge and summed over every point's reverse neighbour list (no atomics)
+        assert ops.lib().m3d_lfa_bwd_edge_rows_ok(idx32.shape[0], k, ch, ops.LRELU_SLOPE) == 1 and num_edges == idx32.numel()
+        rev = ops.knn_reverse(idx32)
     out = ops.LFATrainFn.apply(xg, pos4, idx32, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                               enc_bn.bias, enc_lin, enc_bn, w_att, None, mode)
+                               enc_bn.bias, enc_lin, enc_bn, w_att, None, mode, None, rev)
     out.backward(gy.float().to(device))
     sc = max(1.0, gy.abs().max().item())
     checks = [
@@ -914,7 +947,7 @@ def test_lfa_train_forward_backward(device, ch, k, fused):
 # 1024 / 1024 / 1024 / 512 / 256 workgroups of 8 / 4 / 4 / 4 / 4 centres for ch <= 16 / 32 / 64 / 128 / 256 at K = 16,
 # half as many centres per group at K = 32), so the grid-stride loop, the register prefetch of the NEXT group and the
 # double-buffered neighbour ids (PIPE, ch <= 64) are all compared with the oracle, not only the first trip
-_PERSISTENT_CASES = [(8, 16, 34000), (16, 16, 34000), (32, 16, 17000), (64, 16, 17000), (128, 16, 8500),
+_PERSISTENT_CASES = [(8, 16, 100000), (16, 16, 50000), (32, 16, 17000), (64, 16, 17000), (128, 16, 8500),
                      (256, 16, 4300), (16, 32, 17000), (64, 32, 8500), (256, 32, 2200)]
 
 
@@ -927,12 +960,43 @@ def test_lfa_backward_persistent_loop(device, ch, k, n):
     chp = max(ch, 16)
     rows = 128 if chp == 16 else 64
     cap = {16: 1024, 32: 1024, 64: 1024, 128: 512, 256: 256}[chp]
+    if chp == 16 and k == 16:  # round 5: the wave-autonomous kernel (complete neighbourhoods): 768 workgroups x 4 waves of
+        rows, cap = 8 * ch, 768  # 8 / 4 centres, ids two trips and rows one trip ahead of the arithmetic
     groups = -(-n // (rows // kp))
     assert groups >= 4 * cap, "test sizes must keep every workgroup in its loop for >= 4 trips"
     # the workspace query reports the grid the launcher will use: parts = grid * kspl3
     assert _lib.lib().m3d_lfa_bwd_workspace_bytes(n, k, ch) > 0
     third = n // 3
     _lfa_train_parity(device, ch, k, [third, third + 7, n - 2 * third - 7], seed=ch + k, big=True)
+
+
+@pytest.mark.parametrize("ch,sizes,big", [(8, [200, 17, 90], False), (16, [200, 17, 90], False), (16, [16], False),
+                                          (8, [33000, 33007, 34000], True), (16, [16600, 16607, 16800], True)])
+def test_lfa_backward_edge_rows_and_reverse_lists(device, ch, sizes, big):
+    """Round 5: ``m3d_lfa_bwd`` flags bit 5 — the 8 / 16-channel layers store their input gradient per EDGE ([n K, D] rows,
+    no atomics) and ``m3d_gather_sum_rows`` sums every point's reverse neighbour list (CSR inverse of the K-NN table) —
+    against the fp64 oracle, at the tolerances of the atomic scatter."""
+    _lfa_train_parity(device, ch, 16, sizes, seed=3 * ch, big=big, edge_rows=True)
+
+
+def test_lfa_backward_edge_rows_are_declined_where_no_kernel_stores_them(device):
+    from myria3d_amd import _lib, ops
+
+    lib = _lib.lib()
+    assert lib.m3d_lfa_bwd_edge_rows_ok(1000, 16, 8, 0.2) == 1 and lib.m3d_lfa_bwd_edge_rows_ok(1000, 16, 16, 0.2) == 1
+    assert lib.m3d_lfa_bwd_edge_rows_ok(1000, 16, 32, 0.2) == 0   # four-wave tile kernel: atomics
+    assert lib.m3d_lfa_bwd_edge_rows_ok(1000, 32, 16, 0.2) == 0   # K = 32
+    assert lib.m3d_lfa_bwd_edge_rows_ok(1000, 16, 16, 1.5) == 0   # LeakyReLU is written max(v, slope v)
+    assert lib.m3d_lfa_bwd_edge_rows_ok(1 << 27, 16, 16, 0.2) == 0  # 32-bit byte offsets
+    n, ch, K = 64, 32, 16
+    z = lambda *s: torch.zeros(*s, device=device)
+    idx = torch.zeros(n, K, dtype=torch.int32, device=device)
+    ws = torch.empty(lib.m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=device)
+    p = lambda t: t.data_ptr()
+    rc = lib.m3d_lfa_bwd(p(z(n, ch // 2)), p(z(n, 4)), p(idx), n, K, ch, p(z(ch // 2, 10)), p(z(ch // 2)), p(z(ch * ch)),
+                         p(z(ch * ch)), 0.2, p(z(n, ch)), p(z(n * K, ch // 2)), p(z(ch, ch)), 2 | 8 | 32,
+                         p(torch.zeros(11 * ch // 2, dtype=torch.float64, device=device)), p(ws), None)
+    assert rc == -2  # M3D_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("ch,k,n", [(64, 16, 3000), (128, 16, 2500), (256, 16, 1500), (64, 32, 1500), (256, 32, 900),
