@@ -295,6 +295,28 @@ def stage_rooflines(net, pos, plan):
                 flags, G.data_ptr(), ws.data_ptr(), st)
         return ch, n, D, _time_launch(launch(1 | 2 | 4 | 8)), _time_launch(launch(8))
 
+    def time_lfa_bwd_edge_rows(lfa, lvl, geo):
+        """The 8 / 16-channel layers as the training step runs them since round 5: the wave-autonomous kernel storing its
+        input gradient per edge (flags | 32) + the sum over every point's reverse neighbour list.  (ms of both, ms of the
+        kernel alone)"""
+        ch, n, D, wf, bf, wp, wpt = lfa_operands(lfa, lvl, geo)
+        xin, dout = torch.randn(n, D, device=dev), torch.randn(n, ch, device=dev)
+        dxe, dw = torch.empty((n * K, D), device=dev), torch.zeros((ch, ch), device=dev)
+        dx = torch.empty((n, D), device=dev)
+        G = torch.zeros(11 * D, dtype=torch.float64, device=dev)
+        ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
+        rptr, rinv = ops.knn_reverse(geo.knn[lvl])
+
+        def kernel():
+            ops.call("m3d_lfa_bwd", xin.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
+                     bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dxe.data_ptr(), dw.data_ptr(),
+                     1 | 2 | 4 | 8 | 32, G.data_ptr(), ws.data_ptr(), st)
+
+        def both():
+            kernel()
+            ops.call("m3d_gather_sum_rows", dxe.data_ptr(), D, rptr.data_ptr(), rinv.data_ptr(), dx.data_ptr(), D, n, D, 2, st)
+        return ch, n, D, _time_launch(both), _time_launch(kernel)
+
     def hbm_entry(kernel, nbytes, ms, prefix, grid=None):
         gbs = nbytes / (ms * 1e-3) / 1e9
         return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -391,13 +413,26 @@ def stage_rooflines(net, pos, plan):
             ent["binding_roofline"] = "valu"
             stage.append(ent)
         for lfa in (net.block1.lfa1, net.block1.lfa2):
-            ch1, n1, D1, ms_b, _ = time_lfa_bwd(lfa, 0, geo)
-            ent = hbm_entry(f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})",
-                            n1 * (12 + 4 * D1 + 4 * ch1 + 4 * K) + 4 * n1 * D1, ms_b, f"void lfa_bwd_kernel<{ch1}, 16")
+            edge_rows = bool(ops.USE_LFA_EDGE_ROWS and ops.USE_LFA_FULL and
+                             ops.lib().m3d_lfa_bwd_edge_rows_ok(plan.totals[0], K, lfa.mlp_attention.lins[0].weight.shape[0],
+                                                                ops.LRELU_SLOPE))
+            if edge_rows:
+                ch1, n1, D1, ms_b, ms_k = time_lfa_bwd_edge_rows(lfa, 0, geo)
+                name = f"lfa_bwd_small_kernel<{ch1},edge rows> + gather_sum_rows4 (level 1, ch={ch1}, n={n1}, K={K})"
+                prefix = f"void lfa_bwd_small_kernel<{ch1}, true"
+            else:
+                ch1, n1, D1, ms_b, _ = time_lfa_bwd(lfa, 0, geo)
+                ms_k = ms_b
+                name, prefix = f"lfa_bwd_kernel<{ch1},16> (level 1, ch={ch1}, n={n1}, K={K})", f"void lfa_bwd_kernel<{ch1}, 16"
+            ent = hbm_entry(name, n1 * (12 + 4 * D1 + 4 * ch1 + 4 * K) + 4 * n1 * D1, ms_b, prefix)
             # forward recompute (as above) + softmax backward ch x 6 + activation derivative / scatter ch x 2 per edge
-            ent.update(_valu_fields(f"void lfa_bwd_kernel<{ch1}, 16", n1 * K, ms_b,
-                                    9 + (ch1 // 2) * 11 + ch1 * 4 + ch1 * 8, "edge"))
-            ent["binding_roofline"] = "valu + dx atomics (profiles/r05b_*: 36-42 us of the launch)"
+            ent.update(_valu_fields(prefix, n1 * K, ms_k, 9 + (ch1 // 2) * 11 + ch1 * 4 + ch1 * 8, "edge"))
+            if edge_rows:
+                ent["kernel_alone_ms"] = round(ms_k, 4)
+                ent["binding_roofline"] = ("valu (kernel) + hbm (the [n K, D] edge rows written once and read once by the "
+                                           "reverse-list gather: counted in `traffic` of the kernel, not in the algorithmic bytes)")
+            else:
+                ent["binding_roofline"] = "valu + dx atomics"
             stage.append(ent)
         out["knn_lse"] = stage
     return out

@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __res
   }
 }
 
+#ifndef GATHER_LPL
+#define GATHER_LPL 4  // lanes per list of the long-list gather (4 or 8)
+#endif
+template <int LPL>
 __global__ void gather_sum_rows4_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ ptr,
                                         const int32_t* __restrict__ inv, float* __restrict__ out, int64_t ldo, int64_t m, int C4,
                                         int accumulate);
@@ -255,9 +259,9 @@ extern "C" int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t*
   if (!src || !ptr || !inv || !out) return M3D_ERR_INVALID;
   if ((C & 3) || (lds & 3) || (ldo & 3) || ((((uintptr_t)src) | ((uintptr_t)out)) & 15)) return M3D_ERR_UNSUPPORTED;
   if (accumulate & 2) {  // long lists: four lanes per (target, chunk)
-    int64_t gx4 = m3d_cdiv(m * (int64_t)(C / 4), 64);
-    if (gx4 > 32768) gx4 = 32768;
-    hipLaunchKernelGGL(gather_sum_rows4_kernel, dim3((unsigned)gx4), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
+    int64_t gx4 = m3d_cdiv(m * (int64_t)(C / 4), 256 / GATHER_LPL);
+    if (gx4 > 65536) gx4 = 65536;
+    hipLaunchKernelGGL(gather_sum_rows4_kernel<GATHER_LPL>, dim3((unsigned)gx4), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
                        out, ldo, m, C / 4, accumulate & 1);
     M3D_CHECK_LAUNCH();
     return M3D_OK;
@@ -283,21 +287,22 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
   return v;
 }
+template <int LPL>
 __global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __restrict__ src, int64_t lds,
                                                                const int32_t* __restrict__ ptr,
                                                                const int32_t* __restrict__ inv, float* __restrict__ out,
                                                                int64_t ldo, int64_t m, int C4, int accumulate) {
   const int64_t total = m * C4;
-  const int l = threadIdx.x & 3;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; i < total; i += (int64_t)gridDim.x * 64) {  // (uniform per quad)
+  const int l = threadIdx.x & (LPL - 1);
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPL; i < total; i += (int64_t)gridDim.x * (256 / LPL)) {  // (uniform per lane group)
     const int64_t c = i / C4;
     const int q = (int)(i % C4);
     const int p0 = ptr[c], p1 = ptr[c + 1];
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int p = p0 + l;
-    for (; p + 4 < p1; p += 8) {
+    for (; p + LPL < p1; p += 2 * LPL) {
       const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
-      const float4 b = *(const float4*)(src + (int64_t)inv[p + 4] * lds + 4 * q);
+      const float4 b = *(const float4*)(src + (int64_t)inv[p + LPL] * lds + 4 * q);
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
       s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
@@ -306,6 +311,12 @@ __global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __re
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
     }
     float4 o = make_float4(quad_sum(s0.x + s1.x), quad_sum(s0.y + s1.y), quad_sum(s0.z + s1.z), quad_sum(s0.w + s1.w));
+    if constexpr (LPL == 8) {  // lane 0 of the group: + the quad four lanes up (row_ror:12: lane i reads lane i + 4 of its 16-lane row)
+      o.x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o.x), 0x12C, 0xF, 0xF, false));
+      o.y += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o.y), 0x12C, 0xF, 0xF, false));
+      o.z += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o.z), 0x12C, 0xF, 0xF, false));
+      o.w += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o.w), 0x12C, 0xF, 0xF, false));
+    }
     if (l == 0) {
       float4* d = (float4*)(out + c * ldo + 4 * q);
       if (accumulate) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }

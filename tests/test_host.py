@@ -418,3 +418,21 @@ def test_pending_batchnorm_bookkeeping():
         assert p.materialize() is y                         # no launch once it is done
     finally:
         ops._pending.clear()
+
+
+def test_edge_row_backward_is_offered_for_the_narrow_complete_layers_only():
+    """Host-side decisions of round 5's atomic-free input gradient (no launch): ``m3d_lfa_bwd_edge_rows_ok`` says where
+    ``m3d_lfa_bwd(flags | 32)`` stores per-edge rows (8 / 16 channels, K = 16, 32-bit byte offsets, LeakyReLU slope in [0, 1]),
+    and the reverse-list builder sizes its workspace (ranks [n K], counts [n], block sums)."""
+    from myria3d_amd import _lib
+
+    lib = _lib.lib()
+    ok = lib.m3d_lfa_bwd_edge_rows_ok
+    assert ok(204800, 16, 8, 0.2) == 1 and ok(204800, 16, 16, 0.2) == 1
+    assert ok(204800, 16, 32, 0.2) == 0 and ok(204800, 16, 64, 0.2) == 0
+    assert ok(204800, 32, 16, 0.2) == 0 and ok(204800, 8, 16, 0.2) == 0
+    assert ok(0, 16, 16, 0.2) == 0 and ok(204800, 16, 16, -0.1) == 0 and ok(204800, 16, 16, 1.01) == 0
+    assert ok((1 << 31) // (16 * 8 * 4), 16, 16, 0.2) == 0 and ok((1 << 31) // (16 * 8 * 4) - 1, 16, 16, 0.2) == 1
+    wsb = lib.m3d_knn_reverse_workspace_bytes
+    assert wsb(204800, 16) >= 204800 * 16 * 4 + 204800 * 4 + (204800 // 4096 + 1) * 4
+    assert wsb(-1, 16) == 0 and wsb(10, 0) == 0

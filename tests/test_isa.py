@@ -58,3 +58,35 @@ def test_complete_neighbourhood_lfa_forward_kernels_keep_their_instruction_diet(
         assert sum(1 for o in ops if o.startswith("s_and_saveexec")) <= 4, (key, "exec-mask branches")
     # K = 32: exactly the three joins of the two half neighbourhoods (maximum, numerator, denominator) per column tile
     assert sum(1 for o in kernels[(16, 32)] if o.startswith("v_permlane16_swap")) == 3
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc (cross-compiles without a GPU)")
+def test_wave_autonomous_lfa_backward_has_no_barrier_and_no_spill():
+    """Round 5: ``lfa_bwd_small_kernel`` (8 / 16 channels, complete neighbourhoods) is built on three properties that only the
+    ISA shows: no workgroup barrier anywhere (a wave owns its LDS rows from the gather to the stores), no register spill (a
+    scratch reload behind the prefetch would wait for the next trip's loads), and the encoder weights arriving through
+    scalar loads (constant address space) instead of 44 / 88 uniform vector loads per trip.  The edge-row form has no atomic."""
+    import re
+    import subprocess
+    import tempfile
+
+    src = os.path.join(ROOT, "myria3d_amd", "csrc", "lfa_bwd.hip")
+    with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-w", "--cuda-device-only", "-S",
+                        src, "-o", tmp.name], check=True, cwd=os.path.dirname(src))
+        text = open(tmp.name).read()
+    seen = 0
+    for ch in (8, 16):
+        for edge in (0, 1):
+            m = re.search(r"^_Z20lfa_bwd_small_kernelILi%dELb%dEEv10LfaBwdArgsi:.*?\.Lfunc_end" % (ch, edge), text, re.S | re.M)
+            assert m, (ch, edge)
+            ops = [ln.strip().split()[0] for ln in m.group(0).split("\n")[1:] if ln.strip() and not ln.strip().startswith((";", "."))
+                   and not ln.strip().endswith(":")]
+            assert not any(o == "s_barrier" for o in ops), (ch, edge, "workgroup barrier")
+            assert not any(o.startswith("scratch_") for o in ops), (ch, edge, "register spill")
+            assert sum(1 for o in ops if o.startswith("s_load_dword")) >= 6, (ch, edge, "encoder weights not on the scalar path")
+            atom = sum(1 for o in ops if o.startswith("global_atomic"))
+            assert atom == (0 if edge else 16), (ch, edge, atom)
+            assert sum(1 for o in ops if o.startswith("v_mfma")) == 48, (ch, edge)
+            seen += 1
+    assert seen == 4

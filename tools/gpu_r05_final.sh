@@ -16,7 +16,7 @@ echo "bench: ${SECONDS}s"; grep -E "^\[bench" $OUT/bench_$TAG.err > $OUT/bench_p
 bash tools/gpu_prof.sh $TAG > /dev/null 2>&1
 head -8 $OUT/kernel_stats_$TAG.csv | cut -c1-150
 bash tools/gpu_trace_analyze.sh $TAG "--launch graph" 2>&1 | grep -E "^step:|per queue" | head -3
-K='lfa_bwd_kernel<(8|16|64)|knn_query|lfa_fwd_full_kernel<(8|16),'
+K='lfa_bwd_kernel<64|lfa_bwd_small_kernel|gather_sum_rows4|knn_query|lfa_fwd_full_kernel<(8|16),'
 bash tools/gpu_pmc.sh ${TAG}_fetch "FETCH_SIZE" python tools/pmc_target.py | grep -E "$K" | cut -c1-160
 bash tools/gpu_pmc.sh ${TAG}_write "WRITE_SIZE" python tools/pmc_target.py | grep -E "$K" | cut -c1-160
 bash tools/gpu_pmc.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" python tools/pmc_target.py | grep -E "$K" | cut -c1-260
