@@ -305,16 +305,18 @@ def stage_rooflines(net, pos, plan):
         dx = torch.empty((n, D), device=dev)
         G = torch.zeros(11 * D, dtype=torch.float64, device=dev)
         ws = torch.empty(ops.lib().m3d_lfa_bwd_workspace_bytes(n, K, ch), dtype=torch.uint8, device=dev)
-        rptr, rinv = ops.knn_reverse(geo.knn[lvl])
+        rptr, rinv, rslot = ops.knn_reverse(geo.knn[lvl])
+        slots = ops.USE_LFA_EDGE_SLOTS
 
         def kernel():
-            ops.call("m3d_lfa_bwd", xin.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch, wf.data_ptr(),
-                     bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dxe.data_ptr(), dw.data_ptr(),
-                     1 | 2 | 4 | 8 | 32, G.data_ptr(), ws.data_ptr(), st)
+            ops.call("m3d_lfa_bwd_edge_rows", xin.data_ptr(), geo.pos4[lvl].data_ptr(), geo.knn[lvl].data_ptr(), n, K, ch,
+                     wf.data_ptr(), bf.data_ptr(), wp.data_ptr(), wpt.data_ptr(), ops.LRELU_SLOPE, dout.data_ptr(), dxe.data_ptr(),
+                     rslot.data_ptr() if slots else None, dw.data_ptr(), 1 | 2 | 4, G.data_ptr(), ws.data_ptr(), st)
 
         def both():
             kernel()
-            ops.call("m3d_gather_sum_rows", dxe.data_ptr(), D, rptr.data_ptr(), rinv.data_ptr(), dx.data_ptr(), D, n, D, 2, st)
+            ops.call("m3d_gather_sum_rows", dxe.data_ptr(), D, rptr.data_ptr(), None if slots else rinv.data_ptr(), dx.data_ptr(),
+                     D, n, D, 2, st)
         return ch, n, D, _time_launch(both), _time_launch(kernel)
 
     def hbm_entry(kernel, nbytes, ms, prefix, grid=None):

@@ -35,7 +35,7 @@ extern "C" {
  * no_grad recalibration pass), which advances the live counter, cannot change the mask the backward pass rebuilds. */
 typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; int64_t* snapshot; } M3DDropout;
 
-#define M3D_ABI_VERSION 16
+#define M3D_ABI_VERSION 17
 #define M3D_ADAM_STATE_WORDS 66
 #define M3D_CE_ACC_DOUBLES 516
 int m3d_abi_version(void);
@@ -226,14 +226,16 @@ int m3d_csr_invert_batch(int32_t njobs, const int32_t* const* idx, const int64_t
                          int32_t* const* cnt, int32_t* const* ptr, int32_t* const* inv, void* stream);
 /* out[c][0..C) (+)= sum over f in inv[ptr[c] .. ptr[c + 1]) of src[f][0..C): the transpose of m3d_gather_rows(idx) through
  * the CSR inverse of idx — no atomics, no zero fill (accumulate bit 0: added to what out holds; bit 1: the lists are long
- * (~16 rows, m3d_knn_reverse): four lanes share a list).  C % 4 == 0. */
+ * (~16 rows, m3d_knn_reverse): four lanes share a list).  inv == NULL: list c is rows ptr[c] .. ptr[c + 1] of src themselves
+ * (m3d_lfa_bwd_edge_rows stores them that way).  C % 4 == 0. */
 int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const int32_t* inv, float* out, int64_t ldo,
                         int64_t m, int32_t C, int32_t accumulate, void* stream);
 /* Reverse neighbour lists of a K-NN table idx [n, K] (entries outside [0, n) are left out): edge e = i * K + k with
  * idx[i][k] == j is one of inv[ptr[j] .. ptr[j + 1]) (in no particular order); ptr: [n + 1], inv: [n * K].  With
  * m3d_gather_sum_rows(accumulate | 2) this is the scatter-free backward of every gather x[idx] (m3d_lfa_bwd flags bit 5). */
 size_t m3d_knn_reverse_workspace_bytes(int64_t n, int32_t K);
-int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv, void* ws, void* stream);
+int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv,
+                    int32_t* slot /* NULL or [n * K]: slot[e] = position of edge e in inv (-1: in no list) */, void* ws, void* stream);
 int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64_t n, void* stream);
 /* decimation_indices(): slot r of cloud b <- ptr[b] + P_b(r), P_b a keyed pseudo-random permutation of
  * [0, n_b); ptr_out is the decimated ptr (computed by the caller: max(1, n_b // factor) per cloud);
@@ -318,6 +320,13 @@ int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx, int64_t n
                                  plainly stored: no atomics; the caller sums the rows of every point's reverse neighbour
                                  list (m3d_csr_invert_batch of idx + m3d_gather_sum_rows) */, double* G,
                 void* ws, void* stream);
+/* m3d_lfa_bwd(flags | 8 | 32) with the edge rows in REVERSE-LIST order: edge (i, k) is stored in row edge_slot[i * K + k] of
+ * dx_edges (the slot table of m3d_knn_reverse): a point's contributions are contiguous rows, summed by
+ * m3d_gather_sum_rows(ptr, inv = NULL).  edge_slot == NULL: row i * K + k. */
+int m3d_lfa_bwd_edge_rows(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                          const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                          const float* att_wt_packed, float slope, const float* dout, float* dx_edges,
+                          const int32_t* edge_slot, float* dw_att, int32_t flags, double* G, void* ws, void* stream);
 /* 1: flags bit 5 of m3d_lfa_bwd is honoured for this layer (CH in {8, 16}, K = 16, 32-bit offsets); 0: M3D_ERR_UNSUPPORTED */
 int m3d_lfa_bwd_edge_rows_ok(int64_t n, int32_t K, int32_t CH, float slope);
 /* bf16 matrix-core variant (CH in {64, 128, 256}): the recomputed attention logits, dF and dW_att GEMMs take bf16

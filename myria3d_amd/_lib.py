@@ -66,7 +66,8 @@ SIGNATURES = {
     "m3d_lfa_bwd_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "m3d_lfa_bwd_edge_rows_ok": (_i32, [_i64, _i32, _i32, C.c_float]),
     "m3d_knn_reverse_workspace_bytes": (C.c_size_t, [_i64, _i32]),
-    "m3d_knn_reverse": (_i32, [_p, _i64, _i32, _p, _p, _p, _p]),
+    "m3d_knn_reverse": (_i32, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "m3d_lfa_bwd_edge_rows": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     "m3d_lfa_bwd": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
     "m3d_lfa_bwd_bf16": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _f32, _p, _p, _p, _i32, _p, _p, _p]),
     "m3d_lfa_edge_features": (_i32, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _f32, _p, _p]),
@@ -111,7 +112,7 @@ class M3DBnOnLoad(C.Structure):
                 ("invstd", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("y", C.c_void_p)]
 
 
-ABI_VERSION = 16  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 17  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

@@ -29,6 +29,8 @@ struct LfaBwdArgs {
   const float* dout;  // [n, CH]
   float* dx;          // [n, D], atomically accumulated
   float* dxe;         // (flags bit 5) [n * K, D]: the x-part of dF per EDGE, plainly stored; the caller sums it per neighbour
+  const int32_t* eslot;  // (with dxe; may be null) row of dxe that edge e is stored in — its position in the reverse list of the
+                         // point it names (m3d_knn_reverse), so that a point's contributions are CONTIGUOUS rows; null: row e
   float* dw_part;     // [parts][CHP*CHP]
   float* g_part;      // [parts][GP*16],  GP = max(16, D)
   int64_t n;
@@ -1042,6 +1044,8 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
   float accp[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's (unit, encoder column): sum dy * (p_i, 1)
 
   unsigned jc[EPT], jn[EPT];  // ids of the trip whose rows are in flight / of the trip after it (two trips ahead of the compute)
+  unsigned sc[EPT], sn[EPT];  // (EDGE with a slot table) the rows of dxe these edges are stored in, fetched with the ids
+  const bool slotted = EDGE && a.eslot != nullptr;
   float4 pi[EPT], pj[EPT], xg[EPT][D4];
   float dgn = 0.f;
   auto ld_ids = [&](int64_t g) {
@@ -1051,6 +1055,7 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
       unsigned eo = c0w * 16u + (unsigned)(lane + 64 * q);
       eo = eo < elast ? eo : elast;
       jn[q] = (unsigned)a.idx[eo];
+      if constexpr (EDGE) sn[q] = slotted ? (unsigned)a.eslot[eo] : eo;
     }
   };
   auto ld_rows = [&](int64_t g) {  // everything of trip g that hangs on its ids (jc), plus dout
@@ -1073,7 +1078,7 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
   if (g0 < gend) {
     ld_ids(g0);
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) jc[q] = jn[q];
+    for (int q = 0; q < EPT; ++q) { jc[q] = jn[q]; sc[q] = sn[q]; }
     ld_rows(g0);
     ld_ids(g0 + gs);
   }
@@ -1102,13 +1107,13 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
         for (int t = 0; t < 10; ++t) v += wfc[wz + c * 10 + t] * r[t];
         frow[D + c] = fmaxf(v, v * a.slope);
       }
-      NB[(PACK2 ? (hoff[q] >> 3) * 64 : 0) + prow[q]] = (int)jc[q];
+      NB[(PACK2 ? (hoff[q] >> 3) * 64 : 0) + prow[q]] = EDGE ? (int)sc[q] : (int)jc[q];  // (phase 6 needs one or the other)
       rd[q][0] = r[6]; rd[q][1] = r[7]; rd[q][2] = r[8]; rd[q][3] = r[9];
       if ((lane & 15) == 0) PC[(lane + 64 * q) >> 4] = pi[q];
     }
     // next trip's loads fly during the phases below (past the end of this workgroup's range: loaded, never used)
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) jc[q] = jn[q];
+    for (int q = 0; q < EPT; ++q) { jc[q] = jn[q]; sc[q] = sn[q]; }
     ld_rows(grp + gs);
     ld_ids(grp + 2 * gs);
     wave_lds_fence();
@@ -1184,12 +1189,16 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
       const int* nb = NB + (PACK2 ? (lr >> 3) * 64 : 0) + lg * 4;
       if (is_dx && EDGE) {
         const unsigned ci = ((unsigned)grp * 4u + (unsigned)wid) * UC + (unsigned)(PACK2 ? 2 * lg + (lr >> 3) : lg);
-        if (ci < n32) {
-          float* erow = (float*)((char*)a.dxe + (ci * (unsigned)(16 * D * 4) + (unsigned)(cc * 4)));
+        if (ci < n32) {  // (edges of centres past n are clamped copies of the last edge: their rows must not be written)
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+          for (int m = 0; m < 4; ++m) {
+            const int4 s4 = *(const int4*)(nb + m * 16);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) erow[(4 * m + r) * D] = acc[m][r];
+            for (int r = 0; r < 4; ++r) {
+              const unsigned row = (unsigned)(r == 0 ? s4.x : (r == 1 ? s4.y : (r == 2 ? s4.z : s4.w)));
+              *(float*)((char*)a.dxe + (row * (unsigned)(D * 4) + (unsigned)(cc * 4))) = acc[m][r];
+            }
+          }
         }
       } else if (is_dx) {
 #pragma unroll
@@ -1439,7 +1448,7 @@ extern "C" int m3d_lfa_bwd_edge_rows_ok(int64_t n, int32_t K, int32_t CH, float 
 static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
                         const float* enc_w_folded, const float* enc_b_folded, const void* att_w_packed,
                         const void* att_wt_packed, float slope, const float* dout, float* dx, float* dw_att,
-                        int32_t flags, double* G, void* ws, void* stream, bool bf16) {
+                        int32_t flags, double* G, void* ws, void* stream, bool bf16, const int32_t* edge_slot = nullptr) {
   if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
   if (K > 32) return M3D_ERR_UNSUPPORTED;
   if (CH != 8 && CH != 16 && CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
@@ -1453,7 +1462,7 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   LfaBwdArgs a;
   a.x = x; a.pos4 = (const float4*)pos4; a.idx = idx; a.wf = enc_w_folded; a.bf = enc_b_folded;
   a.wp = (const float4*)att_w_packed; a.wpt = (const float4*)att_wt_packed; a.dout = dout; a.dx = dx;
-  a.dxe = nullptr;
+  a.dxe = nullptr; a.eslot = nullptr;
   a.dw_part = (float*)ws;
   a.g_part = a.dw_part + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
   a.n = n; a.K = K; a.CH = CH; a.D = CH / 2; a.slope = slope;
@@ -1468,7 +1477,8 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
     if (!full || bf16 || !m3d_lfa_bwd_edge_rows_ok(n, K, CH, slope)) return M3D_ERR_UNSUPPORTED;
     a.dxe = dx;
     a.dx = nullptr;
-  }
+    a.eslot = edge_slot;
+  } else if (edge_slot) return M3D_ERR_INVALID;
   switch (CH) {
     case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full, x3); break;
     case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full, x3); break;
@@ -1545,6 +1555,18 @@ extern "C" int m3d_lfa_bwd(const float* x, const float* pos4, const int32_t* idx
                            int32_t flags, double* G, void* ws, void* stream) {
   return lfa_bwd_impl(x, pos4, idx, n, K, CH, enc_w_folded, enc_b_folded, att_w_packed, att_wt_packed, slope, dout, dx,
                       dw_att, flags, G, ws, stream, false);
+}
+
+// m3d_lfa_bwd(flags | 8 | 32) with the edge rows stored in REVERSE-LIST order: row edge_slot[i * K + k] of dx_edges (the slot
+// table of m3d_knn_reverse) holds the gradient edge (i, k) sends to x[idx[i][k]] — the rows of a point are then contiguous and
+// m3d_gather_sum_rows(inv = NULL) streams them (the edge-order gather fetches 2-4 x the rows' bytes: 64-byte fetches of 16 /
+// 32-byte rows scattered over the table, profiles/r05zfin_pmc_fetch_size.csv)
+extern "C" int m3d_lfa_bwd_edge_rows(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,
+                                     const float* enc_w_folded, const float* enc_b_folded, const float* att_w_packed,
+                                     const float* att_wt_packed, float slope, const float* dout, float* dx_edges,
+                                     const int32_t* edge_slot, float* dw_att, int32_t flags, double* G, void* ws, void* stream) {
+  return lfa_bwd_impl(x, pos4, idx, n, K, CH, enc_w_folded, enc_b_folded, att_w_packed, att_wt_packed, slope, dout, dx_edges,
+                      dw_att, flags | 8 | 32, G, ws, stream, false, edge_slot);
 }
 
 // bf16 matrix-core variant (CH in {64, 128, 256}; att_w*_packed: m3d_lfa_pack_att_bf16 / m3d_lfa_prepare(bf16 = 1))

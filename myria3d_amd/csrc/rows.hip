@@ -229,13 +229,13 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __res
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int p = p0;
     for (; p + 1 < p1; p += 2) {
-      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
-      const float4 b = *(const float4*)(src + (int64_t)inv[p + 1] * lds + 4 * q);
+      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
+      const float4 b = *(const float4*)(src + (int64_t)(inv ? inv[p + 1] : p + 1) * lds + 4 * q);
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
       s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
     if (p < p1) {
-      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
+      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
     }
     float4* d = (float4*)(out + c * ldo + 4 * q);
@@ -256,7 +256,7 @@ extern "C" int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t*
                                    int64_t ldo, int64_t m, int32_t C, int32_t accumulate, void* stream) {
   if (m < 0 || C < 0) return M3D_ERR_INVALID;
   if (m == 0 || C == 0) return M3D_OK;
-  if (!src || !ptr || !inv || !out) return M3D_ERR_INVALID;
+  if (!src || !ptr || !out) return M3D_ERR_INVALID;  // (inv == NULL: list c is the rows ptr[c] .. ptr[c + 1] of src themselves)
   if ((C & 3) || (lds & 3) || (ldo & 3) || ((((uintptr_t)src) | ((uintptr_t)out)) & 15)) return M3D_ERR_UNSUPPORTED;
   if (accumulate & 2) {  // long lists: four lanes per (target, chunk)
     int64_t gx4 = m3d_cdiv(m * (int64_t)(C / 4), 256 / GATHER_LPL);
@@ -301,13 +301,13 @@ __global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __re
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int p = p0 + l;
     for (; p + LPL < p1; p += 2 * LPL) {
-      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
-      const float4 b = *(const float4*)(src + (int64_t)inv[p + LPL] * lds + 4 * q);
+      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
+      const float4 b = *(const float4*)(src + (int64_t)(inv ? inv[p + LPL] : p + LPL) * lds + 4 * q);
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
       s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
     if (p < p1) {
-      const float4 a = *(const float4*)(src + (int64_t)inv[p] * lds + 4 * q);
+      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
     }
     float4 o = make_float4(quad_sum(s0.x + s1.x), quad_sum(s0.y + s1.y), quad_sum(s0.z + s1.z), quad_sum(s0.w + s1.w));
@@ -400,18 +400,22 @@ __global__ __launch_bounds__(256) void rev_ptr_kernel(const int32_t* __restrict_
   }
 }
 __global__ __launch_bounds__(256) void rev_fill_kernel(const int32_t* __restrict__ idx, int64_t ne, const int32_t* __restrict__ rank,
-                                                       const int32_t* __restrict__ ptr, int32_t* __restrict__ inv) {
+                                                       const int32_t* __restrict__ ptr, int32_t* __restrict__ inv,
+                                                       int32_t* __restrict__ slot) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= ne) return;
   const int r = rank[e];
-  if (r >= 0) inv[ptr[idx[e]] + r] = (int32_t)e;
+  const int s = r >= 0 ? ptr[idx[e]] + r : -1;
+  if (r >= 0) inv[s] = (int32_t)e;
+  if (slot) slot[e] = s;  // (-1: the edge is in no list)
 }
 static inline size_t rev_al(size_t b) { return (b + 255) & ~(size_t)255; }
 extern "C" size_t m3d_knn_reverse_workspace_bytes(int64_t n, int32_t K) {
   if (n < 0 || K < 1) return 0;
   return rev_al((size_t)n * K * 4) + rev_al((size_t)n * 4) + rev_al((size_t)(m3d_cdiv(n, REV_BLK) + 1) * 4) + 256;
 }
-extern "C" int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv, void* ws, void* stream) {
+extern "C" int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv, int32_t* slot, void* ws,
+                               void* stream) {
   if (n < 0 || K < 1 || n * (int64_t)K > 0x7fffffff) return M3D_ERR_INVALID;
   if (!ptr) return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -428,7 +432,7 @@ extern "C" int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t
   hipLaunchKernelGGL(rev_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, bsum, nb);
   hipLaunchKernelGGL(rev_ptr_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const int32_t*)cnt, n, (const int32_t*)bsum, ptr);
   hipLaunchKernelGGL(rev_fill_kernel, dim3((unsigned)m3d_cdiv(ne, 256)), dim3(256), 0, st, idx, ne, (const int32_t*)rank,
-                     (const int32_t*)ptr, inv);
+                     (const int32_t*)ptr, inv, slot);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

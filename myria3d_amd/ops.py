@@ -477,29 +477,31 @@ def csr_invert_batch(idxs, ms):
     return list(zip(ptrs, invs))
 
 
-def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Tensor, n_out: int, out: Optional[Tensor] = None,
+def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Optional[Tensor], n_out: int, out: Optional[Tensor] = None,
                     long_lists: bool = False) -> Tensor:
     """``out[c] (+)= sum of src[f] over the rows f the CSR inverse ``(ptr, inv)`` lists for c``: what
     ``scatter_add_rows(src, idx, n_out)`` computes, without atomics and without a zero fill.  ``long_lists``: ~16 rows per
-    list (``knn_reverse``): four lanes share a list."""
+    list (``knn_reverse``): four lanes share a list.  ``inv=None``: list c is rows ``ptr[c] .. ptr[c + 1]`` of ``src``."""
     acc = out is not None
     if out is None:
         out = torch.empty((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
-    call("m3d_gather_sum_rows", _p(_chk(src)), src.stride(0), _p(ptr), _p(inv), _p(out), out.stride(0), n_out, src.shape[1],
-         int(acc) | (2 if long_lists else 0), _st())
+    call("m3d_gather_sum_rows", _p(_chk(src)), src.stride(0), _p(ptr), _p(inv) if inv is not None else None, _p(out),
+         out.stride(0), n_out, src.shape[1], int(acc) | (2 if long_lists else 0), _st())
     return out
 
 
 def knn_reverse(idx: Tensor):
-    """Reverse neighbour lists ``(ptr [n + 1], inv [n K])`` of a K-NN table (``m3d_knn_reverse``): edge ``i * K + k`` is in the
-    list of point ``idx[i][k]``."""
+    """Reverse neighbour lists of a K-NN table (``m3d_knn_reverse``): ``(ptr [n + 1], inv [n K], slot [n K])`` — edge
+    ``e = i * K + k`` is entry ``slot[e]`` of ``inv``, inside the list ``inv[ptr[j] : ptr[j + 1]]`` of the point ``j = idx[i][k]``
+    it names (``slot[e] = -1``: padding, in no list)."""
     n, K = idx.shape
     idx = _chk(idx, torch.int32)
-    buf = torch.empty((n + 1 + 3) // 4 * 4 + n * K, dtype=torch.int32, device=idx.device)
-    ptr, inv = buf[:n + 1], buf[(n + 1 + 3) // 4 * 4:]
+    o1 = (n + 1 + 3) // 4 * 4
+    buf = torch.empty(o1 + 2 * n * K, dtype=torch.int32, device=idx.device)
+    ptr, inv, slot = buf[:n + 1], buf[o1:o1 + n * K], buf[o1 + n * K:]
     ws = torch.empty(lib().m3d_knn_reverse_workspace_bytes(n, K), dtype=torch.uint8, device=idx.device)
-    call("m3d_knn_reverse", _p(idx), n, K, _p(ptr), _p(inv), _p(ws), _st())
-    return ptr, inv
+    call("m3d_knn_reverse", _p(idx), n, K, _p(ptr), _p(inv), _p(slot), _p(ws), _st())
+    return ptr, inv, slot
 
 
 def pad_pos(pos: Tensor) -> Tensor:
@@ -1331,6 +1333,7 @@ def lfa_prepare_batch(jobs) -> list:
 
 
 USE_LFA_EDGE_ROWS = os.environ.get("M3D_LFA_EDGE_ROWS", "1") != "0"  # A/B switch: 0 = dx by float atomics everywhere
+USE_LFA_EDGE_SLOTS = os.environ.get("M3D_LFA_EDGE_SLOTS", "1") != "0"  # A/B switch: 0 = edge rows in edge order (gather through inv)
 LFA_BWD_TIMER = None  # bench.py sets {"key": (n, ch), "events": []}: LFATrainFn.backward then brackets that layer's launch with HIP events
 LFA_FULL = 1  # M3D_LFA_FULL (include/m3d_hip.h): every entry of the neighbour table is a valid row
 USE_LFA_FULL = os.environ.get("M3D_LFA_FULL", "1") != "0"  # A/B switch: 0 = the general (masked) kernels everywhere
@@ -1380,9 +1383,10 @@ class LFATrainFn(torch.autograd.Function):
                 sinks=None, bf16=False, prepared=None, rev=None):
         # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
         # prepared = this layer's (wf, bf, mean, invstd, wp, wpt) from lfa_prepare_batch (one launch for all layers)
-        # rev = (ptr, inv): CSR inverse of idx (csr_invert_batch(idx.view(-1), n)) — where the kernel can store its input
-        #       gradient per edge (m3d_lfa_bwd_edge_rows_ok), the backward pass sums every point's reverse neighbour list
-        #       instead of 16 / 32-byte float atomics (round 5: ~30 ps each at the L2, half of the level-1 launches)
+        # rev = (ptr, inv, slot): reverse neighbour lists of idx (knn_reverse) — where the kernel can store its input gradient
+        #       per edge (m3d_lfa_bwd_edge_rows_ok) it writes edge e to row slot[e], i.e. every point's contributions as
+        #       CONTIGUOUS rows, and the backward pass sums them per point (gather_sum_rows(inv=None)) instead of 16 / 32-byte
+        #       float atomics (round 5: ~30 ps each at the L2, half of the level-1 launches)
         ctx.rev = rev
         ctx.sinks = sinks
         ctx.side = _grad_side if sinks is not None else None
@@ -1431,12 +1435,15 @@ class LFATrainFn(torch.autograd.Function):
             if tm is not None and tm["key"] == (n, ch):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
-                 _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), (1 if sk is not None else 0) | 2 |
-                 (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0) | (32 if edge_rows else 0),
-                 _p(G), _p(ws), _st())
+            fl = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0)
             if edge_rows:
-                dx = gather_sum_rows(dx, ctx.rev[0], ctx.rev[1], n, long_lists=True)
+                slot = ctx.rev[2] if (len(ctx.rev) > 2 and USE_LFA_EDGE_SLOTS) else None
+                call("m3d_lfa_bwd_edge_rows", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
+                     _p(dout), _p(dx), _p(slot) if slot is not None else None, _p(dw_att), fl, _p(G), _p(ws), _st())
+                dx = gather_sum_rows(dx, ctx.rev[0], None if slot is not None else ctx.rev[1], n, long_lists=True)
+            else:
+                call("m3d_lfa_bwd_bf16" if ctx.bf16 else "m3d_lfa_bwd", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf),
+                     _p(wp), _p(wpt), LRELU_SLOPE, _p(dout), _p(dx), _p(dw_att), fl, _p(G), _p(ws), _st())
             if ev is not None:
                 ev[1].record()
                 tm["events"].append(ev)

@@ -539,7 +539,7 @@ class HipRandLANet(nn.Module):
         return g
 
     def _reverse_neighbours(self, plan: LevelPlan, lvl: int, idx: Tensor, train: bool):
-        """(ptr, inv): CSR inverse of a level's K-NN table — point j's list holds the edges (i, k) with idx[i][k] == j — for the
+        """(ptr, inv, slot): reverse neighbour lists of a level's K-NN table — point j's list holds the edges (i, k) with idx[i][k] == j — for the
         levels whose LFA backward kernels store their input gradient per EDGE instead of adding it with float atomics
         (``m3d_lfa_bwd`` flags bit 5: the 8 / 16-channel layers of block 1 with complete neighbourhoods; round 5: the atomics
         were half of those launches).  Position-only, enqueued behind the table on the geometry stream (off the step's
@@ -975,7 +975,7 @@ class _Geometry:
         g.dec_ref = [next(it) for _ in self.dec_ref]
         g.nn = [next(it) for _ in self.nn]
         g.nn_inv = [(next(it), next(it)) if pair is not None else None for pair in self.nn_inv]
-        g.knn_inv = [(next(it), next(it)) if pair is not None else None for pair in self.knn_inv]
+        g.knn_inv = [tuple(next(it) for _ in pair) if pair is not None else None for pair in self.knn_inv]
         return g
 
 

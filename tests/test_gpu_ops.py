@@ -276,13 +276,16 @@ def test_knn_reverse_lists_and_the_four_lane_gather(device, n, K, C):
     ix[rs.rand(n, K) < 0.002] = -1
     ix = ix.astype(np.int32)
     idx = torch.from_numpy(ix).to(device)
-    ptr, inv = ops.knn_reverse(idx)
+    ptr, inv, slot = ops.knn_reverse(idx)
     ptr_h, inv_h, flat = ptr.cpu().numpy(), inv.cpu().numpy(), ix.reshape(-1)
     cnt = np.bincount(flat[flat >= 0], minlength=n)
     assert ptr_h[0] == 0 and np.array_equal(np.diff(ptr_h), cnt)
     used = inv_h[:ptr_h[-1]]
     assert np.array_equal(np.sort(used), np.nonzero(flat >= 0)[0])
     assert np.array_equal(flat[used], np.repeat(np.arange(n), cnt))
+    slot_h = slot.cpu().numpy()
+    assert np.array_equal(slot_h < 0, flat < 0)                                   # padding is in no list
+    assert np.array_equal(inv_h[slot_h[flat >= 0]], np.nonzero(flat >= 0)[0])    # slot[e] is where inv holds e
     src = torch.from_numpy(rs.uniform(-1, 1, (n * K, C)).astype(np.float32)).to(device)
     ref = ops.scatter_add_rows(src, idx.view(-1), n, out=torch.zeros(n, C, device=device))
     got = ops.gather_sum_rows(src, ptr, inv, n, long_lists=True)
@@ -290,6 +293,11 @@ def test_knn_reverse_lists_and_the_four_lane_gather(device, n, K, C):
     assert torch.allclose(ops.gather_sum_rows(src, ptr, inv, n), ref, rtol=1e-5, atol=2e-5)
     base = torch.from_numpy(rs.uniform(-1, 1, (n, C)).astype(np.float32)).to(device)
     assert torch.allclose(ops.gather_sum_rows(src, ptr, inv, n, out=base.clone(), long_lists=True), ref + base, rtol=1e-5, atol=2e-5)
+    # rows stored in list order (what m3d_lfa_bwd_edge_rows writes): the lists are the rows themselves, no index table
+    ordered = torch.zeros_like(src)
+    ordered[:int(ptr_h[-1])] = src[inv[:int(ptr_h[-1])].long()]
+    assert torch.allclose(ops.gather_sum_rows(ordered, ptr, None, n, long_lists=True), ref, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(ops.gather_sum_rows(ordered, ptr, None, n), ref, rtol=1e-5, atol=2e-5)
 
 
 def test_scatter_add_rows_distinct_targets(device):
@@ -972,11 +980,19 @@ def test_lfa_backward_persistent_loop(device, ch, k, n):
 
 @pytest.mark.parametrize("ch,sizes,big", [(8, [200, 17, 90], False), (16, [200, 17, 90], False), (16, [16], False),
                                           (8, [33000, 33007, 34000], True), (16, [16600, 16607, 16800], True)])
-def test_lfa_backward_edge_rows_and_reverse_lists(device, ch, sizes, big):
+@pytest.mark.parametrize("slots", [True, False])
+def test_lfa_backward_edge_rows_and_reverse_lists(device, ch, sizes, big, slots):
     """Round 5: ``m3d_lfa_bwd`` flags bit 5 — the 8 / 16-channel layers store their input gradient per EDGE ([n K, D] rows,
     no atomics) and ``m3d_gather_sum_rows`` sums every point's reverse neighbour list (CSR inverse of the K-NN table) —
     against the fp64 oracle, at the tolerances of the atomic scatter."""
-    _lfa_train_parity(device, ch, 16, sizes, seed=3 * ch, big=big, edge_rows=True)
+    from myria3d_amd import ops
+
+    keep = ops.USE_LFA_EDGE_SLOTS
+    ops.USE_LFA_EDGE_SLOTS = slots  # rows in reverse-list order (contiguous per point) / in edge order (gather through inv)
+    try:
+        _lfa_train_parity(device, ch, 16, sizes, seed=3 * ch, big=big, edge_rows=True)
+    finally:
+        ops.USE_LFA_EDGE_SLOTS = keep
 
 
 def test_lfa_backward_edge_rows_are_declined_where_no_kernel_stores_them(device):
