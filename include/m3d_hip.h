@@ -234,7 +234,7 @@ int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const
  * idx[i][k] == j is one of inv[ptr[j] .. ptr[j + 1]) (in no particular order); ptr: [n + 1], inv: [n * K].  With
  * m3d_gather_sum_rows(accumulate | 2) this is the scatter-free backward of every gather x[idx] (m3d_lfa_bwd flags bit 5). */
 size_t m3d_knn_reverse_workspace_bytes(int64_t n, int32_t K);
-int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv,
+int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t* ptr, int32_t* inv /* NULL: not wanted */,
                     int32_t* slot /* NULL or [n * K]: slot[e] = position of edge e in inv (-1: in no list) */, void* ws, void* stream);
 int m3d_pad_pos(const float* pos, int32_t stride, float* out4 /* [n,4] */, int64_t n, void* stream);
 /* decimation_indices(): slot r of cloud b <- ptr[b] + P_b(r), P_b a keyed pseudo-random permutation of

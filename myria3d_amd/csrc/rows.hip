@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void rev_fill_kernel(const int32_t* __restrict
   if (e >= ne) return;
   const int r = rank[e];
   const int s = r >= 0 ? ptr[idx[e]] + r : -1;
-  if (r >= 0) inv[s] = (int32_t)e;
+  if (inv && r >= 0) inv[s] = (int32_t)e;
   if (slot) slot[e] = s;  // (-1: the edge is in no list)
 }
 static inline size_t rev_al(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -420,7 +420,8 @@ extern "C" int m3d_knn_reverse(const int32_t* idx, int64_t n, int32_t K, int32_t
   if (!ptr) return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return hipMemsetAsync(ptr, 0, 4, st) == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
-  if (!idx || !inv || !ws) return M3D_ERR_INVALID;
+  if (!idx || (!inv && !slot) || !ws) return M3D_ERR_INVALID;  // (inv or slot may be NULL: whoever stores rows in list order
+                                                               // needs the slots only, and the scattered writes of inv go away)
   const int64_t ne = n * K;
   int32_t* rank = (int32_t*)ws;
   int32_t* cnt = (int32_t*)((char*)ws + rev_al((size_t)ne * 4));

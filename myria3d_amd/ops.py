@@ -490,17 +490,19 @@ def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Optional[Tensor], n_out: int,
     return out
 
 
-def knn_reverse(idx: Tensor):
+def knn_reverse(idx: Tensor, with_inv: bool = True):
     """Reverse neighbour lists of a K-NN table (``m3d_knn_reverse``): ``(ptr [n + 1], inv [n K], slot [n K])`` — edge
     ``e = i * K + k`` is entry ``slot[e]`` of ``inv``, inside the list ``inv[ptr[j] : ptr[j + 1]]`` of the point ``j = idx[i][k]``
-    it names (``slot[e] = -1``: padding, in no list)."""
+    it names (``slot[e] = -1``: padding, in no list).  ``with_inv=False``: ``inv`` is None (rows stored in list order need the
+    slots only; the builder then skips its scattered writes)."""
     n, K = idx.shape
     idx = _chk(idx, torch.int32)
     o1 = (n + 1 + 3) // 4 * 4
-    buf = torch.empty(o1 + 2 * n * K, dtype=torch.int32, device=idx.device)
-    ptr, inv, slot = buf[:n + 1], buf[o1:o1 + n * K], buf[o1 + n * K:]
+    buf = torch.empty(o1 + (2 if with_inv else 1) * n * K, dtype=torch.int32, device=idx.device)
+    ptr, slot = buf[:n + 1], buf[o1:o1 + n * K]
+    inv = buf[o1 + n * K:] if with_inv else None
     ws = torch.empty(lib().m3d_knn_reverse_workspace_bytes(n, K), dtype=torch.uint8, device=idx.device)
-    call("m3d_knn_reverse", _p(idx), n, K, _p(ptr), _p(inv), _p(slot), _p(ws), _st())
+    call("m3d_knn_reverse", _p(idx), n, K, _p(ptr), _p(inv) if with_inv else None, _p(slot), _p(ws), _st())
     return ptr, inv, slot
 
 
@@ -1437,7 +1439,7 @@ class LFATrainFn(torch.autograd.Function):
                 ev[0].record()
             fl = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0)
             if edge_rows:
-                slot = ctx.rev[2] if (len(ctx.rev) > 2 and USE_LFA_EDGE_SLOTS) else None
+                slot = ctx.rev[2] if (len(ctx.rev) > 2 and (USE_LFA_EDGE_SLOTS or ctx.rev[1] is None)) else None
                 call("m3d_lfa_bwd_edge_rows", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
                      _p(dout), _p(dx), _p(slot) if slot is not None else None, _p(dw_att), fl, _p(G), _p(ws), _st())
                 dx = gather_sum_rows(dx, ctx.rev[0], None if slot is not None else ctx.rev[1], n, long_lists=True)

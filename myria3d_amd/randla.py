@@ -553,7 +553,7 @@ class HipRandLANet(nn.Module):
         chs = [lfa.mlp_attention.lins[0].weight.shape[0] for lfa in (blk.lfa1, blk.lfa2)]
         if not any(ops.lib().m3d_lfa_bwd_edge_rows_ok(n, K, ch, ops.LRELU_SLOPE) for ch in chs):
             return None
-        return ops.knn_reverse(idx)
+        return ops.knn_reverse(idx, with_inv=not ops.USE_LFA_EDGE_SLOTS)  # (rows in list order: the slot table is all it takes)
 
     def _geometry_stages(self, g: "_Geometry", pos: Tensor, plan: LevelPlan, decimation_idx, train: bool):
         """The position-only work as a generator: each ``next()`` enqueues one stage on ``g.side`` (10 stages: grid of
@@ -957,7 +957,7 @@ class _Geometry:
         index workspaces and come along with them)."""
         return [ix.ws for ix in self.index] + self.knn + [m for m in self.mom if m is not None] + self.src + \
             self.dec_ref + self.nn + [t for pair in self.nn_inv if pair is not None for t in pair] + \
-            [t for pair in self.knn_inv if pair is not None for t in pair]
+            [t for pair in self.knn_inv if pair is not None for t in pair if t is not None]
 
     def rebound(self, buffers: List[Tensor], main) -> "_Geometry":
         """A geometry with the same structure whose buffers are ``buffers`` (same order as ``tensors()``); complete
@@ -975,7 +975,7 @@ class _Geometry:
         g.dec_ref = [next(it) for _ in self.dec_ref]
         g.nn = [next(it) for _ in self.nn]
         g.nn_inv = [(next(it), next(it)) if pair is not None else None for pair in self.nn_inv]
-        g.knn_inv = [tuple(next(it) for _ in pair) if pair is not None else None for pair in self.knn_inv]
+        g.knn_inv = [tuple(next(it) if t is not None else None for t in pair) if pair is not None else None for pair in self.knn_inv]
         return g
 
 

@@ -298,6 +298,14 @@ def test_knn_reverse_lists_and_the_four_lane_gather(device, n, K, C):
     ordered[:int(ptr_h[-1])] = src[inv[:int(ptr_h[-1])].long()]
     assert torch.allclose(ops.gather_sum_rows(ordered, ptr, None, n, long_lists=True), ref, rtol=1e-5, atol=2e-5)
     assert torch.allclose(ops.gather_sum_rows(ordered, ptr, None, n), ref, rtol=1e-5, atol=2e-5)
+    # slots alone (no index table): every edge still gets a row of its own inside the list of the point it names
+    ptr2, inv2, slot2 = ops.knn_reverse(idx, with_inv=False)
+    assert inv2 is None and torch.equal(ptr2, ptr)
+    s2 = slot2.cpu().numpy()
+    assert np.array_equal(s2 < 0, flat < 0)
+    v = flat >= 0
+    assert np.array_equal(np.sort(s2[v]), np.arange(int(ptr_h[-1])))
+    assert np.all(s2[v] >= ptr_h[flat[v]]) and np.all(s2[v] < ptr_h[flat[v] + 1])
 
 
 def test_scatter_add_rows_distinct_targets(device):
