@@ -406,11 +406,16 @@ __device__ __forceinline__ void knn_query_direct_body(const KnnWs& w, const int6
       if (kth <= b2) break;
     }
   }
+  // A cloud with at least ooff + k source points fills every slot — unless a position is not finite (NaN distances are never
+  // inserted).  Consumers that were promised complete neighbourhoods (M3D_LFA_FULL: the plan's host-side edge count) read the
+  // table unmasked, so such a slot names the cloud's first row (a valid row in either numbering) instead of -1: the outputs
+  // are NaN like the reference's, not an out-of-bounds access.  The distance stays +inf.
+  const int fallback = g.n >= ooff + k ? (int)ptr_src[b] : -1;
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) {
     if (j < k) {
       bool ok = !KP::is_empty(best[j]);
-      int id = ok ? KP::row(best[j]) : -1;
+      int id = ok ? KP::row(best[j]) : fallback;
       if (sorted_io && ok) id = w.inv[id];  // neighbours selected by (d2, original row); reported as cell-sorted slots
       io[j] = id;
       if (dq) dq[j] = ok ? __uint_as_float(KP::d2bits(best[j])) : __builtin_inff();
@@ -626,12 +631,18 @@ __device__ __forceinline__ void knn_query_queue_body(
   int ids[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) ids[j] = KP::is_empty(best[j]) ? -1 : KP::row(best[j]);
+  // (see knn_query_direct_body: an unfilled slot of a cloud with >= k points — non-finite positions — names the cloud's
+  // first row, never -1: the mask-free consumers must not read out of bounds)
+  const int fallback = g.n >= k ? (int)ptr_src[b] : -1;
   if (sorted_io) {  // neighbours selected by (d2, original row); reported as cell-sorted slots
     int tr[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) tr[j] = w.inv[ids[j] < 0 ? 0 : ids[j]];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? -1 : tr[j];
+    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? fallback : tr[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) ids[j] = ids[j] < 0 ? fallback : ids[j];
   }
   int* io = idx_out + orow * k;
   if (k == KMAX && KMAX % 4 == 0 && (flags & 2)) {

@@ -1317,17 +1317,19 @@ __device__ __forceinline__ void lfa_bwd_reduce_body(const float* __restrict__ dw
   if (t < nw) {
     const int per = (parts3 + ny - 1) / ny;
     const int p0 = y * per, p1 = min(parts3, p0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    // fp64 like G below (round 6): a chunk holds up to a few hundred partials of cancelling terms (dA sums to zero over every
+    // neighbourhood) — the loads bind this pass, the wider adds are free
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int p = p0;
     for (; p + 3 < p1; p += 4) {
-      s0 += dw_part[(size_t)p * nw + t];
-      s1 += dw_part[(size_t)(p + 1) * nw + t];
-      s2 += dw_part[(size_t)(p + 2) * nw + t];
-      s3 += dw_part[(size_t)(p + 3) * nw + t];
+      s0 += (double)dw_part[(size_t)p * nw + t];
+      s1 += (double)dw_part[(size_t)(p + 1) * nw + t];
+      s2 += (double)dw_part[(size_t)(p + 2) * nw + t];
+      s3 += (double)dw_part[(size_t)(p + 3) * nw + t];
     }
-    for (; p < p1; ++p) s0 += dw_part[(size_t)p * nw + t];
+    for (; p < p1; ++p) s0 += (double)dw_part[(size_t)p * nw + t];
     const int c = t / CHP, k = t % CHP;
-    if (c < CH && k < CH && p1 > p0) atomicAdd(&dw_att[c * CH + k], (s0 + s1) + (s2 + s3));
+    if (c < CH && k < CH && p1 > p0) atomicAdd(&dw_att[c * CH + k], (float)((s0 + s1) + (s2 + s3)));
   } else {
     const int u = t - nw;
     if (u < DP * 16) {

@@ -53,7 +53,7 @@ class GraphedStep:
     def __init__(self, net: HipRandLANet, ptr, num_features: int, *, mode: str = "train",
                  optimizer: Optional[FusedAdam] = None, ignore_index: int = 65, lookahead: bool = True,
                  launch: str = "graph", lookahead_mode: Optional[str] = None, optimizer_in_graph: Optional[bool] = None,
-                 warmup: int = 2, collective: str = "captured", tune_streams: int = 6):
+                 warmup: int = 2, collective: str = "captured", tune_streams: int = 6, accumulate: int = 1):
         if lookahead_mode is None:
             # two graphs on two streams pay off when the step is longer than the position-only chain (training: 4.72 vs
             # 4.79 ms); the eval forward is shorter than that chain and would wait for it every step (1.59 vs 1.18 ms)
@@ -62,6 +62,19 @@ class GraphedStep:
             raise ValueError("mode: train|eval, launch: graph|eager, lookahead_mode: dual|single")
         if mode == "train" and optimizer is None:
             raise ValueError("GraphedStep(mode='train') needs the FusedAdam that owns the net's flat buffers")
+        # accumulate = k (Lightning's ``accumulate_grad_batches``; the reference's production run: 3,
+        # configs/experiment/RandLaNet_base_run_FR.yaml:18): ``step()`` is a MICRO-batch — forward, loss, backward into the
+        # flat gradient buffer, which the backward kernels add to — and every k-th call also runs the optimizer (one
+        # all-reduce with N > 1 ranks, like DDP's no_sync, and an update with the mean gradient).  The optimizer then sits
+        # outside the captured step (a graph is the same work at every replay).
+        self.accumulate = int(accumulate)
+        if self.accumulate < 1 or (self.accumulate > 1 and mode != "train"):
+            raise ValueError("accumulate: a positive number of micro-batches per optimizer step (train mode)")
+        if self.accumulate > 1:
+            if optimizer_in_graph:
+                raise ValueError("accumulate > 1 with optimizer_in_graph=True: the optimizer runs every k-th step only")
+            optimizer_in_graph = False
+        self._micro = 0
         self.net, self.opt, self.mode = net, optimizer, mode
         self.ignore_index = ignore_index
         self.lookahead, self.launch, self.lookahead_mode = bool(lookahead), launch, lookahead_mode
@@ -357,10 +370,14 @@ class GraphedStep:
                 self._evReady.record(cur)
             else:
                 gB[k].replay()
-            if self.mode == "train" and not self.opt_in_graph:
-                self.opt.step()  # RCCL all-reduce + Adam: outside the graph, beside A on the other stream
         else:
-            self._body(k, (k ^ 1) if self.lookahead else None, self.mode == "train")
+            self._body(k, (k ^ 1) if self.lookahead else None, self.mode == "train" and self.opt_in_graph)
+        if self.mode == "train" and not self.opt_in_graph:
+            self._micro += 1
+            if self._micro >= self.accumulate:
+                # RCCL all-reduce + Adam: outside the graph, beside A on the other stream
+                self.opt.step(grad_scale=1.0 / self.accumulate)
+                self._micro = 0
         self.turn += 1
         return self.sets[k].out
 

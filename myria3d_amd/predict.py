@@ -30,7 +30,7 @@ from torch import Tensor
 from . import ops
 from .interpolation import DeviceInterpolator, knn_interpolate, predict_reduce, scatter_sum
 from .tiling import tile_select
-from .transforms import grid_sampling, node_budget, normalize_tiles
+from .transforms import grid_sampling, node_budget, node_budget_offsets, normalize_tiles
 
 
 @torch.no_grad()
@@ -91,7 +91,7 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
         p, xx, _, ptr, ptr_host = grid_sampling(pos_copy, x_raw, None, ptr_full, grid_size, return_host_ptr=True)
         p, xx, _, ptr, kept = node_budget(p, xx, None, ptr, minimum=min_nodes, maximum=max_nodes, seed=seed + b * batch_size,
                                           ptr_host=ptr_host)
-        ptr_host = _budget_offsets(ptr_host, min_nodes, max_nodes)  # node_budget's rule, on the host copy of the offsets
+        ptr_host = node_budget_offsets(ptr_host, min_nodes, max_nodes)  # node_budget's own rule (one source of truth)
         pn, xn = normalize_tiles(p, xx, ptr, center=True, nullify_z=True, subtile_width=subtile_width,
                                  intensity_col=intensity_col, rgb_col=rgb_col)
         plan = make_plan(ptr_host) if (make_plan is not None and decimation_idx_fn is None) else None
@@ -157,20 +157,6 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
                 "entropy": torch.zeros(0, device=dev), "idx_in_full_cloud": rows_all.to(torch.int64), "logits_full": acc}
     probas, preds, entropy = predict_reduce(acc, rows_all)
     return {"probas": probas, "preds": preds, "entropy": entropy, "idx_in_full_cloud": rows_all, "logits_full": acc}
-
-
-def _budget_offsets(ptr_host, minimum, maximum):
-    """CSR offsets after ``node_budget(minimum, maximum)`` from the offsets before it (host lists): tiles with fewer than
-    ``minimum`` points (and at least one) are filled up to it, tiles above ``maximum`` are cut to it."""
-    out = [0]
-    for i in range(len(ptr_host) - 1):
-        c = ptr_host[i + 1] - ptr_host[i]
-        if minimum and 0 < c < minimum:
-            c = minimum
-        if maximum is not None:
-            c = min(c, maximum)
-        out.append(out[-1] + c)
-    return out
 
 
 def itp_reduce(itp: DeviceInterpolator, n_full: int, num_classes: int = 0, device=None) -> Dict[str, Tensor]:

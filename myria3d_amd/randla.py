@@ -114,6 +114,16 @@ def make_plan(ptr_host: Sequence[int], decimation: int, num_neighbors: int, devi
     return plan
 
 
+def _check_plan(plan: LevelPlan, pos: Tensor, ptr: Tensor) -> None:
+    """A caller-supplied plan must describe THIS batch: the mask-free kernels are chosen from its host-side edge
+    counts and the per-level launches from its totals, so a plan of another layout would read and write out of bounds where
+    the plan-less path gave masked results.  Host-side arithmetic only — the point of handing over a plan is that nothing
+    is read back from the device; the tile SIZES behind equal totals are the caller's word."""
+    if plan.totals[0] != pos.shape[0] or len(plan.sizes[0]) != ptr.numel() - 1:
+        raise ValueError(f"forward(plan=...): the plan describes {len(plan.sizes[0])} clouds / {plan.totals[0]} points, the "
+                         f"batch has {ptr.numel() - 1} clouds / {pos.shape[0]} points")
+
+
 def plan_ready(plan: LevelPlan) -> None:
     """Order the current stream behind the upload of ``plan.ptrs`` (a no-op once the copy has completed, and inside a
     stream capture — plans are built before a capture begins)."""
@@ -670,6 +680,8 @@ class HipRandLANet(nn.Module):
         ptr = ptr.to(torch.int64).contiguous()
         if plan is None:
             plan = self.plan_for(ptr)
+        else:
+            _check_plan(plan, pos, ptr)
         plan_ready(plan)
         train = self.training if train is None else train
         key = (tuple(pos.shape), id(plan), bool(train))
@@ -781,6 +793,8 @@ class HipRandLANet(nn.Module):
         the next level's permutation into a single row gather."""
         if plan is None:
             plan = self.plan_for(ptr)
+        else:
+            _check_plan(plan, pos, ptr)
         plan_ready(plan)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
         if self.matmul_precision not in ("fp32", "bf16", "bf16x3"):

@@ -131,13 +131,17 @@ class FusedAdam(torch.optim.Optimizer):
                     and (dist.get_world_size() > 1 or self.force_collective))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale: float = 1.0):
+        """``grad_scale``: factor applied to the (all-reduced) gradient inside the update — ``1 / k`` after ``k`` micro-batches
+        whose backward passes accumulated into the flat gradient buffer (the reference's production run uses
+        ``accumulate_grad_batches: 3``, ``configs/experiment/RandLaNet_base_run_FR.yaml:18``; Lightning divides each
+        micro-batch loss by ``k`` instead: the same mean)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         net = self.net
-        scale = self.reduce_gradients()
+        scale = self.reduce_gradients() * float(grad_scale)
         flat_p, flat_g = net.flat_parameters, net.flat_grads
         if flat_p.data_ptr() != getattr(self, "_bound_ptr", flat_p.data_ptr()):
             raise RuntimeError("FusedAdam: the net was re-flattened after the optimizer was created")

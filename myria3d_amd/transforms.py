@@ -81,6 +81,21 @@ def grid_sampling(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Te
     return res + (host[:B + 1],) if return_host_ptr else res
 
 
+def node_budget_offsets(ptr_host: Sequence[int], minimum: int = 0, maximum: Optional[int] = None) -> list:
+    """CSR offsets after ``node_budget(minimum, maximum)`` from the offsets before it, on the host: tiles with fewer than
+    ``minimum`` points (and at least one) are filled up to it, tiles above ``maximum`` are cut to it.  THE rule — ``node_budget``
+    sizes its outputs with it and callers that plan ahead from host-side offsets (``predict_cloud``) call it too."""
+    out = [0]
+    for i in range(len(ptr_host) - 1):
+        c = int(ptr_host[i + 1]) - int(ptr_host[i])
+        if minimum and 0 < c < minimum:
+            c = int(minimum)
+        if maximum is not None:
+            c = min(c, int(maximum))
+        out.append(out[-1] + c)
+    return out
+
+
 def node_budget(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tensor, minimum: int = 0,
                 maximum: Optional[int] = None, seed: int = 0, ptr_host: Optional[Sequence[int]] = None):
     """MinimumNumNodes(minimum) then MaximumNumNodes(maximum) for every tile of a batch: tiles with fewer points are
@@ -92,13 +107,9 @@ def node_budget(pos: Tensor, x: Optional[Tensor], y: Optional[Tensor], ptr: Tens
     dev = pos.device
     ptr_c = torch.tensor(list(ptr_host), dtype=torch.int64) if ptr_host is not None else ptr.cpu().to(torch.int64)
     counts = ptr_c[1:] - ptr_c[:-1]
-    out = counts.clone()
-    if minimum:
-        out = torch.where((counts > 0) & (counts < minimum), torch.full_like(out, minimum), out)
-    if maximum is not None:
-        out = out.clamp(max=maximum)
+    ptr_out = torch.tensor(node_budget_offsets(ptr_c.tolist(), minimum, maximum), dtype=torch.int64)
+    out = ptr_out[1:] - ptr_out[:-1]
     ptr_d = ptr.to(dev, torch.int64).contiguous()
-    ptr_out = torch.cat([out.new_zeros(1), out.cumsum(0)]).to(torch.int64)
     m, B = int(ptr_out[-1]), counts.numel()
     if bool((out == counts).all()):
         return pos, x, y, ptr_d, torch.arange(pos.shape[0], dtype=torch.int32, device=dev)

@@ -15,7 +15,8 @@ For every size set it
      (pyg_randla_net.py:192-231) and switches the classifier dropout off (PyG ``MLP.dropout`` is a plain list; torch's
      dropout stream cannot be injected),
   2. writes the reference's outputs: eval logits, train-mode logits, loss, EVERY parameter gradient (141 tensors, round 4;
-     seven in round 3), running statistics, the level-1 kNN edge list as per-centre squared distances.
+     seven in round 3), running statistics, the level-1 kNN edge list as per-centre squared distances,
+  3. (round 6) runs the same module in fp64 and writes its train logits, loss and every gradient (``grad64:`` keys).
 Size sets: ``[700, 333, 50]`` (keys without prefix) and, round 4, ``[300, 9, 1, 120]`` (prefix ``b/``): a cloud with fewer
 points than K = 16 and a one-point cloud (CHANGELOG 3.4.0 of the reference: tiles down to one point).
 """
@@ -89,11 +90,15 @@ def fixed_decimation(ptr, factor, levels, seed):
     return out
 
 
-def run_reference(mod, x, pos, batch, ptr, dec, y, param_seed=PARAM_SEED):
-    """Eval logits, train logits (dropout off), loss, gradients, running statistics of the REAL PyGRandLANet."""
+def run_reference(mod, x, pos, batch, ptr, dec, y, param_seed=PARAM_SEED, dtype=torch.float32):
+    """Eval logits, train logits (dropout off), loss, gradients, running statistics of the REAL PyGRandLANet.
+    ``dtype=torch.float64``: the same module in double precision (round 6: the yardstick the fp32 run AND the HIP net are
+    measured against — how much of a gradient's difference is the fp32 arithmetic's own rounding)."""
     net = mod.PyGRandLANet(9, 6, decimation=4, num_neighbors=16, return_logits=True)
     fill_params_deterministic(net, param_seed)
     net.mlp_classif.dropout = [0.0, 0.0]
+    net = net.to(dtype)
+    x, pos = x.to(dtype), pos.to(dtype)
     calls = {"i": 0}
     orig = mod.decimation_indices
 
@@ -142,6 +147,13 @@ def main():
             out[f"{pre}dec{i}"] = d.numpy().astype(np.int64)
         for k, g in r["grads"].items():  # every parameter gradient
             out[pre + "grad:" + k] = g.numpy()
+        # round 6: the reference module once more in fp64 — every gradient (stored rounded to fp32: 6e-8 relative) and the
+        # train-mode logits / loss.  Tests bound the HIP net's error against THIS run by max(1e-3, 2 x the fp32 run's own error)
+        r64 = run_reference(mod, x, pos, batch, ptr, dec, y, dtype=torch.float64)
+        out[pre + "logits_train64"] = r64["logits_train"].float().numpy()
+        out[pre + "loss_train64"] = np.float64(r64["loss"].item())
+        for k, g in r64["grads"].items():
+            out[pre + "grad64:" + k] = g.float().numpy()
         for k, b in r["bufs"].items():
             if k.startswith(("block1.lfa1.mlp_encoder", "block3.mlp2", "mlp_summit")):
                 out[pre + "buf:" + k] = b.numpy()

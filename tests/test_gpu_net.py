@@ -3,8 +3,11 @@
 Tolerances (fp32 both sides, different summation orders through ~45 GEMMs / 35 BatchNorms):
   eval logits      |d| <= 1e-4 + 1e-4*|ref|      and identical argmax on >= 99.99 % of the points whose top-2 logits are not
                    tied inside that tolerance (SURVEY 8c's numbers, asserted since round 5; recorded intermediates 2e-4)
-  train logits     |d| <= 2e-3 + 2e-3*|ref|
-  parameter grads  relative L2 error <= 5e-3 per tensor (vs an fp64 oracle run)
+  train logits     |d| <= 1e-3 + 1e-3*|ref|   (the eval bound x 10; asserted since round 6, measured <= 1.5e-4)
+  parameter grads  relative L2 error vs an fp64 oracle run <= max(1e-3, 2 x the error of the fp32 ORACLE against the same fp64
+                   run) per tensor: 1e-3 is SURVEY 8c's number; where fp32 arithmetic itself cannot hold it (cancelling sums:
+                   the reference's own fp32 run is 4.2e-3 off its fp64 run in block2.lfa2.mlp_encoder.norms.0.module.bias) the
+                   bound is what the reference's arithmetic achieves, measured in the same test and printed beside ours
 """
 import os
 
@@ -37,6 +40,41 @@ def _report(name, got, ref, rtol, atol):
           f"fraction of the tolerance used = {used:.3f}")
     bad = err > atol + rtol * ref.abs()
     assert not bool(bad.any()), f"{name}: {int(bad.sum())} / {bad.numel()} outside tol, max err {err.max().item():.3e}"
+
+
+# SURVEY section 8c's train-mode numbers (round 6: asserted as stated)
+TRAIN_RTOL, TRAIN_ATOL, GRAD_TOL = 1e-3, 1e-3, 1e-3
+
+
+def _grad_table(what, got, ref64, ref32, tol=GRAD_TOL, skip_zero=True):
+    """Per parameter tensor: relative L2 error of ``got`` (HIP) and of ``ref32`` (the same arithmetic run in fp32 on the CPU: the
+    oracle, or the reference's own module) against ``ref64`` (its fp64 run).  Asserts HIP <= max(tol, 2 x the fp32 run's error);
+    prints the worst rows.  Dicts name -> tensor."""
+    rows = []
+    for name, g64 in ref64.items():
+        g64 = g64.detach().cpu().double()
+        den = g64.norm().item()
+        gh = got[name].detach().cpu().double()
+        if (".lins." in name and name.endswith("bias")) or den < 1e-8:
+            # a Linear bias in front of a train-mode BatchNorm (and fc0.bias, removed by the BatchNorms of mlp1 / shortcut):
+            # analytically zero, both sides hold rounding noise only
+            if skip_zero:
+                assert gh.abs().max().item() < 1e-5, name
+                continue
+        e_hip = (gh - g64).norm().item() / max(den, 1e-30)
+        e_f32 = (ref32[name].detach().cpu().double() - g64).norm().item() / max(den, 1e-30) if ref32 is not None else float("nan")
+        rows.append((e_hip, e_f32, name))
+    rows.sort(reverse=True)
+    print(f"[parity] {what}: {len(rows)} parameter gradients vs the fp64 run; worst (HIP rel-L2 | fp32 CPU run rel-L2 | tensor):")
+    for e_hip, e_f32, name in rows[:6]:
+        print(f"[parity]     {e_hip:.3e} | {e_f32:.3e} | {name}")
+    over = [(e, f, n) for e, f, n in rows if e > tol]
+    print(f"[parity] {what}: {len(over)} tensors above {tol:g}; all of them within 2 x the fp32 CPU run's own error: "
+          f"{all(e <= 2 * f for e, f, _ in over)}")
+    for e_hip, e_f32, name in rows:
+        bound = max(tol, 2 * e_f32) if ref32 is not None else tol
+        assert e_hip <= bound, f"grad {name}: HIP {e_hip:.3e} vs fp64, fp32 CPU run {e_f32:.3e}, bound {bound:.3e}"
+    return rows
 
 
 # SURVEY section 8c's own numbers for the eval forward (asserted since round 5 on the FINAL logits of every eval test; the
@@ -109,7 +147,7 @@ def test_dense_neighbourhood_k32_matches_oracle(device):
     mask = torch.ones(sum(sizes), 32)
     out_r = ref(x, pos, batch, ptr, decimation_idx=dec, dropout_mask=mask)
     out_g = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec, dropout_mask=mask.to(device))
-    _report("k32.train_logits", out_g, out_r, 2e-3, 2e-3)
+    _report("k32.train_logits", out_g, out_r, TRAIN_RTOL, TRAIN_ATOL)
     out_g.square().mean().backward()
     out_r.square().mean().backward()
     gr = dict(ref.named_parameters())
@@ -137,7 +175,7 @@ def test_golden_fixture(device):
                 torch.from_numpy(g["ptr"]).to(device), decimation_idx=dec,
                 dropout_mask=torch.from_numpy(g["dropout_mask"]).to(device), record=rec)
     assert torch.equal(rec["block1.knn_idx"].cpu().long(), torch.from_numpy(g["knn_idx_level1"]))
-    _report("golden.train_logits", out_t, torch.from_numpy(g["logits_train"]), 2e-3, 2e-3)
+    _report("golden.train_logits", out_t, torch.from_numpy(g["logits_train"]), TRAIN_RTOL, TRAIN_ATOL)
 
 
 def test_reference_fixture_vs_hip_net(device):
@@ -169,33 +207,27 @@ def _reference_fixture_case(device, g, pre):
     assert (out.cpu().argmax(1) == t("logits_eval").argmax(1)).float().mean().item() >= 0.999
     net.train()
     out_t = net(x, pos, None, ptr, decimation_idx=dec)
-    _report(f"reference_fixture[{pre}].train_logits", out_t, t("logits_train"), 2e-3, 2e-3)
+    _report(f"reference_fixture[{pre}].train_logits", out_t, t("logits_train"), TRAIN_RTOL, TRAIN_ATOL)
     loss = torch.nn.functional.cross_entropy(out_t, t("y").to(device))
     assert abs(loss.item() - float(g[pre + "loss_train"])) < 1e-3 * max(1.0, abs(float(g[pre + "loss_train"])))
     loss.backward()
-    params = dict(net.named_parameters())
-    worst, count = ("", 0.0), 0
-    for k in g.files:
-        if k.startswith(pre + "grad:") and (pre or not k.startswith("b/")):
-            name = k[len(pre) + 5:]
-            if (".lins." in name and name.endswith(".bias")) or name == "fc0.bias":
-                continue  # a bias in front of a BatchNorm: exactly 0 in exact arithmetic, rounding noise on both sides
-            a, b = params[name].grad.cpu().double(), torch.from_numpy(g[k]).double()
-            rel = (a - b).norm().item() / max(b.norm().item(), 1e-30)
-            count += 1
-            worst = (name, rel) if rel > worst[1] else worst
-            # (second set: 430 points in all, every statistic a sum over a few hundred rows at most — two fp32 CPU runs of the same
-            # arithmetic differ by 2-4e-3 in several gradients there, tests/test_reference_pin.py: 2e-2)
-            assert rel <= (2e-2 if pre else 5e-3), (k, rel)
-    print(f"[parity] reference_fixture[{pre}]: {count} parameter gradients vs the reference's own, worst rel L2 {worst[1]:.2e} ({worst[0]})")
-    assert count >= 100
+    got = {k: p.grad for k, p in net.named_parameters()}
+    own = lambda k: k.startswith(pre) and (pre or not k.startswith("b/"))
+    ref32 = {k[len(pre) + 5:]: torch.from_numpy(g[k]) for k in g.files if own(k) and k[len(pre):].startswith("grad:")}
+    ref64 = {k[len(pre) + 7:]: torch.from_numpy(g[k]) for k in g.files if own(k) and k[len(pre):].startswith("grad64:")}
+    assert len(ref32) == len(ref64) == 152
+    # round 6: every gradient against the reference module's own FP64 run; the bound is SURVEY 8c's 1e-3, or twice what the
+    # reference's own fp32 run achieves against that yardstick where fp32 cannot hold 1e-3 (rounds 3-5 compared fp32 with fp32
+    # at 5e-3 / 2e-2: the 4.25e-3 of round 5's margins log was the REFERENCE's rounding, not the kernels')
+    rows = _grad_table(f"reference_fixture[{pre}]", got, ref64, ref32)
+    assert len(rows) >= 100
     bufs = dict(net.named_buffers())
     for k in g.files:
         if k.startswith(pre + "buf:") and (pre or not k.startswith("b/")):
             assert torch.allclose(bufs[k[len(pre) + 4:]].cpu(), torch.from_numpy(g[k]), rtol=1e-3, atol=1e-5), k
 
 
-def _train_parity(device, x, pos, batch, ptr, y, seed, k=16, grad_tol=5e-3, flat=False, precision="fp32"):
+def _train_parity(device, x, pos, batch, ptr, y, seed, k=16, grad_tol=GRAD_TOL, flat=False, precision="fp32"):
     """One train-mode forward + cross-entropy + backward of HipRandLANet against the fp64 oracle on the same weights,
     decimation indices and dropout mask: logits, loss, every parameter gradient, the running statistics."""
     from oracle.randla_oracle import fixed_decimation_indices
@@ -229,29 +261,20 @@ def _train_parity(device, x, pos, batch, ptr, y, seed, k=16, grad_tol=5e-3, flat
     else:
         loss_g = torch.nn.functional.cross_entropy(out_g, y.to(device))
         loss_g.backward()
-    _report("train.logits", out_g, out_r, 2e-3, 2e-3)
+    _report("train.logits", out_g, out_r, TRAIN_RTOL, TRAIN_ATOL)
     assert abs(loss_g.item() - loss_r.item()) < 1e-3 * max(1.0, abs(loss_r.item()))
-    ref_params = dict(ref.named_parameters())
-    worst = ("", 0.0)
     for name, p in net.named_parameters():
         assert p.grad is not None, f"{name} got no gradient (DDP find_unused_parameters=False needs all)"
-        gr = ref_params[name].grad.double()
-        gg = p.grad.detach().cpu().double()
-        den = gr.norm().item()
-        if ".lins." in name and name.endswith("bias"):
-            # Linear bias in front of a train-mode BatchNorm: analytically zero (oracle: rounding noise)
-            assert gg.abs().max().item() < 1e-6 and gr.abs().max().item() < 1e-6, name
-            continue
-        if den < 1e-8:
-            # analytically zero as well (fc0.bias: a constant shift of the block input is removed by the train-mode
-            # BatchNorms of mlp1 and shortcut); both sides only hold rounding noise
-            assert gg.abs().max().item() < 1e-5, name
-            continue
-        rel = (gg - gr).norm().item() / max(den, 1e-12)
-        if rel > worst[1]:
-            worst = (name, rel)
-        assert rel <= grad_tol, f"grad {name}: relative L2 error {rel:.3e}"
-    print(f"[parity] worst parameter-gradient relative L2 error: {worst[0]} {worst[1]:.3e}")
+    # the fp32 column: the ORACLE once more in fp32 on the CPU (same weights, indices, mask) — how far plain fp32 arithmetic
+    # lands from the fp64 run, tensor by tensor
+    ref32, _ = _pair(device, seed=seed, k=k)
+    ref32.train()
+    out32 = ref32(x, pos, batch, ptr, decimation_idx=dec, dropout_mask=mask)
+    torch.nn.functional.cross_entropy(out32, y).backward()
+    rows = _grad_table("train", {n: p.grad for n, p in net.named_parameters()},
+                       {n: p.grad for n, p in ref.named_parameters()}, {n: p.grad for n, p in ref32.named_parameters()},
+                       tol=grad_tol)
+    print(f"[parity] worst parameter-gradient relative L2 error: {rows[0][2]} {rows[0][0]:.3e}")
     # running statistics were updated identically
     got_buffers = dict(net.named_buffers())
     for nr, br in ref.named_buffers():
@@ -262,8 +285,8 @@ def _train_parity(device, x, pos, batch, ptr, y, seed, k=16, grad_tol=5e-3, flat
 
 @pytest.mark.parametrize("sizes", [[300, 211], [64, 700]])
 def test_train_forward_backward_match_oracle(device, sizes):
-    # 5e-3: at these tiny sizes the deepest BatchNorms see 1-4 rows per cloud and amplify fp32 rounding / atomic
-    # ordering noise (the well-conditioned cases sit at 1e-4 .. 1e-3)
+    # at these tiny sizes the deepest BatchNorms see 1-4 rows per cloud and amplify fp32 rounding: the bound is
+    # max(1e-3, 2 x what the fp32 oracle itself achieves against the fp64 run), tensor by tensor (_grad_table)
     x, pos, batch, ptr = rand_batch(sizes, seed=sizes[0])
     y = torch.from_numpy(np.random.RandomState(1).randint(0, 6, (sum(sizes),)))
     _train_parity(device, x, pos, batch, ptr, y, seed=7)
@@ -272,8 +295,9 @@ def test_train_forward_backward_match_oracle(device, sizes):
 def test_baseline_tiles_train_and_eval_match_oracle(device):
     """Two full BASELINE-config-2 tiles (12 800 synthetic Lidar-HD-shaped points each, K = 16): the launch shapes the
     bench times — 25 600 / 6 400 / 1 600 / 400 centres per level, every persistent LFA-backward workgroup in its loop
-    at level 1 (3 200 groups over 1 024 workgroups) — with NUMBERS against the oracle: train logits 2e-3, every
-    parameter gradient 5e-3 relative L2 (fp64 oracle), running statistics; then eval logits 2e-4 (fp32 oracle)."""
+    at level 1 (3 200 groups over 1 024 workgroups) — with NUMBERS against the oracle: train logits 1e-3, every
+    parameter gradient max(1e-3, 2 x the fp32 oracle's own error) relative L2 against the fp64 oracle, running statistics;
+    then eval logits 1e-4 (fp32 oracle)."""
     from oracle.randla_oracle import synthetic_batch
 
     x, pos, batch, ptr, y = synthetic_batch([12800, 12800])
@@ -313,7 +337,7 @@ def test_config2_full_batch_eval_logits_match_oracle(device):
 def test_flattened_path_every_gradient_vs_fp64_oracle(device):
     """The flattened / deferred / batched backward (gradient sinks, ``m3d_linear_wgrad_batch``,
     ``m3d_lfa_bwd_reduce_batch``, slot-mode BatchNorm, HIP cross-entropy) at 2 x 12 800 points: EVERY parameter gradient
-    within 5e-3 relative L2 of the fp64 oracle (round 2 compared this path by loss and GPU-vs-GPU only)."""
+    within max(1e-3, 2 x the fp32 oracle's own error) relative L2 of the fp64 oracle."""
     from oracle.randla_oracle import synthetic_batch
 
     x, pos, batch, ptr, y = synthetic_batch([12800, 12800])
@@ -577,8 +601,8 @@ def test_seeded_decimation_is_reproducible(device):
 def test_split_bf16_mode_meets_the_fp32_tolerances(device):
     """``matmul_precision = "bf16x3"`` (round 5 experiment): the attention GEMMs of the LFA layers with >= 64 channels as
     split-bf16 products on the matrix cores, everything else fp32 — the net must meet the tolerances of the fp32 contract:
-    eval logits 1e-4 + 1e-4 |ref| at 2 x 12 800 points, and (train mode, fp64 oracle) train logits 2e-3, loss, EVERY
-    parameter gradient 5e-3 relative L2, running statistics."""
+    eval logits 1e-4 + 1e-4 |ref| at 2 x 12 800 points, and (train mode, fp64 oracle) train logits 1e-3, loss, EVERY
+    parameter gradient at the fp32 contract's bound (_grad_table), running statistics."""
     from oracle.randla_oracle import fixed_decimation_indices, synthetic_batch
 
     ref, net = _pair(device, seed=7)

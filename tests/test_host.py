@@ -373,13 +373,13 @@ def test_zero_arena_learns_its_size_across_an_eval_pass():
 
 
 def test_node_budget_offsets_on_the_host_follow_the_device_rule():
-    """``predict._budget_offsets`` (round 5: the predict chain keeps the CSR offsets of a batch on the host so that the net's
-    level plan needs no device read-back) = the count rule of ``transforms.node_budget`` / the reference's
+    """``transforms.node_budget_offsets`` (round 5: the predict chain keeps the CSR offsets of a batch on the host so that the net's
+    level plan needs no device read-back; round 6: ONE function, which ``node_budget`` itself sizes its outputs with) = the reference's
     ``MinimumNumNodes`` + ``MaximumNumNodes`` (transforms.py:48-87): tiles with 0 points stay empty, tiles below the minimum
     are filled up to it, tiles above the maximum are cut."""
     import torch
 
-    from myria3d_amd.predict import _budget_offsets
+    from myria3d_amd.transforms import node_budget_offsets as _budget_offsets
 
     counts = [0, 1, 299, 300, 301, 39999, 40000, 40001, 123456]
     ptr = [0]
