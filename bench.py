@@ -72,8 +72,9 @@ def parse():
                          "branches (the executor then runs the position-only branch first, ~0.8 ms ahead of the features). "
                          "dual was the slower one while the weight gradients still ran on a side stream (profiles/r02vwx_*), "
                          "and is 0.08 ms faster since they are batched at the end of the backward pass")
-    ap.add_argument("--precision", choices=("fp32", "bf16", "bf16x3"), default="fp32",
-                    help="matmul precision of the timed net (the contract line is fp32; 'bf16' is what the \"bf16\" leg runs)")
+    ap.add_argument("--precision", choices=("fp32", "bf16", "bf16ops", "bf16x3"), default="fp32",
+                    help="precision mode of the timed net (the contract line is fp32; 'bf16' = bf16 activation storage + bf16 "
+                         "matrix-core operands: the \"bf16\" leg; 'bf16ops' = the operands alone, fp32 storage: rounds 2-5's leg)")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--skip-roofline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
@@ -1013,7 +1014,9 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     x, pos, ptr, y = x.to(dev), pos.to(dev), ptr.to(dev), y.to(dev)
     torch.manual_seed(0)
     net = HipRandLANet(9, 6, decimation=4, num_neighbors=K, return_logits=True).to(dev)
-    net.matmul_precision = precision
+    net.matmul_precision = "bf16" if precision in ("bf16", "bf16ops") else precision
+    if precision == "bf16":
+        net.activation_dtype = torch.bfloat16  # every feature matrix and its gradient in HBM as bf16 (round 6)
     # every parameter / gradient becomes a view of one flat buffer: the backward kernels accumulate into it, RCCL
     # all-reduces it as ONE 4.45 MB bucket, m3d_adam_step updates (and clears) it in one launch
     net.flatten_parameters()
@@ -1088,7 +1091,9 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16": "f32 storage / accumulate, bf16 matrix-core operands",
+        "dtype": {"fp32": "f32", "bf16": "bf16 activation storage + bf16 matrix-core operands; f32 accumulate, parameters, "
+                                         "statistics (f64 sums), positions, logits",
+                  "bf16ops": "f32 storage / accumulate, bf16 matrix-core operands",
                   "bf16x3": "f32 storage / accumulate; attention GEMMs of the LFA layers with >= 64 channels as split-bf16 products "
                             "(hi + lo operands, three bf16 matrix-core products); everything else f32"}[precision],
         "data": "synthetic",
@@ -1161,9 +1166,16 @@ def _extra_legs(args, dev, res, B, N, K):
                                      "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
         res["bf16"] = {"value": b16["value"], "unit": "points/s", "ms_per_step": b16["ms_per_step"],
                        "fwd_only": b16["fwd_only"],
-                       "what": "LFA attention GEMMs (ch >= 64, fwd + bwd) and SharedMLP GEMMs with K > 64 (fwd + "
-                               "dgrad; deep-layer wgrad) on v_mfma_f32_16x16x32_bf16, fp32 accumulate; storage / kNN / "
-                               "softmax / BatchNorm / level-1 GEMMs fp32"}
+                       "what": "round 6: every feature matrix and its gradient stored as bf16 (M3D_IO_BF16: GEMM / BatchNorm / "
+                               "weight-gradient / LFA / row kernels read and write 2-byte elements, fp32 registers) + LFA "
+                               "attention GEMMs (ch >= 64, fwd + bwd) and SharedMLP GEMMs with K > 64 on "
+                               "v_mfma_f32_16x16x32_bf16; fp32: accumulate, parameters, statistics (fp64 sums), positions, kNN, "
+                               "softmax, logits, parameter gradients, Adam"}
+        _progress("bf16 operands only (fp32 storage: the leg of rounds 2-5)")
+        bo = _leg_in_fresh_process(["--precision", "bf16ops", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--tiles", str(B), "--points", str(N), "--neighbors", str(K)])
+        res["bf16_operands_only"] = {"value": bo["value"], "unit": "points/s", "ms_per_step": bo["ms_per_step"],
+                                     "fwd_only": bo["fwd_only"], "what": "fp32 storage, bf16 matrix-core operands only"}
 
     def bf16x3():
         # round-5 experiment: the fp32 contract's attention GEMMs as split-bf16 products on the bf16 matrix

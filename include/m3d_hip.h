@@ -35,7 +35,22 @@ extern "C" {
  * no_grad recalibration pass), which advances the live counter, cannot change the mask the backward pass rebuilds. */
 typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* rows; int64_t* snapshot; } M3DDropout;
 
-#define M3D_ABI_VERSION 17
+/* ---- bf16 ACTIVATION STORAGE (round 6; BASELINE config 2 "bf16"; the reference's switch is Lightning's `precision`,
+ * configs/experiment/RandLaNet_base_run_FR-2x3GPUs.yaml:12).  Entry points whose `flags` / `act` / `accumulate` argument
+ * documents "M3D_IO_*" accept these bits:
+ *   M3D_IO_BF16  every ACTIVATION matrix of the call — the [rows, channels] feature tensors and their gradients: a0, a1, c, c1,
+ *                z, y, dy, dz, dx, x, out, src, ... — holds bf16 (2-byte elements, round-to-nearest-even on store) although the
+ *                prototype says `float*`; leading dimensions stay in ELEMENTS, pointers 16-byte aligned as before.  Weights,
+ *                biases, BatchNorm vectors, statistics, positions, index tables and parameter gradients stay fp32 / fp64; all
+ *                arithmetic and accumulation stays fp32 (fp64 statistics).
+ *   M3D_IO_A32   (with M3D_IO_BF16) ... except the FIRST input matrix of the call (a0 / dy / dout), which is fp32: an incoming
+ *                gradient that was accumulated with float atomics (the LFA layers' dx at ch >= 32)
+ *   M3D_IO_C32   (with M3D_IO_BF16) ... except the OUTPUT matrix, which is fp32 (the logits) */
+#define M3D_IO_BF16 0x1000
+#define M3D_IO_A32 0x2000
+#define M3D_IO_C32 0x4000
+
+#define M3D_ABI_VERSION 18
 #define M3D_ADAM_STATE_WORDS 66
 #define M3D_CE_ACC_DOUBLES 516
 int m3d_abi_version(void);
@@ -153,6 +168,8 @@ int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, const int64_t*
                            const int64_t* lddw, int32_t accumulate, void* const* ws, void* stream);
 /* out[N] += column sums of x[M,N] (bias gradient of a Linear without BatchNorm: fc0, fc_classif) */
 int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream);
+/* the same for a bf16 matrix (M3D_IO_BF16 storage): the bias gradient of fc0 / fc_classif from a bf16 incoming gradient */
+int m3d_colsum_bf16(const void* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream);
 
 /* ---- BatchNorm1d(momentum=0.01, eps=1e-6) of SharedMLP (pyg_randla_net.py:92-109) ------------------------ */
 int m3d_bn_finalize(const double* stat_part /* [parts][2][N] from m3d_gemm_f32 */, int32_t parts, int64_t count,
@@ -212,6 +229,11 @@ int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* scale, const 
 /* ---- rows: decimation / upsampling gathers (pyg_randla_net.py:192-238, :250) ---------------------------- */
 int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx /* NULL = identity */, float* out, int64_t m,
                     int32_t C, void* stream);
+/* the same for bf16 rows (M3D_IO_BF16 storage: decimate() and the un-permutation of bf16 feature matrices); ld in elements */
+int m3d_gather_rows_bf16(const void* src, int64_t ld, const int32_t* idx, void* out, int64_t m, int32_t C, void* stream);
+/* dst[i] = bf16(src[i]) (round-to-nearest-even) for n contiguous fp32 values: the network INPUT features of a net with
+ * M3D_IO_BF16 activation storage (x[sum N, F] once per batch; the reference's input is fp32, pyg_randla_net.py:55-58) */
+int m3d_convert_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* out[idx[i]][0..C) += src[i][0..C) (the transpose of m3d_gather_rows; negative ids are skipped).  flags bit 0: the ids are
  * DISTINCT (the transpose of a subset selection, decimate(): pyg_randla_net.py:234-238): plain 16-byte read-modify-writes
  * instead of float atomics (C % 4 == 0; otherwise the atomic kernel runs). */

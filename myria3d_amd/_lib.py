@@ -33,6 +33,7 @@ SIGNATURES = {
     "m3d_linear_wgrad_f32": (_i32, [_p, _i64, _p, _i64, _p, _i32, _p, _i64, _i32, _i64, _i32, _p, _i64, _i32, _p, _p]),
     "m3d_linear_wgrad_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "m3d_colsum_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
+    "m3d_colsum_bf16": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "m3d_bn_finalize": (_i32, [_p, _i32, _i64, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_bn_fold_eval": (_i32, [_p, _p, _p, _p, _f32, _p, _p, _i32, _p]),
     "m3d_bn_apply": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _p]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     "m3d_bn_dgrad_f32": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _f32, _p, _i32, _i64, _i32, _p, _i64, _i32, _p, _i64, _p, _p,
                                 _p, _i32, _i32, _p, _i64, _p, _p]),
     "m3d_gather_rows": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
+    "m3d_gather_rows_bf16": (_i32, [_p, _i64, _p, _p, _i64, _i32, _p]),
+    "m3d_convert_f32_bf16": (_i32, [_p, _p, _i64, _p]),
     "m3d_scatter_add_rows": (_i32, [_p, _p, _p, _i64, _i64, _i32, _i32, _p]),
     "m3d_csr_invert_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p]),
     "m3d_gather_sum_rows": (_i32, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _p]),
@@ -112,7 +115,7 @@ class M3DBnOnLoad(C.Structure):
                 ("invstd", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float), ("y", C.c_void_p)]
 
 
-ABI_VERSION = 17  # M3D_ABI_VERSION in include/m3d_hip.h
+ABI_VERSION = 18  # M3D_ABI_VERSION in include/m3d_hip.h
 
 _ERRORS = {-1: "invalid argument", -2: "unsupported shape", -3: "kernel launch failure"}
 

@@ -96,24 +96,26 @@ extern "C" int m3d_bn_fold_eval(const float* gamma, const float* beta, const flo
 // ------------------------------------------------------------------------------------------
 // y = act(z*scale + shift [+ z2*scale2 + shift2]);  N % 4 == 0, rows contiguous (ld == N)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ z, const float* __restrict__ scale,
+// H: z, z2 and y hold bf16 (M3D_IO_BF16)
+template <bool H>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ z, const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
-                                                       const float4* __restrict__ z2,
+                                                       const void* __restrict__ z2,
                                                        const float* __restrict__ scale2,
                                                        const float* __restrict__ shift2, int act, float slope,
-                                                       float4* __restrict__ y, int64_t total4, int N4) {
+                                                       void* __restrict__ y, int64_t total4, int N4) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
     int c = (int)(i % N4) * 4;
-    float4 v = z[i];
+    float4 v = io_load4<H>(z, 4 * (size_t)i);
     float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
     float4 u = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
     if (z2) {
-      float4 w = z2[i];
+      float4 w = io_load4<H>(z2, 4 * (size_t)i);
       float4 s2 = *(const float4*)(scale2 + c), h2 = *(const float4*)(shift2 + c);
       u.x += w.x * s2.x + h2.x; u.y += w.y * s2.y + h2.y; u.z += w.z * s2.z + h2.z; u.w += w.w * s2.w + h2.w;
     }
     if (act) { u.x = lrelu(u.x, slope); u.y = lrelu(u.y, slope); u.z = lrelu(u.z, slope); u.w = lrelu(u.w, slope); }
-    y[i] = u;
+    io_store4<H>(y, 4 * (size_t)i, u);
   }
 }
 
@@ -129,8 +131,13 @@ extern "C" int m3d_bn_apply(const float* z, const float* scale, const float* shi
   int64_t gx = m3d_cdiv(total4, 256 * 4);
   if (gx > 4096) gx = 4096;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const float4*)z, scale,
-                     shift, (const float4*)z2, scale2, shift2, act, slope, (float4*)y, total4, N / 4);
+  // act: bit 0 = LeakyReLU, M3D_IO_BF16 = z, z2 and y hold bf16
+  if (act & M3D_IO_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const void*)z, scale,
+                       shift, (const void*)z2, scale2, shift2, act & 1, slope, (void*)y, total4, N / 4);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const void*)z, scale,
+                       shift, (const void*)z2, scale2, shift2, act & 1, slope, (void*)y, total4, N / 4);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
@@ -149,7 +156,7 @@ struct BnStatsArgs {
 struct BnStatsApplyArgs {
   BnStatsArgs b1, b2;  // b2.slots == nullptr: no residual branch
   int nslots; double count; float eps, momentum;
-  const float4* z; const float4* z2; int act; float slope; float4* y; int64_t total4; int N;
+  const void* z; const void* z2; int act; float slope; void* y; int64_t total4; int N;  // (fp32, or bf16: template flag H)
   DropArgs drop;  // thr16 != 0: y = dropout(activation) (m3d_common.h)
 };
 
@@ -189,7 +196,7 @@ __device__ __forceinline__ void bn_stats_col(const BnStatsApplyArgs& a, const Bn
   }
 }
 
-template <bool B2>
+template <bool B2, bool H = false>
 __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a) {
   // every block derives the N column constants ONCE (one thread per column, all slot rows at once, fp64) into LDS
   __shared__ float s_sc[BN_MAXN], s_sh[BN_MAXN], s_sc2[BN_MAXN], s_sh2[BN_MAXN];
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t j = at + u * stride < a.total4 ? at + u * stride : a.total4 - 1;  // (clamped: branch-free loads)
-      v[u] = a.z[j];
-      if constexpr (B2) w[u] = a.z2[j];
+      v[u] = io_load4<H>(a.z, 4 * (size_t)j);
+      if constexpr (B2) w[u] = io_load4<H>(a.z2, 4 * (size_t)j);
     }
   };
   load(i);
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_stats_apply_kernel(BnStatsApplyArgs a)
         const float4 m = drop_mul4(dkey, drop_index(a.drop, j / N4, (int)(j % N4), N4), a.drop.thr16, a.drop.scale);
         o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
       }
-      a.y[j] = o;
+      io_store4<H>(a.y, 4 * (size_t)j, o);
     }
     i += U * stride;
     if (i >= a.total4) break;
@@ -261,15 +268,18 @@ extern "C" int m3d_bn_stats_apply(const double* slots, int32_t nslots, int64_t c
   a.b1 = {slots, gamma, beta, running_mean, running_var, scale, shift, mean_out, invstd_out};
   a.b2 = {slots2, gamma2, beta2, running_mean2, running_var2, scale2, shift2, mean_out2, invstd_out2};
   a.nslots = nslots; a.count = (double)count; a.eps = eps; a.momentum = momentum;
-  a.z = (const float4*)z; a.z2 = (const float4*)z2; a.act = act; a.slope = slope; a.y = (float4*)y;
+  a.z = z; a.z2 = z2; a.act = act & 1; a.slope = slope; a.y = y;  // act: bit 0 = LeakyReLU, M3D_IO_BF16 = z, z2, y hold bf16
   a.total4 = M * (N / 4); a.N = N;
   a.drop = drop_args(drop);
   int64_t gx = m3d_cdiv(a.total4, 256 * 8);  // ~8 float4 per thread: the per-block column pass is amortised
   if (gx > 1024) gx = 1024;
   if (gx < 1) gx = 1;
   // stride = gx * 256 must be a multiple of N4 (a power of two <= 256 divides 256)
-  if (slots2) hipLaunchKernelGGL(bn_stats_apply_kernel<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(bn_stats_apply_kernel<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  const bool h = (act & M3D_IO_BF16) != 0;
+  if (slots2 && h) hipLaunchKernelGGL((bn_stats_apply_kernel<true, true>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  else if (slots2) hipLaunchKernelGGL((bn_stats_apply_kernel<true, false>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  else if (h) hipLaunchKernelGGL((bn_stats_apply_kernel<false, true>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((bn_stats_apply_kernel<false, false>), dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, a);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
@@ -297,8 +307,10 @@ struct BnBwdArgs {
 // rows past the end re-read the first row and count as 0): the loads of eight rows — dy, z (, z2) — are in flight together.
 // With the operands' null checks and the activation's scale / shift loads inside the loop every row was two to three
 // DEPENDENT round trips (z, dy -> wait -> scale, shift -> wait -> ...), 16-32 of them per thread: the 9-27 us of the launches.
-template <bool Z2, bool DROP>
+// IO (M3D_IO_* >> 12): bit 0 = z, z2 (and the apply kernel's dz, dz2) hold bf16; dy too unless bit 1 is set (fp32 dy)
+template <bool Z2, bool DROP, int IO = 0>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int rows_per_block, double* __restrict__ part) {
+  constexpr bool SH = (IO & 1) != 0, DH = (IO & 1) != 0 && (IO & 2) == 0;
   __shared__ double red[256 * 12];
   uint32_t dkey = 0u;
   if constexpr (DROP) dkey = drop_key(a.drop);
@@ -334,10 +346,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int row
         ok[u] = rr < r1;
         const int64_t rc = ok[u] ? rr : r;
         const int64_t i = rc * N4 + c4;
-        zv[u] = ((const float4*)a.z)[i];
-        gv[u] = ((const float4*)a.dy)[i];
+        zv[u] = io_load4<SH>(a.z, 4 * (size_t)i);
+        gv[u] = io_load4<DH>(a.dy, 4 * (size_t)i);
         z2v[u] = zero4;
-        if constexpr (Z2) z2v[u] = ((const float4*)a.z2)[i];
+        if constexpr (Z2) z2v[u] = io_load4<SH>(a.z2, 4 * (size_t)i);
         di[u] = 0;
         if constexpr (DROP) di[u] = drop_index(a.drop, rc, c4, N4);
       }
@@ -439,8 +451,9 @@ __device__ __forceinline__ float4 bn_dz(const BnCol& k, float4 g, float4 zv) {
   return o;
 }
 
-template <bool Z2>
+template <bool Z2, int IO = 0>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  constexpr bool SH = (IO & 1) != 0, DH = (IO & 1) != 0 && (IO & 2) == 0;
   if (a.drop.thr16) a.dkey = drop_key(a.drop);
   const int N4 = a.N / 4;
   const int64_t total4 = a.M * N4;
@@ -515,10 +528,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t j = i + u * stride < total4 ? i + u * stride : total4 - 1;
-      zq[u] = ((const float4*)a.z)[j];
-      gq[u] = ((const float4*)a.dy)[j];
+      zq[u] = io_load4<SH>(a.z, 4 * (size_t)j);
+      gq[u] = io_load4<DH>(a.dy, 4 * (size_t)j);
       z2q[u] = make_float4(0, 0, 0, 0);
-      if constexpr (Z2) z2q[u] = ((const float4*)a.z2)[j];
+      if constexpr (Z2) z2q[u] = io_load4<SH>(a.z2, 4 * (size_t)j);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -541,8 +554,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         g.x *= v.x > 0.f ? 1.f : a.slope; g.y *= v.y > 0.f ? 1.f : a.slope;
         g.z *= v.z > 0.f ? 1.f : a.slope; g.w *= v.w > 0.f ? 1.f : a.slope;
       }
-      ((float4*)a.dz)[j] = bn_dz(k1, g, zv);
-      if constexpr (Z2) ((float4*)a.dz2)[j] = bn_dz(k2, g, z2v);
+      io_store4<SH>(a.dz, 4 * (size_t)j, bn_dz(k1, g, zv));
+      if constexpr (Z2) io_store4<SH>(a.dz2, 4 * (size_t)j, bn_dz(k2, g, z2v));
     }
   }
 }
@@ -603,13 +616,21 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
   const BnBwdPlan pl = bn_bwd_plan(M, N);
   double* part = sums_ws + 3 * (size_t)N;  // sums_ws = [3][N] totals, then [blocks][3][N] partial rows
   const int N4 = N / 4;
+  // bits 16..17 of accumulate_param_grads: (M3D_IO_BF16 | M3D_IO_A32) >> 12 — dy, z, z2, dz, dz2 hold bf16 (dy fp32 with A32)
+  const int io = (accumulate_param_grads >> 16) & 3;
+  if (io == 2) return M3D_ERR_INVALID;
   {
     const dim3 rgrid((unsigned)pl.blocks, (unsigned)pl.passes);
     const int rpb = (int)pl.rows_per_block;
-    if (z2 && a.drop.thr16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), rgrid, dim3(256), 0, st, a, rpb, part);
-    else if (z2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), rgrid, dim3(256), 0, st, a, rpb, part);
-    else if (a.drop.thr16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, true>), rgrid, dim3(256), 0, st, a, rpb, part);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), rgrid, dim3(256), 0, st, a, rpb, part);
+#define M3D_BN_RED(IO_) \
+    do { \
+      if (z2 && a.drop.thr16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true, IO_>), rgrid, dim3(256), 0, st, a, rpb, part); \
+      else if (z2) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false, IO_>), rgrid, dim3(256), 0, st, a, rpb, part); \
+      else if (a.drop.thr16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, true, IO_>), rgrid, dim3(256), 0, st, a, rpb, part); \
+      else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false, IO_>), rgrid, dim3(256), 0, st, a, rpb, part); \
+    } while (0)
+    if (io == 1) M3D_BN_RED(1); else if (io == 3) M3D_BN_RED(3); else M3D_BN_RED(0);
+#undef M3D_BN_RED
   }
   if (a.nslots <= 0)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)N, z2 ? 3 : 2), dim3(64), 0, st, a, (const double*)part,
@@ -627,8 +648,13 @@ extern "C" int m3d_bn_bwd(const float* dy, const float* z, const float* scale, c
     if (gy > 1024) gy = 1024;
     if (gy < 1) gy = 1;
   }
-  if (z2) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)gy), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)gy), dim3(256), 0, st, a);
+#define M3D_BN_APP(IO_) \
+  do { \
+    if (z2) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, IO_>), dim3((unsigned)gy), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, IO_>), dim3((unsigned)gy), dim3(256), 0, st, a); \
+  } while (0)
+  if (io == 1) M3D_BN_APP(1); else if (io == 3) M3D_BN_APP(3); else M3D_BN_APP(0);
+#undef M3D_BN_APP
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }

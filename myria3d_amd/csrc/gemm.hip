@@ -221,6 +221,7 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
   g.stat_part = stat_part; g.stat_sum = stat_part; g.stat_sumsq = stat_part ? stat_part + N : nullptr; g.c = c; g.ldc = ldc; g.accumulate = accumulate;
   g.stat_slots = stat_slots;
   g.bf16 = (act >> 8) & 1;  // act: bit 0 = LeakyReLU, bit 8 = bf16 matrix-core operands (deep layers, K % 32 == 0)
+  g.io = (act >> 12) & 7;   // M3D_IO_BF16 / M3D_IO_A32 / M3D_IO_C32: activation storage (fragment-direct kernels only)
   g.act = act & 1;
   const int64_t K = (int64_t)k0 + k1;
   int64_t kchunk = m3d_align(m3d_cdiv(K, splitk), BK);
@@ -275,6 +276,7 @@ extern "C" int m3d_gemm_bn_on_load_f32(const M3DBnOnLoad* pro, const float* z, i
   g.fpro_gamma = pro->gamma; g.fpro_beta = pro->beta; g.fpro_eps = pro->eps; g.fpro_momentum = pro->momentum;
   g.fpro_rmean = pro->running_mean; g.fpro_rvar = pro->running_var; g.fpro_scale = pro->scale; g.fpro_shift = pro->shift;
   g.fpro_mean = pro->mean; g.fpro_invstd = pro->invstd; g.fpro_act = pro->act & 1; g.fpro_slope = pro->slope;
+  g.io = (pro->act & M3D_IO_BF16) ? 1 : 0;  // (pro->act: bit 0 = LeakyReLU, M3D_IO_BF16 = z, y and c hold bf16)
   g.fpro_y = pro->y;
   const int rc = m3d_gemm_direct_try(g, (hipStream_t)stream);
   return rc == 1 ? M3D_ERR_UNSUPPORTED : rc;  // (never the LDS-tiled fallback: it knows no prologue)
@@ -292,7 +294,7 @@ extern "C" int m3d_gemm_pair_f32(const float* const* a, const int64_t* lda, cons
   if (!a || !lda || !k || !b || !ldb || !c || !ldc || !accumulate) return M3D_ERR_INVALID;
   if (M < 0 || N < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
-  const int b_cm = flags & 1, bf16 = (flags >> 8) & 1;
+  const int b_cm = flags & 1, bf16 = (flags >> 8) & 1, io = (flags & M3D_IO_BF16) ? 1 : 0;
   GemmArgs g[2];
   for (int i = 0; i < 2; ++i) {
     if (!a[i] || !b[i] || !c[i] || k[i] < 1) return M3D_ERR_INVALID;
@@ -304,6 +306,7 @@ extern "C" int m3d_gemm_pair_f32(const float* const* a, const int64_t* lda, cons
     z.bias = bias ? bias[i] : nullptr; z.slope = 0.f;
     z.stat_part = sp; z.stat_sum = sp; z.stat_sumsq = sp ? sp + N : nullptr; z.stat_slots = sp ? -stat_parts : 0;
     z.c = c[i]; z.ldc = ldc[i]; z.accumulate = accumulate[i]; z.bf16 = bf16; z.splitk = 1; z.kchunk = m3d_align(k[i], BK);
+    z.io = io;
     g[i] = z;
   }
   int rc = 1;
@@ -311,7 +314,7 @@ extern "C" int m3d_gemm_pair_f32(const float* const* a, const int64_t* lda, cons
   if (rc != 1) return rc;
   for (int i = 0; i < 2; ++i) {
     rc = m3d_gemm_f32(a[i], lda[i], 0, nullptr, k[i], nullptr, 0, 0, b[i], ldb[i], b_cm, M, N, bias ? bias[i] : nullptr,
-                      nullptr, nullptr, bf16 << 8, 0.f, stat_part ? stat_part[i] : nullptr, stat_parts, c[i], ldc[i],
+                      nullptr, nullptr, (bf16 << 8) | (flags & M3D_IO_BF16), 0.f, stat_part ? stat_part[i] : nullptr, stat_parts, c[i], ldc[i],
                       accumulate[i], 1, stream);
     if (rc != M3D_OK) return rc;
   }
@@ -337,6 +340,7 @@ extern "C" int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* sc
   g.c = dx; g.ldc = lddx; g.splitk = 1; g.kchunk = m3d_align((int64_t)N, BK);
   g.bf16 = (flags >> 8) & 1;  // flags: bit 0 = add into dgamma / dbeta, bit 8 = bf16 matrix-core operands,
   g.accumulate = (flags >> 9) & 1;  // bit 9 = add the input gradient into dx (and dx1) instead of storing it
+  g.io = (flags >> 12) & 3;         // M3D_IO_BF16: dy, z, dz, dx, dx1 hold bf16; with M3D_IO_A32 dy is fp32
   g.pro_z = z; g.pro_scale = scale; g.pro_shift = shift; g.pro_mean = mean; g.pro_invstd = invstd;
   g.pro_sums = sums; g.pro_slots = nslots; g.pro_act = act & 1; g.pro_slope = slope;
   g.pro_dz = dz; g.pro_dgamma = dgamma; g.pro_dbeta = dbeta; g.pro_acc = flags & 1;
@@ -348,8 +352,10 @@ extern "C" int m3d_bn_dgrad_f32(const float* dy, const float* z, const float* sc
 
 // per-column sum of a row-major [M, N] matrix, accumulated (atomically) into out[N]:
 // the bias gradient of a Linear that is not followed by BatchNorm (fc0, fc_classif).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int N,
+template <bool H>  // H: x holds bf16 (m3d_colsum_bf16)
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ xv, int64_t ld, int64_t M, int N,
                                                      float* __restrict__ out) {
+  auto X = [&](int64_t e) -> float { return io_load1<H>(xv, (size_t)e); };
   // thread = (column c = tid % cols, row lane rl); grid-stride over rows; one atomic per column per workgroup
   // (same-address atomics serialise at ~15 ns each on MI355X: never one per thread)
   __shared__ float red[256];
@@ -366,12 +372,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
       int64_t r = (int64_t)blockIdx.x * rpp + rl;
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       for (; r + 7 * step < M; r += 8 * step) {
-        const float v0 = x[r * ld + n], v1 = x[(r + step) * ld + n], v2 = x[(r + 2 * step) * ld + n],
-                    v3 = x[(r + 3 * step) * ld + n], v4 = x[(r + 4 * step) * ld + n], v5 = x[(r + 5 * step) * ld + n],
-                    v6 = x[(r + 6 * step) * ld + n], v7 = x[(r + 7 * step) * ld + n];
+        const float v0 = X(r * ld + n), v1 = X((r + step) * ld + n), v2 = X((r + 2 * step) * ld + n),
+                    v3 = X((r + 3 * step) * ld + n), v4 = X((r + 4 * step) * ld + n), v5 = X((r + 5 * step) * ld + n),
+                    v6 = X((r + 6 * step) * ld + n), v7 = X((r + 7 * step) * ld + n);
         a0 += v0 + v4; a1 += v1 + v5; a2 += v2 + v6; a3 += v3 + v7;
       }
-      for (; r < M; r += step) a0 += x[r * ld + n];
+      for (; r < M; r += step) a0 += X(r * ld + n);
       acc = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
@@ -390,10 +396,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // whose offset past the end reads as 0 (no tail loop).  (The dword kernel keeps 2 MB in flight over the chip: 33 us for fc0's
 // 204 800 x 32 bias gradient, whose bytes stream in 4; at most 256 workgroups, because each ends in one same-address atomic
 // per column, ~15 ns apiece — hence the 16 waves per workgroup.)
-__global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__ x, int64_t ld4, int64_t M, int N4,
+template <bool H>  // H: x holds bf16 — 8-byte loads at half the offset through a 1 GiB descriptor (oob >> 1 = its size)
+__global__ __launch_bounds__(1024) void colsum4_kernel(const void* __restrict__ x, int64_t ld4, int64_t M, int N4,
                                                        float* __restrict__ out) {
   __shared__ float4 red[1024];
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, H ? 0x40000000u : 0x80000000u, 0x00020000);
   const unsigned oob = 0x80000000u;
   const int tid = threadIdx.x;
   const int rpp = 1024 / N4;
@@ -405,7 +412,15 @@ __global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t rr = r + u * step;
-      v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, rr < M ? (unsigned)((rr * ld4 + c) * 16) : oob, 0, 0);
+      const unsigned off = rr < M ? (unsigned)((rr * ld4 + c) * 16) : oob;
+      if constexpr (H) {
+        typedef int i32x2_t __attribute__((ext_vector_type(2)));
+        const i32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rs, off >> 1, 0, 0);
+        const float4 t = bf16x4_to_f32(make_uint2((unsigned)w[0], (unsigned)w[1]));
+        v[u] = (f32x4){t.x, t.y, t.z, t.w};
+      } else {
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) { acc.x += v[u][0]; acc.y += v[u][1]; acc.z += v[u][2]; acc.w += v[u][3]; }
@@ -426,7 +441,8 @@ __global__ __launch_bounds__(1024) void colsum4_kernel(const float* __restrict__
   }
 }
 
-extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream) {
+template <bool H>
+static int colsum_impl(const void* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream) {
   if (M < 0 || N < 0) return M3D_ERR_INVALID;
   if (M == 0 || N == 0) return M3D_OK;
   if (!x || !out) return M3D_ERR_INVALID;
@@ -436,7 +452,7 @@ extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, 
     const int rpp4 = 1024 / n4;
     int64_t g4 = m3d_cdiv(M, (int64_t)rpp4 * 8);
     if (g4 > 256) g4 = 256;
-    hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)g4), dim3(1024), 0, (hipStream_t)stream, x, ld / 4, M, n4, out);
+    hipLaunchKernelGGL(colsum4_kernel<H>, dim3((unsigned)g4), dim3(1024), 0, (hipStream_t)stream, x, ld / 4, M, n4, out);
     M3D_CHECK_LAUNCH();
     return M3D_OK;
   }
@@ -445,7 +461,14 @@ extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, 
   int64_t gx = m3d_cdiv(M, (int64_t)rpp * 16);
   if (gx > 256) gx = 256;  // (every workgroup ends in one same-address atomic per column: ~15 ns apiece, serialised)
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out);
+  hipLaunchKernelGGL(colsum_kernel<H>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, ld, M, N, out);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
+}
+extern "C" int m3d_colsum_f32(const float* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream) {
+  return colsum_impl<false>(x, ld, M, N, out, stream);
+}
+// the same for a bf16 matrix (M3D_IO_BF16 storage: the bias gradient of fc0 / fc_classif from a bf16 incoming gradient)
+extern "C" int m3d_colsum_bf16(const void* x, int64_t ld, int64_t M, int32_t N, float* out, void* stream) {
+  return colsum_impl<true>(x, ld, M, N, out, stream);
 }

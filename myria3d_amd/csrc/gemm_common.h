@@ -42,6 +42,10 @@ struct GemmArgs {
   // also stores scale / shift / mean / invstd for the backward pass and updates the running statistics), its MFMAs see
   // y = lrelu(z * scale + shift), and column slice 0 stores y (the weight-gradient GEMM of THIS layer reads it) — the
   // m3d_bn_stats_apply launch between the two GEMMs and one pass over the activation are gone.
+  // activation layouts (round 6): the M3D_IO_* bits of the entry point's flags >> 12.  0: every matrix fp32.  Bit 0: A0, A1,
+  // C, C1, pro_z, pro_dz, fpro_y hold bf16 (declared float* here: the kernels reinterpret; leading dimensions stay in
+  // ELEMENTS); bit 1: ... but A0 is fp32; bit 2: ... but C / C1 are fp32.  Weights, bias, statistics: always fp32 / fp64.
+  int io;
   int fpro;
   const double* fpro_slots; int fpro_nslots; double fpro_count;
   const float* fpro_gamma; const float* fpro_beta; float fpro_eps, fpro_momentum;

@@ -105,6 +105,34 @@ __device__ __forceinline__ float4 ld4(rsrc_t r, unsigned off) {
 __device__ __forceinline__ float ld1(rsrc_t r, unsigned off) {
   return __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+// ---- bf16 activation storage (round 6, M3D_IO_BF16).  Offsets stay what the fp32 code computes — BYTE offsets of fp32
+// elements, OOB = 2 GiB — and a bf16 operand is read at HALF the offset through a descriptor of 1 GiB: OOB >> 1 is then
+// exactly its size, so the hardware range check keeps working without a select.  H = false: the fp32 loads above.
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+template <bool H>
+__device__ __forceinline__ rsrc_t mk_rsrc_h(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, H ? (M3D_BUF_BYTES >> 1) : M3D_BUF_BYTES, 0x00020000);
+}
+template <bool H>
+__device__ __forceinline__ float4 ld4h(rsrc_t r, unsigned off) {
+  if constexpr (H) {
+    const i32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off >> 1, 0, 0);
+    return bf16x4_to_f32(make_uint2((unsigned)v[0], (unsigned)v[1]));
+  } else {
+    return ld4(r, off);
+  }
+}
+template <bool H>
+__device__ __forceinline__ float ld1h(rsrc_t r, unsigned off) {
+  if constexpr (H) return bf16_to_f32((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off >> 1, 0, 0));
+  else return ld1(r, off);
+}
+// activation layouts of a GEMM launch (template parameter IO = the M3D_IO_* bits >> 12): bit 0 = bf16 storage of every
+// activation matrix (A0, A1, C, C1, the prologues' z / dz / y), bit 1 = ... except A0 (fp32: an incoming gradient that was
+// accumulated with float atomics), bit 2 = ... except C / C1 (fp32: the logits)
+#define IO_A0H(IO) ((((IO) & 1) != 0) && (((IO) & 2) == 0))
+#define IO_SH(IO) (((IO) & 1) != 0)
+#define IO_CH(IO) ((((IO) & 1) != 0) && (((IO) & 4) == 0))
 
 struct ARow {
   unsigned o0;  // byte offset of the (gathered) row in A0, OOB when the row does not exist
@@ -125,22 +153,22 @@ __device__ __forceinline__ ARow a_row(const GemmArgs& g, int64_t m) {
 // elements k .. k+3 of the (concatenated) row, zeros past K / for missing rows.
 // VEC: k0, k1 multiples of 4, 16-byte aligned rows -> the four elements are one float4 of A0 or of A1 (CAT: a second
 // operand exists; the lane's offset is OOB in the operand that does not hold k).  !VEC: single operand, dword loads.
-template <bool VEC, bool CAT>
+template <bool VEC, bool CAT, bool AH = false, bool SH = false>
 __device__ __forceinline__ float4 a_frag(const GemmArgs& g, rsrc_t ra0, rsrc_t ra1, const ARow& r, int k, int K) {
   if (VEC) {
     const bool in0 = k < g.k0;
     const unsigned f0 = (in0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
-    float4 v = ld4(ra0, f0);
+    float4 v = ld4h<AH>(ra0, f0);
     if (CAT) {
       const unsigned f1 = (!in0 && k < K && r.o1 != OOB) ? r.o1 + 4u * (unsigned)(k - g.k0) : OOB;
-      const float4 u = ld4(ra1, f1);
+      const float4 u = ld4h<SH>(ra1, f1);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     return v;
   } else {
     float t[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = ld1(ra0, (k + j < K && r.o0 != OOB) ? r.o0 + 4u * (unsigned)(k + j) : OOB);
+    for (int j = 0; j < 4; ++j) t[j] = ld1h<AH>(ra0, (k + j < K && r.o0 != OOB) ? r.o0 + 4u * (unsigned)(k + j) : OOB);
     return make_float4(t[0], t[1], t[2], t[3]);
   }
 }
@@ -197,12 +225,12 @@ __device__ __forceinline__ void pro_setup(const GemmArgs& g, float (&cf)[6][KP])
 __device__ __forceinline__ uint32_t pro_key(const GemmArgs& g) { return g.pro_drop.thr16 ? drop_key(g.pro_drop) : 0u; }
 
 // dz[m][k .. k+3] from dy and z (same arithmetic as bn_bwd_apply_kernel); `store`: also write it to pro_dz
-template <int KP>
+template <int KP, bool AH = false, bool SH = false>
 __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc_t rz, const ARow& r, int k,
                                              const float (&cf)[6][KP], bool store) {
   const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
-  float4 gy = ld4(ra0, f0);
-  const float4 zv = ld4(rz, f0);
+  float4 gy = ld4h<AH>(ra0, f0);
+  const float4 zv = ld4h<SH>(rz, f0);
   if (g.pro_drop.thr16) {  // (f0 / 16 = number of this float4 in the row-major [M, k0] output: lda0 == k0 is checked by the host)
     const int n4 = g.k0 >> 2;
     const int64_t i4 = f0 != OOB ? (int64_t)(f0 >> 4) : 0;  // (rows past the end: gy is 0 anyway, but rows[] must not be read there)
@@ -221,7 +249,7 @@ __device__ __forceinline__ float4 a_frag_pro(const GemmArgs& g, rsrc_t ra0, rsrc
   o.y = sc.y * (gy.y - m1.y - (zv.y - mu.y) * is.y * m2.y);
   o.z = sc.z * (gy.z - m1.z - (zv.z - mu.z) * is.z * m2.z);
   o.w = sc.w * (gy.w - m1.w - (zv.w - mu.w) * is.w * m2.w);
-  if (store && f0 != OOB) *(float4*)((char*)g.pro_dz + f0) = o;
+  if (store && f0 != OOB) io_store4<SH>(g.pro_dz, f0 >> 2, o);
   return o;
 }
 
@@ -265,30 +293,36 @@ __device__ __forceinline__ void fpro_setup(const GemmArgs& g, float (&cf)[2][64]
   __syncthreads();
 }
 // y[m][k .. k+3] = lrelu(z * scale + shift) of the (never gathered) row; `store`: also write it to fpro_y (same layout as z)
+template <bool SH = false>
 __device__ __forceinline__ float4 a_frag_fpro(const GemmArgs& g, rsrc_t ra0, const ARow& r, int k, const float (&cf)[2][64],
                                               bool store) {
   const unsigned f0 = (k < g.k0 && r.o0 != OOB) ? r.o0 + 4u * (unsigned)k : OOB;
-  const float4 z = ld4(ra0, f0);
+  const float4 z = ld4h<SH>(ra0, f0);
   const float4 sc = *(const float4*)&cf[0][k], sh = *(const float4*)&cf[1][k];
   float4 y = make_float4(z.x * sc.x + sh.x, z.y * sc.y + sh.y, z.z * sc.z + sh.z, z.w * sc.w + sh.w);
   if (g.fpro_act) { y.x = lrelu(y.x, g.fpro_slope); y.y = lrelu(y.y, g.fpro_slope); y.z = lrelu(y.z, g.fpro_slope); y.w = lrelu(y.w, g.fpro_slope); }
   const bool live = f0 != OOB;  // (rows / columns that do not exist must stay 0: lrelu(shift) is not)
   y.x = live ? y.x : 0.f; y.y = live ? y.y : 0.f; y.z = live ? y.z : 0.f; y.w = live ? y.w : 0.f;
-  if (store && live) *(float4*)((char*)g.fpro_y + f0) = y;
+  if (store && live) io_store4<SH>(g.fpro_y, f0 >> 2, y);
   return y;
 }
 
 // accumulate, pre-loaded (GemmArgs::acc_pre): the lane's four old output values of row m, columns n0..n0+3 (the C/D
 // fragment layout of the transposed product) as the initial accumulator; zeros where the tile has no output
+template <bool CHh = false>
 __device__ __forceinline__ f32x4 c_prev(const GemmArgs& g, rsrc_t rc, rsrc_t rc1, int64_t m, int n0) {
   const bool ok = m < g.M && n0 < g.N;
+  auto ldc4 = [](rsrc_t r, unsigned off) -> f32x4 {
+    if constexpr (CHh) { const float4 t = ld4h<true>(r, off); return (f32x4){t.x, t.y, t.z, t.w}; }
+    else return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  };
   if (g.c_split > 0) {
     const bool lo = n0 < g.c_split;
-    const f32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rc, (ok && lo) ? (unsigned)((m * g.ldc + n0) * 4) : OOB, 0, 0);
-    const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rc1, (ok && !lo) ? (unsigned)((m * g.ldc1 + (n0 - g.c_split)) * 4) : OOB, 0, 0);
+    const f32x4 u = ldc4(rc, (ok && lo) ? (unsigned)((m * g.ldc + n0) * 4) : OOB);
+    const f32x4 v = ldc4(rc1, (ok && !lo) ? (unsigned)((m * g.ldc1 + (n0 - g.c_split)) * 4) : OOB);
     return u + v;
   }
-  return __builtin_amdgcn_raw_buffer_load_b128(rc, ok ? (unsigned)((m * g.ldc + n0) * 4) : OOB, 0, 0);
+  return ldc4(rc, ok ? (unsigned)((m * g.ldc + n0) * 4) : OOB);
 }
 
 // Epilogue modes (template parameter MODE): the network never needs statistics and an affine map in one launch
@@ -325,7 +359,7 @@ __device__ __forceinline__ Epi<MODE> epi_load(const GemmArgs& g, int n0) {
 }
 
 // finish one 16x16 tile owned by this lane: columns n0..n0+3 of row m
-template <int MODE>
+template <int MODE, bool CHh = false>
 __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e, f32x4 acc, int64_t m, int n0, bool cvec,
                                           double (&ssum)[4], double (&ssq)[4]) {
   const bool rowok = m < g.M;
@@ -351,28 +385,30 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
   // read-modify-write.  Used by the backward pass to add an input gradient into the buffer another consumer of the same
   // tensor has already written (no separate elementwise add, no zero fill)
   const bool acc_c = MODE == 0 && g.accumulate && !g.acc_pre;
+  // (CHh: C / C1 hold bf16 — element offsets, io_load / io_store: m3d_common.h)
   if (MODE == 0 && g.c_split > 0) {  // (c_split, N multiples of 4: a lane's four columns fall on one side)
-    float4* dst = nullptr;
-    if (n0 < g.c_split) dst = (float4*)(g.c + m * g.ldc + n0);
-    else if (n0 < g.N) dst = (float4*)(g.c1 + m * g.ldc1 + (n0 - g.c_split));
+    void* dst = nullptr;
+    size_t eo = 0;
+    if (n0 < g.c_split) { dst = g.c; eo = (size_t)(m * g.ldc + n0); }
+    else if (n0 < g.N) { dst = g.c1; eo = (size_t)(m * g.ldc1 + (n0 - g.c_split)); }
     if (dst) {
       float4 o = make_float4(y[0], y[1], y[2], y[3]);
-      if (acc_c) { const float4 p = *dst; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-      *dst = o;
+      if (acc_c) { const float4 p = io_load4<CHh>(dst, eo); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      io_store4<CHh>(dst, eo, o);
     }
     return;
   }
-  float* cp = g.c + m * g.ldc + n0;
+  const size_t ce = (size_t)(m * g.ldc + n0);
   if (cvec) {  // N % 4 == 0, ldc % 4 == 0, 16-byte aligned C
     if (n0 < g.N) {
       float4 o = make_float4(y[0], y[1], y[2], y[3]);
-      if (acc_c) { const float4 p = *(const float4*)cp; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-      *(float4*)cp = o;
+      if (acc_c) { const float4 p = io_load4<CHh>(g.c, ce); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      io_store4<CHh>(g.c, ce, o);
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n0 + r < g.N) cp[r] = acc_c ? cp[r] + y[r] : y[r];
+      if (n0 + r < g.N) io_store1<CHh>(g.c, ce + r, acc_c ? io_load1<CHh>(g.c, ce + r) + y[r] : y[r]);
   }
 }
 
@@ -422,16 +458,17 @@ __device__ __forceinline__ void stats_flush(const GemmArgs& g, int nb, double (&
 // K <= 16*KQ <= 64, column slice 16*NT <= 64: weights in registers, rows streamed.
 // grid: (row workgroups, column slices); 4 waves per workgroup take interleaved 16-row tiles.
 // ------------------------------------------------------------------------------------------
-template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM, bool PRO = false, bool FPRO = false>
+template <int NT, int KQ, int MODE, bool VEC, bool CAT, bool BCM, bool PRO = false, bool FPRO = false, int IO = 0>
 __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmArgs g, int cvec) {
+  constexpr bool AH = IO_A0H(IO), SH = IO_SH(IO), CHh = IO_CH(IO);
   if constexpr (PRO) g.pro_dkey = pro_key(g);
   __shared__ float fcf[FPRO ? 2 : 1][FPRO ? 64 : 4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int nb = blockIdx.y * 16 * NT;
-  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc(g.c), rc1 = mk_rsrc(g.c1);
+  const rsrc_t ra0 = mk_rsrc_h<AH>(g.a0), ra1 = mk_rsrc_h<SH>(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc_h<CHh>(g.c), rc1 = mk_rsrc_h<CHh>(g.c1);
   __shared__ float cf[PRO ? 6 : 1][PRO ? 64 : 4];
-  const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
+  const rsrc_t rz = mk_rsrc_h<SH>(PRO ? g.pro_z : nullptr);
   float4 w[NT][KQ];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -458,15 +495,15 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
     float4 a[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      if constexpr (PRO) a[q] = a_frag_pro<64>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
-      else if constexpr (FPRO) a[q] = a_frag_fpro(g, ra0, row, 16 * q + 4 * lg, (const float (&)[2][64])fcf, blockIdx.y == 0 && g.fpro_y);
-      else a[q] = a_frag<VEC, CAT>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
+      if constexpr (PRO) a[q] = a_frag_pro<64, AH, SH>(g, ra0, rz, row, 16 * q + 4 * lg, (const float (&)[6][64])cf, blockIdx.y == 0);
+      else if constexpr (FPRO) a[q] = a_frag_fpro<SH>(g, ra0, row, 16 * q + 4 * lg, (const float (&)[2][64])fcf, blockIdx.y == 0 && g.fpro_y);
+      else a[q] = a_frag<VEC, CAT, AH, SH>(g, ra0, ra1, row, 16 * q + 4 * lg, K);
     }
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (MODE == 0 && g.acc_pre) acc[t] = c_prev(g, rc, rc1, m, nb + 16 * t + 4 * lg);
+      if (MODE == 0 && g.acc_pre) acc[t] = c_prev<CHh>(g, rc, rc1, m, nb + 16 * t + 4 * lg);
     }
 #pragma unroll
     for (int q = 0; q < KQ; ++q)
@@ -475,7 +512,7 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = mfma16(f4(w[t][q], i), f4(a[q], i), acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) epi_store<MODE>(g, e[t], acc[t], m, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+    for (int t = 0; t < NT; ++t) epi_store<MODE, CHh>(g, e[t], acc[t], m, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
   }
   if (MODE == 1) stats_flush<NT, 4>(g, nb, ssum, ssq, blockIdx.x);
 }
@@ -489,21 +526,22 @@ __global__ __launch_bounds__(256, GEMM_RS_MINW) void gemm_rowstream_kernel(GemmA
 #define PRO_KMAX 1024  // widest BatchNorm the prologue keeps in LDS (this network: 512)
 // (bx, gx): this workgroup's index among the gx row workgroups of ITS problem — the launch's own blockIdx.x / gridDim.x, or
 // a sub-range of them when one launch carries two problems (gemm_kloop_pair_kernel)
-template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF, bool PRO>
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF, bool PRO, int IO = 0>
 __device__ __forceinline__ void gemm_kloop_body(const GemmArgs& g, int cvec, const unsigned bx, const unsigned gx) {
+  constexpr bool AH = IO_A0H(IO), SH = IO_SH(IO), CHh = IO_CH(IO);
   // a wave owns MTW x NTW tiles of 16x16: every A / W fragment it loads feeds NTW / MTW MFMAs (these shapes are
   // L2-bandwidth bound on operand re-reads when MTW = NTW = 1)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int K = g.k0 + g.k1;
   const int KQ = (K + 15) >> 4;
   const int nb = blockIdx.y * 16 * NTW;
-  const rsrc_t ra0 = mk_rsrc(g.a0), ra1 = mk_rsrc(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc(g.c), rc1 = mk_rsrc(g.c1);
+  const rsrc_t ra0 = mk_rsrc_h<AH>(g.a0), ra1 = mk_rsrc_h<SH>(g.a1), rb = mk_rsrc(g.b), rc = mk_rsrc_h<CHh>(g.c), rc1 = mk_rsrc_h<CHh>(g.c1);
   __shared__ float cf[PRO ? 6 : 1][PRO ? PRO_KMAX : 4];
-  const rsrc_t rz = mk_rsrc(PRO ? g.pro_z : nullptr);
+  const rsrc_t rz = mk_rsrc_h<SH>(PRO ? g.pro_z : nullptr);
   const bool pst = blockIdx.y == 0;  // column slice 0 stores dz
   auto afr = [&](const ARow& r, int k) -> float4 {
-    if constexpr (PRO) return a_frag_pro<PRO_KMAX>(g, ra0, rz, r, k, (const float (&)[6][PRO_KMAX])cf, pst);
-    else return a_frag<VEC, CAT>(g, ra0, ra1, r, k, K);
+    if constexpr (PRO) return a_frag_pro<PRO_KMAX, AH, SH>(g, ra0, rz, r, k, (const float (&)[6][PRO_KMAX])cf, pst);
+    else return a_frag<VEC, CAT, AH, SH>(g, ra0, ra1, r, k, K);
   };
   Epi<MODE> e[NTW];
 #pragma unroll
@@ -531,7 +569,7 @@ __device__ __forceinline__ void gemm_kloop_body(const GemmArgs& g, int cvec, con
         acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // (split K: wave 0 owns the epilogue, so only its accumulators start from the old tile)
         if (MODE == 0 && g.acc_pre && (!ks || wid == 0))
-          acc[mt][t] = c_prev(g, rc, rc1, (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg);
+          acc[mt][t] = c_prev<CHh>(g, rc, rc1, (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg);
       }
     if constexpr (BF) {
       const int nq = K >> 5, per = (nq + 3) >> 2;
@@ -603,27 +641,27 @@ __device__ __forceinline__ void gemm_kloop_body(const GemmArgs& g, int cvec, con
       for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
-          epi_store<MODE>(g, e[t], acc[mt][t], (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
+          epi_store<MODE, CHh>(g, e[t], acc[mt][t], (grp * MTW + mt) * 16 + lr, nb + 16 * t + 4 * lg, cvec, ssum[t], ssq[t]);
     }
     if (ks) __syncthreads();  // kred is reused by the next group
   }
   if (MODE == 1) stats_flush<NTW, 4>(g, nb, ssum, ssq, bx);
 }
 
-template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false, bool PRO = false>
+template <int MTW, int NTW, int MODE, bool VEC, bool CAT, bool BCM, bool BF = false, bool PRO = false, int IO = 0>
 __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_kernel(GemmArgs g, int cvec) {
   if constexpr (PRO) g.pro_dkey = pro_key(g);
-  gemm_kloop_body<MTW, NTW, MODE, VEC, CAT, BCM, BF, PRO>(g, cvec, blockIdx.x, gridDim.x);
+  gemm_kloop_body<MTW, NTW, MODE, VEC, CAT, BCM, BF, PRO, IO>(g, cvec, blockIdx.x, gridDim.x);
 }
 
 // TWO independent products with the same output shape and tile plan in one launch: row workgroups [0, wgs0) work on g0,
 // the rest on g1 (same column slices).  The mlp2 and shortcut Linears of a DilatedResidualBlock (pyg_randla_net.py:172-188)
 // — forward, and their input gradients — on the deep levels: each alone is 400-800 workgroups of a few microseconds.
-template <int MTW, int NTW, int MODE, bool BCM, bool BF>
+template <int MTW, int NTW, int MODE, bool BCM, bool BF, int IO = 0>
 __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_pair_kernel(GemmArgs g0, GemmArgs g1, int cvec0, int cvec1,
                                                                             unsigned wgs0) {
-  if (blockIdx.x < wgs0) gemm_kloop_body<MTW, NTW, MODE, true, false, BCM, BF, false>(g0, cvec0, blockIdx.x, wgs0);
-  else gemm_kloop_body<MTW, NTW, MODE, true, false, BCM, BF, false>(g1, cvec1, blockIdx.x - wgs0, gridDim.x - wgs0);
+  if (blockIdx.x < wgs0) gemm_kloop_body<MTW, NTW, MODE, true, false, BCM, BF, false, IO>(g0, cvec0, blockIdx.x, wgs0);
+  else gemm_kloop_body<MTW, NTW, MODE, true, false, BCM, BF, false, IO>(g1, cvec1, blockIdx.x - wgs0, gridDim.x - wgs0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -631,67 +669,114 @@ __global__ __launch_bounds__(256, GEMM_KL_MINW) void gemm_kloop_pair_kernel(Gemm
 // ------------------------------------------------------------------------------------------
 // variants: 0 vec, 1 vec + concatenated A (forward of the FP modules), 2 vec + column-major W (dgrad), 3 scalar loads,
 // 4 scalar loads + column-major W
-template <int NT, int KQ, int MODE>
-static void launch_rs(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
-  switch (variant) {
-    case 0:
-      if (MODE == 1 && g.fpro) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 1, true, false, false, false, true>), grid, dim3(256), 0, st, g, cvec);
-      else hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec);
-      break;
-    case 1: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 2:
-      if (g.pro_z) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec);
-      else hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec);
-      break;
-    case 3: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
-    default: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+// IO (template): the activation layouts of the launch (M3D_IO_* >> 12, see IO_A0H / IO_SH / IO_CH): 0 = fp32, 1 = bf16
+// storage, 3 = bf16 storage with an fp32 A0 (the BatchNorm-backward prologue only: an incoming gradient accumulated with
+// float atomics), 5 = bf16 storage with an fp32 C (vector-load forward, plain epilogue only: the logits).  false: this
+// combination is not instantiated.
+template <int NT, int KQ, int MODE, int IO>
+static bool launch_rs(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if constexpr (IO == 3) {
+    if (variant != 2 || !g.pro_z || MODE != 0) return false;
+    hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true, true, false, 3>), grid, dim3(256), 0, st, g, cvec);
+    return true;
+  } else if constexpr (IO == 5) {
+    if (variant != 0 || MODE != 0 || g.fpro) return false;
+    hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, false, false, false, 5>), grid, dim3(256), 0, st, g, cvec);
+    return true;
+  } else {
+    switch (variant) {
+      case 0:
+        if (MODE == 1 && g.fpro) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 1, true, false, false, false, true, IO>), grid, dim3(256), 0, st, g, cvec);
+        else hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, false, false, false, false, IO>), grid, dim3(256), 0, st, g, cvec);
+        break;
+      case 1: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, true, true, false, false, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+      case 2:
+        if (g.pro_z) hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true, true, false, IO>), grid, dim3(256), 0, st, g, cvec);
+        else hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, true, false, true, false, false, IO>), grid, dim3(256), 0, st, g, cvec);
+        break;
+      case 3: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, MODE, false, false, false, false, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+      default: hipLaunchKernelGGL((gemm_rowstream_kernel<NT, KQ, 0, false, false, true, false, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+    }
+    return true;
   }
+}
+
+template <int NT, int KQ, int IO>
+static bool launch_rs_mode(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (mode == 1) return launch_rs<NT, KQ, 1, IO>(g, variant, grid, st, cvec);
+  if (mode == 2) return launch_rs<NT, KQ, 2, IO>(g, variant, grid, st, cvec);
+  return launch_rs<NT, KQ, 0, IO>(g, variant, grid, st, cvec);
 }
 
 template <int NT, int KQ>
-static void launch_rs_mode(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
-  if (mode == 1) launch_rs<NT, KQ, 1>(g, variant, grid, st, cvec);
-  else if (mode == 2) launch_rs<NT, KQ, 2>(g, variant, grid, st, cvec);
-  else launch_rs<NT, KQ, 0>(g, variant, grid, st, cvec);
+static bool launch_rs_io(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
+  switch (g.io) {
+    case 0: return launch_rs_mode<NT, KQ, 0>(g, mode, variant, grid, st, cvec);
+    case 1: return launch_rs_mode<NT, KQ, 1>(g, mode, variant, grid, st, cvec);
+    case 3: return mode == 0 && launch_rs<NT, KQ, 0, 3>(g, variant, grid, st, cvec);
+    case 5: return mode == 0 && launch_rs<NT, KQ, 0, 5>(g, variant, grid, st, cvec);
+    default: return false;
+  }
 }
 
 template <int NT>
-static void launch_rowstream(const GemmArgs& g, int mode, int KQ, int variant, dim3 grid, hipStream_t st, int cvec) {
-  if (KQ == 1) launch_rs_mode<NT, 1>(g, mode, variant, grid, st, cvec);
-  else if (KQ == 2) launch_rs_mode<NT, 2>(g, mode, variant, grid, st, cvec);
-  else launch_rs_mode<NT, 4>(g, mode, variant, grid, st, cvec);
+static bool launch_rowstream(const GemmArgs& g, int mode, int KQ, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (KQ == 1) return launch_rs_io<NT, 1>(g, mode, variant, grid, st, cvec);
+  if (KQ == 2) return launch_rs_io<NT, 2>(g, mode, variant, grid, st, cvec);
+  return launch_rs_io<NT, 4>(g, mode, variant, grid, st, cvec);
 }
 
-template <int MTW, int NTW, int MODE>
-static void launch_kl(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
-  if (g.bf16 && variant <= 2 && ((g.k0 + g.k1) & 31) == 0) {  // bf16 matrix cores (vector-load variants only)
+template <int MTW, int NTW, int MODE, int IO>
+static bool launch_kl(const GemmArgs& g, int variant, dim3 grid, hipStream_t st, int cvec) {
+  const bool bf = g.bf16 && variant <= 2 && ((g.k0 + g.k1) & 31) == 0;  // bf16 matrix cores (vector-load variants only)
+  if constexpr (IO == 3) {
+    if (variant != 2 || !g.pro_z || MODE != 0) return false;
+    if (bf) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true, true, 3>), grid, dim3(256), 0, st, g, cvec);
+    else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, false, true, 3>), grid, dim3(256), 0, st, g, cvec);
+    return true;
+  } else {
+    if (IO != 0 && variant > 2) return false;  // (the scalar-load k-loop variants exist for fp32 storage only: odd K > 64)
+    if (bf) {
+      switch (variant) {
+        case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false, true, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+        case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false, true, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+        default:
+          if (g.pro_z) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true, true, IO>), grid, dim3(256), 0, st, g, cvec);
+          else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true, false, IO>), grid, dim3(256), 0, st, g, cvec);
+          break;
+      }
+      return true;
+    }
     switch (variant) {
-      case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
-      case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+      case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false, false, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+      case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false, false, false, IO>), grid, dim3(256), 0, st, g, cvec); break;
+      case 2:
+        if (g.pro_z) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, false, true, IO>), grid, dim3(256), 0, st, g, cvec);
+        else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, false, false, IO>), grid, dim3(256), 0, st, g, cvec);
+        break;
+      case 3:
+        if constexpr (IO == 0) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec);
+        break;
       default:
-        if (g.pro_z) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true, true>), grid, dim3(256), 0, st, g, cvec);
-        else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, true>), grid, dim3(256), 0, st, g, cvec);
+        if constexpr (IO == 0) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec);
         break;
     }
-    return;
-  }
-  switch (variant) {
-    case 0: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, false, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 1: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, true, true, false>), grid, dim3(256), 0, st, g, cvec); break;
-    case 2:
-      if (g.pro_z) hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true, false, true>), grid, dim3(256), 0, st, g, cvec);
-      else hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, true, false, true>), grid, dim3(256), 0, st, g, cvec);
-      break;
-    case 3: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, MODE, false, false, false>), grid, dim3(256), 0, st, g, cvec); break;
-    default: hipLaunchKernelGGL((gemm_kloop_kernel<MTW, NTW, 0, false, false, true>), grid, dim3(256), 0, st, g, cvec); break;
+    return true;
   }
 }
 
 template <int MTW, int NTW>
-static void launch_kloop(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
-  if (mode == 1) launch_kl<MTW, NTW, 1>(g, variant, grid, st, cvec);
-  else if (mode == 2) launch_kl<MTW, NTW, 2>(g, variant, grid, st, cvec);
-  else launch_kl<MTW, NTW, 0>(g, variant, grid, st, cvec);
+static bool launch_kloop(const GemmArgs& g, int mode, int variant, dim3 grid, hipStream_t st, int cvec) {
+  if (g.io == 3) return mode == 0 && launch_kl<MTW, NTW, 0, 3>(g, variant, grid, st, cvec);
+  if (g.io == 1) {
+    if (mode == 1) return launch_kl<MTW, NTW, 1, 1>(g, variant, grid, st, cvec);
+    if (mode == 2) return launch_kl<MTW, NTW, 2, 1>(g, variant, grid, st, cvec);
+    return launch_kl<MTW, NTW, 0, 1>(g, variant, grid, st, cvec);
+  }
+  if (g.io != 0) return false;
+  if (mode == 1) return launch_kl<MTW, NTW, 1, 0>(g, variant, grid, st, cvec);
+  if (mode == 2) return launch_kl<MTW, NTW, 2, 0>(g, variant, grid, st, cvec);
+  return launch_kl<MTW, NTW, 0, 0>(g, variant, grid, st, cvec);
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -753,7 +838,15 @@ int m3d_gemm_direct_stat_parts(int64_t M, int N, int K) {
   return (int)plan_rows(M, N, K, 1).wgs;
 }
 
+static int gemm_direct_try_impl(const GemmArgs& g, hipStream_t st);
+// bf16 activation storage (g.io != 0) exists in these kernels only: "not covered" (1: the caller's LDS-tiled fp32 fallback)
+// becomes M3D_ERR_UNSUPPORTED
 int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
+  if (g.io != 0 && g.io != 1 && g.io != 3 && g.io != 5) return M3D_ERR_INVALID;
+  const int rc = gemm_direct_try_impl(g, st);
+  return (rc == 1 && g.io != 0) ? M3D_ERR_UNSUPPORTED : rc;
+}
+static int gemm_direct_try_impl(const GemmArgs& g, hipStream_t st) {
   const int K = g.k0 + g.k1;
   // debugging aid (compile time): GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
   const int disable = GEMM_DISABLE;
@@ -793,29 +886,37 @@ int m3d_gemm_direct_try(const GemmArgs& g, hipStream_t st) {
   gk.ksplit = rp.ksplit;
   gk.acc_pre = g.accumulate && mode == 0 && cvec && g.M * g.ldc * 4 <= lim &&
                (g.c_split == 0 || g.M * g.ldc1 * 4 <= lim);
+  bool ok;
   if (rp.rowstream) {
-    if (rp.NT == 4) launch_rowstream<4>(gk, mode, rp.KQ, variant, grid, st, cvec);
-    else if (rp.NT == 2) launch_rowstream<2>(gk, mode, rp.KQ, variant, grid, st, cvec);
-    else launch_rowstream<1>(gk, mode, rp.KQ, variant, grid, st, cvec);
+    if (rp.NT == 4) ok = launch_rowstream<4>(gk, mode, rp.KQ, variant, grid, st, cvec);
+    else if (rp.NT == 2) ok = launch_rowstream<2>(gk, mode, rp.KQ, variant, grid, st, cvec);
+    else ok = launch_rowstream<1>(gk, mode, rp.KQ, variant, grid, st, cvec);
   } else {
-    if (rp.MT == 2 && rp.NT == 4) launch_kloop<2, 4>(gk, mode, variant, grid, st, cvec);
-    else if (rp.MT == 2) launch_kloop<2, 2>(gk, mode, variant, grid, st, cvec);
-    else if (rp.NT == 2) launch_kloop<1, 2>(gk, mode, variant, grid, st, cvec);
-    else launch_kloop<1, 1>(gk, mode, variant, grid, st, cvec);
+    if (rp.MT == 2 && rp.NT == 4) ok = launch_kloop<2, 4>(gk, mode, variant, grid, st, cvec);
+    else if (rp.MT == 2) ok = launch_kloop<2, 2>(gk, mode, variant, grid, st, cvec);
+    else if (rp.NT == 2) ok = launch_kloop<1, 2>(gk, mode, variant, grid, st, cvec);
+    else ok = launch_kloop<1, 1>(gk, mode, variant, grid, st, cvec);
   }
+  if (!ok) return M3D_ERR_UNSUPPORTED;  // (an activation layout this shape's kernels are not instantiated for)
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
 }
 
 // ---- two products in one launch (gemm_kloop_pair_kernel) ----
-template <int MTW, int NTW>
-static void launch_kl_pair(const GemmArgs& g0, const GemmArgs& g1, int mode, bool bcm, bool bf, dim3 grid, hipStream_t st,
-                           int cvec0, int cvec1, unsigned wgs0) {
+template <int MTW, int NTW, int IO>
+static void launch_kl_pair_io(const GemmArgs& g0, const GemmArgs& g1, int mode, bool bcm, bool bf, dim3 grid, hipStream_t st,
+                              int cvec0, int cvec1, unsigned wgs0) {
 #define M3D_PAIR(MODE_, BCM_, BF_) \
-  hipLaunchKernelGGL((gemm_kloop_pair_kernel<MTW, NTW, MODE_, BCM_, BF_>), grid, dim3(256), 0, st, g0, g1, cvec0, cvec1, wgs0)
+  hipLaunchKernelGGL((gemm_kloop_pair_kernel<MTW, NTW, MODE_, BCM_, BF_, IO>), grid, dim3(256), 0, st, g0, g1, cvec0, cvec1, wgs0)
   if (mode == 1) { if (bf) M3D_PAIR(1, false, true); else M3D_PAIR(1, false, false); }
   else if (bcm) { if (bf) M3D_PAIR(0, true, true); else M3D_PAIR(0, true, false); }
   else { if (bf) M3D_PAIR(0, false, true); else M3D_PAIR(0, false, false); }
 #undef M3D_PAIR
+}
+template <int MTW, int NTW>
+static void launch_kl_pair(const GemmArgs& g0, const GemmArgs& g1, int mode, bool bcm, bool bf, dim3 grid, hipStream_t st,
+                           int cvec0, int cvec1, unsigned wgs0) {
+  if (g0.io == 1) launch_kl_pair_io<MTW, NTW, 1>(g0, g1, mode, bcm, bf, grid, st, cvec0, cvec1, wgs0);
+  else launch_kl_pair_io<MTW, NTW, 0>(g0, g1, mode, bcm, bf, grid, st, cvec0, cvec1, wgs0);
 }
 
 // M3D_OK when both products went out as one launch; 1 when the pair does not fit (the caller launches them one by one):
@@ -823,7 +924,7 @@ static void launch_kl_pair(const GemmArgs& g0, const GemmArgs& g1, int mode, boo
 // statistics) and tile plan.
 int m3d_gemm_direct_pair_try(const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
   const GemmArgs* gs[2] = {&a, &b};
-  if (a.M != b.M || a.N != b.N || a.b_cm != b.b_cm || a.bf16 != b.bf16) return 1;
+  if (a.M != b.M || a.N != b.N || a.b_cm != b.b_cm || a.bf16 != b.bf16 || a.io != b.io || (a.io != 0 && a.io != 1)) return 1;
   if ((a.stat_part != nullptr) != (b.stat_part != nullptr)) return 1;
   const int mode = a.stat_part ? 1 : 0;
   int cvec[2];
@@ -877,6 +978,7 @@ struct WgradArgs {
   float* ws;  // [S][N][K] partials (S > 1)
   int S; int64_t steps_per_split;
   int bf16;  // != 0 (with vec): operands rounded to bf16, v_mfma_f32_16x16x32_bf16, 32 rows per step (the net's "bf16" mode)
+  int io;   // != 0: dz, x0 and x1 hold bf16 (M3D_IO_BF16; leading dimensions in elements); dw / ws stay fp32
   int vec;  // != 0: permuted tile columns (tile a of a TN-tile group holds n = nb + TN*i + a, likewise k): a lane's TN / TK
             // operand values are consecutive floats -> ONE 4*TN / 4*TK-byte load instead of TN / TK dword loads, and one
             // vector store per accumulator row (the level-1 layers stream at dword granularity otherwise: ~2 TB/s)
@@ -896,13 +998,29 @@ __device__ __forceinline__ void ldv(rsrc_t r, unsigned off, float (&out)[V]) {
   }
 }
 
+// V consecutive elements at the fp32-byte offset `off` (H: stored as bf16, read at off / 2 through a 1 GiB descriptor)
+template <int V, bool H>
+__device__ __forceinline__ void ldvh(rsrc_t r, unsigned off, float (&out)[V]) {
+  if constexpr (!H) {
+    ldv<V>(r, off, out);
+  } else if constexpr (V == 1) {
+    out[0] = ld1h<true>(r, off);
+  } else if constexpr (V == 2) {
+    const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off >> 1, 0, 0);
+    out[0] = __uint_as_float(v << 16); out[1] = __uint_as_float(v & 0xffff0000u);
+  } else {
+    const float4 v = ld4h<true>(r, off);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  }
+}
+
 template <int TN, int TK>
 struct WgradFrag {
   float a[TN], b[TK];
 };
 
 // operands of the 4-row step `s` (rows 4s .. 4s+3, this lane: row 4s + lg); buffer loads, no branches
-template <int TN, int TK>
+template <int TN, int TK, bool H = false>
 // `rr`: the row of x0 that row 4s + lg reads (the caller's prefetched rows[] entry, or the row itself)
 __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc_t rz, rsrc_t rx0, rsrc_t rx1, int64_t s,
                                                         bool live, int64_t rr, int nb, int kb, int lr, int lg, int K) {
@@ -915,12 +1033,12 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
   const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
   if (g.vec) {
     const int n0 = nb + TN * lr;
-    ldv<TN>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, f.a);
+    ldvh<TN, H>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, f.a);
     const int kk = kb + TK * lr;
     const bool in0 = kk < g.k0;
     float t0[TK], t1[TK];
-    ldv<TK>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
-    ldv<TK>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
+    ldvh<TK, H>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
+    ldvh<TK, H>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
 #pragma unroll
     for (int b = 0; b < TK; ++b) f.b[b] = t0[b] + t1[b];
     return f;
@@ -928,15 +1046,15 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
     const int n = nb + 16 * a + lr;
-    f.a[a] = ld1(rz, (oz != OOB && n < g.N) ? oz + 4u * (unsigned)n : OOB);
+    f.a[a] = ld1h<H>(rz, (oz != OOB && n < g.N) ? oz + 4u * (unsigned)n : OOB);
   }
 #pragma unroll
   for (int b = 0; b < TK; ++b) {
     const int k = kb + 16 * b + lr;
     const bool in0 = k < g.k0;
     // both operands are always read: the one that does not hold column k is OOB (returns 0, no memory access)
-    f.b[b] = ld1(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)k : OOB) +
-             ld1(rx1, (!in0 && k < K && o1 != OOB) ? o1 + 4u * (unsigned)(k - g.k0) : OOB);
+    f.b[b] = ld1h<H>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)k : OOB) +
+             ld1h<H>(rx1, (!in0 && k < K && o1 != OOB) ? o1 + 4u * (unsigned)(k - g.k0) : OOB);
   }
   return f;
 }
@@ -952,7 +1070,7 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 #ifndef WGRAD_DEPTH_BIG
 #define WGRAD_DEPTH_BIG 2  // 4-row steps in flight per trip of the waves with 8 or 16 accumulator tiles
 #endif
-template <int TN, int TK, bool BF = false>
+template <int TN, int TK, bool BF = false, bool H = false>
 __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
   // big tiles (16 accumulator quads: the deep, few-row layers) keep one partial per WAVE and two steps in flight: their
   // register budget has no room for four, and their LDS reduction would take 48 KB
@@ -971,7 +1089,7 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TK; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const rsrc_t rz = mk_rsrc(g.dz), rx0 = mk_rsrc(g.x0), rx1 = mk_rsrc(g.x1);
+  const rsrc_t rz = mk_rsrc_h<H>(g.dz), rx0 = mk_rsrc_h<H>(g.x0), rx1 = mk_rsrc_h<H>(g.x1);
 
   if constexpr (BF && TN * TK >= 8) {
     if (g.bf16 && g.vec) {
@@ -989,11 +1107,11 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
           const unsigned o0 = (ok && rr >= 0) ? (unsigned)(rr * g.ldx0 * 4) : OOB;
           const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
           const int n0 = nb + TN * lr, kk = kb + TK * lr;
-          ldv<TN>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, av[j]);
+          ldvh<TN, H>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, av[j]);
           const bool in0 = kk < g.k0;
           float t0[TK], t1[TK];
-          ldv<TK>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
-          ldv<TK>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
+          ldvh<TK, H>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
+          ldvh<TK, H>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
 #pragma unroll
           for (int b = 0; b < TK; ++b) bv[j][b] = t0[b] + t1[b];
         }
@@ -1031,7 +1149,7 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
     WgradFrag<TN, TK> f[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-      f[d] = wgrad_load<TN, TK>(g, rz, rx0, rx1, s + d, s + d < s1, rnext[d], nb, kb, lr, lg, K);
+      f[d] = wgrad_load<TN, TK, H>(g, rz, rx0, rx1, s + d, s + d < s1, rnext[d], nb, kb, lr, lg, K);
     if (g.rows) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) rnext[d] = x0_row(s + DEPTH + d);
@@ -1123,9 +1241,9 @@ reduce_and_store:
       }
 }
 
-template <int TN, int TK>
+template <int TN, int TK, bool H = false>
 __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
-  wgrad2_body<TN, TK>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+  wgrad2_body<TN, TK, false, H>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several weight-gradient GEMMs of one tile class in ONE launch (m3d_linear_wgrad_batch).  The 29 Linear layers of the
@@ -1141,14 +1259,14 @@ struct WgradBatch {
   unsigned gx[WGRAD_BATCH_MAX], gy[WGRAD_BATCH_MAX];
   int njobs;
 };
-template <int TN, int TK, bool BF = false>
+template <int TN, int TK, bool BF = false, bool H = false>
 __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_batch_kernel(WgradBatch b) {
   int j = 0;
 #pragma unroll
   for (int i = 1; i < WGRAD_BATCH_MAX; ++i) j += (i < b.njobs && blockIdx.x >= b.wg_start[i]) ? 1 : 0;
   const unsigned w = blockIdx.x - b.wg_start[j];
   const unsigned gx = b.gx[j], gy = b.gy[j];
-  wgrad2_body<TN, TK, BF>(b.g[j], w % gx, (w / gx) % gy, w / (gx * gy));
+  wgrad2_body<TN, TK, BF, H>(b.g[j], w % gx, (w / gx) % gy, w / (gx * gy));
 }
 
 // dw[n][k] (+)= sum_s ws[s][n][k]
@@ -1249,6 +1367,14 @@ static int wgrad_vec_ok(const WgradArgs& g, int TN, int TK) {
 
 template <int TN>
 static void launch_wgrad2(const WgradArgs& g, int TK, dim3 grid, hipStream_t st) {
+  if (g.io) {
+    switch (TK) {
+      case 1: hipLaunchKernelGGL((wgrad2_kernel<TN, 1, true>), grid, dim3(256), 0, st, g); break;
+      case 2: hipLaunchKernelGGL((wgrad2_kernel<TN, 2, true>), grid, dim3(256), 0, st, g); break;
+      default: hipLaunchKernelGGL((wgrad2_kernel<TN, 4, true>), grid, dim3(256), 0, st, g); break;
+    }
+    return;
+  }
   switch (TK) {
     case 1: hipLaunchKernelGGL((wgrad2_kernel<TN, 1>), grid, dim3(256), 0, st, g); break;
     case 2: hipLaunchKernelGGL((wgrad2_kernel<TN, 2>), grid, dim3(256), 0, st, g); break;
@@ -1266,7 +1392,7 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
   if (!dw) return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (!accumulate) hipLaunchKernelGGL(zero_rows_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, dw, lddw, N, K);
+    if (!(accumulate & 1)) hipLaunchKernelGGL(zero_rows_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, dw, lddw, N, K);
     M3D_CHECK_LAUNCH();
     return M3D_OK;
   }
@@ -1282,6 +1408,9 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
   g.dz = dz; g.lddz = lddz; g.x0 = x0; g.ldx0 = ldx0; g.rows = x0_rows; g.k0 = k0; g.x1 = x1; g.ldx1 = ldx1; g.k1 = k1;
   g.M = M; g.N = N; g.dw = dw; g.lddw = lddw; g.accumulate = accumulate; g.ws = (float*)ws; g.S = (int)p.S;
   g.steps_per_split = p.spw;
+  g.io = (accumulate & M3D_IO_BF16) ? 1 : 0;  // accumulate: bit 0 = add into dw, M3D_IO_BF16 = dz / x0 / x1 hold bf16
+  g.accumulate = accumulate & 1;
+  accumulate &= 1;
   g.vec = wgrad_vec_ok(g, p.TN, p.TK);
   g.bf16 = 0;
   dim3 grid((unsigned)p.wgs, (unsigned)p.by, (unsigned)p.bz);
@@ -1304,13 +1433,16 @@ extern "C" int m3d_linear_wgrad_f32(const float* dz, int64_t lddz, const float* 
 
 template <int TN, int TK>
 static void launch_wgrad2_batch(const WgradBatch& b, unsigned total, hipStream_t st) {
+  const bool h = b.g[0].io != 0;  // (one activation layout per call: m3d_linear_wgrad_batch)
   if constexpr (TN * TK >= 8) {  // bf16 matrix-core variant (its register budget would cost the fp32 kernel a wave per SIMD)
     if (b.g[0].bf16) {
-      hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK, true>), dim3(total), dim3(256), 0, st, b);
+      if (h) hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK, true, true>), dim3(total), dim3(256), 0, st, b);
+      else hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK, true>), dim3(total), dim3(256), 0, st, b);
       return;
     }
   }
-  hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK>), dim3(total), dim3(256), 0, st, b);
+  if (h) hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK, false, true>), dim3(total), dim3(256), 0, st, b);
+  else hipLaunchKernelGGL((wgrad2_batch_kernel<TN, TK>), dim3(total), dim3(256), 0, st, b);
 }
 
 // dW of several layers at once (see WgradBatch).  Host arrays of length njobs; `accumulate` != 0 (gradient sinks) is
@@ -1323,7 +1455,8 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
                                       void* const* ws, void* stream) {
   if (njobs < 0) return M3D_ERR_INVALID;
   if (njobs == 0) return M3D_OK;
-  if (!(accumulate & 1)) return M3D_ERR_UNSUPPORTED;  // bit 0: add into dw (required); bit 8: bf16 matrix cores
+  // bit 0: add into dw (required); bit 8: bf16 matrix cores; M3D_IO_BF16: dz / x0 / x1 of EVERY job hold bf16
+  if (!(accumulate & 1)) return M3D_ERR_UNSUPPORTED;
   if (!dz || !lddz || !x0 || !ldx0 || !x0_rows || !k0 || !x1 || !ldx1 || !k1 || !M || !N || !dw || !lddw || !ws)
     return M3D_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -1388,7 +1521,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
       if (cls < 0) {  // (4,1) / (1,4): rare shapes, launched on their own
         if (v == 0) {
           const int rc = m3d_linear_wgrad_f32(dz[j], lddz[j], x0[j], ldx0[j], x0_rows[j], k0[j], x1[j], ldx1[j], k1[j], M[j],
-                                              N[j], dw[j], lddw[j], 1, ws[j], stream);
+                                              N[j], dw[j], lddw[j], 1 | (accumulate & M3D_IO_BF16), ws[j], stream);
           if (rc != M3D_OK) return rc;
         }
         continue;
@@ -1403,6 +1536,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
       g.dz = dz[j]; g.lddz = lddz[j]; g.x0 = x0[j]; g.ldx0 = ldx0[j]; g.rows = x0_rows[j]; g.k0 = k0[j]; g.x1 = x1[j];
       g.ldx1 = ldx1[j]; g.k1 = k1[j]; g.M = M[j]; g.N = N[j]; g.dw = dw[j]; g.lddw = lddw[j]; g.accumulate = 1;
       g.ws = (float*)ws[j]; g.S = (int)p.S; g.steps_per_split = p.spw;
+      g.io = (accumulate & M3D_IO_BF16) ? 1 : 0;
       g.vec = wgrad_vec_ok(g, p.TN, p.TK);
       g.bf16 = ((accumulate >> 8) & 1) && g.vec && p.TN * p.TK >= 8;  // the matrix-bound (deep) layers only
       b.wg_start[b.njobs] = total;

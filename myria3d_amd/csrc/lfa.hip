@@ -39,7 +39,8 @@
 // BF: the attention GEMM runs on bf16 matrix cores (operands rounded to bf16 when the fragments are built from the fp32
 // LDS tile / pre-packed as bf16, fp32 accumulate): BASELINE config 2's "bf16" arithmetic (torch autocast semantics);
 // everything else — gathers, encoder, softmax, the pooled sum, all storage — stays fp32.  CH >= 32 only.
-template <int CH, int KP, bool BF = false>
+// IOH: x and out hold bf16 (M3D_IO_BF16 in the entry point's flags); the tile, the products and the softmax stay fp32
+template <int CH, int KP, bool BF = false, bool IOH = false>
 __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
       const int e = f / D4, c4 = f % D4;
       const int j = nbr[e];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
+      if (j >= 0) v = io_load4<IOH>(a.x, (size_t)((int64_t)j * D + c4 * 4));
       float* d = &F[e * STR + c4 * 4];
       *(float2*)d = make_float2(v.x, v.y);
       *(float2*)(d + 2) = make_float2(v.z, v.w);
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_kernel(LfaArgs a) {
       num = xgroup_sum(num);
       den = xgroup_sum(den);
       // (v_rcp_f32: 1 ulp, against ~10 instructions of IEEE division per output; the parity bar is 2e-5)
-      if (lg == 0 && i < a.n && col < CH) a.out[i * CH + col] = num * __builtin_amdgcn_rcpf(den + 1e-16f);
+      if (lg == 0 && i < a.n && col < CH) io_store1<IOH>(a.out, (size_t)(i * CH + col), num * __builtin_amdgcn_rcpf(den + 1e-16f));
     }
   }
 }
@@ -243,7 +244,7 @@ template <> struct LfaFullCfg<16> { static constexpr int ROWS = 256; };
 template <int CH> struct LfaFullRows { static constexpr int ROWS = CH == 8 ? 512 : LfaFullCfg<(CH < 16 ? 16 : CH)>::ROWS; };
 
 // BF: 0 = f32-input MFMA, 1 = bf16 operands (one product), 2 = split-bf16 (hi + lo operands, three products: m3d_common.h)
-template <int CH, int KP, int BF>
+template <int CH, int KP, int BF, bool IOH = false>
 __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
   constexpr bool PACK2 = CH == 8;
   constexpr int CHP = CH < 16 ? 16 : CH;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
     pj[q] = *(const float4*)((const char*)a.pos4 + jj[q] * 16u);
 #pragma unroll
     for (int u = 0; u < G4; ++u)
-      xg[q][u] = *(const float4*)((const char*)a.x + (jj[q] * (unsigned)(D * 4) + (unsigned)((g * DG + u * 4) * 4)));
+      xg[q][u] = io_load4_b<IOH>(a.x, jj[q] * (unsigned)(D * 4) + (unsigned)((g * DG + u * 4) * 4));
   }
   // B fragments of the first k-step group: independent of everything above, in flight during phase 1
   float4 b0[NTW];
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void lfa_fwd_full_kernel(LfaArgs a) {
       ocol = (unsigned)col;
     }
     if (KP == 32 && (lg & 1)) ok = false;  // (both halves hold the result: the even group stores it)
-    if (ok) *(float*)((char*)a.out + (orow * (unsigned)(CH * 4) + ocol * 4u)) = num * __builtin_amdgcn_rcpf(den + 1e-16f);
+    if (ok) io_store1_b<IOH>(a.out, orow * (unsigned)(CH * 4) + ocol * 4u, num * __builtin_amdgcn_rcpf(den + 1e-16f));
   }
 }
 
@@ -457,32 +458,38 @@ static inline bool lfa_full_ok(const LfaArgs& a, int flags) {
          a.slope >= 0.f && a.slope <= 1.f;
 }
 
-template <int CH, bool BF = false>
-static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st, int flags) {
+template <int CH, bool BF, bool IOH>
+static int launch_lfa_fwd_io(const LfaArgs& a, hipStream_t st, int flags) {
   constexpr int ROWS = LfaCfg<(CH < 16 ? 16 : CH)>::ROWS;
   if (lfa_full_ok(a, flags)) {
     constexpr int FROWS = LfaFullRows<CH>::ROWS;
     const dim3 g16((unsigned)m3d_cdiv(a.n, FROWS / 16)), g32((unsigned)m3d_cdiv(a.n, FROWS / 32));
     if constexpr (BF) {
       if (flags & 2) {  // split-bf16 operands: att_w_packed holds the hi fragments, then the lo fragments
-        if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, 2>), g16, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, 2>), g32, dim3(256), 0, st, a);
+        if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, 2, IOH>), g16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, 2, IOH>), g32, dim3(256), 0, st, a);
         return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
       }
     }
-    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF ? 1 : 0>), g16, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF ? 1 : 0>), g32, dim3(256), 0, st, a);
+    if (a.K == 16) hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 16, BF ? 1 : 0, IOH>), g16, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lfa_fwd_full_kernel<CH, 32, BF ? 1 : 0, IOH>), g32, dim3(256), 0, st, a);
     if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
     return M3D_OK;
   }
   if (BF && (flags & 2)) return M3D_ERR_UNSUPPORTED;  // the split-bf16 product exists in the complete-neighbourhood kernels only
   if (a.K <= 16) {
-    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 16, BF, IOH>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 16)), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 32, BF>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((lfa_fwd_kernel<CH, 32, BF, IOH>), dim3((unsigned)m3d_cdiv(a.n, ROWS / 32)), dim3(256), 0, st, a);
   }
   if (hipGetLastError() != hipSuccess) return M3D_ERR_LAUNCH;
   return M3D_OK;
+}
+// flags: bit 0 = M3D_LFA_FULL, bit 1 = split-bf16 operands, M3D_IO_BF16 = x and out hold bf16
+template <int CH, bool BF = false>
+static int launch_lfa_fwd(const LfaArgs& a, hipStream_t st, int flags) {
+  if (flags & M3D_IO_BF16) return launch_lfa_fwd_io<CH, BF, true>(a, st, flags);
+  return launch_lfa_fwd_io<CH, BF, false>(a, st, flags);
 }
 
 extern "C" int m3d_lfa_fwd(const float* x, const float* pos4, const int32_t* idx, int64_t n, int32_t K, int32_t CH,

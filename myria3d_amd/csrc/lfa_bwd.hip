@@ -165,7 +165,8 @@ template <> struct BwdCfg<256> { static constexpr int ROWS = BWD_ROWS_256, NW = 
 // computed from clamped rows with dout = 0: every contribution they make is an exact zero.
 // X3 (with BF and FULL): split-bf16 operands — every bf16 product becomes hi*hi + hi*lo + lo*hi (m3d_common.h); a.wp / a.wpt hold
 // the hi fragments followed by the lo fragments (m3d_lfa_prepare(bf16 = 2)).
-template <int CH, int KP, bool PIPE, bool BF = false, bool FULL = false, bool X3 = false>
+// IOH (flags M3D_IO_BF16): x, dout (and the small kernel's edge rows) hold bf16; the atomically accumulated dx stays fp32
+template <int CH, int KP, bool PIPE, bool BF = false, bool FULL = false, bool X3 = false, bool IOH = false>
 __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 16 ? 16 : CH)>::MINW) void lfa_bwd_kernel(LfaBwdArgs a) {
   constexpr int CHP = CH < 16 ? 16 : CH;
   constexpr int D = CH / 2;  // compile-time channel counts: no integer divisions in the index arithmetic
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       for (int u = 0; u < GPT; ++u) {
         const int f = tid + u * NTHR;
         const int e = (f / D4) % ROWS, c4 = f % D4;
-        xg[u] = *(const float4*)((const char*)a.x + ((unsigned)nb[e] * (unsigned)(D * 4) + (unsigned)(c4 * 16)));
+        xg[u] = io_load4_b<IOH>(a.x, (unsigned)nb[e] * (unsigned)(D * 4) + (unsigned)(c4 * 16));
       }
       {
         const int e = tid % ROWS;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
           const int col = (wn * NTW + t) * 16 + lr;
-          dgp[cc][t] = *(const float*)((const char*)a.dout + (i * (unsigned)(CH * 4) + (unsigned)((col < CH ? col : CH - 1) * 4)));
+          dgp[cc][t] = io_load1_b<IOH>(a.dout, i * (unsigned)(CH * 4) + (unsigned)((col < CH ? col : CH - 1) * 4));
         }
       }
       return;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
       const int f = tid + u * NTHR;
       const int e = (f / D4) % ROWS, c4 = f % D4;  // (f >= ROWS*D4 only in a padded last trip: harmless extra load)
       const int j = nb[e];
-      xg[u] = *(const float4*)(a.x + (int64_t)(j < 0 ? 0 : j) * D + c4 * 4);
+      xg[u] = io_load4<IOH>(a.x, (size_t)((int64_t)(j < 0 ? 0 : j) * D + c4 * 4));
     }
     {
       const int e = tid % ROWS;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         const int col = (wn * NTW + t) * 16 + lr;
-        dgp[cc][t] = a.dout[(i < a.n ? i : nlast) * CH + (col < CH ? col : CH - 1)];
+        dgp[cc][t] = io_load1<IOH>(a.dout, (size_t)((i < a.n ? i : nlast) * CH + (col < CH ? col : CH - 1)));
       }
     }
   };
@@ -412,8 +413,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
           int e = f / D4, c4 = f % D4;
           int j = nbr[e];
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if constexpr (FULL) v = *(const float4*)((const char*)a.x + ((unsigned)j * (unsigned)(D * 4) + (unsigned)(c4 * 16)));
-          else if (j >= 0) v = *(const float4*)(a.x + (int64_t)j * D + c4 * 4);
+          if constexpr (FULL) v = io_load4_b<IOH>(a.x, (unsigned)j * (unsigned)(D * 4) + (unsigned)(c4 * 16));
+          else if (j >= 0) v = io_load4<IOH>(a.x, (size_t)((int64_t)j * D + c4 * 4));
           float* d = &F[e * STR + c4 * 4];
           *(float2*)d = make_float2(v.x, v.y);
           *(float2*)(d + 2) = make_float2(v.z, v.w);
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         float g = 0.f;
         if (ic < a.n && col < CH) {
           if constexpr (PIPE) g = dgc[0][t];
-          else g = *(const float*)((const char*)a.dout + ((unsigned)ic * (unsigned)(CH * 4) + (unsigned)(col * 4)));
+          else g = io_load1_b<IOH>(a.dout, (unsigned)ic * (unsigned)(CH * 4) + (unsigned)(col * 4));
         }
         const float gi = g * inv;
 #pragma unroll
@@ -678,8 +679,8 @@ __global__ __launch_bounds__(BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64, BwdCfg<(CH < 
         float g = 0.f;
         if (i < a.n && col < CH) {
           if constexpr (PIPE) g = dgc[cc][t];
-          else if constexpr (FULL) g = *(const float*)((const char*)a.dout + ((unsigned)i * (unsigned)(CH * 4) + (unsigned)(col * 4)));
-          else g = a.dout[i * CH + col];
+          else if constexpr (FULL) g = io_load1_b<IOH>(a.dout, (unsigned)i * (unsigned)(CH * 4) + (unsigned)(col * 4));
+          else g = io_load1<IOH>(a.dout, (size_t)(i * CH + col));
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
@@ -978,7 +979,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // stores) and the caller sums the rows of every point's REVERSE neighbour list (m3d_gather_sum_rows over the CSR inverse of
 // the neighbour table, built with the position-only work).  Measured (profiles/r05p_*): with the atomics this kernel takes
 // 193 / 199 us at level 1, without them 83 / 113 — the L2 needs ~30 ps per 16 / 32-byte row atomic whatever the kernel does.
-template <int CH, bool EDGE>
+template <int CH, bool EDGE, bool IOH = false>
 __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaBwdArgs a, int nwork) {
   constexpr bool PACK2 = CH == 8;
   constexpr int D = CH / 2, D4 = D / 4, STR = 18;
@@ -1067,12 +1068,12 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
       pi[q] = *(const float4*)((const char*)a.pos4 + ci * 16u);
       pj[q] = *(const float4*)((const char*)a.pos4 + jc[q] * 16u);
 #pragma unroll
-      for (int u = 0; u < D4; ++u) xg[q][u] = *(const float4*)((const char*)a.x + (jc[q] * (unsigned)(D * 4) + (unsigned)(u * 16)));
+      for (int u = 0; u < D4; ++u) xg[q][u] = io_load4_b<IOH>(a.x, jc[q] * (unsigned)(D * 4) + (unsigned)(u * 16));
     }
     unsigned cu = PACK2 ? c0w + 2u * (unsigned)lg + (unsigned)(lr >> 3) : c0w + (unsigned)lg;
     const bool ok = cu < n32;  // (centres past n: clamped rows with dout = 0 — every contribution an exact zero)
     cu = ok ? cu : n32 - 1u;
-    const float v = *(const float*)((const char*)a.dout + (cu * (unsigned)(CH * 4) + (unsigned)(cc * 4)));
+    const float v = io_load1_b<IOH>(a.dout, cu * (unsigned)(CH * 4) + (unsigned)(cc * 4));
     dgn = ok ? v : 0.f;
   };
   if (g0 < gend) {
@@ -1196,7 +1197,7 @@ __global__ __launch_bounds__(256, BWD_SMALL_MINW) void lfa_bwd_small_kernel(LfaB
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const unsigned row = (unsigned)(r == 0 ? s4.x : (r == 1 ? s4.y : (r == 2 ? s4.z : s4.w)));
-              *(float*)((char*)a.dxe + (row * (unsigned)(D * 4) + (unsigned)(cc * 4))) = acc[m][r];
+              io_store1_b<IOH>(a.dxe, row * (unsigned)(D * 4) + (unsigned)(cc * 4), acc[m][r]);
             }
           }
         }
@@ -1397,8 +1398,8 @@ extern "C" size_t m3d_lfa_bwd_workspace_bytes(int64_t n, int32_t K, int32_t CH) 
   return ((size_t)p.grid * p.kspl3 * p.chp * p.chp + (size_t)p.grid * p.kspl4 * p.dp * 16) * sizeof(float) + 256;
 }
 
-template <int CH>
-static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full, bool x3) {
+template <int CH, bool IOH>
+static int launch_lfa_bwd_io(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full, bool x3) {
   constexpr int NTHR = BwdCfg<(CH < 16 ? 16 : CH)>::NW * 64;
   // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*; BWD_PIPE_* at compile time)
   constexpr bool pipe = CH <= 64 && !(LFA_BWD_DBG & ~1) &&  // (bit 0, no dx atomics, keeps the pipelined kernel: no `continue` in it)
@@ -1407,15 +1408,15 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
     if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
       constexpr bool P = CH == 64;
       if (full && x3) {
-        if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-        else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+        if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true, true, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+        else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true, true, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
       } else if (x3) {
         return M3D_ERR_UNSUPPORTED;  // (the split-bf16 product exists in the complete-neighbourhood kernels only)
       } else if (full) {
-        if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-        else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-      } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-      else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
+        if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+        else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, false, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+      else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, false, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
       return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
     }
   }
@@ -1426,18 +1427,24 @@ static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st,
       const int64_t ng = (a.n + UC4 - 1) / UC4;
       int nwork = p.grid < (CH == 8 ? BWD_SMALL_CAP_8 : BWD_SMALL_CAP_16) ? p.grid : (CH == 8 ? BWD_SMALL_CAP_8 : BWD_SMALL_CAP_16);
       if (ng < nwork) nwork = (int)ng;
-      if (a.dxe) hipLaunchKernelGGL((lfa_bwd_small_kernel<CH, true>), dim3(p.grid), dim3(256), 0, st, a, nwork);
-      else hipLaunchKernelGGL((lfa_bwd_small_kernel<CH, false>), dim3(p.grid), dim3(256), 0, st, a, nwork);
+      if (a.dxe) hipLaunchKernelGGL((lfa_bwd_small_kernel<CH, true, IOH>), dim3(p.grid), dim3(256), 0, st, a, nwork);
+      else hipLaunchKernelGGL((lfa_bwd_small_kernel<CH, false, IOH>), dim3(p.grid), dim3(256), 0, st, a, nwork);
       return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
     }
   }
   if (a.dxe) return M3D_ERR_UNSUPPORTED;  // (edge rows exist in the wave-autonomous kernels only: m3d_lfa_bwd_edge_rows_ok)
   if (full) {
-    if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe, false, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-    else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe, false, true>), dim3(p.grid), dim3(NTHR), 0, st, a);
-  } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe>), dim3(p.grid), dim3(NTHR), 0, st, a);
+    if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe, false, true, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+    else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe, false, true, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  } else if (a.K <= 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, pipe, false, false, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, pipe, false, false, false, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
   return hipGetLastError() == hipSuccess ? M3D_OK : M3D_ERR_LAUNCH;
+}
+
+template <int CH>
+static int launch_lfa_bwd(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t st, bool bf16, bool full, bool x3, bool io16) {
+  if (io16) return launch_lfa_bwd_io<CH, true>(a, p, st, bf16, full, x3);
+  return launch_lfa_bwd_io<CH, false>(a, p, st, bf16, full, x3);
 }
 
 // 1: m3d_lfa_bwd(flags | 8 | 32) is honoured for this layer shape (the wave-autonomous kernels: ch <= 16, K = 16)
@@ -1475,6 +1482,7 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   const bool full = (flags & 8) && (K == 16 || K == 32) && n > 0 && n * K < lim && n * (int64_t)CH * 4 < lim && n * 16 < lim &&
                     slope >= 0.f && slope <= 1.f && !LFA_BWD_DBG_NOFULL;
   const bool x3 = bf16 && (flags & 16);  // flags bit 4: split-bf16 operands (att_w*_packed hold hi then lo fragments)
+  const bool io16 = (flags & M3D_IO_BF16) != 0;  // x, dout and the edge rows hold bf16 (dx, accumulated with atomics: fp32)
   if (flags & 32) {  // flags bit 5: `dx` is the [n K, D] edge-row buffer (stored, not accumulated)
     if (!full || bf16 || !m3d_lfa_bwd_edge_rows_ok(n, K, CH, slope)) return M3D_ERR_UNSUPPORTED;
     a.dxe = dx;
@@ -1482,12 +1490,12 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
     a.eslot = edge_slot;
   } else if (edge_slot) return M3D_ERR_INVALID;
   switch (CH) {
-    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full, x3); break;
-    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full, x3); break;
-    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16, full, x3); break;
-    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16, full, x3); break;
-    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16, full, x3); break;
-    default: rc = launch_lfa_bwd<256>(a, p, st, bf16, full, x3); break;
+    case 8: rc = launch_lfa_bwd<8>(a, p, st, bf16, full, x3, io16); break;
+    case 16: rc = launch_lfa_bwd<16>(a, p, st, bf16, full, x3, io16); break;
+    case 32: rc = launch_lfa_bwd<32>(a, p, st, bf16, full, x3, io16); break;
+    case 64: rc = launch_lfa_bwd<64>(a, p, st, bf16, full, x3, io16); break;
+    case 128: rc = launch_lfa_bwd<128>(a, p, st, bf16, full, x3, io16); break;
+    default: rc = launch_lfa_bwd<256>(a, p, st, bf16, full, x3, io16); break;
   }
   if (rc != M3D_OK) return rc;
   if (flags & 4) return M3D_OK;  // the caller sums the partials later (m3d_lfa_bwd_reduce_batch): ws must live until then

@@ -218,6 +218,55 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // round-to-n
   f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// ---- bf16 ACTIVATION STORAGE (round 6; M3D_IO_* bits of the entry points' flags, include/m3d_hip.h).  A feature matrix
+// [rows, channels] may live in HBM as bf16 (2-byte elements, round-to-nearest-even on store, exact widening on load); every
+// kernel computes in fp32 registers as before.  The helpers take the element type as a template flag (H = bf16) and ELEMENT
+// offsets, so one kernel body serves both layouts; H = false compiles to the fp32 code it replaces.
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 f32x4_to_bf16(float4 v) { return make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float v) { return (unsigned short)(pack_bf16(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+// four consecutive elements starting at element `e` (a multiple of 4; base 16-byte resp. 8-byte aligned)
+template <bool H>
+__device__ __forceinline__ float4 io_load4(const void* base, size_t e) {
+  if constexpr (H) return bf16x4_to_f32(*(const uint2*)((const unsigned short*)base + e));
+  else return *(const float4*)((const float*)base + e);
+}
+template <bool H>
+__device__ __forceinline__ void io_store4(void* base, size_t e, float4 v) {
+  if constexpr (H) *(uint2*)((unsigned short*)base + e) = f32x4_to_bf16(v);
+  else *(float4*)((float*)base + e) = v;
+}
+template <bool H>
+__device__ __forceinline__ float io_load1(const void* base, size_t e) {
+  if constexpr (H) return bf16_to_f32(((const unsigned short*)base)[e]);
+  else return ((const float*)base)[e];
+}
+template <bool H>
+__device__ __forceinline__ void io_store1(void* base, size_t e, float v) {
+  if constexpr (H) ((unsigned short*)base)[e] = f32_to_bf16(v);
+  else ((float*)base)[e] = v;
+}
+// the same through BYTE offsets computed for fp32 elements (the LFA kernels' 32-bit offset arithmetic): a bf16 element sits
+// at half the offset
+template <bool H>
+__device__ __forceinline__ float4 io_load4_b(const void* base, unsigned byte_off_f32) {
+  if constexpr (H) return bf16x4_to_f32(*(const uint2*)((const char*)base + (byte_off_f32 >> 1)));
+  else return *(const float4*)((const char*)base + byte_off_f32);
+}
+template <bool H>
+__device__ __forceinline__ float io_load1_b(const void* base, unsigned byte_off_f32) {
+  if constexpr (H) return bf16_to_f32(*(const unsigned short*)((const char*)base + (byte_off_f32 >> 1)));
+  else return *(const float*)((const char*)base + byte_off_f32);
+}
+template <bool H>
+__device__ __forceinline__ void io_store1_b(void* base, unsigned byte_off_f32, float v) {
+  if constexpr (H) *(unsigned short*)((char*)base + (byte_off_f32 >> 1)) = f32_to_bf16(v);
+  else *(float*)((char*)base + byte_off_f32) = v;
+}
 union Bf16Frag {
   bf16x8 v;
   unsigned u[4];

@@ -10,8 +10,10 @@
 #include "m3d_common.h"
 #include "../../include/m3d_hip.h"
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t ld,
-                                                          const int32_t* __restrict__ idx, float* __restrict__ out,
+// H: src and out hold bf16 (m3d_gather_rows_bf16)
+template <bool H>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const void* __restrict__ src, int64_t ld,
+                                                          const int32_t* __restrict__ idx, void* __restrict__ out,
                                                           int64_t m, int C) {
   if ((C & 3) == 0 && (ld & 3) == 0) {
     const int C4 = C >> 2;
@@ -21,8 +23,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
       int c = (int)(i % C4);
       int64_t s = idx ? (int64_t)idx[r] : r;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s >= 0) v = *(const float4*)(src + s * ld + c * 4);
-      ((float4*)out)[i] = v;
+      if (s >= 0) v = io_load4<H>(src, (size_t)(s * ld + c * 4));
+      io_store4<H>(out, 4 * (size_t)i, v);
     }
   } else {
     const int64_t total = m * C;
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
       int64_t r = i / C;
       int c = (int)(i % C);
       int64_t s = idx ? (int64_t)idx[r] : r;
-      out[i] = s >= 0 ? src[s * ld + c] : 0.f;
+      io_store1<H>(out, (size_t)i, s >= 0 ? io_load1<H>(src, (size_t)(s * ld + c)) : 0.f);
     }
   }
 }
@@ -43,13 +45,30 @@ extern "C" int m3d_gather_rows(const float* src, int64_t ld, const int32_t* idx,
   if ((((uintptr_t)src) & 15) || (((uintptr_t)out) & 15)) return M3D_ERR_INVALID;
   int64_t gx = m3d_cdiv(m * (int64_t)((C + 3) / 4), 256);
   if (gx > 8192) gx = 8192;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, ld, idx, out, m,
-                     C);
+  hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const void*)src, ld, idx,
+                     (void*)out, m, C);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
 
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src,
+// the same for bf16 rows (M3D_IO_BF16 storage of the feature matrices: decimate() and the output un-permutation of a net
+// whose activations live in bf16); ld in elements, 16-byte aligned bases
+extern "C" int m3d_gather_rows_bf16(const void* src, int64_t ld, const int32_t* idx, void* out, int64_t m, int32_t C,
+                                    void* stream) {
+  if (m < 0 || C < 0) return M3D_ERR_INVALID;
+  if (m == 0 || C == 0) return M3D_OK;
+  if (!src || !out) return M3D_ERR_INVALID;
+  if ((((uintptr_t)src) & 15) || (((uintptr_t)out) & 15)) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(m * (int64_t)((C + 3) / 4), 256);
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, ld, idx, out, m, C);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// H: src holds bf16; the atomically accumulated `out` is fp32 either way
+template <bool H>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const void* __restrict__ src,
                                                                const int32_t* __restrict__ idx,
                                                                float* __restrict__ out, int64_t ldo, int64_t m,
                                                                int C) {
@@ -63,15 +82,17 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     int64_t r = i / C;
     int c = (int)(i % C);
     int64_t d = (int64_t)idx[r];
-    if (d >= 0) atomicAdd(out + d * ldo + c, src[i]);
+    if (d >= 0) atomicAdd(out + d * ldo + c, io_load1<H>(src, (size_t)i));
   }
 }
 
 // the same for DISTINCT targets (the transpose of a subset selection: decimate(), pyg_randla_net.py:234-238): no two
 // rows meet, so a plain 16-byte read-modify-write does what 4 float atomics did
-__global__ __launch_bounds__(256) void scatter_add_distinct_rows_kernel(const float4* __restrict__ src,
+// (H: src AND out hold bf16 — a plain read-modify-write of 8 bytes)
+template <bool H>
+__global__ __launch_bounds__(256) void scatter_add_distinct_rows_kernel(const void* __restrict__ src,
                                                                         const int32_t* __restrict__ idx,
-                                                                        float* __restrict__ out, int64_t ldo, int64_t m,
+                                                                        void* __restrict__ out, int64_t ldo, int64_t m,
                                                                         int C4) {
   const int64_t total = m * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -79,11 +100,11 @@ __global__ __launch_bounds__(256) void scatter_add_distinct_rows_kernel(const fl
     const int q = (int)(i % C4);
     const int64_t d = (int64_t)idx[r];
     if (d < 0) continue;
-    float4* dst = (float4*)(out + d * ldo + 4 * q);
-    const float4 v = src[i];
-    float4 o = *dst;
+    const size_t de = (size_t)(d * ldo + 4 * q);
+    const float4 v = io_load4<H>(src, 4 * (size_t)i);
+    float4 o = io_load4<H>(out, de);
     o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-    *dst = o;
+    io_store4<H>(out, de, o);
   }
 }
 
@@ -92,18 +113,29 @@ extern "C" int m3d_scatter_add_rows(const float* src, const int32_t* idx, float*
   if (m < 0 || C < 0) return M3D_ERR_INVALID;
   if (m == 0 || C == 0) return M3D_OK;
   if (!src || !out || !idx) return M3D_ERR_INVALID;
-  if ((flags & 1) && !(C & 3) && !(ldo & 3) && !((((uintptr_t)src) | ((uintptr_t)out)) & 15)) {
-    int64_t g4 = m3d_cdiv(m * (int64_t)(C / 4), 256);
-    if (g4 > 8192) g4 = 8192;
-    hipLaunchKernelGGL(scatter_add_distinct_rows_kernel, dim3((unsigned)g4), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)src, idx, out, ldo, m, C / 4);
-    M3D_CHECK_LAUNCH();
-    return M3D_OK;
+  // flags: bit 0 = distinct targets; M3D_IO_BF16 = src holds bf16 — and so does out with distinct targets; the ATOMIC
+  // form (bit 0 clear) accumulates into an fp32 `out` whatever src is
+  const bool h = (flags & M3D_IO_BF16) != 0;
+  if (flags & 1) {
+    if ((C & 3) || (ldo & 3) || ((((uintptr_t)src) | ((uintptr_t)out)) & 15)) {
+      if (h) return M3D_ERR_UNSUPPORTED;  // (the fp32 form falls back to atomics; a bf16 target has none)
+    } else {
+      int64_t g4 = m3d_cdiv(m * (int64_t)(C / 4), 256);
+      if (g4 > 8192) g4 = 8192;
+      if (h) hipLaunchKernelGGL(scatter_add_distinct_rows_kernel<true>, dim3((unsigned)g4), dim3(256), 0, (hipStream_t)stream,
+                                (const void*)src, idx, (void*)out, ldo, m, C / 4);
+      else hipLaunchKernelGGL(scatter_add_distinct_rows_kernel<false>, dim3((unsigned)g4), dim3(256), 0, (hipStream_t)stream,
+                              (const void*)src, idx, (void*)out, ldo, m, C / 4);
+      M3D_CHECK_LAUNCH();
+      return M3D_OK;
+    }
   }
   int64_t gx = m3d_cdiv(m * (int64_t)C, 256 * 2);
   if (gx > 8192) gx = 8192;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, idx, out,
+  if (h) hipLaunchKernelGGL(scatter_add_rows_kernel<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const void*)src,
+                            idx, out, ldo, m, C);
+  else hipLaunchKernelGGL(scatter_add_rows_kernel<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const void*)src, idx, out,
                      ldo, m, C);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
@@ -217,9 +249,11 @@ extern "C" int m3d_csr_invert_batch(int32_t njobs, const int32_t* const* idx, co
 // out[c][:] (+)= sum of src[f][:] over f in inv[ptr[c] .. ptr[c + 1])   (C % 4 == 0, 16-byte aligned rows)
 // (round 4 prepared a variant with eight contributors' ids, then rows, per trip — -DROWS_GATHER_BATCH=1; its A/B in round 5,
 // profiles/r05a_step_lfa_full_ab.log, moved nothing: 4.130 vs 4.118 / 4.135 ms per step; removed)
-__global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __restrict__ src, int64_t lds,
+// H: src and out hold bf16 (fp32 sums in registers)
+template <bool H>
+__global__ __launch_bounds__(256) void gather_sum_rows_kernel(const void* __restrict__ src, int64_t lds,
                                                               const int32_t* __restrict__ ptr,
-                                                              const int32_t* __restrict__ inv, float* __restrict__ out,
+                                                              const int32_t* __restrict__ inv, void* __restrict__ out,
                                                               int64_t ldo, int64_t m, int C4, int accumulate) {
   const int64_t total = m * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -229,28 +263,28 @@ __global__ __launch_bounds__(256) void gather_sum_rows_kernel(const float* __res
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int p = p0;
     for (; p + 1 < p1; p += 2) {
-      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
-      const float4 b = *(const float4*)(src + (int64_t)(inv ? inv[p + 1] : p + 1) * lds + 4 * q);
+      const float4 a = io_load4<H>(src, (size_t)((int64_t)(inv ? inv[p] : p) * lds + 4 * q));
+      const float4 b = io_load4<H>(src, (size_t)((int64_t)(inv ? inv[p + 1] : p + 1) * lds + 4 * q));
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
       s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
     if (p < p1) {
-      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
+      const float4 a = io_load4<H>(src, (size_t)((int64_t)(inv ? inv[p] : p) * lds + 4 * q));
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
     }
-    float4* d = (float4*)(out + c * ldo + 4 * q);
+    const size_t de = (size_t)(c * ldo + 4 * q);
     float4 o = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
-    if (accumulate) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-    *d = o;
+    if (accumulate) { const float4 old = io_load4<H>(out, de); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+    io_store4<H>(out, de, o);
   }
 }
 
 #ifndef GATHER_LPL
 #define GATHER_LPL 4  // lanes per list of the long-list gather (4 or 8)
 #endif
-template <int LPL>
-__global__ void gather_sum_rows4_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ ptr,
-                                        const int32_t* __restrict__ inv, float* __restrict__ out, int64_t ldo, int64_t m, int C4,
+template <int LPL, bool H>
+__global__ void gather_sum_rows4_kernel(const void* __restrict__ src, int64_t lds, const int32_t* __restrict__ ptr,
+                                        const int32_t* __restrict__ inv, void* __restrict__ out, int64_t ldo, int64_t m, int C4,
                                         int accumulate);
 extern "C" int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t* ptr, const int32_t* inv, float* out,
                                    int64_t ldo, int64_t m, int32_t C, int32_t accumulate, void* stream) {
@@ -258,18 +292,42 @@ extern "C" int m3d_gather_sum_rows(const float* src, int64_t lds, const int32_t*
   if (m == 0 || C == 0) return M3D_OK;
   if (!src || !ptr || !out) return M3D_ERR_INVALID;  // (inv == NULL: list c is the rows ptr[c] .. ptr[c + 1] of src themselves)
   if ((C & 3) || (lds & 3) || (ldo & 3) || ((((uintptr_t)src) | ((uintptr_t)out)) & 15)) return M3D_ERR_UNSUPPORTED;
+  // accumulate: bit 0 = add into out, bit 1 = long lists, M3D_IO_BF16 = src and out hold bf16
+  const bool h = (accumulate & M3D_IO_BF16) != 0;
+  const void* sv = src;
+  void* ov = out;
   if (accumulate & 2) {  // long lists: four lanes per (target, chunk)
     int64_t gx4 = m3d_cdiv(m * (int64_t)(C / 4), 256 / GATHER_LPL);
     if (gx4 > 65536) gx4 = 65536;
-    hipLaunchKernelGGL(gather_sum_rows4_kernel<GATHER_LPL>, dim3((unsigned)gx4), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
-                       out, ldo, m, C / 4, accumulate & 1);
+    if (h) hipLaunchKernelGGL((gather_sum_rows4_kernel<GATHER_LPL, true>), dim3((unsigned)gx4), dim3(256), 0, (hipStream_t)stream, sv, lds, ptr, inv,
+                              ov, ldo, m, C / 4, accumulate & 1);
+    else hipLaunchKernelGGL((gather_sum_rows4_kernel<GATHER_LPL, false>), dim3((unsigned)gx4), dim3(256), 0, (hipStream_t)stream, sv, lds, ptr, inv,
+                       ov, ldo, m, C / 4, accumulate & 1);
     M3D_CHECK_LAUNCH();
     return M3D_OK;
   }
   int64_t gx = m3d_cdiv(m * (int64_t)(C / 4), 256);
   if (gx > 8192) gx = 8192;
-  hipLaunchKernelGGL(gather_sum_rows_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, lds, ptr, inv,
-                     out, ldo, m, C / 4, accumulate & 1);
+  if (h) hipLaunchKernelGGL(gather_sum_rows_kernel<true>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, sv, lds, ptr, inv,
+                            ov, ldo, m, C / 4, accumulate & 1);
+  else hipLaunchKernelGGL(gather_sum_rows_kernel<false>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, sv, lds, ptr, inv,
+                     ov, ldo, m, C / 4, accumulate & 1);
+  M3D_CHECK_LAUNCH();
+  return M3D_OK;
+}
+
+// fp32 -> bf16 (round-to-nearest-even) of n contiguous values: the network INPUT features of a net whose activations live in
+// bf16 (M3D_IO_BF16) — one pass over [sum N, F] per batch, every later kernel then reads 2-byte elements
+__global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = f32_to_bf16(src[i]);
+}
+extern "C" int m3d_convert_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (n < 0) return M3D_ERR_INVALID;
+  if (n == 0) return M3D_OK;
+  if (!src || !dst) return M3D_ERR_INVALID;
+  int64_t gx = m3d_cdiv(n, 256 * 4);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(convert_bf16_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, n);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
@@ -287,10 +345,10 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
   return v;
 }
-template <int LPL>
-__global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __restrict__ src, int64_t lds,
+template <int LPL, bool H>
+__global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const void* __restrict__ src, int64_t lds,
                                                                const int32_t* __restrict__ ptr,
-                                                               const int32_t* __restrict__ inv, float* __restrict__ out,
+                                                               const int32_t* __restrict__ inv, void* __restrict__ out,
                                                                int64_t ldo, int64_t m, int C4, int accumulate) {
   const int64_t total = m * C4;
   const int l = threadIdx.x & (LPL - 1);
@@ -301,13 +359,13 @@ __global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __re
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int p = p0 + l;
     for (; p + LPL < p1; p += 2 * LPL) {
-      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
-      const float4 b = *(const float4*)(src + (int64_t)(inv ? inv[p + LPL] : p + LPL) * lds + 4 * q);
+      const float4 a = io_load4<H>(src, (size_t)((int64_t)(inv ? inv[p] : p) * lds + 4 * q));
+      const float4 b = io_load4<H>(src, (size_t)((int64_t)(inv ? inv[p + LPL] : p + LPL) * lds + 4 * q));
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
       s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
     if (p < p1) {
-      const float4 a = *(const float4*)(src + (int64_t)(inv ? inv[p] : p) * lds + 4 * q);
+      const float4 a = io_load4<H>(src, (size_t)((int64_t)(inv ? inv[p] : p) * lds + 4 * q));
       s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
     }
     float4 o = make_float4(quad_sum(s0.x + s1.x), quad_sum(s0.y + s1.y), quad_sum(s0.z + s1.z), quad_sum(s0.w + s1.w));
@@ -318,9 +376,9 @@ __global__ __launch_bounds__(256) void gather_sum_rows4_kernel(const float* __re
       o.w += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o.w), 0x12C, 0xF, 0xF, false));
     }
     if (l == 0) {
-      float4* d = (float4*)(out + c * ldo + 4 * q);
-      if (accumulate) { const float4 old = *d; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-      *d = o;
+      const size_t de = (size_t)(c * ldo + 4 * q);
+      if (accumulate) { const float4 old = io_load4<H>(out, de); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      io_store4<H>(out, de, o);
     }
   }
 }

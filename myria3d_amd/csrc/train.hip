@@ -126,11 +126,12 @@ __global__ void ce_finalize_kernel(double* __restrict__ acc, float* __restrict__
 }
 
 // dlogits[i, c] = gout * (softmax(i)[c] - [c == target_i]) / count   (0 for ignored rows)
+template <bool H>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld,
                                                      const int64_t* __restrict__ target, int64_t n, int C,
                                                      int64_t ignore_index, const float* __restrict__ lse,
                                                      const double* __restrict__ acc, const float* __restrict__ gout,
-                                                     float* __restrict__ dlogits) {
+                                                     void* __restrict__ dlogits) {
   const float g = gout[0] / (float)acc[1];
   const int64_t total = n * C;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     const int64_t y = target[i];
     float d = 0.f;
     if (y != ignore_index && y >= 0 && y < C) d = g * (expf(logits[i * ld + c] - lse[i]) - (c == (int)y ? 1.f : 0.f));
-    dlogits[t] = d;
+    io_store1<H>(dlogits, (size_t)t, d);
   }
 }
 
@@ -163,20 +164,25 @@ extern "C" int m3d_ce_loss_fwd(const float* logits, int64_t ld, const int64_t* t
   return M3D_OK;
 }
 
-extern "C" int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
-                               int64_t ignore_index, const float* lse, const double* acc2, const float* gout,
-                               float* dlogits, void* stream) {
+template <bool H>
+static int ce_loss_bwd_impl(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
+                            int64_t ignore_index, const float* lse, const double* acc2, const float* gout,
+                            void* dlogits, void* stream) {
   if (n < 0 || C < 1) return M3D_ERR_INVALID;
   if (n == 0) return M3D_OK;
   if (!logits || !target || !lse || !acc2 || !gout || !dlogits) return M3D_ERR_INVALID;
   int64_t gx = m3d_cdiv(n * C, 256);
   if (gx > 8192) gx = 8192;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, logits, ld, target, n, C,
+  hipLaunchKernelGGL(ce_bwd_kernel<H>, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, logits, ld, target, n, C,
                      ignore_index, lse, acc2, gout, dlogits);
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
-
+extern "C" int m3d_ce_loss_bwd(const float* logits, int64_t ld, const int64_t* target, int64_t n, int32_t C,
+                               int64_t ignore_index, const float* lse, const double* acc2, const float* gout,
+                               float* dlogits, void* stream) {
+  return ce_loss_bwd_impl<false>(logits, ld, target, n, C, ignore_index, lse, acc2, gout, dlogits, stream);
+}
 // ------------------------------------------------------------------------------------------
 // Adam over flat buffers.  state[0] = step count (float, incremented here by a 1-thread launch so that a
 // replayed hipGraph keeps counting), matching torch.optim.Adam(amsgrad=False, maximize=False):

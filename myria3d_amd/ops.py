@@ -122,6 +122,34 @@ def _chk(t: Tensor, dtype=torch.float32):
 
 
 # --------------------------------------------------------------------------------------------------
+# bf16 ACTIVATION STORAGE (round 6; BASELINE config 2 "bf16", the reference's switch: Lightning's ``precision``,
+# configs/experiment/RandLaNet_base_run_FR-2x3GPUs.yaml:12).  Feature matrices ``[rows, channels]`` and their gradients may be
+# torch.bfloat16 tensors; the wrappers below read the layout off the tensors' dtypes and pass the M3D_IO_* bits of
+# include/m3d_hip.h.  Parameters, statistics, positions, logits and parameter gradients stay fp32.
+# --------------------------------------------------------------------------------------------------
+IO_BF16, IO_A32, IO_C32 = 0x1000, 0x2000, 0x4000  # M3D_IO_BF16 / M3D_IO_A32 / M3D_IO_C32
+BF16 = torch.bfloat16
+
+
+def _h(t: Optional[Tensor]) -> bool:
+    return t is not None and t.dtype == BF16
+
+
+def _chka(t: Tensor):
+    """An activation matrix: contiguous fp32 or bf16 on the device."""
+    assert t.is_cuda and t.dtype in (torch.float32, BF16) and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return t
+
+
+def to_bf16(x: Tensor) -> Tensor:
+    """fp32 -> bf16 copy through ``m3d_convert_f32_bf16`` (the net's input features; an fp32 gradient handed to a bf16 layer)."""
+    x = _chk(x.contiguous())
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    call("m3d_convert_f32_bf16", _p(x), _p(out), x.numel(), _st())
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
 # kNN  (torch_cluster.knn via knn_graph / knn_interpolate: pyg_randla_net.py:180,250; model.py:90)
 # --------------------------------------------------------------------------------------------------
 _KNN_KERNEL = {"auto": 0, "queue": 1, "direct": 2}
@@ -196,16 +224,22 @@ def gemm(a0: Tensor, b: Tensor, M: int, N: int, k0: int, *, lda0: Optional[int] 
          b_cm: bool = False, ldb: Optional[int] = None, bias: Optional[Tensor] = None,
          scale: Optional[Tensor] = None, shift: Optional[Tensor] = None, act: bool = False,
          stats: Optional[Tensor] = None, out: Optional[Tensor] = None, ldc: Optional[int] = None,
-         accumulate: bool = False, splitk: int = 1, stat_slots: bool = False, bf16: bool = False) -> Tensor:
-    """C[M,N] (+)= [A0[rows] | A1] B^T, see ``m3d_gemm_f32`` in include/m3d_hip.h."""
+         accumulate: bool = False, splitk: int = 1, stat_slots: bool = False, bf16: bool = False,
+         out_dtype=None) -> Tensor:
+    """C[M,N] (+)= [A0[rows] | A1] B^T, see ``m3d_gemm_f32`` in include/m3d_hip.h.  bf16 operands (``a0`` / ``a1``) give a bf16
+    product unless ``out`` / ``out_dtype`` say fp32 (the logits); an fp32 ``a0`` next to bf16 storage is M3D_IO_A32."""
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a0.device)
+        out = torch.empty((M, N), dtype=out_dtype or a0.dtype, device=a0.device)
+    io = 0
+    if _h(a0) or _h(a1) or _h(out):
+        io = IO_BF16 | (0 if _h(a0) else IO_A32) | (0 if _h(out) else IO_C32)
+        assert a1 is None or _h(a1)
     lda0 = lda0 if lda0 is not None else (a0.stride(0) if not a_cm else a0.stride(0))
     lda1 = lda1 if lda1 is not None else (a1.stride(0) if a1 is not None else 0)
     ldb = ldb if ldb is not None else b.stride(0)
     ldc = ldc if ldc is not None else out.stride(0)
     call("m3d_gemm_f32", _p(a0), lda0, int(a_cm), _p(rows), k0, _p(a1), lda1, k1, _p(b), ldb, int(b_cm), M, N,
-         _p(bias), _p(scale), _p(shift), int(act) | (256 if bf16 else 0), LRELU_SLOPE, _p(stats),
+         _p(bias), _p(scale), _p(shift), int(act) | (256 if bf16 else 0) | io, LRELU_SLOPE, _p(stats),
          0 if stats is None else (-stats.shape[0] if stat_slots else stats.shape[0]),
          _p(out), ldc, int(accumulate), splitk, _st())
     return out
@@ -219,14 +253,17 @@ def gemm_pair(a, b, M: int, N: int, *, bias=None, stats=None, out=None, accumula
     import ctypes
 
     dev = a[0].device
-    outs = [o if o is not None else torch.empty((M, N), dtype=torch.float32, device=dev) for o in (out or (None, None))]
+    assert a[0].dtype == a[1].dtype
+    outs = [o if o is not None else torch.empty((M, N), dtype=a[0].dtype, device=dev) for o in (out or (None, None))]
+    assert all(o.dtype == a[0].dtype for o in outs)
     vp = lambda ts: (ctypes.c_void_p * 2)(*[_p(t) for t in ts])
     i64 = lambda vs: (ctypes.c_int64 * 2)(*vs)
     i32 = lambda vs: (ctypes.c_int32 * 2)(*vs)
     call("m3d_gemm_pair_f32", vp(a), i64([t.stride(0) for t in a]), i32([t.shape[1] for t in a]), vp(b),
          i64([t.stride(0) for t in b]), M, N, vp(bias) if bias is not None else None,
          vp(stats) if stats is not None else None, -stats[0].shape[0] if stats is not None else 0, vp(outs),
-         i64([t.stride(0) for t in outs]), i32([int(x) for x in accumulate]), int(b_cm) | (256 if bf16 else 0), _st())
+         i64([t.stride(0) for t in outs]), i32([int(x) for x in accumulate]),
+         int(b_cm) | (256 if bf16 else 0) | (IO_BF16 if _h(a[0]) else 0), _st())
     return outs
 
 
@@ -323,11 +360,14 @@ class GradSideStream:
         # the bf16 switch of m3d_linear_wgrad_batch applies to a whole call: layers that asked for bf16 matrix-core
         # operands (K > 64 in the net's "bf16" mode) and layers that did not (fc0 / fc_classif, the narrow SharedMLPs) go
         # in separate calls, so that no layer documented as fp32 is rounded
-        lo = [j for j in jobs if not (len(j) > 7 and j[7])]
-        hi = [j for j in jobs if len(j) > 7 and j[7]]
-        for part, flag in ((lo, 0), (hi, 256)):
-            if part:
-                self._launch_wgrad_batch(part, flag)
+        # (likewise the activation layout: a call's jobs all read fp32, or all read bf16, dz / x0 / x1 — M3D_IO_BF16)
+        for io in (0, IO_BF16):
+            sel = [j for j in jobs if (IO_BF16 if _h(j[0]) else 0) == io]
+            lo = [j for j in sel if not (len(j) > 7 and j[7])]
+            hi = [j for j in sel if len(j) > 7 and j[7]]
+            for part, flag in ((lo, 0), (hi, 256)):
+                if part:
+                    self._launch_wgrad_batch(part, flag | io)
 
     @staticmethod
     def _launch_wgrad_batch(jobs, bf16_flag: int) -> None:
@@ -377,6 +417,7 @@ def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None,
     M, N = dz.shape
     K = k0 + k1
     sink = out is not None
+    assert x0.dtype == dz.dtype and (x1 is None or x1.dtype == dz.dtype), (dz.dtype, x0.dtype)
     dw = out if sink else torch.empty((N, K), dtype=torch.float32, device=dz.device)
     if sink and side is not None and DEFER_WGRAD:
         side.defer((dz, x0, k0, rows, x1, k1, dw, bool(bf16)))  # launched with all the others at the end of the backward pass
@@ -386,7 +427,8 @@ def linear_wgrad(dz: Tensor, x0: Tensor, k0: int, rows: Optional[Tensor] = None,
 
     def launch():
         call("m3d_linear_wgrad_f32", _p(dz), dz.stride(0), _p(x0), x0.stride(0), _p(rows), k0, _p(x1),
-             x1.stride(0) if x1 is not None else 0, k1, M, N, _p(dw), dw.stride(0), int(sink), _p(ws), _st())
+             x1.stride(0) if x1 is not None else 0, k1, M, N, _p(dw), dw.stride(0), int(sink) | (IO_BF16 if _h(dz) else 0),
+             _p(ws), _st())
 
     if sink and side is not None:
         side.run(launch, dz, x0, x1, rows, ws)
@@ -400,15 +442,15 @@ def colsum(x: Tensor, out: Optional[Tensor] = None) -> Optional[Tensor]:
     sink = out is not None
     if not sink:
         out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
-    call("m3d_colsum_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _st())
+    call("m3d_colsum_bf16" if _h(x) else "m3d_colsum_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _st())
     return None if sink else out
 
 
 def gather_rows(src: Tensor, idx: Optional[Tensor]) -> Tensor:
     """``src[idx]`` for a row-major fp32 matrix (decimate(): pyg_randla_net.py:234-238)."""
     m = idx.numel() if idx is not None else src.shape[0]
-    out = torch.empty((m, src.shape[1]), dtype=torch.float32, device=src.device)
-    call("m3d_gather_rows", _p(src), src.stride(0), _p(idx), _p(out), m, src.shape[1], _st())
+    out = torch.empty((m, src.shape[1]), dtype=src.dtype, device=src.device)
+    call("m3d_gather_rows_bf16" if _h(src) else "m3d_gather_rows", _p(src), src.stride(0), _p(idx), _p(out), m, src.shape[1], _st())
     return out
 
 
@@ -442,10 +484,14 @@ class GradSlot:
 def scatter_add_rows(src: Tensor, idx: Tensor, n_out: int, out: Optional[Tensor] = None, distinct: bool = False) -> Tensor:
     """``out[idx[i]] += src[i]`` (``out``: an existing ``[n_out, C]`` buffer to add into; default: zeros).  ``distinct``: the
     caller guarantees that no id occurs twice (plain read-modify-writes instead of atomics)."""
+    # bf16 rows: distinct targets are a plain read-modify-write of a bf16 buffer; the ATOMIC form accumulates in fp32 (the
+    # caller gets an fp32 gradient: injected decimation indices, tests)
+    if _h(src) and not distinct:
+        assert out is None or out.dtype == torch.float32
     if out is None:
-        out = arena.zeros((n_out, src.shape[1]), torch.float32, src.device)
-    call("m3d_scatter_add_rows", _p(_chk(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1], int(distinct),
-         _st())
+        out = arena.zeros((n_out, src.shape[1]), src.dtype if distinct else torch.float32, src.device)
+    call("m3d_scatter_add_rows", _p(_chka(src)), _p(idx), _p(out), out.stride(0), src.shape[0], src.shape[1],
+         int(distinct) | (IO_BF16 if _h(src) else 0), _st())
     return out
 
 
@@ -484,9 +530,10 @@ def gather_sum_rows(src: Tensor, ptr: Tensor, inv: Optional[Tensor], n_out: int,
     list (``knn_reverse``): four lanes share a list.  ``inv=None``: list c is rows ``ptr[c] .. ptr[c + 1]`` of ``src``."""
     acc = out is not None
     if out is None:
-        out = torch.empty((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
-    call("m3d_gather_sum_rows", _p(_chk(src)), src.stride(0), _p(ptr), _p(inv) if inv is not None else None, _p(out),
-         out.stride(0), n_out, src.shape[1], int(acc) | (2 if long_lists else 0), _st())
+        out = torch.empty((n_out, src.shape[1]), dtype=src.dtype, device=src.device)
+    assert out.dtype == src.dtype
+    call("m3d_gather_sum_rows", _p(_chka(src)), src.stride(0), _p(ptr), _p(inv) if inv is not None else None, _p(out),
+         out.stride(0), n_out, src.shape[1], int(acc) | (2 if long_lists else 0) | (IO_BF16 if _h(src) else 0), _st())
     return out
 
 
@@ -635,12 +682,13 @@ def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tenso
         p1 = pv[:4]
         p2 = pv[4:] if bn2 is not None else (None,) * 4
         y = torch.empty_like(z)
+    assert y.dtype == z.dtype and (z2 is None or z2.dtype == z.dtype)
     call("m3d_bn_stats_apply", _p(stats), stats.shape[0], count, _p(bn.weight), _p(bn.bias), float(bn.eps),
          float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(p1[0]), _p(p1[1]), _p(p1[2]), _p(p1[3]),
-         _p(_chk(z)), _p(stats2), _p(bn2.weight if bn2 is not None else None),
+         _p(_chka(z)), _p(stats2), _p(bn2.weight if bn2 is not None else None),
          _p(bn2.bias if bn2 is not None else None), _p(bn2.running_mean if bn2 is not None else None),
-         _p(bn2.running_var if bn2 is not None else None), _p(p2[0]), _p(p2[1]), _p(p2[2]), _p(p2[3]), _p(z2), int(act),
-         LRELU_SLOPE, _p(y), z.shape[0], z.shape[1], _drop_ref(drop), _st())
+         _p(bn2.running_var if bn2 is not None else None), _p(p2[0]), _p(p2[1]), _p(p2[2]), _p(p2[3]), _p(z2),
+         int(act) | (IO_BF16 if _h(z) else 0), LRELU_SLOPE, _p(y), z.shape[0], z.shape[1], _drop_ref(drop), _st())
     for b in (bn, bn2):
         if b is not None and not getattr(b, "_m3d_flat_counter", False):  # flattened nets bump all counters at once
             b.num_batches_tracked += 1
@@ -711,11 +759,11 @@ def gemm_bn_on_load(pend: PendingBN, w: Tensor, M: int, N: int, bias: Optional[T
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [{pend.count}, {k0}]")
     if k0 > 64 or k0 % 4 or not pend.z.is_contiguous() or w.shape[1] != k0:
         return None
-    out = torch.empty((M, N), dtype=torch.float32, device=w.device)
+    out = torch.empty((M, N), dtype=pend.z.dtype, device=w.device)
     sc, sh, mu, isd = pend.vecs
     pro = M3DBnOnLoad(_p(pend.stats), pend.stats.shape[0], pend.count, _p(bn.weight), _p(bn.bias), float(bn.eps),
                       float(bn.momentum), _p(bn.running_mean), _p(bn.running_var), _p(sc), _p(sh), _p(mu), _p(isd),
-                      int(pend.act), LRELU_SLOPE, _p(pend.y))
+                      int(pend.act) | (IO_BF16 if _h(pend.z) else 0), LRELU_SLOPE, _p(pend.y))
     rc = lib().m3d_gemm_bn_on_load_f32(ctypes.byref(pro), _p(pend.z), k0, _p(w), w.stride(0), M, N, _p(bias), _p(stats),
                                        stats.shape[0], _p(out), out.stride(0), _st())
     if rc == -2:
@@ -733,8 +781,9 @@ def gemm_bn_on_load(pend: PendingBN, w: Tensor, M: int, N: int, bias: Optional[T
 def bn_apply(z: Tensor, scale: Tensor, shift: Tensor, act: bool, z2: Optional[Tensor] = None,
              scale2: Optional[Tensor] = None, shift2: Optional[Tensor] = None) -> Tensor:
     y = torch.empty_like(z)
-    call("m3d_bn_apply", _p(_chk(z)), _p(scale), _p(shift), _p(z2), _p(scale2), _p(shift2), int(act), LRELU_SLOPE,
-         _p(y), z.shape[0], z.shape[1], _st())
+    assert z2 is None or z2.dtype == z.dtype
+    call("m3d_bn_apply", _p(_chka(z)), _p(scale), _p(shift), _p(z2), _p(scale2), _p(shift2),
+         int(act) | (IO_BF16 if _h(z) else 0), LRELU_SLOPE, _p(y), z.shape[0], z.shape[1], _st())
     return y
 
 
@@ -749,6 +798,8 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
         sums = arena.zeros((slots, 3, N), torch.float64, dev)
     else:
         sums = torch.empty(lib().m3d_bn_bwd_workspace_bytes(M, N) // 8, dtype=torch.float64, device=dev)
+    io = _bn_io(dy, z)
+    assert z2 is None or z2.dtype == z.dtype
     dz = torch.empty_like(z)
     dz2 = dgamma2 = dbeta2 = None
     if sinks is not None:
@@ -761,12 +812,21 @@ def bn_bwd(dy, z, scale, shift, mean, invstd, act, z2=None, scale2=None, shift2=
             dgamma2, dbeta2 = torch.empty(N, device=dev), torch.empty(N, device=dev)
     if z2 is not None:
         dz2 = torch.empty_like(z2)
-    call("m3d_bn_bwd", _p(_chk(dy)), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), _p(z2), _p(scale2),
+    call("m3d_bn_bwd", _p(_chka(dy)), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), _p(z2), _p(scale2),
          _p(shift2), _p(mean2), _p(invstd2), int(act), LRELU_SLOPE, M, N, _p(sums), _p(dz), _p(dz2), _p(dgamma),
-         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None) | (slots << 8), _drop_ref(drop), _st())
+         _p(dbeta), _p(dgamma2), _p(dbeta2), int(sinks is not None) | (slots << 8) | (io << 16), _drop_ref(drop), _st())
     if sinks is not None:
         return dz, None, None, dz2, None, None
     return dz, dgamma, dbeta, dz2, dgamma2, dbeta2
+
+
+def _bn_io(dy: Tensor, z: Tensor) -> int:
+    """(M3D_IO_* >> 12) of a BatchNorm-backward launch: 0 = fp32, 1 = dy and z (dz, dx) bf16, 3 = bf16 storage with an fp32
+    dy (an incoming gradient that was accumulated with float atomics)."""
+    if not _h(z):
+        assert not _h(dy), "a bf16 gradient for an fp32 layer"
+        return 0
+    return 1 if _h(dy) else 3
 
 
 def bn_dgrad_ok(N: int) -> bool:
@@ -783,11 +843,14 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, 
     split): an existing ``[M, Kin]`` buffer the input gradient is ADDED to (and which is returned as ``dx``)."""
     M, N = z.shape
     dev = z.device
-    dy = _chk(dy)
+    dy = _chka(dy)
+    io = _bn_io(dy, z)
+    iof = io << 12  # (IO_BF16 [| IO_A32])
     ns = bn_bwd_slots(M)
     sums = arena.zeros((ns, 3, N), torch.float64, dev)
     call("m3d_bn_bwd", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), None, None, None, None, None,
-         int(act), LRELU_SLOPE, M, N, _p(sums), None, None, None, None, None, None, 2 | (ns << 8), _drop_ref(drop), _st())
+         int(act), LRELU_SLOPE, M, N, _p(sums), None, None, None, None, None, None, 2 | (ns << 8) | (io << 16),
+         _drop_ref(drop), _st())
     if sinks is not None:
         dgamma, dbeta = sinks
     else:
@@ -795,18 +858,18 @@ def bn_dgrad(dy, z, scale, shift, mean, invstd, act, w, sinks=None, bf16=False, 
     Kin = w.shape[1]
     dz = torch.empty_like(z)
     if split:
-        dx = (torch.empty((M, split), dtype=torch.float32, device=dev),
-              torch.empty((M, Kin - split), dtype=torch.float32, device=dev))
+        dx = (torch.empty((M, split), dtype=z.dtype, device=dev),
+              torch.empty((M, Kin - split), dtype=z.dtype, device=dev))
         call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
              _p(sums), ns, M, N, _p(w), w.stride(0), Kin, _p(dx[0]), split, _p(dz), _p(dgamma), _p(dbeta),
-             int(sinks is not None) | (256 if bf16 else 0), split, _p(dx[1]), Kin - split, _drop_ref(drop), _st())
+             int(sinks is not None) | (256 if bf16 else 0) | iof, split, _p(dx[1]), Kin - split, _drop_ref(drop), _st())
     else:
-        dx = acc if acc is not None else torch.empty((M, Kin), dtype=torch.float32, device=dev)
-        assert dx.shape == (M, Kin) and dx.is_contiguous()
+        dx = acc if acc is not None else torch.empty((M, Kin), dtype=z.dtype, device=dev)
+        assert dx.shape == (M, Kin) and dx.is_contiguous() and dx.dtype == z.dtype
         call("m3d_bn_dgrad_f32", _p(dy), _p(z), _p(scale), _p(shift), _p(mean), _p(invstd), int(act), LRELU_SLOPE,
              _p(sums), ns, M, N, _p(w), w.stride(0), Kin, _p(dx), Kin, _p(dz), _p(dgamma), _p(dbeta),
-             int(sinks is not None) | (256 if bf16 else 0) | (512 if acc is not None else 0), 0, None, 0, _drop_ref(drop),
-             _st())
+             int(sinks is not None) | (256 if bf16 else 0) | (512 if acc is not None else 0) | iof, 0, None, 0,
+             _drop_ref(drop), _st())
     if sinks is not None:
         return dx, dz, None, None
     return dx, dz, dgamma, dbeta
@@ -820,24 +883,28 @@ class LinearFn(torch.autograd.Function):
     accumulated straight into the flat gradient buffer and autograd gets None for them)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, sinks=None, rows=None):
+    def forward(ctx, x, w, b, sinks=None, rows=None, out_dtype=None):
         # rows: the layer reads x[rows] (a row gather fused into the GEMM's A operand — fc0 on the cell-sorted order of
         # level 1 — and into the weight gradient's); only for inputs that need no gradient themselves
+        # out_dtype: fp32 logits from bf16 activations (fc_classif of a net with bf16 activation storage)
         x = x.contiguous()
         assert rows is None or not x.requires_grad
         ctx.save_for_backward(x, w, rows)
         ctx.sinks = sinks
         ctx.side = _grad_side if sinks is not None else None
-        return gemm(x, w, x.shape[0] if rows is None else rows.numel(), w.shape[0], w.shape[1], rows=rows, bias=b)
+        return gemm(x, w, x.shape[0] if rows is None else rows.numel(), w.shape[0], w.shape[1], rows=rows, bias=b,
+                    out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, dy):
         x, w, rows = ctx.saved_tensors
         sk = ctx.sinks
         dy = dy.contiguous()
+        if _h(x) and not _h(dy):
+            dy = to_bf16(dy)  # (fp32 logits of a bf16 net: autograd hands over their gradient in fp32)
         dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
         dw = linear_wgrad(dy, x, x.shape[1], rows=rows, out=sk[0] if sk else None, side=ctx.side)
-        return dx, dw, colsum(dy, out=sk[1] if sk else None), None, None
+        return dx, dw, colsum(dy, out=sk[1] if sk else None), None, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -847,7 +914,7 @@ class LinearFn(torch.autograd.Function):
 class SharedLayerTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, w, b, gamma, beta, bn, act, rows, sinks=None, bf16=False, x0_slot=None, x1_slot=None,
-                drop=None, rows_inv=None, defer_apply=False):
+                drop=None, rows_inv=None, defer_apply=False, y_slot=None):
         # sinks = (grad_w, grad_b, grad_gamma, grad_beta) or None;  bf16: matrix-core precision of the K > 64 GEMMs
         # x0_slot: GradSlot of x0, this layer being its LAST consumer in backward order (adds its input gradient to what
         # the others deposited and returns the sum); x1_slot: GradSlot of x1, this layer being the FIRST (deposits)
@@ -855,6 +922,10 @@ class SharedLayerTrainFn(torch.autograd.Function):
         # BatchNorm kernels — masked on the way out here, the incoming gradient masked on load in the backward pass
         # rows_inv = (ptr, inv): CSR inverse of ``rows`` (csr_invert_batch) — the backward pass then sums the gathered rows'
         # gradients per source row instead of scattering them with atomics
+        # y_slot (bf16 activation storage): the layer's ONLY consumer — an LFA layer whose backward kernel accumulates its
+        # input gradient with fp32 atomics — deposits that fp32 buffer there and hands autograd an uninitialised bf16
+        # placeholder (the engine would otherwise cast every such gradient to bf16 with a kernel of its own)
+        ctx.y_slot = y_slot
         ctx.slots = (x0_slot, x1_slot)
         ctx.rows_inv = rows_inv if (rows is not None and x0.shape[1] % 4 == 0) else None
         if drop is not None:
@@ -917,6 +988,8 @@ class SharedLayerTrainFn(torch.autograd.Function):
     def backward(ctx, dy):
         x0, x1, w, z, scale, shift, mean, invstd, rows = ctx.saved_tensors
         sk = ctx.sinks
+        if ctx.y_slot is not None and ctx.y_slot.buf is not None:
+            dy = ctx.y_slot.take()  # (the consumer's real gradient: fp32; `dy` itself is a placeholder)
         k0 = x0.shape[1]
         k1 = x1.shape[1] if x1 is not None else 0
         dx0 = dx1 = None
@@ -972,7 +1045,7 @@ class SharedLayerTrainFn(torch.autograd.Function):
             dx1 = None
         dw = linear_wgrad(dz, x0, k0, rows, x1, k1, out=sk[0] if sk else None, side=ctx.side, bf16=ctx.bf16)
         db = None if sk else torch.zeros_like(dbeta)  # BatchNorm removes the mean: d/d(bias) is exactly 0
-        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx0, dx1, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 # LeakyReLU(BN(mlp2(x2)) + BN(shortcut(xs)))   (DilatedResidualBlock tail, pyg_randla_net.py:186-187)
@@ -1188,7 +1261,11 @@ class GatherRowsFn(torch.autograd.Function):
         if inverse is not None:
             return gather_rows(dy.contiguous(), inverse), None, None, None, None
         prev = ctx.slot.take() if ctx.slot is not None else None
-        if prev is not None and not (prev.shape == (ctx.n, dy.shape[1]) and prev.is_contiguous()):
+        if _h(dy) and not ctx.distinct:
+            # bf16 rows that may repeat (injected decimation indices: tests): float atomics into an fp32 buffer; autograd casts
+            res = scatter_add_rows(dy.contiguous(), idx, ctx.n)
+            return (res if prev is None else res.add_(prev)), None, None, None, None
+        if prev is not None and not (prev.shape == (ctx.n, dy.shape[1]) and prev.is_contiguous() and prev.dtype == dy.dtype):
             return scatter_add_rows(dy.contiguous(), idx, ctx.n, distinct=ctx.distinct).add_(prev), None, None, None, None
         return scatter_add_rows(dy.contiguous(), idx, ctx.n, out=prev, distinct=ctx.distinct), None, None, None, None
 
@@ -1350,16 +1427,19 @@ def lfa_forward(x: Tensor, pos4: Tensor, idx: Tensor, wf: Tensor, bf: Tensor, w_
     fl = LFA_FULL if (full and USE_LFA_FULL) else 0
     ch = w_att.shape[0]
     if K > 32:  # the fused kernels tile one centre's neighbours onto <= 2 MFMA row tiles
+        if _h(x):
+            raise ValueError("bf16 activation storage needs the fused LFA kernels: num_neighbors <= 32")
         return lfa_forward_unfused(x, pos4, idx, wf, bf, w_att)
-    out = torch.empty((n, ch), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, ch), dtype=x.dtype, device=x.device)
+    fl |= IO_BF16 if _h(x) else 0  # (x and out hold bf16)
     if bf16:
         assert wp is not None and wp.dtype == torch.int16
-        call("m3d_lfa_fwd_bf16", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out),
+        call("m3d_lfa_fwd_bf16", _p(_chka(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out),
              fl | (2 if int(bf16) == 2 else 0), _st())
         return out
     if wp is None:
         wp, _ = pack_attention_weights(w_att, False)  # named local: stays alive until the launch is enqueued
-    call("m3d_lfa_fwd", _p(_chk(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), fl, _st())
+    call("m3d_lfa_fwd", _p(_chka(x)), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), LRELU_SLOPE, _p(out), fl, _st())
     return out
 
 
@@ -1382,13 +1462,16 @@ class LFATrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos4, idx, mom, num_edges, enc_w, enc_b, enc_gamma, enc_beta, enc_lin, enc_bn, w_att,
-                sinks=None, bf16=False, prepared=None, rev=None):
+                sinks=None, bf16=False, prepared=None, rev=None, x_slot=None):
         # sinks = (grad_enc_w, grad_enc_b, grad_enc_gamma, grad_enc_beta, grad_w_att) or None
         # prepared = this layer's (wf, bf, mean, invstd, wp, wpt) from lfa_prepare_batch (one launch for all layers)
         # rev = (ptr, inv, slot): reverse neighbour lists of idx (knn_reverse) — where the kernel can store its input gradient
         #       per edge (m3d_lfa_bwd_edge_rows_ok) it writes edge e to row slot[e], i.e. every point's contributions as
         #       CONTIGUOUS rows, and the backward pass sums them per point (gather_sum_rows(inv=None)) instead of 16 / 32-byte
         #       float atomics (round 5: ~30 ps each at the L2, half of the level-1 launches)
+        # x_slot (bf16 activation storage): GradSlot shared with the layer that produced x (its y_slot) — an fp32 input
+        # gradient (float atomics) travels through it instead of through autograd, which would cast it to bf16
+        ctx.x_slot = x_slot
         ctx.rev = rev
         ctx.sinks = sinks
         ctx.side = _grad_side if sinks is not None else None
@@ -1423,9 +1506,11 @@ class LFATrainFn(torch.autograd.Function):
         dev = x.device
         sk = ctx.sinks
         dout = dout.contiguous()
+        io = IO_BF16 if _h(x) else 0  # x, dout and the edge rows hold bf16; the atomically accumulated dx stays fp32
+        assert dout.dtype == x.dtype, (dout.dtype, x.dtype)
         edge_rows = bool(ctx.rev is not None and ctx.full and not ctx.bf16 and USE_LFA_EDGE_ROWS and K <= 32 and
                          not LFATrainFn.force_unfused_backward and lib().m3d_lfa_bwd_edge_rows_ok(n, K, ch, LRELU_SLOPE))
-        dx = torch.empty((n * K, D), dtype=torch.float32, device=dev) if edge_rows else arena.zeros((n, D), torch.float32, dev)
+        dx = torch.empty((n * K, D), dtype=x.dtype, device=dev) if edge_rows else arena.zeros((n, D), torch.float32, dev)
         if K <= 32 and not LFATrainFn.force_unfused_backward:
             G = arena.zeros((11 * D,), torch.float64, dev)  # (pre-zeroed: flag bit 1 below skips the memset)
             dw_att = sk[4] if sk else torch.empty((ch, ch), dtype=torch.float32, device=dev)
@@ -1437,7 +1522,7 @@ class LFATrainFn(torch.autograd.Function):
             if tm is not None and tm["key"] == (n, ch):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            fl = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0)
+            fl = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0) | io
             if edge_rows:
                 slot = ctx.rev[2] if (len(ctx.rev) > 2 and (USE_LFA_EDGE_SLOTS or ctx.rev[1] is None)) else None
                 call("m3d_lfa_bwd_edge_rows", _p(x), _p(pos4), _p(idx), n, K, ch, _p(wf), _p(bf), _p(wp), _p(wpt), LRELU_SLOPE,
@@ -1455,8 +1540,10 @@ class LFATrainFn(torch.autograd.Function):
                 # layer's at the end of the backward pass (GradSideStream.flush) instead of two launches in the chain
                 ctx.side.defer_lfa((n, K, ch, ws, dw_att, G, mom, ctx.num_edges, enc_w, enc_b, enc_gamma, mean, invstd,
                                     sk[0], sk[1], sk[2], sk[3]))
-                return (dx,) + (None,) * 15
+                return (LFATrainFn._dx_out(ctx, x, dx),) + (None,) * 16
         else:
+            if io:
+                raise ValueError("bf16 activation storage needs the fused LFA backward kernel (num_neighbors <= 32)")
             G = torch.empty(11 * D, dtype=torch.float64, device=dev)
             dw_att = _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G)
             if sk:
@@ -1468,9 +1555,20 @@ class LFATrainFn(torch.autograd.Function):
             db, dgamma, dbeta = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
         call("m3d_lfa_enc_bwd_finalize", _p(G), _p(mom), ctx.num_edges, _p(enc_w), _p(enc_b), _p(enc_gamma), _p(mean),
              _p(invstd), _p(dw), _p(db), _p(dgamma), _p(dbeta), D, int(sk is not None), _st())
+        dx = LFATrainFn._dx_out(ctx, x, dx)
         if sk:
-            return (dx,) + (None,) * 15
-        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None, None, None
+            return (dx,) + (None,) * 16
+        return dx, None, None, None, None, dw, db, dgamma, dbeta, None, None, dw_att, None, None, None, None, None
+
+    @staticmethod
+    def _dx_out(ctx, x, dx):
+        """What autograd gets as the gradient of ``x``.  bf16 storage with an fp32 ``dx`` (float atomics): the buffer goes to the
+        producer through ``x_slot`` and autograd sees an uninitialised bf16 placeholder (no cast kernel); without a slot the
+        engine casts it (correct, one elementwise launch)."""
+        if _h(x) and not _h(dx) and ctx.x_slot is not None:
+            ctx.x_slot.buf = dx
+            return torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        return dx
 
 
 def _lfa_backward_unfused(x, pos4, idx, wf, bf, w_att, dout, dx, G):

@@ -185,6 +185,13 @@ class HipRandLANet(nn.Module):
         # the statistics stay fp32.  Also switched on by torch.autocast(dtype=bfloat16) around the call (Lightning's
         # ``trainer.precision: bf16-mixed``), like any autocast-aware module.
         self.matmul_precision = "fp32"
+        # torch.bfloat16: every feature matrix of the pass — fc0's output to the classifier's last hidden layer — and its
+        # gradient live in HBM as bf16 (round 6; BASELINE config 2 "bf16", the storage half of Lightning's ``precision: bf16``,
+        # configs/experiment/RandLaNet_base_run_FR-2x3GPUs.yaml:12): the HBM-bound SharedMLP / BatchNorm / weight-gradient chain
+        # of levels 1-2 moves half the bytes.  Parameters, statistics (fp64 sums of the fp32 accumulators), positions, kNN,
+        # softmax, the logits and every parameter gradient stay fp32; arithmetic is fp32 registers either way.  Usually paired
+        # with ``matmul_precision = "bf16"`` (operands of the matrix-bound layers rounded to bf16 for the matrix cores).
+        self.activation_dtype = torch.float32
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
         # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
         # accumulation adds; False: plain autograd (cross-check)
@@ -414,14 +421,14 @@ class HipRandLANet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _shared_layer(self, mlp: SharedMLPParams, li: int, x0: Tensor, x1: Optional[Tensor] = None,
                       rows: Optional[Tensor] = None, train: bool = False, x0_slot=None, x1_slot=None, drop=None,
-                      rows_inv=None, defer: bool = False) -> Tensor:
+                      rows_inv=None, defer: bool = False, y_slot=None) -> Tensor:
         """``defer`` (train mode): the layer's ONLY consumer is the next SharedMLP layer on the same rows — its BatchNorm +
         LeakyReLU are applied by that layer's GEMM as it loads its input (``ops.PendingBN``, round 5), no launch here."""
         lin, bn = mlp.lins[li], mlp.norms[li].module
         if train:
             sk = self._sinks(lin.weight, lin.bias, bn.weight, bn.bias) if self._use_sinks else None
             return ops.SharedLayerTrainFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows,
-                                                sk, self._bf16, x0_slot, x1_slot, drop, rows_inv, defer)
+                                                sk, self._bf16, x0_slot, x1_slot, drop, rows_inv, defer, y_slot)
         if self._grad_eval:
             return ops.SharedLayerEvalFn.apply(x0, x1, lin.weight, lin.bias, bn.weight, bn.bias, bn, mlp.act, rows)
         scale, shift = self._cached(("bn", id(bn)), lambda: ops.bn_fold_eval(bn), self._bn_deps(bn))
@@ -439,7 +446,10 @@ class HipRandLANet(nn.Module):
         return 2 if (getattr(self, "_bf16x3", False) and full and ops.USE_LFA_FULL and K in (16, 32)) else 0
 
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
-             train: bool, prepared=None, defer_post: bool = False, rev=None) -> Tensor:
+             train: bool, prepared=None, defer_post: bool = False, rev=None, x_slot=None, post_slot=None) -> Tensor:
+        """``x_slot`` / ``post_slot`` (bf16 activation storage, train): GradSlots through which an fp32 input gradient of this
+        LFA layer reaches the layer that produced ``x``, resp. through which the NEXT LFA layer's reaches this one's
+        ``mlp_post_attention`` (``ops.LFATrainFn._dx_out``)."""
         enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
         w_att = p.mlp_attention.lins[0].weight
         bf16 = self._lfa_mode(w_att.shape[0], idx.shape[1], num_edges == idx.shape[0] * idx.shape[1])
@@ -447,7 +457,7 @@ class HipRandLANet(nn.Module):
             sk = self._sinks(enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, w_att) if self._use_sinks \
                 else None
             agg = ops.LFATrainFn.apply(x, pos4, idx, mom, num_edges, enc_lin.weight, enc_lin.bias, enc_bn.weight,
-                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16, prepared, rev)
+                                       enc_bn.bias, enc_lin, enc_bn, w_att, sk, bf16, prepared, rev, x_slot)
         elif self._grad_eval:
             agg = ops.LFAEvalFn.apply(x, pos4, idx, enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias, enc_lin, enc_bn,
                                       w_att)
@@ -462,7 +472,7 @@ class HipRandLANet(nn.Module):
                                           + (None,), (enc_lin.weight, enc_lin.bias, w_att) + self._bn_deps(enc_bn))
             agg = ops.lfa_forward(x, pos4, idx, wf, bf, w_att, wp, bf16=bf16,
                                   full=bool(num_edges == idx.shape[0] * idx.shape[1]))
-        return self._shared_layer(p.mlp_post_attention, 0, agg, train=train, defer=defer_post)
+        return self._shared_layer(p.mlp_post_attention, 0, agg, train=train, defer=defer_post, y_slot=post_slot)
 
     def _block(self, blk: BlockParams, x: Tensor, pos4: Tensor, index: ops.KnnIndex, idx: Tensor,
                mom: Optional[Tensor], num_edges: int, train: bool, rec: Optional[dict], name: str,
@@ -470,20 +480,23 @@ class HipRandLANet(nn.Module):
         # idx: knn_graph(loop=True), pyg_randla_net.py:180 — rows and neighbour ids are cell-sorted slots of this level
         # x_slot (train): the block input has several consumers (mlp1, the shortcut, and on the decimated levels the FP
         # module's skip): their input gradients meet in one buffer, mlp1 — last in backward order — returns the sum
-        h = self._shared_layer(blk.mlp1, 0, x, train=train, x0_slot=x_slot)  # does not need the graph: runs while kNN finishes
+        # (bf16 storage: the fp32 input gradients of the two LFA layers travel through side slots, see _lfa)
+        s1 = ops.GradSlot() if (train and ops._h(x) and torch.is_grad_enabled()) else None
+        s2 = ops.GradSlot() if s1 is not None else None
+        h = self._shared_layer(blk.mlp1, 0, x, train=train, x0_slot=x_slot, y_slot=s1)  # does not need the graph: runs while kNN finishes
         if wait_graph is not None:
             wait_graph()
         if rec is not None:
             rec[name + ".knn_idx"] = _knn_to_reference_order(idx, index)
             rec[name + ".mlp1"] = h[index.inv.long()]
-        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train, prepared[0], rev=rev)
+        h = self._lfa(blk.lfa1, h, pos4, idx, mom, num_edges, train, prepared[0], rev=rev, x_slot=s1, post_slot=s2)
         if rec is not None:
             rec[name + ".lfa1"] = h[index.inv.long()]
         # lfa2's SharedMLP feeds mlp2 only: on levels 1-2 (<= 64 channels: the row-stream GEMM) mlp2's GEMM applies its
         # BatchNorm on load instead of a launch of its own
         defer2 = bool(train and rec is None and ops.BN_ON_LOAD and blk.mlp2.lins[0].weight.shape[1] <= 64
                       and blk.mlp2.lins[0].weight.shape[1] % 4 == 0 and torch.is_grad_enabled())
-        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1], defer_post=defer2, rev=rev)
+        h = self._lfa(blk.lfa2, h, pos4, idx, mom, num_edges, train, prepared[1], defer_post=defer2, rev=rev, x_slot=s2)
         l2, n2 = blk.mlp2.lins[0], blk.mlp2.norms[0].module
         ls, ns = blk.shortcut.lins[0], blk.shortcut.norms[0].module
         if train:
@@ -834,13 +847,23 @@ class HipRandLANet(nn.Module):
         hin: List[Optional[Tensor]] = [None]  # decimated input of block l (= skip tensor of the FP module above it)
         geo.wait(0)
         diff = train or self._grad_eval  # the pass records an autograd graph
+        # bf16 activation storage (not for the differentiable eval pass, whose BatchNorm backward is a few torch ops)
+        act16 = self.activation_dtype == torch.bfloat16 and not self._grad_eval
+        if self.activation_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"activation_dtype must be torch.float32 or torch.bfloat16, got {self.activation_dtype!r}")
+        if act16 and self.num_neighbors > 32:
+            raise ValueError("bf16 activation storage needs the fused LFA kernels: num_neighbors <= 32")
         # fc0 on the cell-sorted order of level 1: the input permutation is a row gather inside the GEMM's A operand (and inside
         # the weight gradient's); an input that needs a gradient itself takes the differentiable gather in front
         if x.requires_grad:
             x = ops.GatherRowsFn.apply(x, index[0].perm, index[0].inv)
             in_rows = None
+            if act16:
+                x = x.to(torch.bfloat16)  # (differentiable; a rare path: saliency of the input features)
         else:
             in_rows = index[0].perm
+            if act16:
+                x = ops.to_bf16(x)  # the input features once, [sum N, F]: every later kernel reads 2-byte elements
         h = ops.LinearFn.apply(x, self.fc0.weight, self.fc0.bias,
                                self._sinks(self.fc0.weight, self.fc0.bias) if self._use_sinks else None, in_rows) if diff else \
             ops.gemm(x, self.fc0.weight, pos.shape[0], self.fc0.weight.shape[0], x.shape[1], rows=in_rows, bias=self.fc0.bias)
@@ -915,7 +938,7 @@ class HipRandLANet(nn.Module):
             if dropout_mask is not None:  # given in the caller's row order
                 mask = ops.gather_rows(dropout_mask.to(h.dtype).contiguous(), index[0].perm)
                 h = h * (mask / (1.0 - p))
-            elif self._flat is not None and h.numel() % 4 == 0:
+            elif self._flat is not None and h.numel() % 4 == 0 and h.dtype == torch.float32:
                 # counter-based mask on the device step counter the step prologue advances (seeded like the decimation:
                 # torch's global seed and the rank)
                 h = ops.DropoutFn.apply(h, p, self._nbt_flat[-1:], self._dropout_seed())
@@ -924,11 +947,11 @@ class HipRandLANet(nn.Module):
         if diff:
             logits = ops.LinearFn.apply(h, self.fc_classif.weight, self.fc_classif.bias,
                                         self._sinks(self.fc_classif.weight, self.fc_classif.bias)
-                                        if self._use_sinks else None)
+                                        if self._use_sinks else None, None, torch.float32)  # (fp32 logits either way)
             logits = ops.GatherRowsFn.apply(logits, index[0].inv, index[0].perm)  # back to the caller's row order
         else:
             logits = ops.gemm(h, self.fc_classif.weight, h.shape[0], self.fc_classif.weight.shape[0], h.shape[1],
-                              bias=self.fc_classif.bias)
+                              bias=self.fc_classif.bias, out_dtype=torch.float32)
             logits = ops.gather_rows(logits, index[0].inv)
         ops.settle_pending()  # (nothing is left pending on the paths above: a guard)
         if self.return_logits:

@@ -1,0 +1,325 @@
+"""GPU parity of bf16 ACTIVATION STORAGE (round 6; BASELINE config 2 names bf16, SURVEY 8c's bar: logits within 3e-2 of the fp32
+oracle, argmax agreement >= 99 %): ``net.activation_dtype = torch.bfloat16`` keeps every feature matrix and its gradient in HBM
+as bf16 (M3D_IO_BF16 of include/m3d_hip.h) while the arithmetic stays fp32 registers.
+
+Op level: a bf16-storage kernel must compute what the fp32 kernel computes on the same (bf16-representable) values and round
+once on store — bit-exact where the summation order is fixed, a few bf16 ulps where an intermediate is re-read from its rounded
+store.  Net level: the stated tolerance against the fp32 CPU oracle on the WHOLE config-2 batch, gradients against the fp32
+kernels, the timed object (``GraphedStep``) against eager launching.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import fill_params_deterministic, rand_batch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _rnd(rs, shape, scale=1.0, device="cuda"):
+    """fp32 values that are exactly representable in bf16 (so both storage layouts hold the SAME numbers)."""
+    t = torch.from_numpy((rs.normal(0, scale, shape)).astype(np.float32)).to(device)
+    return t.to(BF).float()
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-30)
+
+
+# ----------------------------------------------------------------------------------------------- rows
+@pytest.mark.parametrize("C", [4, 32, 6, 128])
+def test_row_gather_scatter_and_list_sums_in_bf16(device, C):
+    """m3d_gather_rows_bf16, m3d_scatter_add_rows (distinct targets: bf16 read-modify-write; repeated targets: fp32 atomics from
+    bf16 rows) and m3d_gather_sum_rows on bf16 rows against the fp32 kernels on the same values."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(C)
+    n, m = 5000, 1700
+    src = _rnd(rs, (n, C))
+    idx = torch.from_numpy(rs.permutation(n)[:m].astype(np.int32)).to(device)
+    g32, g16 = ops.gather_rows(src, idx), ops.gather_rows(src.to(BF), idx)
+    assert g16.dtype == BF and torch.equal(g16.float(), g32)
+    if C % 4:
+        return
+    # distinct targets: out[idx[i]] += rows[i] into an existing buffer
+    rows = _rnd(rs, (m, C))
+    base = _rnd(rs, (n, C))
+    o32 = ops.scatter_add_rows(rows, idx, n, out=base.clone(), distinct=True)
+    o16 = ops.scatter_add_rows(rows.to(BF), idx, n, out=base.to(BF), distinct=True)
+    assert o16.dtype == BF and torch.equal(o16, o32.to(BF))
+    # repeated targets: float atomics, fp32 result either way
+    rep = torch.from_numpy(rs.randint(0, 300, (m,)).astype(np.int32)).to(device)
+    ops.arena.stop()
+    a32 = ops.scatter_add_rows(rows, rep, 300)
+    a16 = ops.scatter_add_rows(rows.to(BF), rep, 300)
+    assert a16.dtype == torch.float32 and torch.allclose(a16, a32, rtol=1e-5, atol=1e-5)
+    # CSR lists: sum of the rows of each list (fixed order: bit-exact, one rounding on store)
+    (ptr, inv), = ops.csr_invert_batch([rep], [300])
+    s32 = ops.gather_sum_rows(rows, ptr, inv, 300)
+    s16 = ops.gather_sum_rows(rows.to(BF), ptr, inv, 300)
+    assert s16.dtype == BF and torch.equal(s16, s32.to(BF))
+    l16 = ops.gather_sum_rows(rows.to(BF), ptr, inv, 300, long_lists=True)
+    assert torch.allclose(l16.float(), s32, rtol=2e-2, atol=2e-2)  # (four lanes per list: another summation order)
+    acc = ops.gather_sum_rows(rows.to(BF), ptr, inv, 300, out=s16.clone())
+    assert torch.equal(acc, (s32.to(BF).float() + s32).to(BF))
+
+
+def test_colsum_and_input_conversion_in_bf16(device):
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(3)
+    for M, N in ((204800, 32), (5001, 6), (777, 64)):
+        x = _rnd(rs, (M, N))
+        ref = ops.colsum(x)
+        got = ops.colsum(x.to(BF))
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-3), (M, N)
+    raw = torch.from_numpy(rs.normal(0, 3, (12345, 9)).astype(np.float32)).to(device)
+    assert torch.equal(ops.to_bf16(raw), raw.to(BF))  # round-to-nearest-even, like torch
+
+
+# ----------------------------------------------------------------------------------------------- SharedMLP layer
+@pytest.mark.parametrize("M,K,N,k1", [(20000, 32, 32, 0), (204800, 32, 4, 0), (51200, 64, 128, 0), (12800, 128, 256, 0),
+                                        (3200, 512, 256, 256), (51200, 128, 32, 32), (5003, 16, 16, 0), (777, 32, 64, 0)])
+def test_shared_layer_train_in_bf16_storage(device, M, K, N, k1):
+    """One SharedMLP layer in train mode (GEMM with statistics, BatchNorm apply, fused BatchNorm-backward + input gradient,
+    weight gradient; row-stream and k-loop kernels, a concatenated / gathered input) on bf16 activations against the fp32
+    kernels on the same values: forward within a few bf16 ulps (z is re-read from its rounded store), the statistics-derived
+    vectors to fp32 accuracy (they come from the UNROUNDED accumulators), gradients within 1e-2 relative L2."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(M % 89 + K + N)
+    k0 = K - k1
+    rows = None
+    if k1:
+        src_rows = M // 4
+        x0 = _rnd(rs, (src_rows, k0))
+        rows = torch.from_numpy(rs.randint(0, src_rows, (M,)).astype(np.int32)).to(device)
+        x1 = _rnd(rs, (M, k1))
+    else:
+        x0, x1 = _rnd(rs, (M, k0)), None
+    w = torch.from_numpy(rs.normal(0, K ** -0.5, (N, K)).astype(np.float32)).to(device)
+    b = torch.from_numpy(rs.normal(0, 0.1, (N,)).astype(np.float32)).to(device)
+    dy = _rnd(rs, (M, N), 0.1)
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("bf16", BF)):
+        bn = torch.nn.BatchNorm1d(N, eps=1e-6, momentum=0.01).to(device)
+        ops.arena.stop()
+        a0 = x0.to(dt).requires_grad_(True)
+        a1 = x1.to(dt).requires_grad_(True) if x1 is not None else None
+        ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.SharedLayerTrainFn.apply(a0, a1, ww, bb, bn.weight, bn.bias, bn, True, rows)
+        assert y.dtype == dt
+        y.backward(dy.to(dt))
+        torch.cuda.synchronize()
+        assert a0.grad.dtype == dt
+        res[tag] = (y.detach().float(), a0.grad.float(), None if a1 is None else a1.grad.float(), ww.grad.clone(),
+                    bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone())
+    f, h = res["f32"], res["bf16"]
+    assert torch.allclose(h[0], f[0], rtol=2e-2, atol=2e-2), (h[0] - f[0]).abs().max().item()
+    assert torch.allclose(h[6], f[6], rtol=1e-5, atol=1e-6) and torch.allclose(h[7], f[7], rtol=1e-5, atol=1e-6)
+    print(f"[parity] bf16 storage, layer {M}x{K}->{N}: dx {_rel(h[1], f[1]):.2e} dW {_rel(h[3], f[3]):.2e} "
+          f"dgamma {_rel(h[4], f[4]):.2e} dbeta {_rel(h[5], f[5]):.2e}")
+    assert _rel(h[1], f[1]) <= 1.5e-2 and _rel(h[3], f[3]) <= 1e-2
+    if f[2] is not None:
+        assert _rel(h[2], f[2]) <= 1.5e-2
+    assert _rel(h[4], f[4]) <= 1e-2 and _rel(h[5], f[5]) <= 1e-2
+
+
+@pytest.mark.parametrize("M,N,Kin", [(51200, 32, 32), (12800, 128, 128), (3200, 64, 256)])
+def test_bn_backward_with_an_fp32_incoming_gradient(device, M, N, Kin):
+    """M3D_IO_A32: a layer with bf16 storage whose incoming gradient is fp32 (the LFA layers accumulate their input gradient
+    with float atomics) — the fused BatchNorm-backward + input-gradient launch and the two-pass path read dy as fp32, z as bf16
+    and write dz / dx as bf16: the same numbers as with a bf16 dy holding the same values."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(N + Kin)
+    z = _rnd(rs, (M, N))
+    dy = _rnd(rs, (M, N), 0.1)
+    w = torch.from_numpy(rs.normal(0, Kin ** -0.5, (N, Kin)).astype(np.float32)).to(device)
+    sc, sh, mu, isd = (torch.from_numpy(rs.uniform(0.5, 1.5, N).astype(np.float32)).to(device) for _ in range(4))
+    ops.arena.stop()
+    outs = []
+    for g in (dy.to(BF), dy):  # bf16 dy, then the same values as fp32 (A32)
+        dx, dz, dgam, dbet = ops.bn_dgrad(g, z.to(BF), sc, sh, mu, isd, True, w)
+        dz2, dgam2, dbet2, _, _, _ = ops.bn_bwd(g, z.to(BF), sc, sh, mu, isd, True)
+        assert dx.dtype == BF and dz.dtype == BF and dz2.dtype == BF
+        outs.append((dx, dz, dgam, dbet, dz2))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.allclose(a_.float(), b_.float(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(outs[0][1].float(), outs[0][4].float(), rtol=2e-2, atol=1e-4)  # fused vs two-pass dz
+    # against the all-fp32 kernels
+    dx32, dz32, _, _ = ops.bn_dgrad(dy, z, sc, sh, mu, isd, True, w)
+    assert _rel(outs[1][0], dx32) <= 1e-2 and _rel(outs[1][1], dz32) <= 1e-2
+
+
+# ----------------------------------------------------------------------------------------------- LFA
+@pytest.mark.parametrize("ch,sizes", [(8, [700, 333]), (16, [1000, 41, 600]), (32, [900, 500]), (64, [640, 300]),
+                                       (128, [400, 200]), (256, [300, 120])])
+def test_lfa_layer_in_bf16_storage(device, ch, sizes):
+    """LocalFeatureAggregation (gather, encoder, attention product, softmax, pooling) and its backward kernel — the
+    complete-neighbourhood kernels of every channel count, edge rows + reverse lists at ch 8 / 16, float atomics above — with
+    x, out, dout and the edge rows in bf16 against the fp32 kernels on the same values."""
+    from myria3d_amd import ops
+    from myria3d_amd.randla import LFAParams
+
+    k = 16
+    rs = np.random.RandomState(ch)
+    n = sum(sizes)
+    pos = torch.from_numpy(rs.uniform(0, 1, (n, 3)).astype(np.float32)).to(device)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64, device=device)
+    index = ops.KnnIndex(ops.pad_pos(pos), ptr)
+    idx, _ = index.query(k, qry=index, sorted_io=True)
+    pos4 = index.sorted_pos4
+    mom = ops.lfa_moments(pos4, idx)
+    rev = ops.knn_reverse(idx, with_inv=False)
+    p = LFAParams(ch)
+    fill_params_deterministic(p, ch)
+    p = p.to(device)
+    x = _rnd(rs, (n, ch // 2))
+    dout = _rnd(rs, (n, ch), 0.1)
+    enc_lin, enc_bn = p.mlp_encoder.lins[0], p.mlp_encoder.norms[0].module
+    w_att = p.mlp_attention.lins[0].weight
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("bf16", BF)):
+        ops.arena.stop()
+        for q in p.parameters():
+            q.grad = None
+        xin = x.to(dt).requires_grad_(True)
+        slot = ops.GradSlot()
+        out = ops.LFATrainFn.apply(xin, pos4, idx, mom, n * k, enc_lin.weight, enc_lin.bias, enc_bn.weight, enc_bn.bias,
+                                   enc_lin, enc_bn, w_att, None, 0, None, rev, slot)
+        assert out.dtype == dt
+        out.backward(dout.to(dt))
+        torch.cuda.synchronize()
+        dx = slot.take() if slot.buf is not None else xin.grad
+        if tag == "bf16":
+            # ch <= 16: edge rows + list sums -> a bf16 gradient through autograd; above: fp32 atomics -> the side slot
+            assert (dx.dtype == BF) == (ch <= 16), (ch, dx.dtype)
+        res[tag] = (out.detach().float(), dx.float(), w_att.grad.clone(), enc_lin.weight.grad.clone())
+    f, h = res["f32"], res["bf16"]
+    assert torch.allclose(h[0], f[0], rtol=1e-2, atol=1e-2), (h[0] - f[0]).abs().max().item()  # one rounding on store
+    print(f"[parity] bf16 storage, LFA ch={ch}: out {_rel(h[0], f[0]):.2e} dx {_rel(h[1], f[1]):.2e} dW_att {_rel(h[2], f[2]):.2e} "
+          f"dW_enc {_rel(h[3], f[3]):.2e}")
+    assert _rel(h[0], f[0]) <= 4e-3 and _rel(h[1], f[1]) <= 1e-2
+    assert _rel(h[2], f[2]) <= 1e-3 and _rel(h[3], f[3]) <= 1e-3  # (parameter gradients: same inputs, fp32 sums)
+
+
+# ----------------------------------------------------------------------------------------------- the net
+def _net_pair(device, seed=16, k=16):
+    from myria3d_amd import HipRandLANet
+    from oracle.randla_oracle import RandLANetOracle
+
+    ref = RandLANetOracle(9, 6, num_neighbors=k, return_logits=True, knn="kdtree")
+    fill_params_deterministic(ref, seed)
+    net = HipRandLANet(9, 6, num_neighbors=k, return_logits=True)
+    net.load_state_dict(ref.state_dict())
+    return ref, net.to(device)
+
+
+def test_config2_full_batch_eval_logits_with_bf16_storage(device):
+    """SURVEY 8c's bf16 bar on BASELINE config 2's WHOLE batch (16 x 12 800 points, the bench's launch shapes): eval logits
+    within 3e-2 of the fp32 CPU oracle, argmax agreement >= 99 % — with bf16 activation storage alone and together with bf16
+    matrix-core operands (the ``bf16`` leg of bench.py)."""
+    from oracle.randla_oracle import fixed_decimation_indices, synthetic_batch
+
+    x, pos, batch, ptr, _ = synthetic_batch([12800] * 16)
+    ref, net = _net_pair(device)
+    ref.eval(), net.eval()
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=12)
+    args = (x.to(device), pos.to(device), None, ptr.to(device))
+    with torch.no_grad():
+        out_r = ref(x, pos, batch, ptr, decimation_idx=dec)
+        out32 = net(*args, decimation_idx=dec)
+        for mm in ("fp32", "bf16"):
+            net.matmul_precision, net.activation_dtype = mm, BF
+            out = net(*args, decimation_idx=dec)
+            assert out.dtype == torch.float32 and out.shape == out_r.shape
+            assert not torch.equal(out, out32), "the bf16-storage kernels really ran"
+            err = (out.cpu() - out_r).abs().max().item()
+            agree = (out.cpu().argmax(1) == out_r.argmax(1)).float().mean().item()
+            print(f"[parity] bf16 storage (matmul {mm}), config-2 batch: max |d logit| = {err:.3e} (bar 3e-2), argmax agreement "
+                  f"{agree:.5f} (bar 0.99), logit range {out_r.abs().max().item():.2f}")
+            assert err <= 3e-2 and agree >= 0.99
+
+
+def test_train_step_with_bf16_storage_against_the_fp32_kernels(device):
+    """Train-mode forward + cross-entropy + backward on 2 x 12 800 points with bf16 activation storage (flat buffers, deferred
+    weight gradients, fused dropout off): train logits within 3e-2 of the fp64 oracle, the loss within 2e-3, every parameter
+    receives a finite gradient, and every gradient is within 0.25 relative L2 of the fp32 kernels' (median <= 3e-2): bf16 has
+    8 mantissa bits — this is the contract of the mode, not of the fp32 path."""
+    from myria3d_amd import FusedAdam, cross_entropy
+    from oracle.randla_oracle import fixed_decimation_indices, synthetic_batch
+
+    x, pos, batch, ptr, y = synthetic_batch([12800, 12800])
+    dec = fixed_decimation_indices(ptr.tolist(), 4, seed=3)
+    mask = torch.ones(25600, 32)
+    ref, _ = _net_pair(device, seed=7)
+    ref = ref.double().train()
+    out_r = ref(x.double(), pos.double(), batch, ptr, decimation_idx=dec, dropout_mask=mask.double())
+    loss_r = torch.nn.functional.cross_entropy(out_r, y).item()
+    grads = {}
+    for tag, dt in (("fp32", torch.float32), ("bf16", BF)):
+        _, net = _net_pair(device, seed=7)
+        net.flatten_parameters()
+        opt = FusedAdam(net, lr=1e-3)
+        net.train()
+        net.activation_dtype = dt
+        out = net(x.to(device), pos.to(device), None, ptr.to(device), decimation_idx=dec, dropout_mask=mask.to(device))
+        loss = cross_entropy(out, y.to(device), ignore_index=65)
+        loss.backward()
+        opt.reduce_gradients()
+        torch.cuda.synchronize()
+        assert out.dtype == torch.float32
+        err = (out.detach().cpu().double() - out_r.detach()).abs().max().item()
+        print(f"[parity] {tag} storage: train logits max |d| vs fp64 oracle {err:.3e}, loss {loss.item():.6f} vs {loss_r:.6f}")
+        assert err <= (3e-2 if dt == BF else 1e-3)
+        assert abs(loss.item() - loss_r) <= (2e-3 if dt == BF else 1e-4) * max(1.0, abs(loss_r))
+        grads[tag] = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        for k, g in grads[tag].items():
+            assert bool(torch.isfinite(g).all()), k
+    rels = sorted(((_rel(grads["bf16"][k], g), k) for k, g in grads["fp32"].items() if g.norm().item() > 1e-6), reverse=True)
+    med = rels[len(rels) // 2][0]
+    print(f"[parity] bf16 storage vs fp32 kernels, parameter gradients: worst relative L2 {rels[0][0]:.3e} ({rels[0][1]}), "
+          f"median {med:.3e}")
+    assert rels[0][0] <= 0.25 and med <= 3e-2, rels[:4]
+
+
+def test_graphed_step_runs_in_bf16_storage_and_matches_eager_launching(device):
+    """The timed object in the bf16 leg's configuration (bf16 storage + bf16 matrix-core operands, fused dropout, Adam in the
+    graph): three replayed steps follow three eagerly launched ones (same seeds, same draws) — losses within 2e-3."""
+    from myria3d_amd import FusedAdam, GraphedStep, HipRandLANet, cross_entropy
+
+    sizes = [2600, 2200]
+    xa, pa, _, ptr = rand_batch(sizes, seed=41)
+    ya = torch.from_numpy(np.random.RandomState(7).randint(0, 6, (sum(sizes),)))
+    a = (xa.to(device), pa.to(device), ya.to(device))
+
+    def fresh():
+        net = HipRandLANet(9, 6, return_logits=True)
+        fill_params_deterministic(net, 31)
+        net = net.to(device).flatten_parameters().train()
+        net.matmul_precision, net.activation_dtype = "bf16", BF
+        net._drop_seed = 1234
+        return net, FusedAdam(net, lr=1e-3, eps=0.1)
+
+    net_e, opt_e = fresh()
+    net_e.set_decimation_seed(5)
+    ptrd = ptr.to(device)
+    eager = []
+    for _ in range(3):
+        loss = cross_entropy(net_e(a[0], a[1], None, ptrd), a[2], ignore_index=65)
+        loss.backward()
+        opt_e.step()
+        eager.append(loss.item())
+    net_g, opt_g = fresh()
+    gs = GraphedStep(net_g, ptr, 9, mode="train", optimizer=opt_g)
+    gs.load_all(*a)
+    gs.prepare()
+    net_g.set_decimation_seed(5)
+    for i in range(3):
+        loss = gs.step()
+        torch.cuda.synchronize()
+        print(f"[parity] bf16 leg, step {i}: graph {loss.item():.6f} eager {eager[i]:.6f}")
+        assert np.isfinite(loss.item()) and abs(loss.item() - eager[i]) <= 2e-3 * max(1.0, abs(eager[i]))

@@ -13,7 +13,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def test_batchnorm_column_sums_keep_their_row_loads_in_flight():
     """Round 4's largest single gain (4.46 -> 4.31 ms per step) was a row loop that had become a chain of dependent round trips
     because loads sat behind null checks inside it.  ``bn_bwd_reduce_kernel`` must have NO loop block whose full
-    ``s_waitcnt vmcnt(0)`` follows one or two loads, in any of its four instantiations."""
+    ``s_waitcnt vmcnt(0)`` follows one or two loads, in any of its twelve instantiations (<Z2, DROP> x the three activation
+    layouts of round 6: fp32, bf16, bf16 with an fp32 dy)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import isa_audit
@@ -21,7 +22,7 @@ def test_batchnorm_column_sums_keep_their_row_loads_in_flight():
         sys.path.pop(0)
     rows = isa_audit.audit(os.path.join(ROOT, "myria3d_amd", "csrc", "bn.hip"), [])
     reduce_rows = [r for r in rows if "bn_bwd_reduce_kernel" in r[3]]
-    assert len(reduce_rows) == 4, [r[3] for r in rows]  # <Z2, DROP> = four instantiations, each with loop blocks
+    assert len(reduce_rows) == 12, [r[3] for r in rows]  # <Z2, DROP, IO> = twelve instantiations, each with loop blocks
     for flagged, blocks, fewest, name in reduce_rows:
         assert flagged == 0, (name, flagged, blocks, fewest)
 
@@ -43,10 +44,11 @@ def test_complete_neighbourhood_lfa_forward_kernels_keep_their_instruction_diet(
                         src, "-o", tmp.name], check=True, cwd=os.path.dirname(src))
         text = open(tmp.name).read()
     kernels = {}
-    for m in re.finditer(r"^(_Z19lfa_fwd_full_kernelILi(\d+)ELi(\d+)ELi0EEv7LfaArgs):.*?\.Lfunc_end", text, re.S | re.M):
+    kernels16 = {}  # the same kernels with bf16 activation storage (IOH, round 6)
+    for m in re.finditer(r"^(_Z19lfa_fwd_full_kernelILi(\d+)ELi(\d+)ELi0ELb([01])EEv7LfaArgs):.*?\.Lfunc_end", text, re.S | re.M):
         body = [ln.strip().split()[0] for ln in m.group(0).split("\n")[1:] if ln.strip() and not ln.strip().startswith((";", "."))
                 and not ln.strip().endswith(":")]
-        kernels[(int(m.group(2)), int(m.group(3)))] = body
+        (kernels16 if m.group(4) == "1" else kernels)[(int(m.group(2)), int(m.group(3)))] = body
     assert (8, 16) in kernels and (16, 16) in kernels and (64, 16) in kernels, sorted(kernels)
     valu = lambda ops: sum(1 for o in ops if o.startswith("v_") and not o.startswith(("v_mfma", "v_accvgpr")))
     assert valu(kernels[(8, 16)]) <= 300, valu(kernels[(8, 16)])
@@ -58,6 +60,12 @@ def test_complete_neighbourhood_lfa_forward_kernels_keep_their_instruction_diet(
         assert sum(1 for o in ops if o.startswith("s_and_saveexec")) <= 4, (key, "exec-mask branches")
     # K = 32: exactly the three joins of the two half neighbourhoods (maximum, numerator, denominator) per column tile
     assert sum(1 for o in kernels[(16, 32)] if o.startswith("v_permlane16_swap")) == 3
+    # bf16 activation storage: the widening of the gathered rows (shift / mask) and the rounding of the stored outputs
+    # (v_cvt_pk_bf16_f32) cost a few instructions per thread, nothing more
+    for key, extra in (((8, 16), 24), ((16, 16), 24), ((64, 16), 40)):
+        assert key in kernels16, sorted(kernels16)
+        assert valu(kernels16[key]) <= valu(kernels[key]) + extra, (key, valu(kernels16[key]), valu(kernels[key]))
+        assert not any(o.startswith("v_permlane") for o in kernels16[key]), key
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc (cross-compiles without a GPU)")
@@ -78,15 +86,16 @@ def test_wave_autonomous_lfa_backward_has_no_barrier_and_no_spill():
     seen = 0
     for ch in (8, 16):
         for edge in (0, 1):
-            m = re.search(r"^_Z20lfa_bwd_small_kernelILi%dELb%dEEv10LfaBwdArgsi:.*?\.Lfunc_end" % (ch, edge), text, re.S | re.M)
-            assert m, (ch, edge)
+          for io in (0, 1):  # (fp32 / bf16 activation storage: the same structure)
+            m = re.search(r"^_Z20lfa_bwd_small_kernelILi%dELb%dELb%dEEv10LfaBwdArgsi:.*?\.Lfunc_end" % (ch, edge, io), text, re.S | re.M)
+            assert m, (ch, edge, io)
             ops = [ln.strip().split()[0] for ln in m.group(0).split("\n")[1:] if ln.strip() and not ln.strip().startswith((";", "."))
                    and not ln.strip().endswith(":")]
-            assert not any(o == "s_barrier" for o in ops), (ch, edge, "workgroup barrier")
-            assert not any(o.startswith("scratch_") for o in ops), (ch, edge, "register spill")
-            assert sum(1 for o in ops if o.startswith("s_load_dword")) >= 6, (ch, edge, "encoder weights not on the scalar path")
+            assert not any(o == "s_barrier" for o in ops), (ch, edge, io, "workgroup barrier")
+            assert not any(o.startswith("scratch_") for o in ops), (ch, edge, io, "register spill")
+            assert sum(1 for o in ops if o.startswith("s_load_dword")) >= 6, (ch, edge, io, "encoder weights not on the scalar path")
             atom = sum(1 for o in ops if o.startswith("global_atomic"))
-            assert atom == (0 if edge else 16), (ch, edge, atom)
-            assert sum(1 for o in ops if o.startswith("v_mfma")) == 48, (ch, edge)
+            assert atom == (0 if edge else 16), (ch, edge, io, atom)
+            assert sum(1 for o in ops if o.startswith("v_mfma")) == 48, (ch, edge, io)
             seen += 1
-    assert seen == 4
+    assert seen == 8
