@@ -1404,9 +1404,9 @@ static int launch_lfa_bwd_io(const LfaBwdArgs& a, const BwdPlan& p, hipStream_t 
   // software-pipelined variant: per channel count where it measured faster (profiles/r01p_*; BWD_PIPE_* at compile time)
   constexpr bool pipe = CH <= 64 && !(LFA_BWD_DBG & ~1) &&  // (bit 0, no dx atomics, keeps the pipelined kernel: no `continue` in it)
                         (CH == 8 ? BWD_PIPE_8 : (CH == 16 ? BWD_PIPE_16 : (CH == 32 ? BWD_PIPE_32 : BWD_PIPE_64)));
-  if constexpr (CH >= 64) {
+  if constexpr (CH >= 32) {
     if (bf16) {  // bf16 matrix-core operands for the three attention GEMMs
-      constexpr bool P = CH == 64;
+      constexpr bool P = pipe;
       if (full && x3) {
         if (a.K == 16) hipLaunchKernelGGL((lfa_bwd_kernel<CH, 16, P, true, true, true, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
         else hipLaunchKernelGGL((lfa_bwd_kernel<CH, 32, P, true, true, true, IOH>), dim3(p.grid), dim3(NTHR), 0, st, a);
@@ -1461,7 +1461,7 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   if (n < 0 || K < 1 || CH < 8) return M3D_ERR_INVALID;
   if (K > 32) return M3D_ERR_UNSUPPORTED;
   if (CH != 8 && CH != 16 && CH != 32 && CH != 64 && CH != 128 && CH != 256) return M3D_ERR_UNSUPPORTED;
-  if (bf16 && CH < 64) return M3D_ERR_UNSUPPORTED;
+  if (bf16 && CH < 32) return M3D_ERR_UNSUPPORTED;
   if (!dw_att || !G || !ws) return M3D_ERR_INVALID;
   if (n > 0 && (!x || !pos4 || !idx || !enc_w_folded || !enc_b_folded || !att_w_packed || !att_wt_packed || !dout || !dx))
     return M3D_ERR_INVALID;

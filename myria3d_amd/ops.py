@@ -1349,8 +1349,10 @@ def lfa_enc_fold(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int):
 
 
 def lfa_bf16_ok(ch: int, K: int) -> bool:
-    """The bf16 matrix-core variants exist where the layer is matrix-bound: ch >= 64 (and K <= 32)."""
-    return ch >= 64 and K <= 32
+    """The bf16 matrix-core variants of the LFA kernels exist for ch >= 32 (one 32-deep bf16 k-step; and K <= 32).  The net
+    uses them from ch = 64 in the split-bf16 mode (where the layer is matrix-bound) and from ch = 32 in the bf16 mode
+    (round 6: the level-2 lfa1 layer, 94 -> ~70 us backward)."""
+    return ch >= 32 and K <= 32
 
 
 def lfa_prepare(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int, w_att: Tensor, bf16: bool, want_t: bool):

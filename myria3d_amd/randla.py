@@ -443,7 +443,7 @@ class HipRandLANet(nn.Module):
             return 0
         if self._bf16:
             return 1
-        return 2 if (getattr(self, "_bf16x3", False) and full and ops.USE_LFA_FULL and K in (16, 32)) else 0
+        return 2 if (ch >= 64 and getattr(self, "_bf16x3", False) and full and ops.USE_LFA_FULL and K in (16, 32)) else 0
 
     def _lfa(self, p: LFAParams, x: Tensor, pos4: Tensor, idx: Tensor, mom: Optional[Tensor], num_edges: int,
              train: bool, prepared=None, defer_post: bool = False, rev=None, x_slot=None, post_slot=None) -> Tensor:

@@ -1023,7 +1023,7 @@ def test_lfa_backward_edge_rows_are_declined_where_no_kernel_stores_them(device)
     assert rc == -2  # M3D_ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("ch,k,n", [(64, 16, 3000), (128, 16, 2500), (256, 16, 1500), (64, 32, 1500), (256, 32, 900),
+@pytest.mark.parametrize("ch,k,n", [(32, 16, 3000), (32, 32, 1200), (64, 16, 3000), (128, 16, 2500), (256, 16, 1500), (64, 32, 1500), (256, 32, 900),
                                     (64, 16, 17000)])
 def test_lfa_bf16_matrix_core_variant(device, ch, k, n):
     """BASELINE config 2's "bf16": the attention GEMMs of the LFA kernels on bf16 matrix cores (fp32 accumulate, fp32

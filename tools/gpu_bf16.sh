@@ -5,7 +5,7 @@ set -u
 TAG=${1:-b}; FULL=${2:-}
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout -s KILL 900 python -m pytest tests/test_gpu_bf16_storage.py -q -s --timeout 400 -x 2>&1 | grep -v "^  File\|^Extension modules\|amdgpu.ids" > $OUT/pytest_bf16_$TAG.log
+timeout -s KILL 900 python -m pytest tests/test_gpu_bf16_storage.py -q -s --timeout 400 2>&1 | grep -v "^  File\|^Extension modules\|amdgpu.ids" > $OUT/pytest_bf16_$TAG.log
 grep -E "passed|failed" $OUT/pytest_bf16_$TAG.log | tail -2 | cut -c1-200
 grep -E "^(FAILED|ERROR)|Error|assert |^E  " $OUT/pytest_bf16_$TAG.log | head -60 | cut -c1-300
 grep -E "^\[parity\]" $OUT/pytest_bf16_$TAG.log | cut -c1-230
@@ -23,4 +23,7 @@ if [ -n "$FULL" ]; then
   timeout -s KILL 1500 python -m pytest tests -m gpu -q --timeout 600 -x 2>&1 | grep -v "^  File\|^Extension modules\|amdgpu.ids" > $OUT/pytest_gpu_full_$TAG.log
   grep -E "passed|failed" $OUT/pytest_gpu_full_$TAG.log | tail -2 | cut -c1-200
   grep -E "^(FAILED|ERROR)|^E  " $OUT/pytest_gpu_full_$TAG.log | head -40 | cut -c1-300
+fi
+if [ "${3:-}" = "trace" ]; then
+  bash tools/gpu_trace_analyze.sh ${TAG}_bf16 "--launch graph --precision bf16" 2>&1 | grep -E "^step:|per queue|^  " | head -16
 fi

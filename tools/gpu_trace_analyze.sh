@@ -24,7 +24,7 @@ if len(adam) >= 4:
     with open(os.path.join(os.environ.get("OUT", "."), "step_timeline_" + os.environ.get("TAG", "t") + ".csv"), "w") as fh:
         fh.write("start_us,dur_us,queue,grid_x,kernel\n")
         for s_, e_, n_, q_, g_ in seg:
-            short = n_.split('(')[0][:70]
+            short = n_.split('(')[0].replace('void ', '').replace(',', ';').replace(' ', '')[:100]
             if "at::native" in n_:  # torch kernels: the functor says what it is (the template head does not)
                 import re
                 m_ = re.search(r"(CUDAFunctor\w+<[\w ]+>|FillFunctor<[\w ]+>|fused_dropout\w+|masked_scale\w+|\w+Functor\w*<[\w ]+>|normal_kernel|CatArray\w+)", n_)
