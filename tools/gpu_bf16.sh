@@ -20,7 +20,7 @@ except Exception as e:
 PY
 done
 if [ -n "$FULL" ]; then
-  timeout -s KILL 1500 python -m pytest tests -m gpu -q --timeout 600 -x 2>&1 | grep -v "^  File\|^Extension modules\|amdgpu.ids" > $OUT/pytest_gpu_full_$TAG.log
+  timeout -s KILL 1500 python -m pytest tests -m gpu -q --timeout 600 2>&1 | grep -v "^  File\|^Extension modules\|amdgpu.ids" > $OUT/pytest_gpu_full_$TAG.log
   grep -E "passed|failed" $OUT/pytest_gpu_full_$TAG.log | tail -2 | cut -c1-200
   grep -E "^(FAILED|ERROR)|^E  " $OUT/pytest_gpu_full_$TAG.log | head -40 | cut -c1-300
 fi
