@@ -1349,9 +1349,14 @@ def lfa_enc_fold(enc_lin, enc_bn, mom: Optional[Tensor], num_edges: int):
 
 
 def lfa_bf16_ok(ch: int, K: int) -> bool:
-    """The bf16 matrix-core variants of the LFA kernels exist for ch >= 32 (one 32-deep bf16 k-step; and K <= 32).  The net
-    uses them from ch = 64 in the split-bf16 mode (where the layer is matrix-bound) and from ch = 32 in the bf16 mode
-    (round 6: the level-2 lfa1 layer, 94 -> ~70 us backward)."""
+    """The bf16 matrix-core variants are used where the layer is matrix-bound: ch >= 64 (and K <= 32).  (The kernels exist from
+    ch = 32 — tests/test_gpu_ops.py::test_lfa_bf16_matrix_core_variant — but at ch = 32 they measured nothing, 3.075 vs 3.083
+    ms per step, and cost block 1's attention-weight gradient 0.09 -> 0.19 relative L2 against the fp32 kernels: round 6.)"""
+    return ch >= 64 and K <= 32
+
+
+def lfa_bf16_kernels_ok(ch: int, K: int) -> bool:
+    """Shapes the bf16 matrix-core LFA kernels are instantiated for (``LFATrainFn`` honours a caller's request there)."""
     return ch >= 32 and K <= 32
 
 
@@ -1479,7 +1484,7 @@ class LFATrainFn(torch.autograd.Function):
         ctx.side = _grad_side if sinks is not None else None
         x = x.contiguous()
         K = idx.shape[1]
-        bf16 = int(bf16) if lfa_bf16_ok(w_att.shape[0], K) else 0  # 0 fp32, 1 bf16 operands, 2 split-bf16 (three products)
+        bf16 = int(bf16) if lfa_bf16_kernels_ok(w_att.shape[0], K) else 0  # 0 fp32, 1 bf16 operands, 2 split-bf16 (three products)
         if bf16 == 2 and not (num_edges == idx.shape[0] * K and USE_LFA_FULL and K in (16, 32)):
             assert prepared is None, "split-bf16 needs complete neighbourhoods: the caller packs fp32 weights otherwise"
             bf16 = 0  # (the split product exists in the complete-neighbourhood kernels only)
