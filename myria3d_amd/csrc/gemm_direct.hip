@@ -264,9 +264,12 @@ __device__ __forceinline__ void fpro_setup(const GemmArgs& g, float (&cf)[2][64]
   for (int k = threadIdx.x; k < 64; k += 256) {
     float sc = 0.f, sh = 0.f;
     if (k < K) {
-      const float gam0 = (g.fpro_gamma ? g.fpro_gamma : g.fpro_scale)[k], bet0 = (g.fpro_beta ? g.fpro_beta : g.fpro_scale)[k];
-      const float rm = (writer && g.fpro_rmean ? g.fpro_rmean : g.fpro_scale)[k];
-      const float rv = (writer && g.fpro_rvar ? g.fpro_rvar : g.fpro_scale)[k];
+      // (absent operands read the slot table instead — a read-only address — and are dropped: a load under its own branch
+      // would be waited for there; never through fpro_scale, which workgroup (0, 0) is writing: ADVICE r5)
+      const float* dummy = (const float*)g.fpro_slots;
+      const float gam0 = (g.fpro_gamma ? g.fpro_gamma : dummy)[k], bet0 = (g.fpro_beta ? g.fpro_beta : dummy)[k];
+      const float rm = (writer && g.fpro_rmean ? g.fpro_rmean : dummy)[k];
+      const float rv = (writer && g.fpro_rvar ? g.fpro_rvar : dummy)[k];
       const float gam = g.fpro_gamma ? gam0 : 1.f, bet = g.fpro_beta ? bet0 : 0.f;
       double sq[2];
       slot_sums<2>(g.fpro_slots + k, g.fpro_nslots, 2 * (size_t)K, (size_t)K, sq);

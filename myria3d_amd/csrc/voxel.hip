@@ -742,6 +742,21 @@ extern "C" int m3d_tile_select(const float* pos, int32_t pos_stride, int64_t n, 
   hipStream_t st = (hipStream_t)stream;
   const int64_t nwg = m3d_cdiv(n > 0 ? n : 1, TS_CHUNK);
   if (S * nwg + 1 >= (1ll << 31)) return M3D_ERR_UNSUPPORTED;
+  {
+    // the write pass keeps a 12-byte record per sample in DYNAMIC LDS on top of the kernels' static 16 KB: beyond
+    // the default 64 KB per workgroup the launch has to ask for it (gfx950: 160 KB per CU), and what the device cannot give
+    // is reported as "unsupported", not as a failed launch
+    const size_t dyn = (size_t)S * 12 + 16;
+    int dev = 0, lim = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+      return M3D_ERR_LAUNCH;
+    if (dyn + 16384 > (size_t)lim) return M3D_ERR_UNSUPPORTED;
+    if (dyn + 16384 > 65536 &&
+        (hipFuncSetAttribute((const void*)tile_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess ||
+         hipFuncSetAttribute((const void*)tile_select_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess))
+      return M3D_ERR_UNSUPPORTED;
+  }
   char* p = (char*)ws;
   int32_t* hist = (int32_t*)p; p += al256((size_t)(S * nwg + 1) * 4);
   float* part = (float*)p;  // [1024][2] partial minima, then [2] final at part + 2048

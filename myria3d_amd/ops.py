@@ -747,6 +747,15 @@ def settle_pending() -> None:
         _pending.pop().materialize()
 
 
+def drop_pending() -> None:
+    """Start of a forward: entries a forward that RAISED left behind (out of memory, a one-row BatchNorm) are forgotten, not
+    materialised — that would push an extra momentum update of the old batch's statistics into the running buffers, on
+    whatever net and stream happen to be current."""
+    global _last_pending
+    _pending.clear()
+    _last_pending = None
+
+
 def gemm_bn_on_load(pend: PendingBN, w: Tensor, M: int, N: int, bias: Optional[Tensor], stats: Tensor) -> Optional[Tensor]:
     """``C = lrelu(BN(pend.z)) W^T + bias`` with slot-mode statistics into ``stats``; also writes ``pend.y`` and
     ``pend.vecs`` and updates the running statistics.  None when the shape is not covered (nothing was launched)."""

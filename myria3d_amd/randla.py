@@ -557,11 +557,12 @@ class HipRandLANet(nn.Module):
         g = _Geometry(main, side)
         if side is not main and wait_main:
             side.wait_stream(main)
-        for _ in self._geometry_stages(g, pos, plan, decimation_idx, train):
+        # (in place, inside the forward: whether a backward pass can follow is known)
+        for _ in self._geometry_stages(g, pos, plan, decimation_idx, train, differentiable=torch.is_grad_enabled()):
             pass
         return g
 
-    def _reverse_neighbours(self, plan: LevelPlan, lvl: int, idx: Tensor, train: bool):
+    def _reverse_neighbours(self, plan: LevelPlan, lvl: int, idx: Tensor, train: bool, differentiable: bool = True):
         """(ptr, inv, slot): reverse neighbour lists of a level's K-NN table — point j's list holds the edges (i, k) with idx[i][k] == j — for the
         levels whose LFA backward kernels store their input gradient per EDGE instead of adding it with float atomics
         (``m3d_lfa_bwd`` flags bit 5: the 8 / 16-channel layers of block 1 with complete neighbourhoods; round 5: the atomics
@@ -570,7 +571,10 @@ class HipRandLANet(nn.Module):
         level's layers scatter with atomics."""
         K = self.num_neighbors
         n = plan.totals[lvl]
-        if not (train and ops.USE_LFA_FULL and ops.USE_LFA_EDGE_ROWS and plan.num_edges[lvl] == n * K):
+        # (only a pass that will be differentiated needs them: a train-mode forward under no_grad — a BatchNorm recalibration, a
+        # metrics pass — skips the six launches; ADVICE r5)
+        # (a prefetch cannot know: it builds them for every train-mode batch)
+        if not (train and differentiable and ops.USE_LFA_FULL and ops.USE_LFA_EDGE_ROWS and plan.num_edges[lvl] == n * K):
             return None
         blk = (self.block1, self.block2, self.block3, self.block4)[lvl]
         chs = [lfa.mlp_attention.lins[0].weight.shape[0] for lfa in (blk.lfa1, blk.lfa2)]
@@ -578,7 +582,8 @@ class HipRandLANet(nn.Module):
             return None
         return ops.knn_reverse(idx, with_inv=not ops.USE_LFA_EDGE_SLOTS)  # (rows in list order: the slot table is all it takes)
 
-    def _geometry_stages(self, g: "_Geometry", pos: Tensor, plan: LevelPlan, decimation_idx, train: bool):
+    def _geometry_stages(self, g: "_Geometry", pos: Tensor, plan: LevelPlan, decimation_idx, train: bool,
+                         differentiable: bool = True):
         """The position-only work as a generator: each ``next()`` enqueues one stage on ``g.side`` (10 stages: grid of
         level 1; then per level its kNN table + encoder moments, and its decimation + the next level's grid; last the
         decoder's four 1-NN tables).  ``_geometry`` runs them back to back; an interleaved prefetch lets the forward pass
@@ -602,7 +607,7 @@ class HipRandLANet(nn.Module):
                     g.knn.append(idx)
                     g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
                     g.mark(1 + 2 * lvl)
-                    g.knn_inv.append(self._reverse_neighbours(plan, lvl, idx, train))
+                    g.knn_inv.append(self._reverse_neighbours(plan, lvl, idx, train, differentiable))
                 yield
             with torch.cuda.stream(side):
                 ix = g.index[lvl]
@@ -635,7 +640,7 @@ class HipRandLANet(nn.Module):
                 g.mom.extend(ops.lfa_moments_batch(g.pos4[:4], g.knn) if train else [None] * 4)
                 for lvl in range(4):
                     g.mark(1 + 2 * lvl, new=(lvl == 0))
-                g.knn_inv.extend(self._reverse_neighbours(plan, lvl, g.knn[lvl], train) for lvl in range(4))
+                g.knn_inv.extend(self._reverse_neighbours(plan, lvl, g.knn[lvl], train, differentiable) for lvl in range(4))
             yield
         with torch.cuda.stream(side):
             if batched:
@@ -809,6 +814,7 @@ class HipRandLANet(nn.Module):
         else:
             _check_plan(plan, pos, ptr)
         plan_ready(plan)
+        ops.drop_pending()  # (a forward that raised may have left unapplied BatchNorms behind: never materialised later)
         self._use_sinks = bool(train and torch.is_grad_enabled() and self._check_flat())
         if self.matmul_precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError(f"matmul_precision must be 'fp32', 'bf16' or 'bf16x3', got {self.matmul_precision!r}")
