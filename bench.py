@@ -336,17 +336,25 @@ def stage_rooflines(net, pos, plan):
         n2_, was_training = plan.totals[1], net.training
         xs = torch.randn(pos.shape[0], net.fc0.weight.shape[1], device=dev)
         ys = torch.randint(0, net.fc_classif.weight.shape[0], (pos.shape[0],), device=dev)
-        ops.LFA_BWD_TIMER = {"key": (n2_, 64), "events": []}
+        # (round 6: the three big launches of the family — ch 64 / 128 / 256, the lfa2 layers of blocks 2-4 — are bracketed)
+        big_keys = {(plan.totals[1], 64): net.block2.lfa2, (plan.totals[2], 128): net.block3.lfa2, (plan.totals[3], 256): net.block4.lfa2}
+        ops.LFA_BWD_TIMER = {"key": (n2_, 64), "keys": set(big_keys), "events": []}
         net.train()
         for _ in range(12):
             cross_entropy(net(xs, pos, None, plan.ptrs[0], plan=plan), ys, 65).backward()
             if net.grad_side is not None:
                 net.grad_side.join()
         torch.cuda.synchronize()
-        evs = ops.LFA_BWD_TIMER["events"][4:]  # (the first steps settle the allocator / arena)
+        by_key = ops.LFA_BWD_TIMER.get("by_key", {})
+        evs = by_key.get((n2_, 64), [])[4:]  # (the first steps settle the allocator / arena)
         if evs:
             in_step = {"ms": sum(a.elapsed_time(b) for a, b in evs) / len(evs), "launches": len(evs),
                        "flags": ops.LFA_BWD_TIMER.get("flags")}
+            in_step["family"] = {}
+            for (nn_, cc_), ev_ in by_key.items():
+                ev_ = ev_[4:]
+                if ev_:
+                    in_step["family"][cc_] = {"n": nn_, "ms": sum(a.elapsed_time(b) for a, b in ev_) / len(ev_)}
         if net.flat_grads is not None:
             net.flat_grads.zero_()
         net.train(was_training)
@@ -389,6 +397,33 @@ def stage_rooflines(net, pos, plan):
                            # the kernel): kept beside it for continuity
                            "self_contained_call_ms": round(ms_self, 4),
                            "frac_self_contained_call": round(flop_alg / (ms_self * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+        # round 6: the ch = 64 launch is the one with the largest share of the step, but not the slowest of
+        # its family against the roofline — the three big launches side by side, `frac` of the entry = their MINIMUM
+        fam = (in_step or {}).get("family") or {}
+        if fam:
+            rows = []
+            for cc_, v in sorted(fam.items()):
+                fa = 2 * 2 * v["n"] * K * (cc_ * cc_ + 10 * (cc_ // 2))
+                rows.append({"kernel": f"lfa_bwd_kernel<{cc_},16,...,fp32,FULL>", "n": v["n"], "ch": cc_, "avg_launch_ms": round(v["ms"], 4),
+                             "algorithmic_flop_per_launch": fa,
+                             "frac": round(fa / (v["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)})
+            out["dominant"]["family_in_step"] = rows
+            worst = min(rows, key=lambda r: r["frac"])
+            if worst["ch"] != 64:
+                # the headline fields describe the launch FURTHEST from the roofline; the ch = 64 launch (largest share of the
+                # step: what rounds 1-5 reported) moves to "largest_share_launch"
+                d = out["dominant"]
+                d["largest_share_launch"] = {k: d[k] for k in ("kernel", "achieved", "frac", "frac_executed", "avg_launch_ms",
+                                                               "algorithmic_flop_per_launch", "executed_flop_per_launch", "traffic")
+                                             if k in d}
+                tfw = worst["algorithmic_flop_per_launch"] / (worst["avg_launch_ms"] * 1e-3) / 1e12
+                d.update({"kernel": f"{worst['kernel']} (block{2 + (worst['ch'] // 128)}.lfa2 ... ch={worst['ch']}, n={worst['n']}, K={K}): the launch of "
+                                    "the family furthest from its roofline inside training steps",
+                          "achieved": round(tfw, 1), "frac": worst["frac"], "frac_algorithmic": worst["frac"],
+                          "frac_executed": round(1.5 * worst["frac"], 4), "avg_launch_ms": worst["avg_launch_ms"],
+                          "algorithmic_flop_per_launch": worst["algorithmic_flop_per_launch"],
+                          "executed_flop_per_launch": worst["algorithmic_flop_per_launch"] * 3 // 2})
+                d.update(_traffic_fields(f"void lfa_bwd_kernel<{worst['ch']}, 16"))
         # ---- kNN + LSE gather stage: the K-NN tables of all four levels, both LFA layers of level 1 fwd + bwd
         stage = []
         for lvl in range(4):

@@ -1429,7 +1429,7 @@ def lfa_prepare_batch(jobs) -> list:
 
 USE_LFA_EDGE_ROWS = os.environ.get("M3D_LFA_EDGE_ROWS", "1") != "0"  # A/B switch: 0 = dx by float atomics everywhere
 USE_LFA_EDGE_SLOTS = os.environ.get("M3D_LFA_EDGE_SLOTS", "1") != "0"  # A/B switch: 0 = edge rows in edge order (gather through inv)
-LFA_BWD_TIMER = None  # bench.py sets {"key": (n, ch), "events": []}: LFATrainFn.backward then brackets that layer's launch with HIP events
+LFA_BWD_TIMER = None  # bench.py sets {"key": (n, ch) | "keys": {(n, ch), ...}, "events": []}: LFATrainFn.backward then brackets those layers' launches with HIP events (per layer in "by_key")
 LFA_FULL = 1  # M3D_LFA_FULL (include/m3d_hip.h): every entry of the neighbour table is a valid row
 USE_LFA_FULL = os.environ.get("M3D_LFA_FULL", "1") != "0"  # A/B switch: 0 = the general (masked) kernels everywhere
 
@@ -1535,7 +1535,7 @@ class LFATrainFn(torch.autograd.Function):
             defer = sk is not None and ctx.side is not None and DEFER_WGRAD
             tm = LFA_BWD_TIMER  # (bench.py: HIP events around ONE layer's launch inside real training steps)
             ev = None
-            if tm is not None and tm["key"] == (n, ch):
+            if tm is not None and ((n, ch) == tm.get("key") or (n, ch) in tm.get("keys", ())):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             fl = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0) | (16 if ctx.bf16 == 2 else 0) | io
@@ -1550,6 +1550,7 @@ class LFATrainFn(torch.autograd.Function):
             if ev is not None:
                 ev[1].record()
                 tm["events"].append(ev)
+                tm.setdefault("by_key", {}).setdefault((n, ch), []).append(ev)
                 tm["flags"] = (1 if sk is not None else 0) | 2 | (4 if defer else 0) | (8 if ctx.full else 0)
             if defer:
                 # dW_att, G and the encoder parameter gradients are leaves: summed / finished with every other LFA

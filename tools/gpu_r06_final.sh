@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU box, round-5 evidence run (ONE per round): full parity suite (margins printed), the default bench line (all legs), eager
+# GPU box, round-6 evidence run (ONE per round): full parity suite (margins printed), the default bench line (all legs), eager
 # kernel-trace stats of the bench command, graph-mode step timeline, HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE) and two SQ
-# passes over the roofline kernels.   usage: tools/gpu_r05_final.sh TAG   -> copy gpurun_out/*TAG* into profiles/
+# passes over the roofline kernels.   usage: tools/gpu_r06_final.sh TAG   -> copy gpurun_out/*TAG* into profiles/
 set -u
-TAG=${1:-r05fin}
+TAG=${1:-r06fin}
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout -s KILL 1100 python -m pytest tests -m gpu -q -s --timeout 400 --durations=8 2>&1 | grep -v "^  File\|^Extension modules\|amdgpu.ids" > $OUT/pytest_gpu_full_$TAG.log
@@ -21,3 +21,5 @@ bash tools/gpu_pmc.sh ${TAG}_fetch "FETCH_SIZE" python tools/pmc_target.py | gre
 bash tools/gpu_pmc.sh ${TAG}_write "WRITE_SIZE" python tools/pmc_target.py | grep -E "$K" | cut -c1-160
 bash tools/gpu_pmc.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" python tools/pmc_target.py | grep -E "$K" | cut -c1-260
 bash tools/gpu_pmc.sh ${TAG}_sq2 "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT" python tools/pmc_target.py | grep -E "$K" | cut -c1-260
+# round 6: the "bf16" leg (bf16 activation storage + bf16 matrix-core operands) kernel by kernel
+bash tools/gpu_trace_analyze.sh ${TAG}_bf16 "--launch graph --precision bf16" 2>&1 | grep -E "^step:|per queue" | head -3
