@@ -328,3 +328,47 @@ def test_graphed_step_runs_in_bf16_storage_and_matches_eager_launching(device):
         torch.cuda.synchronize()
         print(f"[parity] bf16 leg, step {i}: graph {loss.item():.6f} eager {eager[i]:.6f}")
         assert np.isfinite(loss.item()) and abs(loss.item() - eager[i]) <= 2e-3 * max(1.0, abs(eager[i]))
+
+
+def test_reference_fixture_in_bf16_storage_incl_short_and_one_point_clouds(device):
+    """The committed reference vectors (``tests/golden/randla_reference.npz``: outputs of the reference's own module) with bf16
+    activation storage: the second size set holds a 9-point and a 1-point cloud — neighbourhoods shorter than K (-1 padding: the
+    MASKED LFA kernels, forward and backward, with bf16 rows), one-row levels, the atomic row scatter of injected decimation
+    indices.  Eval logits within 3e-2 of the reference's, train loss within 1e-2, every gradient finite and the weight
+    gradients within 0.35 relative L2 of the reference's fp64 run."""
+    import os
+
+    from myria3d_amd import HipRandLANet
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "randla_reference.npz"))
+    for pre in [str(s) for s in g["sets"]]:
+        t = lambda k: torch.from_numpy(g[pre + k])
+        net = HipRandLANet(9, 6, return_logits=True)
+        fill_params_deterministic(net, int(g["param_seed"]))
+        net.mlp_classif.dropout = [0.0, 0.0]
+        net = net.to(device).eval()
+        net.activation_dtype = BF
+        dec = [t(f"dec{i}") for i in range(4)]
+        x, pos, ptr = t("x").to(device), t("pos").to(device), t("ptr").to(device)
+        with torch.no_grad():
+            out = net(x, pos, None, ptr, decimation_idx=dec)
+        err = (out.cpu() - t("logits_eval")).abs().max().item()
+        print(f"[parity] bf16 storage, reference fixture [{pre}]: eval max |d logit| = {err:.3e}")
+        assert out.dtype == torch.float32 and err <= 3e-2
+        net.train()
+        out_t = net(x, pos, None, ptr, decimation_idx=dec)
+        loss = torch.nn.functional.cross_entropy(out_t, t("y").to(device))
+        assert abs(loss.item() - float(g[pre + "loss_train"])) <= 1e-2 * max(1.0, abs(float(g[pre + "loss_train"])))
+        loss.backward()
+        torch.cuda.synchronize()
+        worst = ("", 0.0)
+        for name, p in net.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+            key = pre + "grad64:" + name
+            ref = torch.from_numpy(g[key]).double()
+            if name.endswith("weight") and ".lins." in name and ref.norm().item() > 1e-6:
+                rel = _rel(p.grad, ref)
+                worst = (name, rel) if rel > worst[1] else worst
+        print(f"[parity] bf16 storage, reference fixture [{pre}]: worst Linear weight gradient vs the reference's fp64 run "
+              f"{worst[1]:.3e} ({worst[0]})")
+        assert worst[1] <= 0.35, worst
