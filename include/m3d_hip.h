@@ -87,7 +87,9 @@ int m3d_knn_build_map(const float* pos_src, int32_t pos_stride, const int64_t* p
  * and neighbour ids = cell-sorted slots of the source workspace (selection and tie-breaking stay on original rows).
  * flags bits 1-2: which of the two bit-identical search kernels runs — 0: chosen by size (deferred insertion from
  * 2^20 (query, neighbour) pairs), 1: deferred insertion (used for 4 < k <= 64), 2: direct insertion; for parity tests
- * and A/B timing (the library has no other switch). */
+ * and A/B timing (the library has no other switch).
+ * flags bits 8-15 (round 6): BACKGROUND launch — at most that many x 64 wavefronts (0: as many as the queries fill); every
+ * wavefront then walks several groups of queries.  Same tables; for a launch that shares the chip with another stream. */
 int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t num_clouds, const float* pos_qry,
                   int32_t qry_stride, const void* qry_ws, const int64_t* ptr_qry, int64_t n_qry, int32_t k,
                   int32_t flags, int32_t* idx_out /* [n_qry, k] */, float* d2_out /* [n_qry, k] or NULL */,

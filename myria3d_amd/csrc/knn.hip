@@ -430,8 +430,11 @@ __global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_kernel(KnnWs w,
                                                         const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
                                                         int* __restrict__ idx_out, float* __restrict__ d2_out,
                                                         int sorted_io, int ostride, int ooff, int lower_col) {
-  knn_query_direct_body<KMAX>(w, ptr_src, B, pos_qry, qstride, qsorted, ptr_qry, n_qry, k, idx_out, d2_out, sorted_io,
-                              ostride, ooff, lower_col, (int64_t)blockIdx.x * 256 + threadIdx.x);
+  // (a BACKGROUND launch — flags bits 8-15 of m3d_knn_query — has fewer workgroups than blocks of 256 queries: each walks several)
+  const int64_t nblk = (n_qry + 255) >> 8;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x)
+    knn_query_direct_body<KMAX>(w, ptr_src, B, pos_qry, qstride, qsorted, ptr_qry, n_qry, k, idx_out, d2_out, sorted_io,
+                                ostride, ooff, lower_col, blk * 256 + threadIdx.x);
 }
 
 // Several independent query problems in ONE launch (m3d_knn_query_batch): the K-NN tables of the four resolution levels
@@ -675,9 +678,11 @@ template <int KMAX>
 __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
     KnnWs w, const int64_t* __restrict__ ptr_src, int B, const float* __restrict__ pos_qry, int qstride,
     const float4* __restrict__ qsorted, const int64_t* __restrict__ ptr_qry, int64_t n_qry, int k,
-    int* __restrict__ idx_out, float* __restrict__ d2_out, int flags) {
-  knn_query_queue_body<KMAX>(w, ptr_src, B, pos_qry, qstride, qsorted, ptr_qry, n_qry, k, idx_out, d2_out, flags,
-                             blockIdx.x, gridDim.x);
+    int* __restrict__ idx_out, float* __restrict__ d2_out, int flags, int64_t nblk) {
+  // nblk query groups of 64 on gridDim.x <= nblk one-wave workgroups: with fewer workgroups than groups (flags bits 8-15 of
+  // m3d_knn_query: a BACKGROUND launch that shares the chip with another stream's work) every wave walks several groups
+  for (int64_t wg = blockIdx.x; wg < nblk; wg += gridDim.x)
+    knn_query_queue_body<KMAX>(w, ptr_src, B, pos_qry, qstride, qsorted, ptr_qry, n_qry, k, idx_out, d2_out, flags, wg, nblk);
 }
 
 template <int KMAX>
@@ -725,18 +730,26 @@ extern "C" int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_s
   if (n_qry == 0 || num_clouds == 0) return M3D_OK;
   KnnWs w = ws_carve((void*)ws, num_clouds, n_src);
   const float4* qs = qry_ws ? ws_carve((void*)qry_ws, num_clouds, n_qry).sorted : nullptr;
-  dim3 grid((unsigned)m3d_cdiv(n_qry, 256)), block(256);
+  // flags bits 8-15: BACKGROUND launch — at most that many x 64 wavefronts (0: as many as the queries fill).  The tables are
+  // the same; a launch that shares the chip with another stream's work (HipRandLANet.prefetch_geometry beside a training
+  // step) then occupies one wave slot per SIMD instead of flooding every CU for its whole duration (round 6: the level-1
+  // self-kNN capped at 1 024 waves costs the step 0.05 ms less, profiles/r06i_*)
+  const int64_t wcap = (int64_t)((flags >> 8) & 0xff) * 64;
+  const int64_t dblk = m3d_cdiv(n_qry, 256);
+  dim3 grid((unsigned)((wcap > 0 && wcap / 4 < dblk) ? (wcap / 4 > 0 ? wcap / 4 : 1) : dblk)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int qflags = (sorted_io ? 1 : 0) | (((((uintptr_t)idx_out) | ((uintptr_t)d2_out)) & 15) == 0 ? 2 : 0);
   const bool use_queue = choice == 0 ? n_qry * (int64_t)k >= KNNQ_MIN_PAIRS : choice == 1;
+  const int64_t qblk = m3d_cdiv(n_qry, 64);
+  const int64_t qgrid = (wcap > 0 && wcap < qblk) ? wcap : qblk;
 #define LAUNCH(KM, KK, OOFF, LOWER)                                                                              \
   hipLaunchKernelGGL((knn_query_kernel<KM>), grid, block, 0, st, w, ptr_src, num_clouds, pos_qry, qry_stride, qs, \
                      ptr_qry, n_qry, KK, idx_out, d2_out, sorted_io, k, OOFF, LOWER)
 #define LAUNCHQ(KM)                                                                                               \
   do {                                                                                                            \
     if (use_queue)                                                                                                \
-      hipLaunchKernelGGL((knn_query_queue_kernel<KM>), dim3((unsigned)m3d_cdiv(n_qry, 64)), dim3(64), 0, st, w,   \
-                         ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags); \
+      hipLaunchKernelGGL((knn_query_queue_kernel<KM>), dim3((unsigned)qgrid), dim3(64), 0, st, w,                 \
+                         ptr_src, num_clouds, pos_qry, qry_stride, qs, ptr_qry, n_qry, k, idx_out, d2_out, qflags, qblk); \
     else LAUNCH(KM, k, 0, -1);                                                                                    \
   } while (0)
   if (k == 1) LAUNCH(1, k, 0, -1);

@@ -198,11 +198,13 @@ class KnnIndex:
 
     def query(self, k: int, qry: Optional["KnnIndex"] = None, pos_qry: Optional[Tensor] = None,
               ptr_qry: Optional[Tensor] = None, want_d2: bool = False,
-              sorted_io: bool = False, kernel: str = "auto") -> Tuple[Tensor, Optional[Tensor]]:
+              sorted_io: bool = False, kernel: str = "auto", background: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
         """``qry`` (another built index, possibly ``self``) gives wave-coherent cell-sorted queries;
         otherwise ``pos_qry``/``ptr_qry`` rows are queried in order.  Returns int32 ``[nq, k]`` (+ fp32 d2).
         ``sorted_io``: rows and neighbour ids are cell-sorted slots (of ``qry`` / of ``self``).  ``kernel``: "auto" (by
-        size), "queue" (deferred insertion) or "direct" — bit-identical tables; parity tests and A/B timing."""
+        size), "queue" (deferred insertion) or "direct" — bit-identical tables; parity tests and A/B timing.
+        ``background`` (0 ... 255): a launch that runs BESIDE another stream's work takes at most that many x 64 wavefronts
+        (flags bits 8-15 of ``m3d_knn_query``; 0: as many as the queries fill) — same tables."""
         if qry is not None:
             nq, ptr_q, qws, pq, qs = qry.n, qry.ptr, qry.ws, None, 0
             assert qry.num_clouds == self.num_clouds
@@ -212,7 +214,7 @@ class KnnIndex:
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.ws.device)
         d2 = torch.empty((nq, k), dtype=torch.float32, device=self.ws.device) if want_d2 else None
         call("m3d_knn_query", _p(self.ws), _p(self.ptr), self.n, self.num_clouds, _p(pq), qs, _p(qws), _p(ptr_q), nq, k,
-             int(sorted_io) | (_KNN_KERNEL[kernel] << 1), _p(idx), _p(d2), _st())
+             int(sorted_io) | (_KNN_KERNEL[kernel] << 1) | ((int(background) & 0xff) << 8), _p(idx), _p(d2), _st())
         return idx, d2
 
 

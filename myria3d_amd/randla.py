@@ -193,6 +193,12 @@ class HipRandLANet(nn.Module):
         # with ``matmul_precision = "bf16"`` (operands of the matrix-bound layers rounded to bf16 for the matrix cores).
         self.activation_dtype = torch.float32
         self.overlap_geometry = True  # run the position-only work (kNN, decimation) on a side stream
+        # K-NN / 1-NN queries of a PREFETCH (the next batch's tables beside the current step: prefetch_geometry, graph A of a
+        # GraphedStep) take at most this many x 64 wavefronts (0: no cap).  The level-1 query is 3 200 wavefronts of pure VALU
+        # work that otherwise flood every CU for 140-200 us and make the step's latency-bound chain queue up behind them; at
+        # one wave per SIMD it takes ~2 x as long — hidden, the prefetch has the whole step — and costs the step 0.05 ms less
+        # (3.962 -> 3.915 ms, same box: profiles/r06i_knn_background_cap_ab.log).  Tables are bit-identical.
+        self.background_knn_cap = int(__import__("os").environ.get("M3D_KNN_BG_CAP", "16"))
         # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
         # accumulation adds; False: plain autograd (cross-check)
         self.share_input_gradients = __import__("os").environ.get("M3D_GRAD_SLOTS", "1") != "0"
@@ -583,13 +589,14 @@ class HipRandLANet(nn.Module):
         return ops.knn_reverse(idx, with_inv=not ops.USE_LFA_EDGE_SLOTS)  # (rows in list order: the slot table is all it takes)
 
     def _geometry_stages(self, g: "_Geometry", pos: Tensor, plan: LevelPlan, decimation_idx, train: bool,
-                         differentiable: bool = True):
+                         differentiable: bool = True, background: bool = False):
         """The position-only work as a generator: each ``next()`` enqueues one stage on ``g.side`` (10 stages: grid of
         level 1; then per level its kNN table + encoder moments, and its decimation + the next level's grid; last the
         decoder's four 1-NN tables).  ``_geometry`` runs them back to back; an interleaved prefetch lets the forward pass
         enqueue one stage between its own blocks (see ``prefetch_geometry(interleave=True)``)."""
         K = self.num_neighbors
         side = g.side
+        bg = max(0, min(255, int(self.background_knn_cap))) if background else 0
         # batched launches pay off where launches are the cost: eagerly (7.5 -> 6.8 ms per training step).  Inside a
         # captured graph the per-level launches are free for the host and run one after the other without competing with
         # the feature kernels, which measured 0.04 ms better (profiles/r02x_geo_batch.log) — same tables either way
@@ -603,7 +610,7 @@ class HipRandLANet(nn.Module):
             if not batched:
                 with torch.cuda.stream(side):
                     ix = g.index[lvl]
-                    idx, _ = ix.query(K, qry=ix, sorted_io=True)
+                    idx, _ = ix.query(K, qry=ix, sorted_io=True, background=bg)
                     g.knn.append(idx)
                     g.mom.append(ops.lfa_moments(g.pos4[lvl], idx) if train else None)
                     g.mark(1 + 2 * lvl)
@@ -647,7 +654,7 @@ class HipRandLANet(nn.Module):
                 g.nn.extend(ops.knn_query_batch([(g.index[l + 1], g.index[l]) for l in range(4)], 1))
             else:
                 for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
-                    g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True)[0])
+                    g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True, background=bg)[0])
             g.mark(9)
             # CSR inverses of the four 1-NN tables (train): the backward pass of the decoder's x[nn] gathers sums rows per
             # coarse point instead of scattering them with atomics (ops.gather_sum_rows).  A stage of its own: the forward
@@ -721,7 +728,7 @@ class HipRandLANet(nn.Module):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
         geo = _Geometry(main, side)
-        stages = self._geometry_stages(geo, pos, plan, None, train)
+        stages = self._geometry_stages(geo, pos, plan, None, train, background=True)
         self._look_job = (stages, geo, turn, key, pos, main)
         if interleave:
             next(stages)
