@@ -728,7 +728,8 @@ class HipRandLANet(nn.Module):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
         geo = _Geometry(main, side)
-        stages = self._geometry_stages(geo, pos, plan, None, train, background=True)
+        # (background launches only beside a TRAINING step: the eval forward is shorter than the position-only chain and waits for it)
+        stages = self._geometry_stages(geo, pos, plan, None, train, background=bool(train))
         self._look_job = (stages, geo, turn, key, pos, main)
         if interleave:
             next(stages)
