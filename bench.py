@@ -800,8 +800,20 @@ def pointnet2_bench(args, dev):
     for _ in range(3):
         step()
     dt_serial = timed(step, steps, 1) / steps
+    # round 5: ONE batch ahead (the step is then bound by the sampler's latency)
+    net.prefetch_depth = 1
     net.prefetch_geometry(pos, ptr)
     for _ in range(3):
+        step_pipelined()
+    dt_depth1 = timed(step_pipelined, steps, 1) / steps
+    net._look = None
+    torch.cuda.synchronize()
+    # round 6: three batches' position-only work in flight, each on its own stream pair (a sampler chain completes every
+    # ~11 ms: the step is bound by the feature kernels)
+    net.prefetch_depth = 3
+    for _ in range(2):
+        net.prefetch_geometry(pos, ptr)
+    for _ in range(4):
         step_pipelined()
     dt = timed(step_pipelined, steps, 1) / steps
     net._look = None
@@ -834,6 +846,7 @@ def pointnet2_bench(args, dev):
     dts1 = timed(sampler_single, max(1, steps // 2), 1) / max(1, steps // 2)
     print(json.dumps({"metric": "points/sec fwd+bwd, PointNet++ set-abstraction variant", "value": round(B * N / dt, 1),
                       "unit": "points/s", "ms_per_step": round(dt * 1e3, 3), "serial_ms_per_step": round(dt_serial * 1e3, 3),
+                      "one_batch_ahead_ms_per_step": round(dt_depth1 * 1e3, 3), "prefetch_depth": 3,
                       "fwd_only_ms": round(dtf * 1e3, 3),
                       "fps_ms": round(dts * 1e3, 3), "fps_plain_ms": round(dts1 * 1e3, 3), "dtype": "f32", "data": "synthetic",
                       "workload": f"HipPointNet2 train step, {B} tiles x {N} pts, K={K}, decimation 4, FPS sampling, eager "

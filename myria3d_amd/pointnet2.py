@@ -114,6 +114,13 @@ class HipPointNet2(nn.Module):
         # position-only work of the NEXT batch (prefetch_geometry): (pos tensor, its version, ptr key, train flag, tables, event)
         self._look = None
         self._side = self._side_q = None
+        # how many batches' position-only work may be in flight (prefetch_geometry): every one on a stream pair of its own.  The
+        # farthest-point sampler is ONE serial chain per cloud — 33.5 ms for 16 x 40 000 points on 16 of the 256 CUs — so a
+        # single chain in flight bounds the step at its latency; with three, a chain completes every ~11 ms and the step is
+        # bound by the feature kernels (round 6).  A dataloader's prefetch queue holds the future batches' positions.
+        self.prefetch_depth = 3
+        self._sides: list = []
+        self._look_n = 0
 
     # ------------------------------------------------------------------------------------------
     def plan_for(self, ptr: Tensor) -> SAPlan:
@@ -197,8 +204,8 @@ class HipPointNet2(nn.Module):
     def prefetch_geometry(self, pos: Tensor, ptr: Tensor, wait_main: bool = True) -> None:
         """Enqueue the position-only work of the batch ``(pos, ptr)`` on a side stream now; a later ``forward`` on the SAME
         ``pos`` tensor (unchanged since: identity + version counter) and tile layout picks the tables up instead of
-        computing them (first in, first out: up to two batches may be waiting).  Call it for the NEXT batch in front of the
-        current step's ``forward``: the sampler then runs under that whole step.  ``wait_main=False``: ``pos`` is known to be
+        computing them (first in, first out: up to ``prefetch_depth`` batches may be waiting, each on its own pair of streams).
+        Call it for the NEXT batch(es) in front of the current step's ``forward``: the sampler then runs under whole steps.  ``wait_main=False``: ``pos`` is known to be
         complete (a resident / already transferred batch) — the side stream then does not wait for what the calling stream
         still has queued (the previous step's backward and optimizer).  Sampling is deterministic (farthest-point from point
         0 of every cloud; with ``random_start`` / ``subsampling="random"`` the draw happens here instead of in the forward)."""
@@ -206,18 +213,20 @@ class HipPointNet2(nn.Module):
             raise RuntimeError("HipPointNet2 runs on an MI355X only (no CPU fallback by design)")
         plan = self.plan_for(ptr)
         main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=pos.device)
-            self._side_q = torch.cuda.Stream(device=pos.device)
-        side = self._side
+        depth = max(1, int(self.prefetch_depth))
+        while len(self._sides) < depth:
+            self._sides.append((torch.cuda.Stream(device=pos.device), torch.cuda.Stream(device=pos.device)))
+        side, side_q = self._sides[self._look_n % depth]
+        self._look_n += 1
+        self._side, self._side_q = side, side_q
         if wait_main:
             side.wait_stream(main)  # (pos may just have been written on the calling stream)
         train = self.training
         with torch.cuda.stream(side), torch.no_grad():
-            geo = self._geometry(pos, plan, train, query_stream=self._side_q)
+            geo = self._geometry(pos, plan, train, query_stream=side_q)
             ev = torch.cuda.Event()
             ev.record(side)
-        self._look = ((self._look or []) + [(pos, pos._version, tuple(plan.totals), train, geo, ev)])[-2:]
+        self._look = ((self._look or []) + [(pos, pos._version, tuple(plan.totals), train, geo, ev)])[-depth:]
 
     def _take_lookahead(self, pos: Tensor, plan: SAPlan, train: bool) -> Optional[dict]:
         queue = self._look or []

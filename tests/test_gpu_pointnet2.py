@@ -276,6 +276,16 @@ def test_prefetched_geometry_gives_the_same_step(device):
         assert torch.equal(o3, o0) and len(net._look) == 1
         net(*B)
     assert net._look is None
+    # round 6: three batches in flight, each on its own stream pair (prefetch_depth = 3): the same batch queued three times is
+    # consumed three times, oldest first, with identical results; a fourth entry pushes the oldest out
+    assert net.prefetch_depth == 3
+    for _ in range(3):
+        net.prefetch_geometry(A[1], A[3], wait_main=False)
+    assert len(net._look) == 3 and len(net._sides) == 3
+    with torch.no_grad():
+        for left in (2, 1, 0):
+            o4 = net(*A, dropout_mask=torch.ones(A[0].shape[0], 32, device=device))
+            assert torch.equal(o4, o0) and len(net._look or []) == left
     pa2 = A[1].clone()
     net.prefetch_geometry(pa2, A[3])
     pa2.mul_(1.0)  # (bumps the version counter)
