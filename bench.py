@@ -800,22 +800,27 @@ def pointnet2_bench(args, dev):
     for _ in range(3):
         step()
     dt_serial = timed(step, steps, 1) / steps
-    # round 5: ONE batch ahead (the step is then bound by the sampler's latency)
-    net.prefetch_depth = 1
+    # round 5: ONE batch ahead (the step is then bound by the sampler's latency: one chain in flight)
+    net.prefetch_depth = 2
     net.prefetch_geometry(pos, ptr)
     for _ in range(3):
         step_pipelined()
     dt_depth1 = timed(step_pipelined, steps, 1) / steps
     net._look = None
     torch.cuda.synchronize()
-    # round 6: three batches' position-only work in flight, each on its own stream pair (a sampler chain completes every
-    # ~11 ms: the step is bound by the feature kernels)
-    net.prefetch_depth = 3
-    for _ in range(2):
-        net.prefetch_geometry(pos, ptr)
-    for _ in range(4):
-        step_pipelined()
-    dt = timed(step_pipelined, steps, 1) / steps
+    # round 6: several batches' position-only work in flight, each on its own stream pair (with three, a sampler chain
+    # completes every ~11 ms: the step is bound by the feature kernels)
+    by_depth = {}
+    for depth in (4, 3):
+        net.prefetch_depth = depth
+        for _ in range(depth - 1):
+            net.prefetch_geometry(pos, ptr)
+        for _ in range(depth + 1):
+            step_pipelined()
+        by_depth[depth] = timed(step_pipelined, steps, 1) / steps
+        net._look = None
+        torch.cuda.synchronize()
+    dt = by_depth[3]  # (the class default)
     net._look = None
     net.eval()
 
@@ -847,6 +852,7 @@ def pointnet2_bench(args, dev):
     print(json.dumps({"metric": "points/sec fwd+bwd, PointNet++ set-abstraction variant", "value": round(B * N / dt, 1),
                       "unit": "points/s", "ms_per_step": round(dt * 1e3, 3), "serial_ms_per_step": round(dt_serial * 1e3, 3),
                       "one_batch_ahead_ms_per_step": round(dt_depth1 * 1e3, 3), "prefetch_depth": 3,
+                      "ms_per_step_by_prefetch_depth": {str(k): round(v * 1e3, 3) for k, v in sorted(by_depth.items())},
                       "fwd_only_ms": round(dtf * 1e3, 3),
                       "fps_ms": round(dts * 1e3, 3), "fps_plain_ms": round(dts1 * 1e3, 3), "dtype": "f32", "data": "synthetic",
                       "workload": f"HipPointNet2 train step, {B} tiles x {N} pts, K={K}, decimation 4, FPS sampling, eager "
