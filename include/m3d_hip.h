@@ -102,20 +102,6 @@ int m3d_knn_query(const void* ws, const int64_t* ptr_src, int64_t n_src, int32_t
 int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const int64_t* const* ptr_src, const int64_t* n_src,
                         const void* const* qry_ws, const int64_t* const* ptr_qry, const int64_t* n_qry,
                         int32_t num_clouds, int32_t k, int32_t flags, int32_t* const* idx_out, void* stream);
-/* The decoder's four 1-NN tables WITHOUT a search (round 6).  FPModule / knn_interpolate(k = 1) (pyg_randla_net.py:249-252) asks,
- * for every point of level l, its nearest point of level l + 1 — a SUBSET of level l (decimate(), :234-238) whose K-NN table
- * among level l exists already (:180).  The nearest survivor is the first survivor in a point's ascending neighbour list; ties
- * are resolved by the level-(l + 1) row like the query does, and a point whose list does not settle the answer (no survivor
- * in it, ~(1 - 1/decimation)^K of the points; or a tie with the list's last entry) is searched by brute force over its
- * cloud's level-(l + 1) points.  njobs <= 4 levels per call, four launches; nn_out[j] [n_fine[j]] int32 is BIT-IDENTICAL to
- * m3d_knn_query(ws_coarse[j], qry_ws = ws_fine[j], k = 1, sorted_io) (cell-sorted slots in, cell-sorted slots out).
- * knn[j]: level l's self table [n_fine, K] (m3d_knn_query, sorted_io); src[j][t]: level-l slot of level-(l + 1) slot t
- * (m3d_knn_build_map's carried decimation map); scratch[j]: m3d_nn_from_knn_workspace_bytes(n_fine[j]) bytes. */
-size_t m3d_nn_from_knn_workspace_bytes(int64_t n_fine);
-int m3d_nn_from_knn(int32_t njobs, const void* const* ws_fine, const int64_t* const* ptr_fine, const int64_t* n_fine,
-                    const void* const* ws_coarse, const int64_t* const* ptr_coarse, const int64_t* n_coarse,
-                    int32_t num_clouds, const int32_t* const* knn, int32_t K, const int32_t* const* src,
-                    int32_t* const* nn_out, void* const* scratch, void* stream);
 
 /* ---- SharedMLP GEMM -------------------------------------------------------------------------------------
  * Linear of PyG MLP / torch.nn.Linear (pyg_randla_net.py:42,53,97-109), forward, dgrad and wgrad:

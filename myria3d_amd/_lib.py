@@ -56,8 +56,6 @@ SIGNATURES = {
     "m3d_lfa_moments": (_i32, [_p, _p, _i64, _i32, _p, _p]),
     "m3d_lfa_moments_batch": (_i32, [_i32, _p, _p, _p, _i32, _p, _i64, _p]),
     "m3d_knn_query_batch": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p]),
-    "m3d_nn_from_knn_workspace_bytes": (C.c_size_t, [_i64]),
-    "m3d_nn_from_knn": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p]),
     "m3d_lfa_enc_finalize": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "m3d_lfa_pack_att": (_i32, [_p, _i32, _p, _p, _p]),
     "m3d_lfa_prepare": (_i32, [_p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _i32,

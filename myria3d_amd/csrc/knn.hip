@@ -829,184 +829,3 @@ extern "C" int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const i
   M3D_CHECK_LAUNCH();
   return M3D_OK;
 }
-
-// ------------------------------------------------------------------------------------------
-// m3d_nn_from_knn (round 6): the decoder's 1-NN tables WITHOUT a search.
-//
-// FPModule / knn_interpolate(k = 1) (/root/reference/myria3d/models/modules/pyg_randla_net.py:249-252) asks, for every point
-// s of level l, the nearest point of level l + 1 — and level l + 1 is a SUBSET of level l (random decimation, :234-238) whose
-// K-NN table among level l the encoder has already built (:180).  That table lists the K nearest level-l points of s in
-// ascending (d2, row) order, so the nearest SURVIVOR of the decimation is the first survivor in the list: every point
-// outside the list is at least as far as the list's last entry.  One pass over the table (a few random 4-byte reads per
-// point) replaces a grid walk per point (the level-1 launch: 204 800 queries, 60 us of VALU work that floods the chip beside
-// the feature kernels).  Exactness (the table is bit-identical to m3d_knn_query(k = 1), which orders candidates by
-// (d2, row in level l + 1)):
-//   * ties at the nearest survivor's distance inside the list are resolved by the level-(l + 1) row, like the query does;
-//   * a point is a MISS — handed to a brute-force pass over its cloud's level-(l + 1) points, one wavefront per miss — when
-//     its list holds no survivor (probability ~ (1 - 1/decimation)^K: 1 % at K = 16, decimation 4) or when the nearest
-//     survivor's distance equals the distance of the list's LAST entry (an unseen point may tie with it).
-// All rows / ids are cell-sorted slots (sorted_io), as the net uses them.
-// ------------------------------------------------------------------------------------------
-#define NN_BATCH_MAX 4
-struct NnBatch {
-  const float4* fine[NN_BATCH_MAX];    // level l records (x, y, z, row bits), cell-sorted
-  const float4* coarse[NN_BATCH_MAX];  // level l + 1 records
-  const int* coarse_inv[NN_BATCH_MAX]; // level l + 1: original row -> slot
-  const int* idx[NN_BATCH_MAX];        // [n_fine, K] K-NN table of level l (slots of level l, -1 padding)
-  const int* src[NN_BATCH_MAX];        // [n_coarse] slot of level l + 1 -> slot of level l
-  const int64_t* ptr_fine[NN_BATCH_MAX];
-  const int64_t* ptr_coarse[NN_BATCH_MAX];
-  int* child[NN_BATCH_MAX];            // [n_fine] scratch: slot of level l -> 1 + slot of level l + 1, 0 = did not survive
-  int* miss[NN_BATCH_MAX];             // [n_fine] scratch: slots whose list does not settle them
-  int* nmiss[NN_BATCH_MAX];            // [1]
-  int* out[NN_BATCH_MAX];              // [n_fine]
-  int64_t n_fine[NN_BATCH_MAX], n_coarse[NN_BATCH_MAX];
-  int64_t start_fine[NN_BATCH_MAX + 1], start_coarse[NN_BATCH_MAX + 1];  // flattened thread ranges of the jobs
-  int njobs;
-};
-__device__ __forceinline__ int nn_job(const int64_t* start, int njobs, int64_t t) {
-  int j = 0;
-#pragma unroll
-  for (int i = 1; i < NN_BATCH_MAX; ++i) j += (i < njobs && t >= start[i]) ? 1 : 0;
-  return j;
-}
-__global__ __launch_bounds__(256) void nn_zero_kernel(NnBatch a) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.start_fine[a.njobs]) return;
-  const int j = nn_job(a.start_fine, a.njobs, t);
-  const int64_t s = t - a.start_fine[j];
-  a.child[j][s] = 0;
-  if (s == 0) a.nmiss[j][0] = 0;
-}
-__global__ __launch_bounds__(256) void nn_child_kernel(NnBatch a) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.start_coarse[a.njobs]) return;
-  const int j = nn_job(a.start_coarse, a.njobs, t);
-  const int64_t c = t - a.start_coarse[j];
-  const int s = a.src[j][c];
-  if (s >= 0 && s < a.n_fine[j]) a.child[j][s] = (int)c + 1;
-}
-__global__ __launch_bounds__(256) void nn_scan_kernel(NnBatch a, int K) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.start_fine[a.njobs]) return;
-  const int j = nn_job(a.start_fine, a.njobs, t);
-  const int64_t s = t - a.start_fine[j];
-  const int* __restrict__ row = a.idx[j] + s * K;
-  const int* __restrict__ child = a.child[j];
-  const float4 q = a.fine[j][s];
-  int best = -1;            // slot of level l + 1
-  unsigned best_row = 0u;   // its original row (the query's tie-break)
-  float dstar = 0.f;
-  bool settled = false, complete = false;  // settled: a list entry beyond the ties was seen; complete: the list holds the whole cloud
-  int last = -1;
-  for (int k = 0; k < K; ++k) {
-    const int nb = row[k];
-    if (nb < 0) { complete = true; break; }
-    last = nb;
-    const int c = child[nb];
-    if (c == 0) continue;
-    const float d2 = dist2_exact(q.x, q.y, q.z, a.fine[j][nb]);
-    if (best < 0) {
-      best = c - 1; dstar = d2; best_row = (unsigned)__float_as_int(a.coarse[j][c - 1].w);
-    } else if (d2 > dstar) {
-      settled = true;
-      break;
-    } else {  // a tie at the nearest survivor's distance: the smaller level-(l + 1) row wins
-      const unsigned r = (unsigned)__float_as_int(a.coarse[j][c - 1].w);
-      if (r < best_row) { best = c - 1; best_row = r; }
-    }
-  }
-  if (best >= 0 && !settled && !complete) {
-    // no farther survivor inside the list: the list's last entry decides whether an unseen point may tie
-    settled = dist2_exact(q.x, q.y, q.z, a.fine[j][last]) > dstar;
-  }
-  if (best >= 0 && (settled || complete)) {
-    a.out[j][s] = best;
-  } else {
-    a.miss[j][atomicAdd(a.nmiss[j], 1)] = (int)s;
-  }
-}
-// one wavefront per miss: brute force over the cloud's level-(l + 1) records, minimum of (d2 bits, row) — the query's key
-__global__ __launch_bounds__(256) void nn_miss_kernel(NnBatch a, int B) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(((int64_t)gridDim.x * 256) >> 6);
-  for (int j = 0; j < a.njobs; ++j) {
-    const int nm = a.nmiss[j][0];
-    for (int m = wave; m < nm; m += nwaves) {
-      const int s = a.miss[j][m];
-      const float4 q = a.fine[j][s];
-      const int b = cloud_of(a.ptr_fine[j], B, (int64_t)s);
-      const int64_t c0 = a.ptr_coarse[j][b], c1 = a.ptr_coarse[j][b + 1];
-      unsigned long long key = ~0ull;
-      for (int64_t c = c0 + lane; c < c1; c += 64) {
-        const float4 r = a.coarse[j][c];
-        const unsigned long long kk = ((unsigned long long)__float_as_uint(dist2_exact(q.x, q.y, q.z, r)) << 32) |
-                                      (unsigned)__float_as_int(r.w);
-        key = kk < key ? kk : key;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o, 64);
-        key = other < key ? other : key;
-      }
-      if (lane == 0) a.out[j][s] = key == ~0ull ? -1 : a.coarse_inv[j][(int)(unsigned)(key & 0xffffffffull)];
-    }
-  }
-}
-
-extern "C" size_t m3d_nn_from_knn_workspace_bytes(int64_t n_fine) {
-  return n_fine < 0 ? 0 : (size_t)m3d_align(n_fine * 4, 256) * 2 + 256;
-}
-
-// njobs <= 4 levels in one call (four launches).  Job j: ws_fine[j] / ws_coarse[j] = the built workspaces of level l and
-// l + 1 (the SAME num_clouds), knn[j] = level l's self-K-NN table in cell-sorted slots (m3d_knn_query, sorted_io, k = K),
-// src[j][t] = the level-l slot of level-(l + 1) slot t (m3d_knn_build_map's carried decimation map), nn_out[j] [n_fine]
-// int32 = what m3d_knn_query(ws_coarse, qry_ws = ws_fine, k = 1, sorted_io) writes.  scratch[j]: m3d_nn_from_knn_workspace_bytes.
-extern "C" int m3d_nn_from_knn(int32_t njobs, const void* const* ws_fine, const int64_t* const* ptr_fine, const int64_t* n_fine,
-                               const void* const* ws_coarse, const int64_t* const* ptr_coarse, const int64_t* n_coarse,
-                               int32_t num_clouds, const int32_t* const* knn, int32_t K, const int32_t* const* src,
-                               int32_t* const* nn_out, void* const* scratch, void* stream) {
-  if (njobs < 0 || njobs > NN_BATCH_MAX) return M3D_ERR_UNSUPPORTED;
-  if (njobs == 0 || num_clouds == 0) return M3D_OK;
-  if (!ws_fine || !ptr_fine || !n_fine || !ws_coarse || !ptr_coarse || !n_coarse || !knn || !src || !nn_out || !scratch || K < 1 ||
-      num_clouds < 0)
-    return M3D_ERR_INVALID;
-  NnBatch a;
-  a.njobs = njobs;
-  int64_t tf = 0, tc = 0;
-  for (int j = 0; j < NN_BATCH_MAX; ++j) {
-    a.start_fine[j] = tf; a.start_coarse[j] = tc;
-    if (j < njobs) {
-      if (n_fine[j] < 0 || n_coarse[j] < 0 || n_fine[j] >= (1ll << 31)) return M3D_ERR_INVALID;
-      if (n_fine[j] > 0 && (!ws_fine[j] || !ws_coarse[j] || !ptr_fine[j] || !ptr_coarse[j] || !knn[j] || !src[j] || !nn_out[j] ||
-                            !scratch[j]))
-        return M3D_ERR_INVALID;
-      const KnnWs wf = ws_carve((void*)ws_fine[j], num_clouds, n_fine[j]), wc = ws_carve((void*)ws_coarse[j], num_clouds, n_coarse[j]);
-      a.fine[j] = wf.sorted; a.coarse[j] = wc.sorted; a.coarse_inv[j] = wc.inv; a.idx[j] = knn[j]; a.src[j] = src[j];
-      a.ptr_fine[j] = ptr_fine[j]; a.ptr_coarse[j] = ptr_coarse[j];
-      char* p = (char*)scratch[j];
-      a.child[j] = (int*)p; p += m3d_align(n_fine[j] * 4, 256);
-      a.miss[j] = (int*)p; p += m3d_align(n_fine[j] * 4, 256);
-      a.nmiss[j] = (int*)p;
-      a.out[j] = nn_out[j]; a.n_fine[j] = n_fine[j]; a.n_coarse[j] = n_coarse[j];
-      tf += n_fine[j]; tc += n_coarse[j];
-    } else {
-      a.fine[j] = a.coarse[j] = nullptr; a.coarse_inv[j] = nullptr; a.idx[j] = a.src[j] = nullptr;
-      a.ptr_fine[j] = a.ptr_coarse[j] = nullptr; a.child[j] = a.miss[j] = a.nmiss[j] = a.out[j] = nullptr;
-      a.n_fine[j] = a.n_coarse[j] = 0;
-    }
-  }
-  a.start_fine[NN_BATCH_MAX] = tf; a.start_coarse[NN_BATCH_MAX] = tc;
-  for (int j = njobs; j < NN_BATCH_MAX; ++j) { a.start_fine[j] = tf; a.start_coarse[j] = tc; }
-  if (tf == 0) return M3D_OK;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(nn_zero_kernel, dim3((unsigned)m3d_cdiv(tf, 256)), dim3(256), 0, st, a);
-  if (tc > 0) hipLaunchKernelGGL(nn_child_kernel, dim3((unsigned)m3d_cdiv(tc, 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(nn_scan_kernel, dim3((unsigned)m3d_cdiv(tf, 256)), dim3(256), 0, st, a, K);
-  int64_t gm = m3d_cdiv(tf, 64 * 64);  // one wavefront per ~64 points: the expected miss rate is ~1 %
-  if (gm > 512) gm = 512;
-  if (gm < 1) gm = 1;
-  hipLaunchKernelGGL(nn_miss_kernel, dim3((unsigned)gm), dim3(256), 0, st, a, num_clouds);
-  M3D_CHECK_LAUNCH();
-  return M3D_OK;
-}

@@ -1337,36 +1337,6 @@ def knn_query_batch(pairs, k: int, sorted_io: bool = True, kernel: str = "auto")
     return outs
 
 
-def nn_from_knn(fine, coarse, knn, src) -> List[Tensor]:
-    """The decoder's 1-NN tables from the encoder's K-NN tables (``m3d_nn_from_knn``): for up to four levels,
-    ``fine[j]`` / ``coarse[j]`` = the built ``KnnIndex`` of level l and l + 1, ``knn[j]`` = level l's self table in
-    cell-sorted slots, ``src[j]`` = level-l slot of every level-(l + 1) slot.  Returns int32 ``[n_l, 1]`` tables bit-identical
-    to ``coarse[j].query(1, qry=fine[j], sorted_io=True)``."""
-    import ctypes
-
-    m = len(fine)
-    assert 0 < m <= 4 and m == len(coarse) == len(knn) == len(src)
-    dev = fine[0].ws.device
-    K = knn[0].shape[1]
-    outs = [torch.empty((f.n, 1), dtype=torch.int32, device=dev) for f in fine]
-    need = [(lib().m3d_nn_from_knn_workspace_bytes(f.n) + 255) // 256 * 256 for f in fine]
-    ws = torch.empty(max(sum(need), 1), dtype=torch.uint8, device=dev)
-    offs, o = [], 0
-    for nb in need:
-        offs.append(o)
-        o += nb
-    for f, c, t, r in zip(fine, coarse, knn, src):
-        assert f.num_clouds == c.num_clouds == fine[0].num_clouds and t.shape == (f.n, K) and r.numel() == c.n
-        _chk(t, torch.int32), _chk(r, torch.int32)
-    vp = lambda vals: (ctypes.c_void_p * m)(*vals)
-    i64 = lambda vals: (ctypes.c_int64 * m)(*vals)
-    call("m3d_nn_from_knn", m, vp([f.ws.data_ptr() for f in fine]), vp([f.ptr.data_ptr() for f in fine]), i64([f.n for f in fine]),
-         vp([c.ws.data_ptr() for c in coarse]), vp([c.ptr.data_ptr() for c in coarse]), i64([c.n for c in coarse]),
-         fine[0].num_clouds, vp([t.data_ptr() for t in knn]), K, vp([r.data_ptr() for r in src]),
-         vp([t.data_ptr() for t in outs]), vp([ws.data_ptr() + q for q in offs]), _st())
-    return outs
-
-
 def lfa_moments(pos4: Tensor, idx: Tensor) -> Tensor:
     mom = torch.empty(65, dtype=torch.float64, device=pos4.device)
     call("m3d_lfa_moments", _p(pos4), _p(idx), idx.shape[0], idx.shape[1], _p(mom), _st())

@@ -199,9 +199,6 @@ class HipRandLANet(nn.Module):
         # one wave per SIMD it takes ~2 x as long — hidden, the prefetch has the whole step — and costs the step 0.05 ms less
         # (3.962 -> 3.915 ms, same box: profiles/r06i_knn_background_cap_ab.log).  Tables are bit-identical.
         self.background_knn_cap = int(__import__("os").environ.get("M3D_KNN_BG_CAP", "16"))
-        # the decoder's 1-NN tables read off the encoder's K-NN tables (ops.nn_from_knn: bit-identical to the searches they
-        # replace); M3D_NN_FROM_KNN=0: the four 1-NN searches (A/B and cross-check)
-        self.nn_from_knn_tables = __import__("os").environ.get("M3D_NN_FROM_KNN", "1") != "0"
         # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
         # accumulation adds; False: plain autograd (cross-check)
         self.share_input_gradients = __import__("os").environ.get("M3D_GRAD_SLOTS", "1") != "0"
@@ -653,11 +650,7 @@ class HipRandLANet(nn.Module):
                 g.knn_inv.extend(self._reverse_neighbours(plan, lvl, g.knn[lvl], train, differentiable) for lvl in range(4))
             yield
         with torch.cuda.stream(side):
-            if self.nn_from_knn_tables and K >= 4:
-                # FPModule(k=1), pyg_randla_net.py:250 — level l + 1 is a subset of level l: the nearest survivor of a point
-                # is the first survivor in its (ascending) K-NN list; four light launches instead of four searches (round 6)
-                g.nn.extend(ops.nn_from_knn(g.index[:4], g.index[1:5], g.knn[:4], g.src[:4]))
-            elif batched:
+            if batched:
                 g.nn.extend(ops.knn_query_batch([(g.index[l + 1], g.index[l]) for l in range(4)], 1))
             else:
                 for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250

@@ -1143,64 +1143,3 @@ def test_device_interpolator_matches_reference_arithmetic(device, C):
     itp2.store_predictions(logits_list[0].to(device), [idx_list[0]])
     out2 = itp2.reduce_predictions(nb_points)
     assert torch.equal(out2["preds"].cpu(), torch.argmax(logits_list[0], dim=1) * 10 + 1)
-
-
-@pytest.mark.parametrize("case", ["lidar", "lattice", "duplicates", "tiny", "keep_one", "k4"])
-def test_one_nn_tables_from_the_knn_tables_are_bit_identical_to_the_search(device, case):
-    """Round 6: ``m3d_nn_from_knn`` reads the decoder's 1-NN tables (FPModule, pyg_randla_net.py:249-252) off the encoder's K-NN
-    tables — the nearest SURVIVOR of the decimation is the first survivor in a point's ascending neighbour list — instead of
-    searching.  It must reproduce ``m3d_knn_query(k = 1, sorted_io)`` bit for bit: on Lidar-shaped tiles, on a lattice (every
-    distance tied many times: the in-list tie rule and the "tie with the last list entry" fallback), with duplicated points
-    (MinimumNumNodes duplicates points, transforms.py:74-77), with clouds smaller than K and one-point clouds (complete
-    lists), and when one point per cloud survives (nearly every point is a miss: the brute-force pass)."""
-    from myria3d_amd import ops
-    from myria3d_amd.synthetic import synthetic_batch
-
-    rs = np.random.RandomState(len(case))
-    K = 4 if case == "k4" else 16
-    if case in ("lidar", "k4"):
-        _, pos, _, ptr, _ = synthetic_batch([12800, 5000, 777])
-    elif case == "lattice":
-        g = np.stack(np.meshgrid(np.arange(40), np.arange(40), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
-        pos = torch.from_numpy(np.concatenate([g * 0.25, g[:1500] * 0.5]))
-        ptr = torch.tensor([0, g.shape[0], g.shape[0] + 1500])
-    elif case == "duplicates":
-        base = rs.uniform(0, 1, (900, 3)).astype(np.float32)
-        pos = torch.from_numpy(np.concatenate([base, base[:400], base[:100]]))  # every point of the head two or three times
-        ptr = torch.tensor([0, 1400])
-    elif case == "tiny":
-        pos = torch.from_numpy(rs.uniform(0, 1, (3 + 9 + 1 + 40, 3)).astype(np.float32))
-        ptr = torch.tensor([0, 3, 12, 13, 53])
-    else:
-        pos = torch.from_numpy(rs.uniform(0, 1, (3000, 3)).astype(np.float32))
-        ptr = torch.tensor([0, 1800, 3000])
-    pos, ptr = pos.to(device), ptr.to(torch.int64).to(device)
-    sizes = (ptr[1:] - ptr[:-1]).tolist()
-    levels = 1 if case == "keep_one" else 3
-    index = [ops.KnnIndex(ops.pad_pos(pos), ptr)]
-    knn, src, ptrs = [], [], [ptr]
-    seed = torch.tensor([12345], dtype=torch.int64, device=device)
-    for lvl in range(levels):
-        ix = index[lvl]
-        knn.append(ix.query(K, qry=ix, sorted_io=True)[0])
-        nxt_sizes = [1 if case == "keep_one" else max(1, n // 4) for n in sizes]
-        ptr_out = torch.tensor([0] + list(np.cumsum(nxt_sizes)), dtype=torch.int64, device=device)
-        _, d_int, pos_next = ops.decimate_level(ptrs[lvl], ptr_out, int(ptr_out[-1]), seed, lvl, ix)
-        nxt = ops.KnnIndex(pos_next, ptr_out, carry=d_int)
-        src.append(nxt.carried)
-        index.append(nxt)
-        ptrs.append(ptr_out)
-        sizes = nxt_sizes
-    got = ops.nn_from_knn(index[:levels], index[1:levels + 1], knn, src)
-    misses = 0
-    for lvl in range(levels):
-        want = index[lvl + 1].query(1, qry=index[lvl], sorted_io=True)[0]
-        assert got[lvl].shape == want.shape and torch.equal(got[lvl], want), (case, lvl, int((got[lvl] != want).sum()))
-        # how many points the list did not settle (diagnostic: the brute-force share)
-        child = torch.zeros(index[lvl].n, dtype=torch.bool, device=device)
-        child[src[lvl].long()] = True
-        valid = knn[lvl] >= 0
-        misses += int((~(child[knn[lvl].clamp(min=0).long()] & valid).any(1)).sum())
-    print(f"[stats] nn_from_knn[{case}]: {misses} points without a survivor in their K = {K} list over {levels} level(s)")
-    if case == "keep_one":
-        assert misses > 2000  # (the brute-force pass did the work)
