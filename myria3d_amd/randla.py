@@ -206,6 +206,7 @@ class HipRandLANet(nn.Module):
         # the K-NN tables / encoder moments / decoder 1-NN tables of the four levels as one launch each (see
         # _geometry_stages); M3D_GEO_BATCH=0: level by level (A/B and cross-check)
         self.batch_geometry = __import__("os").environ.get("M3D_GEO_BATCH", "1") != "0"
+        self.batch_geometry_eval_capture = __import__("os").environ.get("M3D_GEO_BATCH_EVAL", "1") != "0"
         self.grad_side: Optional[ops.GradSideStream] = None  # weight-gradient side stream (owned by FusedAdam)
         self._flat: Optional[tuple] = None  # (flat_params, flat_grads) once flatten_parameters() has run
         # geometry of the NEXT forward (see prefetch_geometry()): two persistent slots used in turn
@@ -600,7 +601,10 @@ class HipRandLANet(nn.Module):
         # batched launches pay off where launches are the cost: eagerly (7.5 -> 6.8 ms per training step).  Inside a
         # captured graph the per-level launches are free for the host and run one after the other without competing with
         # the feature kernels, which measured 0.04 ms better (profiles/r02x_geo_batch.log) — same tables either way
-        batched = self.batch_geometry and not torch.cuda.is_current_stream_capturing()
+        # (eval: the forward is SHORTER than the position-only chain and waits for it — there the four K-NN queries as one launch
+        # take the time of the slowest instead of the sum, captured or not: M3D_GEO_BATCH_EVAL, round 6)
+        batched = self.batch_geometry and (not torch.cuda.is_current_stream_capturing() or
+                                           (not train and self.batch_geometry_eval_capture))
         with torch.cuda.stream(side):
             g.index.append(ops.KnnIndex(ops.pad_pos(pos), plan.ptrs[0]))
             g.pos4.append(g.index[0].sorted_pos4)
