@@ -453,18 +453,21 @@ struct KnnBatch {
   unsigned wg_start[KNN_BATCH_MAX + 1];
   int njobs;
 };
-__device__ __forceinline__ int knn_batch_job(const KnnBatch& a) {
+__device__ __forceinline__ int knn_batch_job(const KnnBatch& a, unsigned vb) {
   int j = 0;
 #pragma unroll
-  for (int i = 1; i < KNN_BATCH_MAX; ++i) j += (i < a.njobs && blockIdx.x >= a.wg_start[i]) ? 1 : 0;
+  for (int i = 1; i < KNN_BATCH_MAX; ++i) j += (i < a.njobs && vb >= a.wg_start[i]) ? 1 : 0;
   return j;
 }
 template <int KMAX>
 __global__ __launch_bounds__(256, KNN_MIN_BLOCKS) void knn_query_batch_kernel(KnnBatch a, int B, int k, int sorted_io) {
-  const int j = knn_batch_job(a);
-  knn_query_direct_body<KMAX>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
-                              a.idx_out[j], nullptr, sorted_io, k, 0, -1,
-                              (int64_t)(blockIdx.x - a.wg_start[j]) * 256 + threadIdx.x);
+  // (virtual workgroups: a BACKGROUND launch — flags bits 8-15 of m3d_knn_query_batch — has fewer real ones)
+  const unsigned total = a.wg_start[KNN_BATCH_MAX];
+  for (unsigned vb = blockIdx.x; vb < total; vb += gridDim.x) {
+    const int j = knn_batch_job(a, vb);
+    knn_query_direct_body<KMAX>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
+                                a.idx_out[j], nullptr, sorted_io, k, 0, -1, (int64_t)(vb - a.wg_start[j]) * 256 + threadIdx.x);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -687,10 +690,13 @@ __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_kernel(
 
 template <int KMAX>
 __global__ __launch_bounds__(64, KNNQ_MINW) void knn_query_queue_batch_kernel(KnnBatch a, int B, int k, int flags) {
-  const int j = knn_batch_job(a);
-  knn_query_queue_body<KMAX>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
-                             a.idx_out[j], nullptr, flags, (int64_t)(blockIdx.x - a.wg_start[j]),
-                             (int64_t)(a.wg_start[j + 1] - a.wg_start[j]));
+  const unsigned total = a.wg_start[KNN_BATCH_MAX];
+  for (unsigned vb = blockIdx.x; vb < total; vb += gridDim.x) {
+    const int j = knn_batch_job(a, vb);
+    knn_query_queue_body<KMAX>(a.w[j], a.ptr_src[j], B, nullptr, 0, a.qsorted[j], a.ptr_qry[j], a.n_qry[j], k,
+                               a.idx_out[j], nullptr, flags, (int64_t)(vb - a.wg_start[j]),
+                               (int64_t)(a.wg_start[j + 1] - a.wg_start[j]));
+  }
 }
 
 // m3d_knn_build that also carries one int32 per source row into cell-sorted order: map_out[slot] = map_in[row] (the
@@ -814,10 +820,14 @@ extern "C" int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const i
   if (total == 0) return M3D_OK;
   hipStream_t st = (hipStream_t)stream;
   const int qflags = (sorted_io ? 1 : 0) | (al ? 2 : 0);
+  // flags bits 8-15: BACKGROUND launch, at most that many x 64 wavefronts (as m3d_knn_query)
+  const unsigned wcap = (unsigned)((flags >> 8) & 0xff) * 64u;
+  const unsigned cap_wg = use_queue ? wcap : (wcap / 4 > 0 ? wcap / 4 : (wcap ? 1u : 0u));
+  const unsigned grid_b = (cap_wg > 0 && cap_wg < total) ? cap_wg : total;
 #define LAUNCH_B(KM)                                                                                                    \
   do {                                                                                                                  \
-    if (use_queue) hipLaunchKernelGGL((knn_query_queue_batch_kernel<KM>), dim3(total), dim3(64), 0, st, a, num_clouds, k, qflags); \
-    else hipLaunchKernelGGL((knn_query_batch_kernel<KM>), dim3(total), dim3(256), 0, st, a, num_clouds, k, sorted_io);  \
+    if (use_queue) hipLaunchKernelGGL((knn_query_queue_batch_kernel<KM>), dim3(grid_b), dim3(64), 0, st, a, num_clouds, k, qflags); \
+    else hipLaunchKernelGGL((knn_query_batch_kernel<KM>), dim3(grid_b), dim3(256), 0, st, a, num_clouds, k, sorted_io);  \
   } while (0)
   if (k == 1) LAUNCH_B(1);
   else if (k <= 4) LAUNCH_B(4);

@@ -1319,7 +1319,7 @@ def lfa_moments_batch(pos4s, idxs) -> List[Tensor]:
     return [mom[i, :65] for i in range(m)]
 
 
-def knn_query_batch(pairs, k: int, sorted_io: bool = True, kernel: str = "auto") -> List[Tensor]:
+def knn_query_batch(pairs, k: int, sorted_io: bool = True, kernel: str = "auto", background: int = 0) -> List[Tensor]:
     """``src.query(k, qry=qry, sorted_io=...)`` for up to 8 ``(src, qry)`` pairs of built ``KnnIndex`` objects in ONE
     launch (``m3d_knn_query_batch``); bit-identical tables."""
     import ctypes
@@ -1332,8 +1332,8 @@ def knn_query_batch(pairs, k: int, sorted_io: bool = True, kernel: str = "auto")
     vp = lambda ts: (ctypes.c_void_p * m)(*[t.data_ptr() for t in ts])
     call("m3d_knn_query_batch", m, vp([s_.ws for s_, _ in pairs]), vp([s_.ptr for s_, _ in pairs]),
          (ctypes.c_int64 * m)(*[s_.n for s_, _ in pairs]), vp([q.ws for _, q in pairs]), vp([q.ptr for _, q in pairs]),
-         (ctypes.c_int64 * m)(*[q.n for _, q in pairs]), pairs[0][0].num_clouds, k, int(sorted_io) | (_KNN_KERNEL[kernel] << 1),
-         vp(outs), _st())
+         (ctypes.c_int64 * m)(*[q.n for _, q in pairs]), pairs[0][0].num_clouds, k,
+         int(sorted_io) | (_KNN_KERNEL[kernel] << 1) | ((int(background) & 0xff) << 8), vp(outs), _st())
     return outs
 
 

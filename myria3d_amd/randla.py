@@ -199,6 +199,7 @@ class HipRandLANet(nn.Module):
         # one wave per SIMD it takes ~2 x as long — hidden, the prefetch has the whole step — and costs the step 0.05 ms less
         # (3.962 -> 3.915 ms, same box: profiles/r06i_knn_background_cap_ab.log).  Tables are bit-identical.
         self.background_knn_cap = int(__import__("os").environ.get("M3D_KNN_BG_CAP", "16"))
+        self.background_knn_eval = __import__("os").environ.get("M3D_KNN_BG_EVAL", "0") != "0"
         # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
         # accumulation adds; False: plain autograd (cross-check)
         self.share_input_gradients = __import__("os").environ.get("M3D_GRAD_SLOTS", "1") != "0"
@@ -603,6 +604,7 @@ class HipRandLANet(nn.Module):
         # the feature kernels, which measured 0.04 ms better (profiles/r02x_geo_batch.log) — same tables either way
         # (eval: the forward is SHORTER than the position-only chain and waits for it — there the four K-NN queries as one launch
         # take the time of the slowest instead of the sum, captured or not: M3D_GEO_BATCH_EVAL, round 6)
+        # (training: batched under capture measured 3.96-3.98 vs 3.905 ms per step even with the background cap, r06s)
         batched = self.batch_geometry and (not torch.cuda.is_current_stream_capturing() or
                                            (not train and self.batch_geometry_eval_capture))
         with torch.cuda.stream(side):
@@ -647,7 +649,7 @@ class HipRandLANet(nn.Module):
             # level the deep ones are latency-bound (105 / 77 / 45 us for 51 200 / 12 800 / 3 200 queries) and the
             # level-1 launch ends on its slowest wavefronts with most SIMDs idle (profiles/r02u_step_timeline.csv)
             with torch.cuda.stream(side):
-                g.knn.extend(ops.knn_query_batch([(g.index[l], g.index[l]) for l in range(4)], K))
+                g.knn.extend(ops.knn_query_batch([(g.index[l], g.index[l]) for l in range(4)], K, background=bg))
                 g.mom.extend(ops.lfa_moments_batch(g.pos4[:4], g.knn) if train else [None] * 4)
                 for lvl in range(4):
                     g.mark(1 + 2 * lvl, new=(lvl == 0))
@@ -655,7 +657,7 @@ class HipRandLANet(nn.Module):
             yield
         with torch.cuda.stream(side):
             if batched:
-                g.nn.extend(ops.knn_query_batch([(g.index[l + 1], g.index[l]) for l in range(4)], 1))
+                g.nn.extend(ops.knn_query_batch([(g.index[l + 1], g.index[l]) for l in range(4)], 1, background=bg))
             else:
                 for lvl in range(4):  # FPModule(k=1): pyg_randla_net.py:250
                     g.nn.append(g.index[lvl + 1].query(1, qry=g.index[lvl], sorted_io=True, background=bg)[0])
@@ -732,8 +734,9 @@ class HipRandLANet(nn.Module):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
         geo = _Geometry(main, side)
-        # (background launches only beside a TRAINING step: the eval forward is shorter than the position-only chain and waits for it)
-        stages = self._geometry_stages(geo, pos, plan, None, train, background=bool(train))
+        # (eval: the forward used to be shorter than the position-only chain and waited for it; with the queries of the four
+        # levels as one launch each the chain ends at 40 % of the forward: M3D_KNN_BG_EVAL, A/B switch)
+        stages = self._geometry_stages(geo, pos, plan, None, train, background=bool(train) or self.background_knn_eval)
         self._look_job = (stages, geo, turn, key, pos, main)
         if interleave:
             next(stages)
