@@ -1081,9 +1081,8 @@ def train_bench(args, dev, world, rank, B, N, K, steps, warmup, with_eager=False
     mode = "eager" if args.no_graph else args.launch
 
     def make(kind, launch):
-        # (the eval forward is shorter than the position-only chain it would wait for in the two-graph form: one graph)
         gs = GraphedStep(net, ptr, x.shape[1], mode=kind, optimizer=opt if kind == "train" else None, ignore_index=65,
-                         lookahead=look, launch=launch, lookahead_mode=args.lookahead_mode if kind == "train" else "single",
+                         lookahead=look, launch=launch, lookahead_mode=args.lookahead_mode,
                          collective=args.collective)
         gs.load_all(x, pos, y)
         made[kind, launch] = gs

@@ -56,8 +56,11 @@ class GraphedStep:
                  warmup: int = 2, collective: str = "captured", tune_streams: int = 6, accumulate: int = 1):
         if lookahead_mode is None:
             # two graphs on two streams pay off when the step is longer than the position-only chain (training: 4.72 vs
-            # 4.79 ms); the eval forward is shorter than that chain and would wait for it every step (1.59 vs 1.18 ms)
-            lookahead_mode = "dual" if mode == "train" else "single"
+            # 4.79 ms).  Rounds 2-5: the eval forward was shorter than that chain and waited for it every step (1.59 vs
+            # 1.18 ms) -> one graph.  Round 6: with the K-NN / 1-NN queries of the four levels as one launch each the chain
+            # ends at 40 % of the eval forward, and two graphs win there too (0.99 vs 1.015 ms; bf16 0.757 vs 0.810:
+            # profiles/r06t_eval_lookahead_mode_ab.log)
+            lookahead_mode = "dual"
         if mode not in ("train", "eval") or launch not in ("graph", "eager") or lookahead_mode not in ("dual", "single"):
             raise ValueError("mode: train|eval, launch: graph|eager, lookahead_mode: dual|single")
         if mode == "train" and optimizer is None:
