@@ -199,7 +199,9 @@ class HipRandLANet(nn.Module):
         # one wave per SIMD it takes ~2 x as long — hidden, the prefetch has the whole step — and costs the step 0.05 ms less
         # (3.962 -> 3.915 ms, same box: profiles/r06i_knn_background_cap_ab.log).  Tables are bit-identical.
         self.background_knn_cap = int(__import__("os").environ.get("M3D_KNN_BG_CAP", "16"))
-        self.background_knn_eval = __import__("os").environ.get("M3D_KNN_BG_EVAL", "0") != "0"
+        # (the prefetch beside a graphed EVAL forward: the chain has less slack there — 24 x 64 wavefronts: 0.989 -> 0.978 ms,
+        # bf16 0.759 -> 0.742; 16: slower, 1.02; 0 = uncapped.  profiles/r06v_*)
+        self.background_knn_cap_eval = int(__import__("os").environ.get("M3D_KNN_BG_CAP_EVAL", "24"))
         # the input gradients of a tensor with several consumers meet in one buffer (ops.GradSlot) instead of autograd's
         # accumulation adds; False: plain autograd (cross-check)
         self.share_input_gradients = __import__("os").environ.get("M3D_GRAD_SLOTS", "1") != "0"
@@ -598,7 +600,7 @@ class HipRandLANet(nn.Module):
         enqueue one stage between its own blocks (see ``prefetch_geometry(interleave=True)``)."""
         K = self.num_neighbors
         side = g.side
-        bg = max(0, min(255, int(self.background_knn_cap))) if background else 0
+        bg = max(0, min(255, int(self.background_knn_cap if train else self.background_knn_cap_eval))) if background else 0
         # batched launches pay off where launches are the cost: eagerly (7.5 -> 6.8 ms per training step).  Inside a
         # captured graph the per-level launches are free for the host and run one after the other without competing with
         # the feature kernels, which measured 0.04 ms better (profiles/r02x_geo_batch.log) — same tables either way
@@ -734,9 +736,7 @@ class HipRandLANet(nn.Module):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
         geo = _Geometry(main, side)
-        # (eval: the forward used to be shorter than the position-only chain and waited for it; with the queries of the four
-        # levels as one launch each the chain ends at 40 % of the forward: M3D_KNN_BG_EVAL, A/B switch)
-        stages = self._geometry_stages(geo, pos, plan, None, train, background=bool(train) or self.background_knn_eval)
+        stages = self._geometry_stages(geo, pos, plan, None, train, background=True)
         self._look_job = (stages, geo, turn, key, pos, main)
         if interleave:
             next(stages)
