@@ -115,7 +115,9 @@ int m3d_knn_query_batch(int32_t njobs, const void* const* ws, const int64_t* con
  * act: bit 0 = LeakyReLU(slope) on the output; bit 8 = bf16 matrix-core operands (both operands rounded to bf16 as
  * the fragments are built, v_mfma_f32_16x16x32_bf16, fp32 accumulate / epilogue / storage) — honoured by the K > 64
  * kernels when K % 32 == 0, ignored elsewhere (the K <= 64 layers are HBM-bound).
- * accumulate != 0: atomically add into C (required when splitk > 1, which splits the K dimension). */
+ * accumulate != 0: add into C (atomically when splitk > 1, which splits the K dimension).  With the affine epilogue
+ * (scale / shift / act) accumulate is a RESIDUAL (round 6): C = act(scale * (A B^T + bias) + shift + C_old) — the tail of a
+ * DilatedResidualBlock in eval mode (pyg_randla_net.py:186-187) over the buffer the shortcut's GEMM has written. */
 int m3d_gemm_stat_parts(int64_t M, int32_t N, int32_t K);
 int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, const int32_t* a0_rows, int32_t k0,
                  const float* a1, int64_t lda1, int32_t k1, const float* b, int64_t ldb, int32_t b_colmajor,

@@ -235,6 +235,7 @@ extern "C" int m3d_gemm_f32(const float* a0, int64_t lda0, int32_t a_colmajor, c
       if (rc != 1) return rc;
     }
   }
+  if (accumulate && (scale || shift || g.act)) return M3D_ERR_UNSUPPORTED;  // (the residual epilogue: fragment-direct kernels only)
   // fallback: atomically accumulated statistics in partial row 0, the other rows stay zero
   if (stat_part && !stat_slots &&
       hipMemsetAsync(stat_part, 0, sizeof(double) * 2 * (size_t)N * stat_parts, (hipStream_t)stream) != hipSuccess)

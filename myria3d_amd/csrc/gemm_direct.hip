@@ -367,6 +367,19 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
                                           double (&ssum)[4], double (&ssq)[4]) {
   const bool rowok = m < g.M;
   float y[4];
+  // affine epilogue with a RESIDUAL (MODE 2 + accumulate, round 6): C = act(scale * (A B^T + bias) + shift + C_old) — the tail of
+  // a DilatedResidualBlock in eval mode, LeakyReLU(BN(mlp2(x)) + BN(shortcut(x))) (pyg_randla_net.py:186-187), as the epilogue of
+  // the mlp2 GEMM over the buffer the shortcut GEMM (affine epilogue, no activation) has just written: no bn_apply launch
+  float res[4] = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 2 && g.accumulate && rowok) {
+    const size_t re = (size_t)(m * g.ldc + n0);
+    if (cvec) {
+      if (n0 < g.N) { const float4 p = io_load4<CHh>(g.c, re); res[0] = p.x; res[1] = p.y; res[2] = p.z; res[3] = p.w; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) res[r] = n0 + r < g.N ? io_load1<CHh>(g.c, re + r) : 0.f;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float z = acc[r] + f4(e.bia, r);
@@ -378,7 +391,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, const Epi<MODE>& e,
     }
     float v = z;
     if (MODE == 2) {
-      v = z * f4(e.sc, r) + f4(e.sh, r);
+      v = z * f4(e.sc, r) + f4(e.sh, r) + res[r];
       if (g.act) v = lrelu(v, g.slope);
     }
     y[r] = v;
@@ -854,7 +867,9 @@ static int gemm_direct_try_impl(const GemmArgs& g, hipStream_t st) {
   // debugging aid (compile time): GEMM_DISABLE bit mask (2 rowstream, 4 kloop, 8 statistics mode) -> LDS-tiled fallback
   const int disable = GEMM_DISABLE;
   if (g.a_cm || g.splitk > 1) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // column-major A / split-K: the LDS-tiled kernel
-  if (g.accumulate && (g.stat_part || g.scale || g.shift || g.act)) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;  // plain epilogue only
+  // accumulate: the plain epilogue (C += A B^T), or — round 6 — the affine one as a residual (C = act(affine(A B^T) + C))
+  if (g.accumulate && g.stat_part) return g.pro_z ? M3D_ERR_UNSUPPORTED : 1;
+  if (g.accumulate && (g.scale || g.shift || g.act) && (g.c_split > 0 || g.pro_z)) return M3D_ERR_UNSUPPORTED;
   if ((disable & 2) && K <= 64) return 1;
   if ((disable & 4) && K > 64) return 1;
   if ((disable & 8) && g.stat_part) return 1;

@@ -704,6 +704,8 @@ def bn_stats_apply(stats: Tensor, count: int, bn: torch.nn.BatchNorm1d, z: Tenso
 # (m3d_gemm_bn_on_load_f32).  The producer hands over ``y`` — allocated, NOT yet written — tagged with a PendingBN.
 # --------------------------------------------------------------------------------------------------
 BN_ON_LOAD = os.environ.get("M3D_BN_ON_LOAD", "1") != "0"  # A/B switch
+# eval mode: the residual tail of a block as the affine + residual epilogue of mlp2's GEMM instead of a bn_apply launch (A/B switch)
+EVAL_RESIDUAL_EPILOGUE = os.environ.get("M3D_EVAL_RESIDUAL", "1") != "0"
 
 
 class PendingBN:

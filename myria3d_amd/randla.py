@@ -520,9 +520,17 @@ class HipRandLANet(nn.Module):
         else:
             sc2, sh2 = self._cached(("bn", id(n2)), lambda: ops.bn_fold_eval(n2), self._bn_deps(n2))
             scs, shs = self._cached(("bn", id(ns)), lambda: ops.bn_fold_eval(ns), self._bn_deps(ns))
-            z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias, bf16=self._bf16)
-            zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias, bf16=self._bf16)
-            out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
+            if ops.EVAL_RESIDUAL_EPILOGUE:
+                # LeakyReLU(BN(mlp2(h)) + BN(shortcut(x))) as two launches (round 6): the shortcut's GEMM with its folded
+                # BatchNorm as the epilogue, then mlp2's GEMM whose epilogue adds that buffer before the activation
+                out = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias, scale=scs, shift=shs,
+                               bf16=self._bf16)
+                ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias, scale=sc2, shift=sh2, act=True,
+                         out=out, accumulate=True, bf16=self._bf16)
+            else:
+                z2 = ops.gemm(h, l2.weight, h.shape[0], l2.weight.shape[0], h.shape[1], bias=l2.bias, bf16=self._bf16)
+                zs = ops.gemm(x, ls.weight, x.shape[0], ls.weight.shape[0], x.shape[1], bias=ls.bias, bf16=self._bf16)
+                out = ops.bn_apply(z2, sc2, sh2, True, zs, scs, shs)
         if rec is not None:
             rec[name + ".out"] = out[index.inv.long()]
         return out
