@@ -45,7 +45,16 @@ typedef struct { const int64_t* counter; uint64_t seed; float p; const int32_t* 
  *                arithmetic and accumulation stays fp32 (fp64 statistics).
  *   M3D_IO_A32   (with M3D_IO_BF16) ... except the FIRST input matrix of the call (a0 / dy / dout), which is fp32: an incoming
  *                gradient that was accumulated with float atomics (the LFA layers' dx at ch >= 32)
- *   M3D_IO_C32   (with M3D_IO_BF16) ... except the OUTPUT matrix, which is fp32 (the logits) */
+ *   M3D_IO_C32   (with M3D_IO_BF16) ... except the OUTPUT matrix, which is fp32 (the logits)
+ * Which argument carries the bits (everything else about the call is unchanged):
+ *   m3d_gemm_f32 `act` (all three bits; bf16 storage exists in the fragment-direct kernels: -2 for shapes only the LDS-tiled
+ *   fallback covers), m3d_gemm_pair_f32 `flags`, m3d_gemm_bn_on_load_f32 `pro->act`, m3d_bn_dgrad_f32 `flags` (BF16, A32),
+ *   m3d_linear_wgrad_f32 / m3d_linear_wgrad_batch `accumulate` (BF16: dz, x0, x1 of every job), m3d_bn_stats_apply / m3d_bn_apply
+ *   `act`, m3d_bn_bwd `accumulate_param_grads` bits 16-17 (= (BF16 | A32) >> 12 << 16: its bits 8-15 hold the slot count),
+ *   m3d_lfa_fwd / m3d_lfa_fwd_bf16 / m3d_lfa_bwd / m3d_lfa_bwd_bf16 / m3d_lfa_bwd_edge_rows `flags` (x, out, dout and the edge
+ *   rows; the atomically accumulated dx stays fp32), m3d_scatter_add_rows `flags` (src; out too with distinct targets),
+ *   m3d_gather_sum_rows `accumulate` (src and out); own entry points: m3d_gather_rows_bf16, m3d_colsum_bf16,
+ *   m3d_convert_f32_bf16. */
 #define M3D_IO_BF16 0x1000
 #define M3D_IO_A32 0x2000
 #define M3D_IO_C32 0x4000
