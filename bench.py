@@ -922,16 +922,11 @@ def predict_bench(args, dev, world=1, rank=0, reps=None):
                        "launch": "eager"}}
 
 
-def predict_e2e_bench(args, dev, side_m=1000.0, density=10.0, reps=2):
-    """BASELINE config 3 END TO END: one synthetic 1 km^2 cloud (10 M points at 10 pts/m^2; raw Lambert-style coordinates minus a
-    file offset, raw Intensity / colour features) in HBM through the whole ``predict.py`` chain on the device —
-    ``myria3d_amd.predict_cloud``: tile selection (400 samples of 50 m) -> GridSampling(0.25) -> node budget -> Center /
-    NullifyLowestZ / NormalizePos / StandardizeRGBAndIntensity -> forward (batches of 50 samples) -> knn_interpolate(k=10) onto
-    every original point -> scatter_sum merge -> softmax / argmax / entropy.  The timed call starts from the resident cloud
-    and ends with the per-point predictions on the device (LAS reading / writing is pdal's: storage, out of scope)."""
+def predict_e2e_inputs(dev, side_m=1000.0, density=10.0):
+    """(net, pos, x): the synthetic cloud of ``predict_e2e_bench`` resident on the device and a random-init eval-mode net."""
     import numpy as np
 
-    from myria3d_amd import HipRandLANet, predict_cloud
+    from myria3d_amd import HipRandLANet
 
     rs = np.random.RandomState(0)
     n = int(side_m * side_m * density)
@@ -945,6 +940,20 @@ def predict_e2e_bench(args, dev, side_m=1000.0, density=10.0, reps=2):
     x[:, 7] = x[:, 7] * 255.0
     torch.manual_seed(0)
     net = HipRandLANet(9, 7, num_neighbors=16, return_logits=True).to(dev).eval()
+    return net, pos, x
+
+
+def predict_e2e_bench(args, dev, side_m=1000.0, density=10.0, reps=2):
+    """BASELINE config 3 END TO END: one synthetic 1 km^2 cloud (10 M points at 10 pts/m^2; raw Lambert-style coordinates minus a
+    file offset, raw Intensity / colour features) in HBM through the whole ``predict.py`` chain on the device —
+    ``myria3d_amd.predict_cloud``: tile selection (400 samples of 50 m) -> GridSampling(0.25) -> node budget -> Center /
+    NullifyLowestZ / NormalizePos / StandardizeRGBAndIntensity -> forward (batches of 50 samples) -> knn_interpolate(k=10) onto
+    every original point -> scatter_sum merge -> softmax / argmax / entropy.  The timed call starts from the resident cloud
+    and ends with the per-point predictions on the device (LAS reading / writing is pdal's: storage, out of scope)."""
+    from myria3d_amd import predict_cloud
+
+    net, pos, x = predict_e2e_inputs(dev, side_m, density)
+    n = pos.shape[0]
     out = predict_cloud(net, pos, x, tile_width=side_m, subtile_width=50, batch_size=50)  # warm-up (allocator, plans)
     # every point is predicted (a point exactly ON a sample border belongs to both samples — the reference's closed ball — and
     # is predicted twice, its logits summed: a handful among 10 M fp32 coordinates)

@@ -26,21 +26,17 @@ def _ptr_from_batch(batch: Optional[Tensor], n: int, device) -> Tensor:
     return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int64)
 
 
-def knn_interpolate(x: Tensor, pos_x: Tensor, pos_y: Tensor, batch_x: Optional[Tensor] = None,
-                    batch_y: Optional[Tensor] = None, k: int = 3, num_workers: int = 1,
-                    ptr_x: Optional[Tensor] = None, ptr_y: Optional[Tensor] = None) -> Tensor:
-    """Same signature and semantics as PyG's ``knn_interpolate`` (``batch_*`` must be sorted, as PyG requires).
-    ``num_workers`` is accepted and ignored (it only steers torch_cluster's CPU path).  Extension: ``ptr_x`` / ``ptr_y``
-    (device int64 ``[B + 1]`` CSR offsets, what ``Batch.ptr`` holds) instead of the batch vectors — converting a batch vector
-    costs a ``bincount`` and a device read-back per call."""
-    if not x.is_cuda:
-        raise RuntimeError("myria3d_amd.knn_interpolate runs on the HIP device only (no CPU fallback)")
-    dev = x.device
+def knn_interpolation_table(pos_x: Tensor, pos_y: Tensor, ptr_x: Tensor, ptr_y: Tensor, k: int,
+                            background: int = 0) -> Tuple[Tensor, Tensor]:
+    """The position-only half of ``knn_interpolate``: ``(idx [Ny, k] int32, d2 [Ny, k] fp32)``, the ``k`` nearest points of
+    ``pos_x`` for every point of ``pos_y`` inside the same cloud (-1 / padding where a cloud holds fewer) and the squared
+    distances.  ``predict_cloud`` computes it for the NEXT batch beside the current batch's forward (``background``: the
+    launch cap of ``KnnIndex.query``)."""
+    dev = pos_x.device
     with torch.no_grad():
         pos_x = pos_x.to(dev, torch.float32).contiguous()
         pos_y = pos_y.to(dev, torch.float32).contiguous()
-        ptr_x = ptr_x.to(dev, torch.int64) if ptr_x is not None else _ptr_from_batch(batch_x, pos_x.shape[0], dev)
-        ptr_y = ptr_y.to(dev, torch.int64) if ptr_y is not None else _ptr_from_batch(batch_y, pos_y.shape[0], dev)
+        ptr_x, ptr_y = ptr_x.to(dev, torch.int64), ptr_y.to(dev, torch.int64)
         if ptr_y.numel() < ptr_x.numel():  # trailing clouds without queries
             ptr_y = torch.cat([ptr_y, ptr_y[-1:].expand(ptr_x.numel() - ptr_y.numel())])
         elif ptr_x.numel() < ptr_y.numel():
@@ -49,7 +45,29 @@ def knn_interpolate(x: Tensor, pos_x: Tensor, pos_y: Tensor, batch_x: Optional[T
         # the queries get a grid of their own: cell-sorted query order keeps every wavefront inside a few grid cells
         # (rows of the result stay in the caller's order)
         qindex = ops.KnnIndex(pos_y, ptr_y.contiguous())
-        idx, d2 = index.query(k, qry=qindex, want_d2=True)
+        return index.query(k, qry=qindex, want_d2=True, background=background)
+
+
+def knn_interpolate(x: Tensor, pos_x: Tensor, pos_y: Tensor, batch_x: Optional[Tensor] = None,
+                    batch_y: Optional[Tensor] = None, k: int = 3, num_workers: int = 1,
+                    ptr_x: Optional[Tensor] = None, ptr_y: Optional[Tensor] = None,
+                    table: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
+    """Same signature and semantics as PyG's ``knn_interpolate`` (``batch_*`` must be sorted, as PyG requires).
+    ``num_workers`` is accepted and ignored (it only steers torch_cluster's CPU path).  Extensions: ``ptr_x`` / ``ptr_y``
+    (device int64 ``[B + 1]`` CSR offsets, what ``Batch.ptr`` holds) instead of the batch vectors — converting a batch vector
+    costs a ``bincount`` and a device read-back per call; ``table``: the result of ``knn_interpolation_table`` for these
+    positions, computed earlier (the positions are then not looked at)."""
+    if not x.is_cuda:
+        raise RuntimeError("myria3d_amd.knn_interpolate runs on the HIP device only (no CPU fallback)")
+    dev = x.device
+    with torch.no_grad():
+        if table is None:
+            pos_x = pos_x.to(dev, torch.float32)
+            pos_y = pos_y.to(dev, torch.float32)
+            ptr_x = ptr_x if ptr_x is not None else _ptr_from_batch(batch_x, pos_x.shape[0], dev)
+            ptr_y = ptr_y if ptr_y is not None else _ptr_from_batch(batch_y, pos_y.shape[0], dev)
+            table = knn_interpolation_table(pos_x, pos_y, ptr_x, ptr_y, k)
+        idx, d2 = table
         return ops.idw_interpolate(x.to(torch.float32).contiguous(), idx, d2)
 
 

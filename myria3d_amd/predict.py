@@ -28,9 +28,23 @@ import torch
 from torch import Tensor
 
 from . import ops
-from .interpolation import DeviceInterpolator, knn_interpolate, predict_reduce, scatter_sum
+from .interpolation import DeviceInterpolator, knn_interpolate, knn_interpolation_table, predict_reduce, scatter_sum
 from .tiling import tile_select
 from .transforms import grid_sampling, node_budget, node_budget_offsets, normalize_tiles
+
+
+_SIDE: Dict[torch.device, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    """One preparation stream per device for the life of the process."""
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
 
 
 @torch.no_grad()
@@ -38,13 +52,16 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
                   subtile_overlap: float = 0, batch_size: int = 50, grid_size: float = 0.25, min_nodes: int = 300,
                   max_nodes: int = 40000, interpolation_k: int = 10, intensity_col: int = 0, rgb_col: int = 7,
                   seed: int = 0, rank: int = 0, world_size: int = 1, process_group=None,
-                  decimation_idx_fn=None) -> Dict[str, Tensor]:
+                  decimation_idx_fn=None, lookahead: bool = True) -> Dict[str, Tensor]:
     """``pos [N, 3]`` (raw coordinates, as read from the LAS), ``x [N, F]`` (the raw feature matrix) on the device.
     Returns ``probas [M, C]``, ``preds [M]``, ``entropy [M]`` and ``idx_in_full_cloud [M]`` for the ``M`` stored predictions
     (every point of every non-empty sample, in sample order: ``interpolation.py:142-164``), plus ``logits_full [N, C]`` (the
     merged accumulator).  ``batch_size`` samples per forward (``configs/experiment/predict.yaml:21-23``: 50).
     ``decimation_idx_fn(ptr_host_list) -> per-level index lists``: parity runs inject the oracle's random decimation draw
-    (the net draws its own otherwise, as the reference's ``torch.randperm`` does)."""
+    (the net draws its own otherwise, as the reference's ``torch.randperm`` does).
+    ``lookahead`` (round 6): everything that depends on POSITIONS only — the interpolation's k-NN table and the net's own
+    (``HipRandLANet.prefetch_geometry``: grids, K-NN tables, decimation draw, decoder 1-NN tables) — is computed for batch b + 1
+    on side streams while the main stream runs batch b's feature kernels; the same kernels and results either way."""
     if not pos.is_cuda:
         raise RuntimeError("myria3d_amd.predict_cloud runs on the HIP device only (no CPU fallback)")
     dev = pos.device
@@ -72,8 +89,11 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
     make_plan = getattr(net, "plan_from_host_sizes", None)  # HipRandLANet / HipPointNet2: level plan from host-side tile sizes
 
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev)
+    side = _side_stream(dev)
     side.wait_stream(main)
+    bg = int(getattr(net, "background_knn_cap_eval", 0)) if lookahead else 0  # launch cap of work that runs beside the forward
+    look_net = lookahead and decimation_idx_fn is None and hasattr(net, "background_knn_cap_eval") \
+        and hasattr(net, "prefetch_geometry")
 
     def prepare(b):
         """Everything in front of the net for batch ``b`` — row lists, CopyFullPos, GridSampling, node budget, normalisations —
@@ -96,12 +116,25 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
                                  intensity_col=intensity_col, rgb_col=rgb_col)
         plan = make_plan(ptr_host) if (make_plan is not None and decimation_idx_fn is None) else None
         ev = torch.cuda.Event()
-        ev.record(side)
+        ev.record(side)  # (what the net reads is complete here)
+        table = None
+        if lookahead:
+            table = knn_interpolation_table(p, pos_copy, ptr, ptr_full, interpolation_k, background=bg)
+        ev2 = torch.cuda.Event()
+        ev2.record(side)
         out = {"rows": rows, "ptr_full": ptr_full, "pos_copy": pos_copy, "p": p, "pn": pn, "xn": xn, "ptr": ptr,
-               "ptr_host": ptr_host, "plan": plan, "ready": ev}
-        for t in (rows, ptr_full, pos_copy, p, pn, xn, ptr):  # allocated on the side stream, consumed on the main one
-            t.record_stream(main)
+               "ptr_host": ptr_host, "plan": plan, "ready": ev, "table": table, "table_ready": ev2}
+        for t in (rows, ptr_full, pos_copy, p, pn, xn, ptr) + (table if table is not None else ()):
+            t.record_stream(main)  # allocated on the side stream, consumed on the main one
         return out
+
+    def prefetch(nb, first):
+        """The net's own position-only work for the batch ``nb`` on ITS side stream, ordered behind the preparation (and, past
+        the first batch, behind the START of the forward just enqueued: the buffer set it rewrites was last read by the
+        forward before that one)."""
+        if look_net and nb["plan"] is not None:
+            net.prefetch_geometry(nb["pn"], nb["ptr"], plan=nb["plan"], train=False,
+                                  after="now" if first else "forward_start", after_event=nb["ready"])
 
     acc = None
     nxt = None
@@ -109,6 +142,7 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
     if batches:
         with torch.cuda.stream(side):
             nxt = prepare(0)
+        prefetch(nxt, True)
     for b in range(len(batches)):
         cur, nxt = nxt, None
         main.wait_event(cur["ready"])
@@ -118,7 +152,17 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
             logits = net(cur["xn"], cur["pn"], None, cur["ptr"], plan=cur["plan"])
         else:
             logits = net(cur["xn"], cur["pn"], None, cur["ptr"])
-        full = knn_interpolate(logits, cur["p"], cur["pos_copy"], ptr_x=cur["ptr"], ptr_y=cur["ptr_full"], k=interpolation_k)
+        if b + 1 < len(batches) and lookahead:
+            # the next batch's preparation and position-only work, enqueued on the side streams once this batch's FORWARD is
+            # queued: the host then blocks on the side stream's read-back while the main stream has ~4 ms of kernels in front
+            # of it, and the net's tables for batch b + 1 are built beside them
+            with torch.cuda.stream(side):
+                nxt = prepare(b + 1)
+            prefetch(nxt, False)
+        if cur["table"] is not None:
+            main.wait_event(cur["table_ready"])
+        full = knn_interpolate(logits, cur["p"], cur["pos_copy"], ptr_x=cur["ptr"], ptr_y=cur["ptr_full"], k=interpolation_k,
+                               table=cur["table"])
         if acc is None:
             acc = torch.zeros((n_full, full.shape[1]), dtype=torch.float32, device=dev)
         # Interpolator.store_predictions + reduce_predicted_logits (interpolation.py:94-121) in one go: the logits of a batch are
@@ -126,7 +170,7 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
         scatter_sum(full, cur["rows"], out=acc, dim=0)
         if world_size > 1:
             kept_rows.append(cur["rows"])
-        if b + 1 < len(batches):
+        if b + 1 < len(batches) and not lookahead:
             # the next batch's preparation, enqueued on the side stream once ALL of this batch's main-stream work is queued: the
             # host then blocks on the side stream's read-back while the main stream has ~6 ms of kernels in front of it
             with torch.cuda.stream(side):

@@ -694,7 +694,7 @@ class HipRandLANet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def prefetch_geometry(self, pos: Tensor, ptr: Tensor, plan: Optional[LevelPlan] = None,
                           train: Optional[bool] = None, after: str = "now", interleave: bool = False,
-                          slot: Optional[int] = None, owner=None) -> None:
+                          slot: Optional[int] = None, owner=None, after_event=None) -> None:
         """Enqueue the position-only work for a batch the network will see later (at most two may be outstanding:
         the one the next ``forward`` consumes and the one after it).  The tables are matched to the forward that
         consumes them by the IDENTITY of ``pos`` (the same tensor object, unmodified since: its autograd version
@@ -708,6 +708,7 @@ class HipRandLANet(nn.Module):
         started SINCE the one that consumed the buffer set rewritten here (that forward's start is then behind the
         consumer's backward pass in stream order — one training step in flight at a time); otherwise the call falls
         back to ``"now"``: the consumer's forward and backward kernels still read the buffers.
+        ``after_event``: an event the position-only work must also wait for (``pos`` written on a stream of the caller's).
         ``interleave=True``: only the first stage is enqueued now; the NEXT ``forward`` call (which consumes an older
         prefetch, or works in place) enqueues the remaining stages one by one between its own blocks.  A captured
         hipGraph submits its nodes in capture order at several microseconds apiece: a hundred position-only nodes in
@@ -740,6 +741,8 @@ class HipRandLANet(nn.Module):
                 side.wait_event(plan.ready)  # (this branch does not wait for the main stream, which carries the plan's upload)
         else:
             side.wait_stream(main)
+        if after_event is not None:
+            side.wait_event(after_event)
         with torch.cuda.stream(side):
             self._seed_decimation()
             self._decim_seed += 0x9E3779B97F4A7C15 - (1 << 64)  # (side stream: ordered with the kernels that read it)
@@ -776,7 +779,10 @@ class HipRandLANet(nn.Module):
         with torch.cuda.stream(geo.side):
             fresh = geo.tensors()
             if slot is None or slot.key != key:
-                slot = self._look_slots[turn] = _GeoSlot(key, [t.clone() for t in fresh], geo, main)
+                # (a new layout: eagerly the fresh tables BECOME the buffer set — a predict chain changes layout with every
+                # batch; under capture they live in the graph's pool and are copied out)
+                adopt = ops.capture_id(geo.side) == 0
+                slot = self._look_slots[turn] = _GeoSlot(key, list(fresh) if adopt else [t.clone() for t in fresh], geo, main)
             else:
                 ops.copy_many(slot.bufs, fresh)  # one launch (a replayed graph pays ~9 us per memcpy node)
             slot.ready = torch.cuda.Event()

@@ -119,3 +119,29 @@ def test_predict_chain_sharded_over_two_ranks_merges_to_the_same_logits():
     hit = shards[1] + shards[3]
     assert bool((hit > 0).all())
     assert torch.allclose(acc, whole["logits_full"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch_size", [1, 4])
+def test_predict_chain_lookahead_of_the_position_only_work_changes_nothing(batch_size):
+    """Round 6: ``predict_cloud`` builds the position-only tables of batch b + 1 (the interpolation's k-NN table, the net's
+    grids / K-NN tables / decimation draw / decoder 1-NN tables through ``HipRandLANet.prefetch_geometry``) on side streams
+    while batch b's feature kernels run.  Same kernels on the same inputs, the net drawing its own decimation either way:
+    the merged logits are BIT-identical with and without, on layouts that change with every batch (9 samples of different
+    sizes, the last batch shorter)."""
+    from myria3d_amd import HipRandLANet, predict_cloud
+
+    dev = torch.device("cuda:0")
+    pos, x = _cloud(150, 3.0, seed=11)
+    torch.manual_seed(2)
+    net = HipRandLANet(9, 6, return_logits=True).to(dev).eval()
+    outs = []
+    for look in (False, True, True):
+        net.set_decimation_seed(77)
+        outs.append(predict_cloud(net, pos.to(dev), x.to(dev), tile_width=150, subtile_width=50, subtile_overlap=10,
+                                  batch_size=batch_size, lookahead=look))
+    for o in outs[1:]:
+        assert torch.equal(o["idx_in_full_cloud"], outs[0]["idx_in_full_cloud"])
+        assert torch.equal(o["logits_full"], outs[0]["logits_full"])
+        assert torch.equal(o["preds"], outs[0]["preds"])
+    assert bool(torch.isfinite(outs[0]["logits_full"]).all())
+    assert not net._look_queue, "every prefetched table set was consumed by its forward"
