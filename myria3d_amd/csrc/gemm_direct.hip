@@ -69,6 +69,9 @@
 #ifndef WGRAD_VEC
 #define WGRAD_VEC 1
 #endif
+#ifndef WGRAD_XCD
+#define WGRAD_XCD 1  // batched weight gradients: the output tiles of one row slice on ONE XCD (see wgrad2_batch_kernel)
+#endif
 #ifndef WGRAD_BATCH_WAVES_BIG
 #define WGRAD_BATCH_WAVES_BIG 4096
 #endif
@@ -1077,6 +1080,72 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
   return f;
 }
 
+// The 4-row steps s0 .. s1 of one wave on permuted columns (WgradArgs::vec), DEPTH steps per trip.  A trip is: the row
+// numbers of the NEXT trip (x0[rows]: the FP modules' gather, fc0's cell order), every operand load of this trip, ONE wait,
+// the DEPTH x TN x TK MFMAs.  Nothing is computed from a loaded value in front of the last load and there is no branch in
+// the body.  Round 6: the earlier body added the two halves of a concatenated X row (x0 | x1) inside the load helper of each
+// step and branched on `vec` there — the compiler could not move the next step's loads across either, a trip was DEPTH + 1
+// dependent round trips to memory (5.4 us for 32 MFMAs on the 16-tile waves: 23 % of the fp32 matrix peak with the matrix
+// pipe idle three quarters of the time, and the same time for 1, 2 or 4 steps per trip: profiles/r04u_*).
+// ONEX: the tile's 16 TK columns lie in ONE of the two X operands (k0 a multiple of the tile width, or no x1): one load.
+template <int TN, int TK, bool H, bool ONEX, int DEPTH>
+__device__ __forceinline__ void wgrad_trips_vec(const WgradArgs& g, int64_t s0, int64_t s1, int nb, int kb, int lr, int lg,
+                                                f32x4 (&acc)[TN][TK]) {
+  const int K = g.k0 + g.k1;
+  const bool has_rows = g.rows != nullptr;
+  const rsrc_t rrows = mk_rsrc(g.rows);
+  const rsrc_t rz = mk_rsrc_h<H>(g.dz);
+  const int n0 = nb + TN * lr, kk = kb + TK * lr;
+  const unsigned acol = n0 < g.N ? 4u * (unsigned)n0 : OOB;
+  const bool in0 = kb < g.k0;  // (ONEX: uniform over the tile)
+  const rsrc_t rxa = mk_rsrc_h<H>(ONEX ? (in0 ? g.x0 : g.x1) : g.x0), rxb = mk_rsrc_h<H>(g.x1);
+  const int64_t ldxa = ONEX ? (in0 ? g.ldx0 : g.ldx1) : g.ldx0;
+  const unsigned xcol = ONEX ? (kk < K ? 4u * (unsigned)(in0 ? kk : kk - g.k0) : OOB)
+                             : (kk < g.k0 ? 4u * (unsigned)kk : OOB);
+  const unsigned xcol1 = (!ONEX && kk >= g.k0 && kk < K) ? 4u * (unsigned)(kk - g.k0) : OOB;
+  const bool mapped = has_rows && (!ONEX || in0);  // x0 is read through rows[]
+  auto row_req = [&](int64_t st) -> int32_t {  // rows[4 st + lg] (0 where there is none: the lane then reads no operand either)
+    const int64_t m = 4 * st + lg;
+    return __builtin_amdgcn_raw_buffer_load_b32(rrows, (mapped && st < s1 && m < g.M) ? (unsigned)(4 * m) : OOB, 0, 0);
+  };
+  int32_t rnext[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) rnext[d] = row_req(s0 + d);
+  for (int64_t s = s0; s < s1; s += DEPTH) {
+    float a[DEPTH][TN], b0[DEPTH][TK], b1[DEPTH][ONEX ? 1 : TK];
+    int32_t rcur[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { rcur[d] = rnext[d]; rnext[d] = row_req(s + DEPTH + d); }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int64_t m = 4 * (s + d) + lg;
+      const bool ok = s + d < s1 && m < g.M;
+      const int64_t mc = ok ? m : 0;
+      const int64_t rr = mapped ? (int64_t)rcur[d] : mc;
+      const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
+      const unsigned ox = (ok && rr >= 0) ? (unsigned)(rr * ldxa * 4) : OOB;
+      ldvh<TN, H>(rz, (oz != OOB && acol != OOB) ? oz + acol : OOB, a[d]);
+      ldvh<TK, H>(rxa, (ox != OOB && xcol != OOB) ? ox + xcol : OOB, b0[d]);
+      if constexpr (!ONEX) {
+        const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
+        ldvh<TK, H>(rxb, (o1 != OOB && xcol1 != OOB) ? o1 + xcol1 : OOB, b1[d]);
+      }
+    }
+    // (the scheduler otherwise sinks the last loads between the MFMA groups to save registers and waits for them there)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          float bv = b0[d][j];
+          if constexpr (!ONEX) bv += b1[d][j];
+          acc[i][j] = mfma16(a[d][i], bv, acc[i][j]);
+        }
+  }
+}
+
 // Every WAVE owns a contiguous row range; the four waves of a workgroup then add their [16*TN, 16*TK] accumulators
 // through LDS (plain stores + one barrier; LDS float atomics run at ~1 lane per 3 clocks on gfx950) and the workgroup
 // stores ONE partial to ws, so the chip can be filled with waves (HBM streaming needs bytes in flight: with 2 048 waves
@@ -1085,14 +1154,16 @@ __device__ __forceinline__ WgradFrag<TN, TK> wgrad_load(const WgradArgs& g, rsrc
 #ifndef WGRAD_DEPTH
 #define WGRAD_DEPTH 4
 #endif
+#ifndef WGRAD_WGR16
+#define WGRAD_WGR16 1  // the 16-tile waves (64 x 64 outputs: the deep layers) also meet in LDS (48 KB per workgroup): a quarter of
+#endif                 // the partial-sum traffic, which was most of those layers' time (62 partials of 512 KB for a 3 200-row layer)
 #ifndef WGRAD_DEPTH_BIG
-#define WGRAD_DEPTH_BIG 2  // 4-row steps in flight per trip of the waves with 8 or 16 accumulator tiles
+#define WGRAD_DEPTH_BIG 4  // 4-row steps in flight per trip of the waves with 8 or 16 accumulator tiles
 #endif
 template <int TN, int TK, bool BF = false, bool H = false>
 __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
-  // big tiles (16 accumulator quads: the deep, few-row layers) keep one partial per WAVE and two steps in flight: their
-  // register budget has no room for four, and their LDS reduction would take 48 KB
-  constexpr bool WGR = TN * TK < 16;
+  // (WGRAD_WGR16 = 0: the 16-tile waves of the deep, few-row layers keep one partial per WAVE, rounds 3-5)
+  constexpr bool WGR = TN * TK < 16 || WGRAD_WGR16;
   constexpr int DEPTH = TN * TK < 8 ? WGRAD_DEPTH : WGRAD_DEPTH_BIG;
   __shared__ float red[WGR ? 3 : 1][WGR ? TN * TK * 256 : 1];  // accumulators of waves 1..3 (wave 0 keeps its own)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
@@ -1150,7 +1221,11 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
       goto reduce_and_store;
     }
   }
-  {
+  if (g.vec) {
+    // (uniform) one X load per step where the tile does not straddle the seam of a concatenated input
+    if (g.k1 == 0 || g.k0 % (16 * TK) == 0) wgrad_trips_vec<TN, TK, H, true, DEPTH>(g, s0, s1, nb, kb, lr, lg, acc);
+    else wgrad_trips_vec<TN, TK, H, false, (TN * TK < 8 ? DEPTH : 2)>(g, s0, s1, nb, kb, lr, lg, acc);  // (3 loads per step)
+  } else {
   // x0[rows] (fc0 on the cell-sorted order): the row numbers of a trip are requested one trip AHEAD, behind the operand
   // loads of the trip before — read inside wgrad_load they were a dependent round trip in front of every 4-row step, and the
   // wait for them drained the operand loads of the step before (the waves of that job ran one step at a time)
@@ -1274,9 +1349,16 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_kernel(WgradArgs g) {
 struct WgradBatch {
   WgradArgs g[WGRAD_BATCH_MAX];
   unsigned wg_start[WGRAD_BATCH_MAX + 1];
-  unsigned gx[WGRAD_BATCH_MAX], gy[WGRAD_BATCH_MAX];
+  unsigned gx[WGRAD_BATCH_MAX], gy[WGRAD_BATCH_MAX], gz[WGRAD_BATCH_MAX];
   int njobs;
 };
+// Which workgroup of a job works on what (WGRAD_XCD, round 6).  Workgroups go to the 8 XCDs round-robin by their flat index and
+// every XCD has an L2 of its own.  The gy x gz output tiles of ONE row slice read the same rows of dZ and X (dZ gz times, X gy
+// times over): with the slice as the fastest index (rounds 3-5) those tiles landed on all eight XCDs and every one of them
+// fetched its operands from the Infinity Cache — the 16-tile class moved ~540 MB for ~100 MB of operands and ran at that
+// traffic's pace whatever the depth of its pipeline or the number of its waves.  Now XCD c (= flat index % 8; every job
+// starts at a multiple of 8) takes the c-th eighth of the job in (tile fastest, slice slowest) order: the tiles of a slice
+// run on one XCD at the same time and share its L2.
 template <int TN, int TK, bool BF = false, bool H = false>
 __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_batch_kernel(WgradBatch b) {
   int j = 0;
@@ -1284,7 +1366,15 @@ __global__ __launch_bounds__(256, WGRAD_MINW) void wgrad2_batch_kernel(WgradBatc
   for (int i = 1; i < WGRAD_BATCH_MAX; ++i) j += (i < b.njobs && blockIdx.x >= b.wg_start[i]) ? 1 : 0;
   const unsigned w = blockIdx.x - b.wg_start[j];
   const unsigned gx = b.gx[j], gy = b.gy[j];
+#if WGRAD_XCD
+  const unsigned tiles = gy * b.gz[j], per = (b.wg_start[j + 1] - b.wg_start[j]) >> 3;
+  const unsigned l = (w & 7u) * per + (w >> 3);
+  if (l >= gx * tiles) return;  // (padding of the job to a multiple of 8 workgroups)
+  const unsigned t = l % tiles;
+  wgrad2_body<TN, TK, BF, H>(b.g[j], l / tiles, t % gy, t / gy);
+#else
   wgrad2_body<TN, TK, BF, H>(b.g[j], w % gx, (w / gx) % gy, w / (gx * gy));
+#endif
 }
 
 // dw[n][k] (+)= sum_s ws[s][n][k]
@@ -1344,11 +1434,11 @@ static WgradPlan wgrad_plan(int64_t M, int N, int K, int64_t target_waves = 0) {
   p.TK = tk >= 4 ? 4 : (tk >= 2 ? 2 : 1);
   p.by = m3d_cdiv(N, 16 * p.TN);
   p.bz = m3d_cdiv(K, 16 * p.TK);
-  const bool wgr = p.TN * p.TK < 16;  // workgroup-level partials (see wgrad2_kernel)
+  const bool wgr = p.TN * p.TK < 16 || WGRAD_WGR16;  // workgroup-level partials (see wgrad2_kernel)
   const int64_t steps_total = m3d_cdiv(M > 0 ? M : 1, 4);
   const int target_env = WGRAD_WAVES;
   // target_waves > 0: this job's share of a batched launch (m3d_linear_wgrad_batch), instead of the whole chip
-  const int64_t target = target_waves > 0 ? target_waves : (target_env > 0 ? target_env : (wgr ? 8192 : 2048));
+  const int64_t target = target_waves > 0 ? target_waves : (target_env > 0 ? target_env : (p.TN * p.TK < 16 ? 8192 : 2048));
   int64_t waves = m3d_cdiv(target, p.by * p.bz);  // streaming tiles: ~8 waves per SIMD over the chip
   if (waves > steps_total / 8) waves = steps_total / 8;  // >= 8 steps (32 rows) per wave
   if (waves < 1) waves = 1;
@@ -1521,7 +1611,7 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
       if (b.njobs == 0) return;
       b.wg_start[b.njobs] = total;
       for (int i = b.njobs + 1; i <= WGRAD_BATCH_MAX; ++i) b.wg_start[i] = total;
-      for (int i = b.njobs; i < WGRAD_BATCH_MAX; ++i) { b.g[i] = b.g[0]; b.gx[i] = 1; b.gy[i] = 1; }
+      for (int i = b.njobs; i < WGRAD_BATCH_MAX; ++i) { b.g[i] = b.g[0]; b.gx[i] = 1; b.gy[i] = 1; b.gz[i] = 1; }
       const int TN = variants[v][0], TK = variants[v][1];
       if (TN == 4 && TK == 4) launch_wgrad2_batch<4, 4>(b, total, st);
       else if (TN == 4 && TK == 2) launch_wgrad2_batch<4, 2>(b, total, st);
@@ -1558,8 +1648,9 @@ extern "C" int m3d_linear_wgrad_batch(int32_t njobs, const float* const* dz, con
       g.vec = wgrad_vec_ok(g, p.TN, p.TK);
       g.bf16 = ((accumulate >> 8) & 1) && g.vec && p.TN * p.TK >= 8;  // the matrix-bound (deep) layers only
       b.wg_start[b.njobs] = total;
-      b.gx[b.njobs] = (unsigned)p.wgs; b.gy[b.njobs] = (unsigned)p.by;
+      b.gx[b.njobs] = (unsigned)p.wgs; b.gy[b.njobs] = (unsigned)p.by; b.gz[b.njobs] = (unsigned)p.bz;
       total += (unsigned)(p.wgs * p.by * p.bz);
+      if (WGRAD_XCD) total = (total + 7u) & ~7u;  // every job starts on XCD 0 (see wgrad2_batch_kernel)
       if (++b.njobs == WGRAD_BATCH_MAX) flush();
     }
     flush();

@@ -127,7 +127,8 @@ def test_predict_chain_lookahead_of_the_position_only_work_changes_nothing(batch
     grids / K-NN tables / decimation draw / decoder 1-NN tables through ``HipRandLANet.prefetch_geometry``) on side streams
     while batch b's feature kernels run.  Same kernels on the same inputs, the net drawing its own decimation either way:
     the merged logits are BIT-identical with and without, on layouts that change with every batch (9 samples of different
-    sizes, the last batch shorter)."""
+    sizes, the last batch shorter; no overlap between samples: a point predicted three times would be summed in the order its
+    atomics arrive, lookahead or not)."""
     from myria3d_amd import HipRandLANet, predict_cloud
 
     dev = torch.device("cuda:0")
@@ -137,7 +138,7 @@ def test_predict_chain_lookahead_of_the_position_only_work_changes_nothing(batch
     outs = []
     for look in (False, True, True):
         net.set_decimation_seed(77)
-        outs.append(predict_cloud(net, pos.to(dev), x.to(dev), tile_width=150, subtile_width=50, subtile_overlap=10,
+        outs.append(predict_cloud(net, pos.to(dev), x.to(dev), tile_width=150, subtile_width=50, subtile_overlap=0,
                                   batch_size=batch_size, lookahead=look))
     for o in outs[1:]:
         assert torch.equal(o["idx_in_full_cloud"], outs[0]["idx_in_full_cloud"])
