@@ -1146,6 +1146,74 @@ __device__ __forceinline__ void wgrad_trips_vec(const WgradArgs& g, int64_t s0, 
   }
 }
 
+// The same on the bf16 matrix cores (the net's "bf16" mode): a trip is a 32-row step; lane (lr, lg) supplies rows 8 lg .. 8 lg + 7
+// of the step for its TN / TK (permuted) columns: 8 vector loads per operand, all in flight behind the row numbers of the NEXT
+// trip, then TN x TK MFMAs of 32 rows each.  (Rounds 3-5 read rows[] inside the step and waited for it in front of every one of
+// the 8 row loads: the FP modules' jobs — 29 % of the class's flops — were 8 dependent round trips per 16 MFMAs.)
+template <int TN, int TK, bool H, bool ONEX>
+__device__ __forceinline__ void wgrad_trips_bf16(const WgradArgs& g, int64_t s0, int64_t s1, int nb, int kb, int lr, int lg,
+                                                 f32x4 (&acc)[TN][TK]) {
+  const int K = g.k0 + g.k1;
+  const bool has_rows = g.rows != nullptr;
+  const rsrc_t rrows = mk_rsrc(g.rows);
+  const rsrc_t rz = mk_rsrc_h<H>(g.dz);
+  const int n0 = nb + TN * lr, kk = kb + TK * lr;
+  const unsigned acol = n0 < g.N ? 4u * (unsigned)n0 : OOB;
+  const bool in0 = kb < g.k0;
+  const rsrc_t rxa = mk_rsrc_h<H>(ONEX ? (in0 ? g.x0 : g.x1) : g.x0), rxb = mk_rsrc_h<H>(g.x1);
+  const int64_t ldxa = ONEX ? (in0 ? g.ldx0 : g.ldx1) : g.ldx0;
+  const unsigned xcol = ONEX ? (kk < K ? 4u * (unsigned)(in0 ? kk : kk - g.k0) : OOB)
+                             : (kk < g.k0 ? 4u * (unsigned)kk : OOB);
+  const unsigned xcol1 = (!ONEX && kk >= g.k0 && kk < K) ? 4u * (unsigned)(kk - g.k0) : OOB;
+  const bool mapped = has_rows && (!ONEX || in0);
+  auto row_req = [&](int64_t s, int j) -> int32_t {
+    const int64_t m = 4 * s + 8 * lg + j;
+    return __builtin_amdgcn_raw_buffer_load_b32(rrows, (mapped && m < 4 * s1 && m < g.M) ? (unsigned)(4 * m) : OOB, 0, 0);
+  };
+  int32_t rnext[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rnext[j] = row_req(s0, j);
+  for (int64_t s = s0; s < s1; s += 8) {
+    float av[8][TN], b0[8][TK], b1[8][ONEX ? 1 : TK];
+    int32_t rcur[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rcur[j] = rnext[j]; rnext[j] = row_req(s + 8, j); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t m = 4 * s + 8 * lg + j;
+      const bool ok = m < 4 * s1 && m < g.M;
+      const int64_t mc = ok ? m : 0;
+      const int64_t rr = mapped ? (int64_t)rcur[j] : mc;
+      const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
+      const unsigned ox = (ok && rr >= 0) ? (unsigned)(rr * ldxa * 4) : OOB;
+      ldvh<TN, H>(rz, (oz != OOB && acol != OOB) ? oz + acol : OOB, av[j]);
+      ldvh<TK, H>(rxa, (ox != OOB && xcol != OOB) ? ox + xcol : OOB, b0[j]);
+      if constexpr (!ONEX) {
+        const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
+        ldvh<TK, H>(rxb, (o1 != OOB && xcol1 != OOB) ? o1 + xcol1 : OOB, b1[j]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Bf16Frag fa[TN], fb[TK];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[a].u[i] = pack_bf16(av[2 * i][a], av[2 * i + 1][a]);
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float lo = b0[2 * i][b], hi = b0[2 * i + 1][b];
+        if constexpr (!ONEX) { lo += b1[2 * i][b]; hi += b1[2 * i + 1][b]; }
+        fb[b].u[i] = pack_bf16(lo, hi);
+      }
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TK; ++b) acc[a][b] = mfma_bf16(fa[a].v, fb[b].v, acc[a][b]);
+  }
+}
+
 // Every WAVE owns a contiguous row range; the four waves of a workgroup then add their [16*TN, 16*TK] accumulators
 // through LDS (plain stores + one barrier; LDS float atomics run at ~1 lane per 3 clocks on gfx950) and the workgroup
 // stores ONE partial to ws, so the chip can be filled with waves (HBM streaming needs bytes in flight: with 2 048 waves
@@ -1182,42 +1250,8 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& g, const unsigned b
 
   if constexpr (BF && TN * TK >= 8) {
     if (g.bf16 && g.vec) {
-      // bf16 matrix cores: a 32-row step; lane (lr, lg) supplies rows 8 lg .. 8 lg + 7 of the step for its TN / TK
-      // (permuted) columns: 8 vector loads per operand, all 16 in flight, then TN x TK MFMAs of 32 rows each
-      for (int64_t s = s0; s < s1; s += 8) {
-        float av[8][TN], bv[8][TK];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int64_t m = 4 * s + 8 * lg + j;
-          const bool ok = m < 4 * s1 && m < g.M;
-          const int64_t mc = ok ? m : 0;
-          const int64_t rr = g.rows ? (int64_t)g.rows[mc] : mc;
-          const unsigned oz = ok ? (unsigned)(mc * g.lddz * 4) : OOB;
-          const unsigned o0 = (ok && rr >= 0) ? (unsigned)(rr * g.ldx0 * 4) : OOB;
-          const unsigned o1 = (ok && g.k1 > 0) ? (unsigned)(mc * g.ldx1 * 4) : OOB;
-          const int n0 = nb + TN * lr, kk = kb + TK * lr;
-          ldvh<TN, H>(rz, (oz != OOB && n0 < g.N) ? oz + 4u * (unsigned)n0 : OOB, av[j]);
-          const bool in0 = kk < g.k0;
-          float t0[TK], t1[TK];
-          ldvh<TK, H>(rx0, (in0 && o0 != OOB) ? o0 + 4u * (unsigned)kk : OOB, t0);
-          ldvh<TK, H>(rx1, (!in0 && kk < K && o1 != OOB) ? o1 + 4u * (unsigned)(kk - g.k0) : OOB, t1);
-#pragma unroll
-          for (int b = 0; b < TK; ++b) bv[j][b] = t0[b] + t1[b];
-        }
-        Bf16Frag fa[TN], fb[TK];
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) fa[a].u[i] = pack_bf16(av[2 * i][a], av[2 * i + 1][a]);
-#pragma unroll
-        for (int b = 0; b < TK; ++b)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) fb[b].u[i] = pack_bf16(bv[2 * i][b], bv[2 * i + 1][b]);
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int b = 0; b < TK; ++b) acc[a][b] = mfma_bf16(fa[a].v, fb[b].v, acc[a][b]);
-      }
+      if (g.k1 == 0 || g.k0 % (16 * TK) == 0) wgrad_trips_bf16<TN, TK, H, true>(g, s0, s1, nb, kb, lr, lg, acc);
+      else wgrad_trips_bf16<TN, TK, H, false>(g, s0, s1, nb, kb, lr, lg, acc);
       goto reduce_and_store;
     }
   }
