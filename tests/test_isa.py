@@ -99,3 +99,42 @@ def test_wave_autonomous_lfa_backward_has_no_barrier_and_no_spill():
             assert sum(1 for o in ops if o.startswith("v_mfma")) == 48, (ch, edge, io)
             seen += 1
     assert seen == 8
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="needs hipcc (cross-compiles without a GPU)")
+def test_weight_gradient_trips_issue_every_operand_load_before_the_first_wait():
+    """Round 6: the batched weight-gradient kernels spent three quarters of their time in dependent round trips to memory — the
+    two halves of a concatenated X row were added inside the load helper of each 4-row step and the helper branched on the
+    column layout, so the loads of step d + 1 sat behind a wait for step d (``s_waitcnt vmcnt(1)`` after three loads, DEPTH
+    times per trip).  ``wgrad_trips_vec`` / ``wgrad_trips_bf16``: in every loop block that holds a trip's operand loads, no
+    wait may ask for an operand load of the SAME block (``vmcnt(N)`` with N below the number of vector loads issued so far
+    in the block), in the fp32 and bf16-storage instantiations of the 16-tile class and in the bf16 matrix-core variant."""
+    import re
+    import subprocess
+    import tempfile
+
+    src = os.path.join(ROOT, "myria3d_amd", "csrc", "gemm_direct.hip")
+    with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-w", "--cuda-device-only", "-S",
+                        src, "-o", tmp.name], check=True, cwd=os.path.dirname(src))
+        text = open(tmp.name).read()
+    checked = 0
+    for bf, h in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        m = re.search(r"^_Z19wgrad2_batch_kernelILi4ELi4ELb%dELb%dEEv10WgradBatch:.*?\.Lfunc_end" % (bf, h), text, re.S | re.M)
+        assert m, (bf, h)
+        trip_blocks = 0
+        for block in re.split(r"^\.LBB\d+_\d+:", m.group(0), flags=re.M)[1:]:
+            wide = 0  # operand loads (dwordx4 / dwordx2: the row numbers are dword loads) issued so far in this block
+            total = sum(1 for ln in block.split("\n") if re.match(r"\s*buffer_load_dwordx[24]", ln))
+            if total < 6:
+                continue  # not a trip's load phase
+            trip_blocks += 1
+            for ln in block.split("\n"):
+                if re.match(r"\s*buffer_load_dwordx[24]", ln):
+                    wide += 1
+                w = re.match(r"\s*s_waitcnt .*vmcnt\((\d+)\)", ln)
+                if w and wide < total:  # (behind the last load the waits of the MFMA phase begin)
+                    assert int(w.group(1)) >= wide, (bf, h, "a wait for an operand load in front of the next load", ln.strip(), wide)
+        assert trip_blocks >= 1, (bf, h)
+        checked += 1
+    assert checked == 4
