@@ -22,6 +22,7 @@ of one cloud, in which case the ``[N, C]`` logit accumulators are summed over th
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -52,7 +53,7 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
                   subtile_overlap: float = 0, batch_size: int = 50, grid_size: float = 0.25, min_nodes: int = 300,
                   max_nodes: int = 40000, interpolation_k: int = 10, intensity_col: int = 0, rgb_col: int = 7,
                   seed: int = 0, rank: int = 0, world_size: int = 1, process_group=None,
-                  decimation_idx_fn=None, lookahead: bool = True) -> Dict[str, Tensor]:
+                  decimation_idx_fn=None, lookahead: Optional[bool] = None) -> Dict[str, Tensor]:
     """``pos [N, 3]`` (raw coordinates, as read from the LAS), ``x [N, F]`` (the raw feature matrix) on the device.
     Returns ``probas [M, C]``, ``preds [M]``, ``entropy [M]`` and ``idx_in_full_cloud [M]`` for the ``M`` stored predictions
     (every point of every non-empty sample, in sample order: ``interpolation.py:142-164``), plus ``logits_full [N, C]`` (the
@@ -61,9 +62,16 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
     (the net draws its own otherwise, as the reference's ``torch.randperm`` does).
     ``lookahead`` (round 6): everything that depends on POSITIONS only — the interpolation's k-NN table and the net's own
     (``HipRandLANet.prefetch_geometry``: grids, K-NN tables, decimation draw, decoder 1-NN tables) — is computed for batch b + 1
-    on side streams while the main stream runs batch b's feature kernels; the same kernels and results either way."""
+    on side streams while the main stream runs batch b's feature kernels; the same kernels and bit-identical results either way.
+    OFF by default (``None``: the environment's ``M3D_PREDICT_LOOKAHEAD``, "0"): measured on the 10 M-point cloud of
+    ``bench.py`` it gains nothing at 50 samples per batch (48.8 vs 48.9 ms: the chip is full of kernels either way, the
+    chain is bound by their sum), 5 % at 25 (53.7 -> 50.9 ms), and it COSTS 6 ms when clouds follow each other without a
+    synchronisation (the tables cross streams: their blocks are not reusable until the consumer's events complete and the
+    allocator goes to hipMalloc; ``profiles/r06y_*``, ``r06zg_*``)."""
     if not pos.is_cuda:
         raise RuntimeError("myria3d_amd.predict_cloud runs on the HIP device only (no CPU fallback)")
+    if lookahead is None:
+        lookahead = os.environ.get("M3D_PREDICT_LOOKAHEAD", "0") != "0"
     dev = pos.device
     net.eval()
     pos = pos.to(torch.float32).contiguous()

@@ -7,6 +7,8 @@ import bench
 from myria3d_amd import predict_cloud
 
 dev = torch.device("cuda:0")
+# stream -> hardware-queue aliasing probe: torch hands out its pool streams in turn, ROCclr maps them onto 4 hardware queues
+_dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("M3D_DUMMY_STREAMS", "0")))]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 net, pos, x = bench.predict_e2e_inputs(dev)
 
@@ -34,6 +36,7 @@ for bs in sizes:
     for look in (False, True):
         v = sorted(T[look])
         print(f"batch_size {bs} lookahead={look}: min {v[0]:.2f} median {v[len(v) // 2]:.2f} ms per 10 M points   {['%.2f' % t for t in T[look]]}")
-pr = cProfile.Profile()
-pr.enable(); run(True); torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
+if os.environ.get("M3D_PREDICT_HOST_PROFILE"):
+    pr = cProfile.Profile()
+    pr.enable(); run(True); torch.cuda.synchronize(); pr.disable()
+    st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(28)
