@@ -65,9 +65,10 @@ def predict_cloud(net: torch.nn.Module, pos: Tensor, x: Tensor, *, tile_width: f
     on side streams while the main stream runs batch b's feature kernels; the same kernels and bit-identical results either way.
     OFF by default (``None``: the environment's ``M3D_PREDICT_LOOKAHEAD``, "0"): measured on the 10 M-point cloud of
     ``bench.py`` it gains nothing at 50 samples per batch (48.8 vs 48.9 ms: the chip is full of kernels either way, the
-    chain is bound by their sum), 5 % at 25 (53.7 -> 50.9 ms), and it COSTS 6 ms when clouds follow each other without a
-    synchronisation (the tables cross streams: their blocks are not reusable until the consumer's events complete and the
-    allocator goes to hipMalloc; ``profiles/r06y_*``, ``r06zg_*``)."""
+    chain is bound by their sum), 5 % at 25 (53.7 -> 50.9 ms), and it COSTS 6-8 ms per cloud for the first clouds of a
+    process (``bench.py``'s protocol — one warm-up call, two timed ones — measures 56.8 instead of 49.2 ms): the tables
+    cross streams, their blocks are not reusable until the consumer's events complete, and the allocator's pool grows by
+    1.4 GiB of ``hipMalloc`` calls before it is steady (``profiles/r06y_*``, ``r06zg_*``, ``r06zk_*``)."""
     if not pos.is_cuda:
         raise RuntimeError("myria3d_amd.predict_cloud runs on the HIP device only (no CPU fallback)")
     if lookahead is None:
