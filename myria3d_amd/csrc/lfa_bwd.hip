@@ -1313,31 +1313,54 @@ __device__ __forceinline__ void lfa_bwd_reduce_body(const float* __restrict__ dw
                                                     int parts4, int DP, int D, double* __restrict__ G, unsigned bx,
                                                     unsigned by, unsigned nyy) {
   const int t = bx * 256 + threadIdx.x;
-  const int nw = CHP * CHP;
+  const int nw = CHP * CHP, nq = nw >> 2;  // (CHP is a multiple of 16: a thread sums FOUR consecutive elements, 16-byte loads)
   const int ny = (int)nyy, y = (int)by;
-  if (t < nw) {
+  if (t < nq) {
     const int per = (parts3 + ny - 1) / ny;
     const int p0 = y * per, p1 = min(parts3, p0 + per);
     // fp64 like G below (round 6): a chunk holds up to a few hundred partials of cancelling terms (dA sums to zero over every
     // neighbourhood) — the loads bind this pass, the wider adds are free
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const float4* __restrict__ src = (const float4*)dw_part + t;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, r[4] = {0.0, 0.0, 0.0, 0.0};
     int p = p0;
-    for (; p + 3 < p1; p += 4) {
-      s0 += (double)dw_part[(size_t)p * nw + t];
-      s1 += (double)dw_part[(size_t)(p + 1) * nw + t];
-      s2 += (double)dw_part[(size_t)(p + 2) * nw + t];
-      s3 += (double)dw_part[(size_t)(p + 3) * nw + t];
+    for (; p + 7 < p1; p += 8) {  // eight 16-byte loads in flight per thread
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(p + j) * nq];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        s[0] += (double)v[j].x; s[1] += (double)v[j].y; s[2] += (double)v[j].z; s[3] += (double)v[j].w;
+        r[0] += (double)v[j + 1].x; r[1] += (double)v[j + 1].y; r[2] += (double)v[j + 1].z; r[3] += (double)v[j + 1].w;
+      }
     }
-    for (; p < p1; ++p) s0 += (double)dw_part[(size_t)p * nw + t];
-    const int c = t / CHP, k = t % CHP;
-    if (c < CH && k < CH && p1 > p0) atomicAdd(&dw_att[c * CH + k], (float)((s0 + s1) + (s2 + s3)));
+    for (; p < p1; ++p) {
+      const float4 a = src[(size_t)p * nq];
+      s[0] += (double)a.x; s[1] += (double)a.y; s[2] += (double)a.z; s[3] += (double)a.w;
+    }
+    const int e = 4 * t, c = e / CHP, k = e % CHP;
+    if (c < CH && p1 > p0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k + j < CH) atomicAdd(&dw_att[c * CH + k + j], (float)(s[j] + r[j]));
+    }
   } else {
-    const int u = t - nw;
+    const int u = t - nq;
     if (u < DP * 16) {
       const int per = (parts4 + ny - 1) / ny;
       const int p0 = y * per, p1 = min(parts4, p0 + per);
+      // (eight partials in flight: one load at a time this loop was a chain of round trips as long as the chunk — the pass
+      // took the same ~70 us whatever its dW half did)
       double s = 0.0;
-      for (int p = p0; p < p1; ++p) s += (double)g_part[(size_t)p * DP * 16 + u];
+      const size_t gs = (size_t)DP * 16;
+      int p = p0;
+      for (; p + 7 < p1; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g_part[(size_t)(p + j) * gs + u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (double)v[j];
+      }
+      for (; p < p1; ++p) s += (double)g_part[(size_t)p * gs + u];
       const int c = u / 16, q = u % 16;
       if (c < D && q < 11 && p1 > p0) atomicAdd(&G[c * 11 + q], s);
     }
@@ -1354,6 +1377,9 @@ __global__ __launch_bounds__(256) void lfa_bwd_reduce_kernel(const float* __rest
 // the partial sums of several LFA layers in one launch (m3d_lfa_bwd_reduce_batch): dW_att and the encoder sums G are
 // PARAMETER-gradient material — nothing in the backward chain reads them — so every layer's reduce can wait for the
 // end of the backward pass (8 launches of 10-20 us in the dependent chain otherwise)
+#ifndef LFA_RED_WGS
+#define LFA_RED_WGS 256  // workgroups per layer of the partial-sum reduce: every chunk of partials costs one float atomic per element
+#endif
 #define LFA_RED_BATCH_MAX 16
 struct LfaRedBatch {
   const float* dw_part[LFA_RED_BATCH_MAX]; const float* g_part[LFA_RED_BATCH_MAX];
@@ -1499,10 +1525,10 @@ static int lfa_bwd_impl(const float* x, const float* pos4, const int32_t* idx, i
   }
   if (rc != M3D_OK) return rc;
   if (flags & 4) return M3D_OK;  // the caller sums the partials later (m3d_lfa_bwd_reduce_batch): ws must live until then
-  const int total = p.chp * p.chp + p.dp * 16;
+  const int total = p.chp * p.chp / 4 + p.dp * 16;  // (a thread sums four dW elements or one G element)
   const int gx = (total + 255) / 256;
   const int parts = p.grid * p.kspl3;
-  int gy = 2048 / gx;            // ~2k blocks in flight; >= 8 partials per chunk
+  int gy = LFA_RED_WGS / gx;     // blocks in flight per layer; >= 8 partials per chunk
   if (gy > parts / 8) gy = parts / 8;
   if (gy < 1) gy = 1;
   if (!accumulate_dw && hipMemsetAsync(dw_att, 0, sizeof(float) * (size_t)CH * CH, st) != hipSuccess)
@@ -1542,9 +1568,9 @@ extern "C" int m3d_lfa_bwd_reduce_batch(int32_t njobs, const int64_t* n, const i
       b.g_part[i] = b.dw_part[i] + (size_t)p.grid * p.kspl3 * p.chp * p.chp;
       b.dw_att[i] = dw_att[j]; b.G[i] = G[j];
       b.parts3[i] = p.grid * p.kspl3; b.parts4[i] = p.grid * p.kspl4; b.chp[i] = p.chp; b.ch[i] = CH[j]; b.dp[i] = p.dp;
-      const int total = p.chp * p.chp + p.dp * 16;
+      const int total = p.chp * p.chp / 4 + p.dp * 16;
       const int gx = (total + 255) / 256;
-      int gy = 2048 / gx;
+      int gy = LFA_RED_WGS / gx;
       if (gy > b.parts3[i] / 8) gy = b.parts3[i] / 8;
       if (gy < 1) gy = 1;
       b.gx[i] = (unsigned)gx; b.gy[i] = (unsigned)gy;
