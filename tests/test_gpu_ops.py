@@ -1143,3 +1143,54 @@ def test_device_interpolator_matches_reference_arithmetic(device, C):
     itp2.store_predictions(logits_list[0].to(device), [idx_list[0]])
     out2 = itp2.reduce_predictions(nb_points)
     assert torch.equal(out2["preds"].cpu(), torch.argmax(logits_list[0], dim=1) * 10 + 1)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16_storage", "bf16_operands"])
+def test_batched_weight_gradients_every_tile_class_seam_and_row_map(device, mode):
+    """Round 6 rewrote the row loops of the weight-gradient kernels (``wgrad_trips_vec`` / ``wgrad_trips_bf16``: row numbers one
+    trip ahead, every load of a trip before the first use, ONE X load per step where a tile lies wholly in x0 or x1, the
+    64 x 64-tile waves meeting in LDS, XCD-aware workgroup order of the batched launch).  The network's shapes exercise only
+    some of the paths (every concatenated input of its 16-tile jobs has its seam on a tile border): this batch holds all seven
+    tile classes, seams on and OFF tile borders with and without a row map on x0, ragged row counts (not a multiple of 4 / 32),
+    a job with a single row, in one ``m3d_linear_wgrad_batch`` call per activation layout, against fp64."""
+    from myria3d_amd import ops
+
+    rs = np.random.RandomState(7)
+    dt = torch.bfloat16 if mode == "bf16_storage" else torch.float32
+    # (M, N, k0, k1, rows?)                 tile class (TN, TK) / what it adds
+    cases = [(3203, 128, 192, 0, False),   # (4, 4) one operand
+             (3203, 128, 128, 64, True),   # (4, 4) seam on a tile border, x0 through a row map
+             (1601, 64, 96, 96, True),     # (4, 4) seam INSIDE a tile (two X loads per step), row map
+             (1601, 64, 96, 96, False),    # ... without
+             (5003, 32, 32, 32, True),     # (2, 4) seam inside the tile (the FP1 layer's shape)
+             (5003, 64, 32, 0, False),     # (4, 2)
+             (4099, 32, 32, 0, False),     # (2, 2)
+             (4099, 16, 32, 0, False),     # (1, 2)
+             (4099, 32, 9, 0, True),       # (2, 1) fc0's shape: odd K, row map
+             (4099, 6, 16, 0, False),      # (1, 1)
+             (1, 64, 64, 0, False),        # a single row
+             (37, 256, 256, 256, True)]    # fewer rows than one 32-row bf16 step has lanes for
+    side = ops.GradSideStream(device)
+    jobs, refs = [], []
+    for M, N, k0, k1, mapped in cases:
+        n_src = M // 3 + 1 if mapped else M
+        dz = torch.from_numpy(rs.uniform(-1, 1, (M, N)).astype(np.float32)).to(device).to(dt)
+        x0 = torch.from_numpy(rs.uniform(-1, 1, (n_src, k0)).astype(np.float32)).to(device).to(dt)
+        x1 = torch.from_numpy(rs.uniform(-1, 1, (M, k1)).astype(np.float32)).to(device).to(dt) if k1 else None
+        rows = torch.from_numpy(rs.randint(0, n_src, (M,)).astype(np.int32)).to(device) if mapped else None
+        sink = torch.full((N, k0 + k1), 0.5, dtype=torch.float32, device=device)
+        a = x0.double()[rows.long()] if mapped else x0.double()
+        if k1:
+            a = torch.cat([a, x1.double()], 1)
+        refs.append(0.5 + dz.double().t() @ a)
+        jobs.append((dz, x0, k0, rows, x1, k1, sink, mode == "bf16_operands"))
+        side.defer(jobs[-1])
+    side.join()
+    torch.cuda.synchronize()
+    for (M, N, k0, k1, mapped), job, ref in zip(cases, jobs, refs):
+        name = f"wgrad batch {mode} M={M} N={N} k0={k0} k1={k1} rows={mapped}"
+        if mode == "bf16_operands":
+            # products of bf16-rounded operands, fp32 accumulate: relative to the column scale sqrt(M)
+            _close(name, job[6], ref, 2e-2, 2e-2 * np.sqrt(M))
+        else:
+            _close(name, job[6], ref, 1e-5, 3e-6 * np.sqrt(M) + 2e-7 * M)
