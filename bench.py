@@ -482,12 +482,12 @@ KNN_KERNEL_PREFIX = ("void knn_query_queue_kernel<16", "void knn_query_kernel<16
 
 
 def _pick_threads():
-    """Thread count for the CPU baseline: the fastest of {1, 4, 8, 16, all cores} on a micro-probe shaped like the
-    oracle's level-1 edge tensors (some hosts — e.g. oversubscribed VMs — are slower with every core)."""
+    """Thread count for the CPU baseline: the fastest of {1, 4, 8, 16, 32, 64, 128, all cores} on a micro-probe shaped like
+    the oracle's level-1 edge tensors (some hosts — e.g. oversubscribed VMs — are slower with every core)."""
     ncpu = os.cpu_count() or 1
     a, b, w = torch.rand(204800, 16), torch.rand(204800, 16), torch.rand(16, 16)
     best, best_t = 1, float("inf")
-    for th in sorted({1, min(4, ncpu), min(8, ncpu), min(16, ncpu), ncpu}):
+    for th in sorted({1, min(4, ncpu), min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu), min(128, ncpu), ncpu}):
         torch.set_num_threads(th)
         (a * b) @ w  # warm-up
         t0 = time.perf_counter()
@@ -558,7 +558,7 @@ def cpu_baseline(tiles, points, K, full=False):
            "sample": f"{tiles} tiles x {points} pts (the GPU line's whole batch), median of {reps} timed iterations after {warm} "
                      f"warm-up (BASELINE.md section 3's protocol); fwd+bwd = train mode + CE loss + backward, fwd_only = eval / no_grad; "
                      f"oracle/randla_oracle.py (unfused torch CPU ops, cKDTree kNN); threads = {picked} (fastest of "
-                     f"{{1,4,8,16,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
+                     f"{{1,4,8,16,32,64,128,{ncpu}}} on a micro-probe), host has {ncpu} cores"}
     if full and picked != ncpu:
         # every host core: on the 256-core GPU host the oversubscribed run did not finish 3 iterations of 2 tiles in 460 s
         # (profiles/r03f_bench.err) — only on request
