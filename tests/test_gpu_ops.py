@@ -1169,7 +1169,11 @@ def test_batched_weight_gradients_every_tile_class_seam_and_row_map(device, mode
              (4099, 32, 9, 0, True),       # (2, 1) fc0's shape: odd K, row map
              (4099, 6, 16, 0, False),      # (1, 1)
              (1, 64, 64, 0, False),        # a single row
-             (37, 256, 256, 256, True)]    # fewer rows than one 32-row bf16 step has lanes for
+             (37, 256, 256, 256, True),    # fewer rows than one 32-row bf16 step has lanes for
+             (3203, 128, 128, 0, False),   # whole 128 x 128 blocks (fp32: the LDS-shared form, wgrad_lds_body), ragged last trip
+             (1601, 256, 256, 128, True),  # ... seam on a block border, x0 through a row map
+             (12800, 256, 128, 0, False),  # ... many row slices
+             (31, 512, 512, 0, False)]     # ... less than one 32-row trip
     side = ops.GradSideStream(device)
     jobs, refs = [], []
     for M, N, k0, k1, mapped in cases:
